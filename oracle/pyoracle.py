@@ -1,0 +1,454 @@
+"""ctypes binding of the CPU oracle (oracle/libsmvs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package (smvs_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_u8_p = C.POINTER(C.c_uint8)
+c_u16_p = C.POINTER(C.c_uint16)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u64_p = C.POINTER(C.c_uint64)
+c_i32_p = C.POINTER(C.c_int32)
+
+
+def build():
+    """(Re)build the oracle shared library (and oracle/_ref when the
+    reference tree is present)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libsmvs_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_bicubic_eval.restype = C.c_double
+        _LIB.orc_vec_dot.restype = C.c_double
+        _LIB.orc_linear_at_f32.restype = C.c_float
+        _LIB.orc_linear_at_u8.restype = C.c_uint8
+    return _LIB
+
+
+def ref_ldl():
+    """The reference's own ldl_inverse compiled from /root/reference (None if
+    oracle/_ref was never built)."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libref_ldl.so")
+        if not os.path.exists(path):
+            return None
+        _REF = C.CDLL(path)
+    return _REF
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------ bicubic
+def bicubic_coeffs(nodes16):
+    nodes16 = f64(nodes16).reshape(16)
+    out = np.zeros(16)
+    lib().orc_bicubic_coeffs(_p(nodes16, c_double_p), _p(out, c_double_p))
+    return out
+
+
+def bicubic_eval(coeffs, kind, x, y):
+    coeffs = f64(coeffs)
+    return lib().orc_bicubic_eval(_p(coeffs, c_double_p), C.c_int(kind),
+                                  C.c_double(x), C.c_double(y))
+
+
+def node_derivatives(x, y):
+    out = np.zeros(96)
+    lib().orc_node_derivatives(C.c_double(x), C.c_double(y), _p(out, c_double_p))
+    return out
+
+
+def node_derivatives_for_patchsize(x, y, patchsize):
+    out = np.zeros(96)
+    lib().orc_node_derivatives_for_patchsize(C.c_double(x), C.c_double(y),
+        C.c_double(patchsize), _p(out, c_double_p))
+    return out
+
+
+def node_derivatives_for_pixel(pid, patchsize):
+    out = np.zeros(96)
+    lib().orc_node_derivatives_for_pixel(C.c_int(pid), C.c_int(patchsize),
+                                         _p(out, c_double_p))
+    return out
+
+
+def patch_values_at_pixels(nodes16, px, py, size, subsample=1):
+    nodes16 = f64(nodes16).reshape(16)
+    n = size * size
+    pixels = np.zeros((n, 2)); depths = np.zeros(n)
+    first = np.zeros((n, 2)); second = np.zeros((n, 3))
+    pids = np.zeros(n, dtype=np.int32)
+    cnt = lib().orc_patch_values_at_pixels(_p(nodes16, c_double_p), px, py,
+        size, subsample, _p(pixels, c_double_p), _p(depths, c_double_p),
+        _p(first, c_double_p), _p(second, c_double_p), _p(pids, c_i32_p))
+    return pixels[:cnt], depths[:cnt], first[:cnt], second[:cnt], pids[:cnt]
+
+
+# ----------------------------------------------------------- correspondence
+class Corr(C.Structure):
+    _fields_ = [("p", C.c_double), ("q", C.c_double), ("r", C.c_double),
+                ("t", C.c_double * 3), ("w", C.c_double),
+                ("w_prime", C.c_double * 2), ("a", C.c_double),
+                ("b", C.c_double), ("d", C.c_double), ("d2", C.c_double),
+                ("p_prime", C.c_double * 2), ("q_prime", C.c_double * 2),
+                ("r_prime", C.c_double * 2)]
+
+
+class Correspondence:
+    def __init__(self, M, t, u, v, w, w_dx=0.0, w_dy=0.0):
+        self.c = Corr()
+        M = f64(M).reshape(9); t = f64(t).reshape(3)
+        lib().orc_corr_update(C.byref(self.c), _p(M, c_double_p),
+            _p(t, c_double_p), C.c_double(u), C.c_double(v), C.c_double(w),
+            C.c_double(w_dx), C.c_double(w_dy))
+
+    def fill(self):
+        out = np.zeros(2)
+        lib().orc_corr_fill(C.byref(self.c), _p(out, c_double_p))
+        return out
+
+    def jacobian(self):
+        out = np.zeros(4)
+        lib().orc_corr_fill_jacobian(C.byref(self.c), _p(out, c_double_p))
+        return out
+
+    def derivative(self, dn):
+        dn = f64(dn); out = np.zeros((16, 2))
+        lib().orc_corr_fill_derivative(C.byref(self.c), _p(dn, c_double_p),
+                                       _p(out, c_double_p))
+        return out
+
+    def jacobian_derivative_grad(self, grad, dn):
+        dn = f64(dn); grad = f64(grad); out = np.zeros((16, 2))
+        lib().orc_corr_fill_jacobian_derivative_grad(C.byref(self.c),
+            _p(grad, c_double_p), _p(dn, c_double_p), _p(out, c_double_p))
+        return out
+
+    @property
+    def depth(self):
+        return self.c.d
+
+
+# ------------------------------------------------------ surface derivative
+def fill_normal(x, y, inv_flen, w, dx, dy):
+    out = np.zeros(3)
+    lib().orc_fill_normal(*(C.c_double(v) for v in (x, y, inv_flen, w, dx, dy)),
+                          _p(out, c_double_p))
+    return out
+
+
+def normal_derivative(dn, x, y, f, w, dx, dy):
+    dn = f64(dn); out = np.zeros(48)
+    lib().orc_normal_derivative(_p(dn, c_double_p),
+        *(C.c_double(v) for v in (x, y, f, w, dx, dy)), _p(out, c_double_p))
+    return out
+
+
+def normal_divergence(x, y, f, w, dx, dy, dxy, dxx, dyy):
+    out = np.zeros(6)
+    lib().orc_normal_divergence(
+        *(C.c_double(v) for v in (x, y, f, w, dx, dy, dxy, dxx, dyy)),
+        _p(out, c_double_p))
+    return out
+
+
+def normal_divergence_deriv(dn, x, y, f, w, dx, dy, dxy, dxx, dyy):
+    dn = f64(dn); out = np.zeros(96)
+    lib().orc_normal_divergence_deriv(_p(dn, c_double_p),
+        *(C.c_double(v) for v in (x, y, f, w, dx, dy, dxy, dxx, dyy)),
+        _p(out, c_double_p))
+    return out
+
+
+def sh_evaluate_4_band(n):
+    n = f64(n); out = np.zeros(16)
+    lib().orc_sh_evaluate_4_band(_p(n, c_double_p), _p(out, c_double_p))
+    return out
+
+
+def sh_derivative_4_band(n):
+    n = f64(n); out = np.zeros(48)
+    lib().orc_sh_derivative_4_band(_p(n, c_double_p), _p(out, c_double_p))
+    return out
+
+
+# -------------------------------------------------------------------- algebra
+def ldl_inverse(A):
+    A = f64(A).copy(); n = A.shape[0]
+    lib().orc_ldl_inverse(_p(A, c_double_p), C.c_int(n))
+    return A
+
+
+def ref_ldl_inverse(A):
+    A = f64(A).copy(); n = A.shape[0]
+    ref_ldl().ref_ldl_inverse(_p(A, c_double_p), C.c_int(n))
+    return A
+
+
+def vec_dot(a, b):
+    a = f64(a); b = f64(b)
+    return lib().orc_vec_dot(_p(a, c_double_p), _p(b, c_double_p),
+                             C.c_size_t(a.size))
+
+
+def linear_at_f32(img, x, y, ch):
+    img = f32(img); h, w, c = img.shape
+    return lib().orc_linear_at_f32(_p(img, c_float_p), w, h, c, C.c_float(x),
+                                   C.c_float(y), ch)
+
+
+# ------------------------------------------------------------ GN structures
+class Surface(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("scale", C.c_int),
+                ("patchsize", C.c_int), ("npx", C.c_int), ("npy", C.c_int),
+                ("start_x", C.c_int), ("start_y", C.c_int),
+                ("nodes", c_double_p), ("node_valid", c_u8_p),
+                ("patch_valid", c_u8_p), ("patch_vis", c_u32_p)]
+
+
+class SubView(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int),
+                ("grad", c_float_p), ("hess", c_float_p)]
+
+
+class Views(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int),
+                ("flen", C.c_float), ("inv_flen", C.c_float),
+                ("grad", c_float_p), ("shading", c_float_p),
+                ("shading_grad", c_float_p), ("n_subs", C.c_int),
+                ("subs", C.POINTER(SubView)), ("M", c_double_p),
+                ("t", c_double_p)]
+
+
+class GNOptions(C.Structure):
+    _fields_ = [("regularization", C.c_double),
+                ("light_surf_regularization", C.c_double)]
+
+
+class OracleProblem:
+    """Owns the numpy buffers behind orc_views / orc_surface.
+
+    `surf` is a dict with keys width,height,scale,npx,npy,start_x,start_y,
+    nodes [(N,4) f64], node_valid [N u8], patch_valid [P u8], patch_vis [P u32];
+    `views` a dict with flen, inv_flen, grad [(H,W,2) f32], optional shading
+    [(H,W)], shading_grad [(H,W,2)], subs = list of (grad (h,w,2), hess (h,w,3)),
+    M [(S,9)], t [(S,3)].
+    """
+
+    def __init__(self, surf, views):
+        self.nodes = f64(surf["nodes"]).reshape(-1, 4).copy()
+        self.node_valid = np.ascontiguousarray(surf["node_valid"], dtype=np.uint8).copy()
+        self.patch_valid = np.ascontiguousarray(surf["patch_valid"], dtype=np.uint8).copy()
+        self.patch_vis = np.ascontiguousarray(surf["patch_vis"], dtype=np.uint32).copy()
+        s = Surface()
+        s.width, s.height = surf["width"], surf["height"]
+        s.scale = surf["scale"]; s.patchsize = 1 << surf["scale"]
+        s.npx, s.npy = surf["npx"], surf["npy"]
+        s.start_x, s.start_y = surf["start_x"], surf["start_y"]
+        s.nodes = _p(self.nodes, c_double_p)
+        s.node_valid = _p(self.node_valid, c_u8_p)
+        s.patch_valid = _p(self.patch_valid, c_u8_p)
+        s.patch_vis = _p(self.patch_vis, c_u32_p)
+        self.surf = s
+        self.num_nodes = (s.npx + 1) * (s.npy + 1)
+        self.node_stride = s.npx + 1
+
+        self.grad = f32(views["grad"])
+        self.shading = f32(views["shading"]) if views.get("shading") is not None else None
+        self.shading_grad = f32(views["shading_grad"]) if views.get("shading_grad") is not None else None
+        self.sub_bufs = [(f32(g), f32(h)) for g, h in views["subs"]]
+        self.M = f64(views["M"]).reshape(-1, 9)
+        self.t = f64(views["t"]).reshape(-1, 3)
+        n = len(self.sub_bufs)
+        self.subs = (SubView * n)()
+        for i, (g, h) in enumerate(self.sub_bufs):
+            self.subs[i].height, self.subs[i].width = g.shape[0], g.shape[1]
+            self.subs[i].grad = _p(g, c_float_p)
+            self.subs[i].hess = _p(h, c_float_p)
+        v = Views()
+        v.height, v.width = self.grad.shape[0], self.grad.shape[1]
+        v.flen = views["flen"]; v.inv_flen = views["inv_flen"]
+        v.grad = _p(self.grad, c_float_p)
+        v.shading = _p(self.shading, c_float_p)
+        v.shading_grad = _p(self.shading_grad, c_float_p)
+        v.n_subs = n
+        v.subs = self.subs
+        v.M = _p(self.M, c_double_p); v.t = _p(self.t, c_double_p)
+        self.views = v
+
+    def gn_patch(self, patch_id, regularization, light_reg=0.0, lighting=None):
+        ps = self.surf.patchsize
+        nd = np.concatenate([node_derivatives_for_pixel(i, ps)
+                             for i in range(ps * ps)])
+        opts = GNOptions(regularization, light_reg)
+        g = np.zeros(16); H = np.zeros(256)
+        lt = f64(lighting) if lighting is not None else None
+        lib().orc_gn_patch(C.byref(self.views), C.byref(self.surf),
+            C.byref(opts), _p(lt, c_double_p), C.c_int(patch_id),
+            _p(nd, c_double_p), _p(g, c_double_p), _p(H, c_double_p))
+        return g, H.reshape(16, 16)
+
+    def gn_construct(self, active, regularization, light_reg=0.0, lighting=None):
+        N = self.num_nodes
+        active = np.ascontiguousarray(active, dtype=np.uint8)
+        opts = GNOptions(regularization, light_reg)
+        H9 = np.zeros((N, 9, 16)); present = np.zeros((N, 9), dtype=np.uint8)
+        g = np.zeros(4 * N); P = np.zeros((N, 16))
+        lt = f64(lighting) if lighting is not None else None
+        cnt = lib().orc_gn_construct(C.byref(self.views), C.byref(self.surf),
+            C.byref(opts), _p(lt, c_double_p), _p(active, c_u8_p),
+            _p(H9, c_double_p), _p(present, c_u8_p), _p(g, c_double_p),
+            _p(P, c_double_p))
+        return dict(H9=H9, present=present, g=g, P=P, active_patches=cnt)
+
+    def spmv(self, H9, present, x):
+        x = f64(x); y = np.zeros_like(x)
+        lib().orc_block_spmv(self.num_nodes, self.node_stride,
+            _p(f64(H9), c_double_p), _p(present, c_u8_p), _p(x, c_double_p),
+            _p(y, c_double_p))
+        return y
+
+    def cg_solve(self, H9, present, P, b, max_iterations=200,
+                 error_tolerance=1e-20, q_tolerance=1e-3):
+        b = f64(b); x = np.zeros_like(b); it = C.c_int(0)
+        info = lib().orc_cg_solve(self.num_nodes, self.node_stride,
+            _p(f64(H9), c_double_p), _p(present, c_u8_p), _p(f64(P), c_double_p),
+            _p(b, c_double_p), _p(x, c_double_p), C.c_int(max_iterations),
+            C.c_double(error_tolerance), C.c_double(q_tolerance), C.byref(it))
+        return x, it.value, info
+
+    def update_and_reactivate(self, delta, active, full_optimization=False):
+        delta = f64(delta)
+        active = np.ascontiguousarray(active, dtype=np.uint8).copy()
+        mean = C.c_double(0.0)
+        n = lib().orc_update_and_reactivate(C.byref(self.views),
+            C.byref(self.surf), _p(delta, c_double_p), _p(active, c_u8_p),
+            C.c_int(1 if full_optimization else 0), C.byref(mean))
+        return active, n, mean.value
+
+    def depth_map(self):
+        out = np.zeros((self.surf.height, self.surf.width), dtype=np.float32)
+        lib().orc_depth_map(C.byref(self.surf), _p(out, c_float_p))
+        return out
+
+    def normal_map(self, inv_flen=None):
+        out = np.zeros((self.surf.height, self.surf.width, 3), dtype=np.float32)
+        lib().orc_normal_map(C.byref(self.surf),
+            C.c_float(self.views.inv_flen if inv_flen is None else inv_flen),
+            _p(out, c_float_p))
+        return out
+
+
+def light_accumulate(normals, image):
+    normals = f32(normals); image = f32(image)
+    A = np.zeros((16, 16)); b = np.zeros(16)
+    lib().orc_light_accumulate(_p(normals, c_float_p), _p(image, c_float_p),
+        C.c_int(image.size), _p(A, c_double_p), _p(b, c_double_p))
+    return A, b
+
+
+def light_solve(A, b):
+    A = f64(A); b = f64(b); out = np.zeros(16)
+    lib().orc_light_solve(_p(A, c_double_p), _p(b, c_double_p), _p(out, c_double_p))
+    return out
+
+
+# ------------------------------------------------------------------------ SGM
+def census_filter(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    h, w, c = img.shape
+    out = np.zeros((h, w, c), dtype=np.uint64)
+    lib().orc_census_filter(_p(img, c_u8_p), w, h, c, _p(out, c_u64_p))
+    return out
+
+
+def sgm_depths(min_depth, max_depth, num_steps):
+    out = np.zeros(num_steps, dtype=np.float32)
+    lib().orc_sgm_depths(C.c_float(min_depth), C.c_float(max_depth),
+                         C.c_int(num_steps), _p(out, c_float_p))
+    return out
+
+
+def sgm_cost_volume(main_img, neighbor, M, t, depths):
+    main_img = np.ascontiguousarray(main_img, dtype=np.uint8)
+    neighbor = np.ascontiguousarray(neighbor, dtype=np.uint8)
+    M = f32(M).reshape(9); t = f32(t).reshape(3); depths = f32(depths)
+    h, w = main_img.shape; nh, nw = neighbor.shape
+    cost = np.zeros((h, w, depths.size), dtype=np.uint16)
+    lib().orc_sgm_cost_volume(_p(main_img, c_u8_p), w, h, _p(neighbor, c_u8_p),
+        nw, nh, _p(M, c_float_p), _p(t, c_float_p), _p(depths, c_float_p),
+        C.c_int(depths.size), _p(cost, c_u16_p))
+    return cost
+
+
+def sgm_aggregate(cost, p1=6, p2=96, literal=False):
+    cost = np.ascontiguousarray(cost, dtype=np.uint16)
+    h, w, d = cost.shape
+    sgm = np.zeros_like(cost)
+    lib().orc_sgm_set_literal(C.c_int(1 if literal else 0))
+    lib().orc_sgm_aggregate(_p(cost, c_u16_p), w, h, d, C.c_uint16(p1),
+                            C.c_uint16(p2), _p(sgm, c_u16_p))
+    lib().orc_sgm_set_literal(C.c_int(0))
+    return sgm
+
+
+def sgm_depth_from_volume(sgm, main_img, depths):
+    sgm = np.ascontiguousarray(sgm, dtype=np.uint16)
+    main_img = np.ascontiguousarray(main_img, dtype=np.uint8)
+    depths = f32(depths)
+    h, w, d = sgm.shape
+    depth = np.zeros((h, w), dtype=np.float32)
+    argmin = np.zeros((h, w), dtype=np.int32)
+    lib().orc_sgm_depth_from_volume(_p(sgm, c_u16_p), _p(main_img, c_u8_p), w, h,
+        _p(depths, c_float_p), d, _p(depth, c_float_p), _p(argmin, c_i32_p))
+    return depth, argmin
+
+
+def sgm_lr_check(d_main, d_neig, M, t):
+    d_main = f32(d_main).copy(); d_neig = f32(d_neig)
+    M = f32(M).reshape(9); t = f32(t).reshape(3)
+    h, w = d_main.shape; nh, nw = d_neig.shape
+    lib().orc_sgm_lr_check(_p(d_main, c_float_p), w, h, _p(d_neig, c_float_p),
+                           nw, nh, _p(M, c_float_p), _p(t, c_float_p))
+    return d_main
+
+
+def bilateral_upsample(dm, ci, sigma=5.0, kernel_size=5):
+    dm = f32(dm); ci = f32(ci)
+    if ci.ndim == 2:
+        ci = ci[:, :, None]
+    h, w, c = ci.shape; dh, dw = dm.shape
+    out = np.zeros((h, w), dtype=np.float32)
+    lib().orc_bilateral_upsample(_p(dm, c_float_p), dw, dh, _p(ci, c_float_p),
+        w, h, c, C.c_float(sigma), C.c_int(kernel_size), _p(out, c_float_p))
+    return out

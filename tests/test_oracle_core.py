@@ -1,0 +1,243 @@
+"""Pins the CPU oracle (oracle/) against what the reference itself holds:
+
+* the known-answer values of tests/gtest_bicubic_patch.cc and
+  tests/gtest_matrix_vector.cc (tests/golden/reference_known_answers.json);
+* the reference's own ldl_inverse compiled from /root/reference
+  (oracle/_ref/libref_ldl.so), bit for bit;
+* the finite-difference identities the reference's gtest files assert for
+  Correspondence, surface_derivative, spherical_harmonics and the bicubic
+  basis table (tests/gtest_correspondence.cc, gtest_surface_deriv.cc,
+  gtest_spherical_harmonics.cc, gtest_bicubic_patch.cc:164-615).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden",
+                      "reference_known_answers.json")
+KIND = {"f": 0, "dx": 1, "dy": 2, "dxy": 3, "dxx": 4, "dyy": 5}
+
+
+@pytest.fixture(scope="module")
+def known():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def test_bicubic_known_answers(oracle, known):
+    for case in known["bicubic"]:
+        coeffs = oracle.bicubic_coeffs(np.array(case["nodes"], dtype=float))
+        for kind, x, y, want in case["checks"]:
+            got = oracle.bicubic_eval(coeffs, KIND[kind], x, y)
+            # reference asserts EXPECT_NEAR(..., 1e-20), i.e. exact
+            assert got == want, (case["source"], kind, x, y, got, want)
+
+
+def test_bicubic_interpolates_nodes(oracle):
+    rng = np.random.default_rng(0)
+    nodes = rng.normal(size=(4, 4))
+    c = oracle.bicubic_coeffs(nodes)
+    corners = [(0, 0), (1, 0), (0, 1), (1, 1)]
+    for n, (x, y) in enumerate(corners):
+        for k in range(4):
+            assert abs(oracle.bicubic_eval(c, k, x, y) - nodes[n, k]) < 1e-12
+
+
+def test_ldl_known_answer(oracle, known):
+    case = known["ldl_inverse"]
+    inv = oracle.ldl_inverse(np.array(case["A"], dtype=float))
+    assert np.max(np.abs(inv - np.array(case["inverse"], dtype=float))) <= case["eps"]
+
+
+def test_ldl_matches_reference_build_bitwise(oracle):
+    if oracle.ref_ldl() is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(1)
+    for n in (2, 3, 4, 7, 16):
+        for _ in range(20):
+            B = rng.normal(size=(n, n))
+            A = B @ B.T + 0.1 * np.eye(n)
+            mine = oracle.ldl_inverse(A)
+            ref = oracle.ref_ldl_inverse(A)
+            assert np.array_equal(mine, ref)
+    # zero pivot: both leave the input untouched (ldl_decomposition.h:60-61)
+    Z = np.zeros((4, 4))
+    assert np.array_equal(oracle.ldl_inverse(Z), oracle.ref_ldl_inverse(Z))
+    S = np.array([[1.0, 1, 0, 0], [1, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert np.array_equal(oracle.ldl_inverse(S), oracle.ref_ldl_inverse(S))
+
+
+def test_vec_dot_known_answer(oracle, known):
+    case = known["vec_dot"]
+    assert oracle.vec_dot(case["a"], case["b"]) == case["dot"]
+
+
+def _embed(blocks, n_nodes=2):
+    """Embed the reference's 2x2-block test matrices into the 4x4 block /
+    9-slot stencil storage of a 1 x n_nodes node row (stride = n_nodes)."""
+    H9 = np.zeros((n_nodes, 9, 16)); present = np.zeros((n_nodes, 9), np.uint8)
+    for row, col, vals in blocks:
+        r, c = row // 2, col // 2
+        slot = 4 + (c - r)
+        blk = np.zeros((4, 4)); blk[:2, :2] += np.array(vals, float).reshape(2, 2)
+        H9[r, slot] += blk.reshape(16); present[r, slot] = 1
+    return H9, present
+
+
+def test_block_multiply_known_answers(oracle, known):
+    import ctypes as C
+    for case in known["block_multiply"]:
+        H9, present = _embed(case["blocks"])
+        x = np.zeros(8); x[0:2] = case["x"][0:2]; x[4:6] = case["x"][2:4]
+        y = np.zeros(8)
+        oracle.lib().orc_block_spmv(2, 2, H9.ctypes.data_as(oracle.c_double_p),
+            present.ctypes.data_as(oracle.c_u8_p),
+            x.ctypes.data_as(oracle.c_double_p),
+            y.ctypes.data_as(oracle.c_double_p))
+        assert list(y[0:2]) + list(y[4:6]) == case["y"], case["source"]
+
+
+# ---------------------------------------------------------------- FD tests
+def _patch_vals(oracle, nodes, u, v, p2p):
+    c = oracle.bicubic_coeffs(nodes)
+    f = oracle.bicubic_eval(c, 0, u, v)
+    dx = oracle.bicubic_eval(c, 1, u, v) * p2p
+    dy = oracle.bicubic_eval(c, 2, u, v) * p2p
+    dxy = oracle.bicubic_eval(c, 3, u, v) * p2p * p2p
+    dxx = oracle.bicubic_eval(c, 4, u, v) * p2p * p2p
+    dyy = oracle.bicubic_eval(c, 5, u, v) * p2p * p2p
+    return f, dx, dy, dxy, dxx, dyy
+
+
+def test_basis_table_is_derivative_of_patch_values(oracle, known):
+    """gtest_bicubic_patch.cc:164-615: dn == d(values)/d(node params)."""
+    fx = known["correspondence_fixture"]
+    nodes = np.array(fx["nodes"], dtype=float)
+    u, v, p2p = fx["u"], fx["v"], fx["patch_to_pixel"]
+    dn = oracle.node_derivatives_for_patchsize(u, v, 1.0 / p2p)
+    base = np.array(_patch_vals(oracle, nodes, u, v, p2p))
+    delta = 1e-6
+    for n in range(4):
+        for i in range(4):
+            pert = nodes.copy(); pert[n, i] += delta
+            fd = (np.array(_patch_vals(oracle, pert, u, v, p2p)) - base) / delta
+            for kind in range(6):
+                assert abs(dn[24 * n + 4 * kind + i] - fd[kind]) < 1e-6
+
+
+def test_correspondence_jacobian_and_derivatives_fd(oracle, known):
+    """gtest_correspondence.cc:17-260 and :286-493."""
+    fx = known["correspondence_fixture"]
+    M, t = np.array(fx["M"]), np.array(fx["t"])
+    nodes = np.array(fx["nodes"], dtype=float)
+    u, v, p2p, x, y = fx["u"], fx["v"], fx["patch_to_pixel"], fx["x"], fx["y"]
+    grad = np.array(fx["grad"])
+    dn = oracle.node_derivatives_for_patchsize(u, v, 1.0 / p2p)
+    f, dx, dy = _patch_vals(oracle, nodes, u, v, p2p)[:3]
+    Cb = oracle.Correspondence(M, t, x, y, f, dx, dy)
+    base = Cb.fill() - 0.5
+    jac = Cb.jacobian()
+
+    delta, eps = 1e-8, 1e-5
+    c = oracle.bicubic_coeffs(nodes)
+    fnew = oracle.bicubic_eval(c, 0, u + delta * p2p, v)
+    d = (oracle.Correspondence(M, t, x + delta, y, fnew, dx, dy).fill() - 0.5 - base) / delta
+    assert abs(jac[0] - d[0]) < eps and abs(jac[1] - d[1]) < eps
+    fnew = oracle.bicubic_eval(c, 0, u, v + delta * p2p)
+    d = (oracle.Correspondence(M, t, x, y + delta, fnew, dx, dy).fill() - 0.5 - base) / delta
+    assert abs(jac[2] - d[0]) < eps and abs(jac[3] - d[1]) < eps
+
+    c_dn = Cb.derivative(dn)
+    jdg = Cb.jacobian_derivative_grad(grad, dn)
+    J = jac.reshape(2, 2)
+    for n in range(4):
+        for i in range(4):
+            pert = nodes.copy(); pert[n, i] += delta
+            f2, dx2, dy2 = _patch_vals(oracle, pert, u, v, p2p)[:3]
+            C2 = oracle.Correspondence(M, t, x, y, f2, dx2, dy2)
+            fd_proj = (C2.fill() - 0.5 - base) / delta
+            assert np.max(np.abs(c_dn[4 * n + i] - fd_proj)) < 1e-4
+            fd_jac = ((C2.jacobian().reshape(2, 2) - J) / delta) @ grad
+            assert np.max(np.abs(jdg[4 * n + i] - fd_jac)) < eps
+
+
+def test_surface_derivatives_fd(oracle, known):
+    """gtest_surface_deriv.cc:208-666."""
+    fx = known["correspondence_fixture"]
+    nodes = np.array(fx["nodes"], dtype=float)
+    u, v, p2p = fx["u"], fx["v"], fx["patch_to_pixel"]
+    dn = oracle.node_derivatives_for_patchsize(u, v, 1.0 / p2p)
+    x, y, flen = 12.5, -31.5, 1400.0
+    vals = _patch_vals(oracle, nodes, u, v, p2p)
+    div0 = oracle.normal_divergence(x, y, flen, *vals)
+    n0 = oracle.fill_normal(x, y, 1.0 / flen, *vals[:3])
+    ddiv = oracle.normal_divergence_deriv(dn, x, y, flen, *vals).reshape(6, 16)
+    dnorm = oracle.normal_derivative(dn, x, y, flen, *vals[:3]).reshape(3, 16)
+    delta = 1e-7
+    for n in range(4):
+        for i in range(4):
+            pert = nodes.copy(); pert[n, i] += delta
+            v2 = _patch_vals(oracle, pert, u, v, p2p)
+            fd_div = (oracle.normal_divergence(x, y, flen, *v2) - div0) / delta
+            fd_n = (oracle.fill_normal(x, y, 1.0 / flen, *v2[:3]) - n0) / delta
+            assert np.max(np.abs(ddiv[:, 4 * n + i] - fd_div)) < 1e-5
+            assert np.max(np.abs(dnorm[:, 4 * n + i] - fd_n)) < 1e-5
+
+
+def test_normal_divergence_is_pixel_gradient_of_normal(oracle):
+    """gtest_surface_deriv.cc:377-468: div = d(normal)/d(pixel x, y)."""
+    rng = np.random.default_rng(3)
+    nodes = np.array([[5.0, 0.3, -0.2, 0.05], [5.4, 0.2, -0.1, -0.02],
+                      [4.9, 0.35, 0.1, 0.03], [5.2, 0.1, 0.2, 0.01]])
+    ps, flen = 8.0, 900.0
+    c = oracle.bicubic_coeffs(nodes)
+
+    def normal_at(px, py):
+        uu, vv = px / ps, py / ps
+        f = oracle.bicubic_eval(c, 0, uu, vv)
+        dx = oracle.bicubic_eval(c, 1, uu, vv) / ps
+        dy = oracle.bicubic_eval(c, 2, uu, vv) / ps
+        return oracle.fill_normal(px - 3.0, py + 7.0, 1.0 / flen, f, dx, dy)
+
+    px, py = 3.3, 4.1
+    uu, vv = px / ps, py / ps
+    vals = [oracle.bicubic_eval(c, 0, uu, vv),
+            oracle.bicubic_eval(c, 1, uu, vv) / ps,
+            oracle.bicubic_eval(c, 2, uu, vv) / ps,
+            oracle.bicubic_eval(c, 3, uu, vv) / ps / ps,
+            oracle.bicubic_eval(c, 4, uu, vv) / ps / ps,
+            oracle.bicubic_eval(c, 5, uu, vv) / ps / ps]
+    div = oracle.normal_divergence(px - 3.0, py + 7.0, flen, *vals)
+    d = 1e-6
+    fdx = (normal_at(px + d, py) - normal_at(px - d, py)) / (2 * d)
+    fdy = (normal_at(px, py + d) - normal_at(px, py - d)) / (2 * d)
+    assert np.max(np.abs(div[:3] - fdx)) < 1e-7
+    assert np.max(np.abs(div[3:] - fdy)) < 1e-7
+
+
+def test_spherical_harmonics_derivative_fd(oracle):
+    """gtest_spherical_harmonics.cc:17-59."""
+    rng = np.random.default_rng(5)
+    for _ in range(10):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        d = oracle.sh_derivative_4_band(n).reshape(16, 3)
+        delta = 1e-7
+        for k in range(3):
+            n2 = n.copy(); n2[k] += delta
+            fd = (oracle.sh_evaluate_4_band(n2) - oracle.sh_evaluate_4_band(n)) / delta
+            assert np.max(np.abs(d[:, k] - fd)) < 1e-5
+
+
+def test_patch_subsampling_walk(oracle):
+    """surface_patch.cc:111-119: every `subsample`-th row and column."""
+    nodes = np.zeros((4, 4)); nodes[:, 0] = 1.0
+    for size, sub in ((4, 1), (8, 2), (16, 2), (32, 4), (64, 4)):
+        pixels, depths, first, second, pids = oracle.patch_values_at_pixels(
+            nodes, 10, 20, size, sub)
+        want = [j * size + i for j in range(0, size, sub) for i in range(0, size, sub)]
+        assert list(pids) == want
+        assert np.all(pixels[:, 0] == 10 + (pids % size))
+        assert np.all(pixels[:, 1] == 20 + (pids // size))
+        assert np.allclose(depths, 1.0)
