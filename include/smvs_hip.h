@@ -1,0 +1,237 @@
+/*
+ * smvs_hip.h -- C ABI of the MI355X (gfx950) depth-optimisation hot path.
+ *
+ * This is the drop-in boundary: a host DepthOptimizer (ours in
+ * smvs_amd/csrc/host/, or the reference's lib/depth_optimizer.cc with the
+ * binding shown in INTEGRATION.md) calls these entry points instead of
+ * GaussNewtonStep / ConjugateGradient / Surface::update_nodes /
+ * LightOptimizer / SGMStereo.  file:line citations are relative to the
+ * flanggut/smvs tree and name the reference interface each entry replaces.
+ *
+ * Conventions
+ *  - every function returns 0 (SMVS_OK) or a negative smvs_status; nothing
+ *    throws; smvs_last_error() gives the text of the last failure of the
+ *    calling thread.  The reference throws std::invalid_argument on
+ *    dimension mismatch (block_sparse_matrix.h:136-138, sse_vector.cc:22-23,
+ *    conjugate_gradient.h:77-78): the host wrapper re-throws from the status.
+ *  - pointers are caller-owned HOST memory unless the name ends in _dev.
+ *  - images use MVE's layout: interleaved channels, row-major,
+ *    index (y*W + x)*C + c.
+ *  - one context is used by one host thread at a time; different contexts
+ *    may be used concurrently (one reference view per context, as the
+ *    reference's one-task-per-view pool, app/smvsrecon.cc:658-733).
+ *  - a context owns its device buffers and one HIP stream.
+ */
+#ifndef SMVS_HIP_H
+#define SMVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smvs_ctx smvs_ctx;
+
+typedef enum {
+    SMVS_OK = 0,
+    SMVS_ERR_INVALID = -1,   /* bad argument / dimension mismatch */
+    SMVS_ERR_HIP = -2,       /* HIP runtime error (see smvs_last_error) */
+    SMVS_ERR_STATE = -3,     /* call order violated (e.g. solve before construct) */
+    SMVS_ERR_NOMEM = -4
+} smvs_status;
+
+/* ConjugateGradient::ReturnInfo, conjugate_gradient.h:22-27 */
+typedef enum {
+    SMVS_CG_CONVERGENCE = 0,
+    SMVS_CG_MAX_ITERATIONS = 1,
+    SMVS_CG_INVALID_INPUT = 2
+} smvs_cg_info;
+
+#define SMVS_MAX_SUBS 16
+
+const char *smvs_last_error(void);
+/* Number of HIP devices visible (0 when none / no driver). */
+int smvs_device_count(void);
+
+/* ------------------------------------------------------------------ */
+/* context                                                            */
+/* ------------------------------------------------------------------ */
+
+/* One reference view (StereoView main + n_subs neighbours,
+ * depth_optimizer.h:48-51).  width/height = main view size. */
+int smvs_ctx_create(int device, int width, int height, int n_subs,
+    smvs_ctx **out);
+int smvs_ctx_destroy(smvs_ctx *ctx);
+int smvs_ctx_synchronize(smvs_ctx *ctx);
+
+/* DepthOptimizer::prepare_correspondences, depth_optimizer.cc:679-699:
+ * Mi[n_subs][9] row-major and ti[n_subs][3], already widened from the float
+ * CameraInfo::fill_reprojection result; flen / inv_flen =
+ * StereoView::get_flen / get_inverse_flen (stereo_view.h:132-148). */
+int smvs_ctx_set_cameras(smvs_ctx *ctx, const double *Mi, const double *ti,
+    float flen, float inv_flen);
+
+/* Per-scale planes of the main view, StereoView::get_image_gradients /
+ * get_shading_image / get_shading_gradients (stereo_view.h:43-47).
+ * shading / shading_grad may be NULL (no -S). */
+int smvs_ctx_upload_main(smvs_ctx *ctx, const float *grad2,
+    const float *shading1, const float *shading_grad2);
+/* Per-scale planes of neighbour `sub`: get_image_gradients (2 ch) and
+ * get_image_hessian (3 ch: I_xx, I_xy, I_yy), stereo_view.cc:167-187. */
+int smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
+    const float *grad2, const float *hess3);
+
+/* Surface state (surface.h:106-120) as flat arrays.
+ *   nodes[(npx+1)*(npy+1)][4] = f, dx, dy, dxy (patch units);
+ *   node_valid / patch_valid: non-null node / patch;
+ *   patch_vis[p] bit j <=> j in subsurfaces[p] (depth_optimizer.h:108).
+ * Resets the active set to "all valid nodes" (depth_optimizer.cc:204-212). */
+int smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy,
+    int start_x, int start_y, const double *nodes, const uint8_t *node_valid,
+    const uint8_t *patch_valid, const uint32_t *patch_vis);
+/* active_nodes (std::vector<char>, depth_optimizer.cc:205); NULL = all valid */
+int smvs_ctx_set_active(smvs_ctx *ctx, const uint8_t *active);
+int smvs_get_active(smvs_ctx *ctx, uint8_t *active, int *num_active);
+int smvs_get_nodes(smvs_ctx *ctx, double *nodes);
+int smvs_set_nodes(smvs_ctx *ctx, const double *nodes);
+
+/* ------------------------------------------------------------------ */
+/* Gauss-Newton step                                                  */
+/* ------------------------------------------------------------------ */
+
+/* GaussNewtonStep::construct, gauss_newton_step.cc:33-143, with
+ * GaussNewtonStep::Options {regularization, light_surf_regularization}
+ * (gauss_newton_step.h:28-34); lighting16 = GlobalLighting::Params or NULL.
+ * H, g, P stay on the device.  num_active_patches (may be NULL) = patches
+ * with at least one active node (gauss_newton_step.cc:73-79). */
+int smvs_gn_construct(smvs_ctx *ctx, double regularization,
+    double light_surf_regularization, const double *lighting16,
+    int *num_active_patches);
+
+/* Test / parity hooks: download the assembled system.  H9[n][s][16]: 4x4
+ * row-major block (row node n, col node n + dy*(npx+1) + dx), slot
+ * s = (dy+1)*3 + dx+1; zero where the reference holds no block.
+ * g[4n+k]; P[n][16] inverted diagonal blocks.  Any pointer may be NULL. */
+int smvs_gn_download(smvs_ctx *ctx, double *H9, double *g, double *P);
+/* per-patch 16x16 systems and 16-gradients before assembly
+ * (sub_hessian / sub_gradient, gauss_newton_step.cc:61-62); entries of
+ * patches that were not evaluated are unspecified. */
+int smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp);
+/* Overwrite the assembled system (solver tests on arbitrary systems). */
+int smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
+    const double *P);
+
+/* ConjugateGradient::solve, conjugate_gradient.h:72-202, on b = -g with the
+ * block-Jacobi preconditioner, x0 = 0.  error_tolerance < 0 selects the
+ * optimizer's rule error_tolerance = 0.01 * ||g|| (depth_optimizer.cc:247).
+ * num_iterations / info as ConjugateGradient::Status. */
+int smvs_cg_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
+    double q_tolerance, int *num_iterations, int *info);
+int smvs_cg_download_x(smvs_ctx *ctx, double *x);
+int smvs_cg_upload_x(smvs_ctx *ctx, const double *x);
+
+/* depth_optimizer.cc:267-303: NaN guard on delta[0], fill_node_reprojections,
+ * Surface::update_nodes (surface.cc:957-981), fill_node_reprojections, then
+ * either the mean reprojection delta (full_optimization) or the new active
+ * set (node active if any pixel of an incident patch moved by more than
+ * `threshold` = 0.15).  When nan_flag is set nothing was updated. */
+int smvs_update_and_reactivate(smvs_ctx *ctx, double threshold,
+    int full_optimization, int *num_active, double *mean_delta,
+    int *nan_flag);
+
+/* The whole Newton loop of one outer iteration, depth_optimizer.cc:204-304,
+ * without host round trips inside a step. */
+typedef struct {
+    double regularization;             /* DepthOptimizer::Options */
+    double light_surf_regularization;
+    int full_optimization;
+    int max_newton_steps;              /* 200, depth_optimizer.cc:219 */
+    int cg_max_iterations;             /* 200, :246 */
+    double cg_q_tolerance;             /* 1e-3, conjugate_gradient.h:34 */
+    double active_threshold;           /* 0.15, :296 */
+    double full_opt_threshold;         /* 0.01, :285 */
+    int use_lighting;                  /* lighting != nullptr */
+    double lighting[16];
+    int reset_active;                  /* 1: start from all valid nodes */
+} smvs_gn_loop_params;
+
+typedef struct {
+    int newton_steps;
+    int linear_iterations;             /* sum of CG iterations, :257 */
+    long long active_patch_steps;      /* sum over steps of active patches */
+    int final_active_nodes;
+    int nan_break;                     /* loop left through :267-268 */
+} smvs_gn_loop_stats;
+
+int smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *params,
+    smvs_gn_loop_stats *stats);
+
+/* ------------------------------------------------------------------ */
+/* surface outputs + lighting                                         */
+/* ------------------------------------------------------------------ */
+
+/* Surface::get_depth_map / get_normal_map, surface.cc:155-183 (float
+ * images, zero where no patch). depth[W*H], normals[W*H*3]. */
+int smvs_get_depth_map(smvs_ctx *ctx, float *depth);
+int smvs_get_normal_map(smvs_ctx *ctx, float *normals);
+
+/* LightOptimizer::fit_lighting_to_image accumulation,
+ * light_optimizer.cc:32-49, over the uploaded shading image: A[16][16],
+ * b[16] (the 16x16 pseudo inverse stays on the host).  The _dev variant
+ * leaves 272 doubles (A then b) in a device buffer for an optional RCCL
+ * all-reduce ("shared lighting" extension) and returns its
+ * device pointer. */
+int smvs_light_accumulate(smvs_ctx *ctx, double *A256, double *b16);
+int smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev);
+
+/* ------------------------------------------------------------------ */
+/* SGM                                                                */
+/* ------------------------------------------------------------------ */
+
+/* SGMStereo::run_sgm, sgm_stereo.cc:98-124, for one (main, neighbour)
+ * pair of u8 images already at SGM scale (sgm_stereo.cc:31-39):
+ * census cost volume over num_steps inverse-depth planes, 8-path
+ * aggregation (constant P2, the SSE branch :361-406), WTA.
+ * M[9], t[3]: float reprojection main -> neighbour at SGM resolution
+ * (sgm_stereo.cc:154-160).  Outputs (any may be NULL):
+ *   depth[w*h]  (sgm_stereo.cc:274-306),
+ *   argmin[w*h] winning plane index,
+ *   cost[w*h*num_steps], sgm[w*h*num_steps] u16 volumes (parity tests). */
+int smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
+    const uint8_t *neighbor_img, int nw, int nh, const float *M,
+    const float *t, float min_depth, float max_depth, int num_steps,
+    uint16_t penalty1, uint16_t penalty2, float *depth, int32_t *argmin,
+    uint16_t *cost, uint16_t *sgm);
+
+/* DepthOptimizer::depthmap_bilateral_filter, depth_optimizer.cc:957-1004 */
+int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
+    const float *ci, int w, int h, int channels, float sigma,
+    int kernel_size, float *out);
+
+/* ------------------------------------------------------------------ */
+/* measurement                                                        */
+/* ------------------------------------------------------------------ */
+
+/* Kernel classes timed with HIP events on the context's stream. */
+enum {
+    SMVS_K_PATCH = 0,     /* per-patch J^T W J + g  (K1-K4) */
+    SMVS_K_ASSEMBLE,      /* block gather + 4x4 LDL (K5)    */
+    SMVS_K_CG_SPMV,       /* block-stencil SpMV + d.Ad (K6) */
+    SMVS_K_CG_UPDATE,     /* x, r, z update + reductions (K7/K8) */
+    SMVS_K_CG_DIR,        /* d = z + beta d */
+    SMVS_K_CG_INIT,
+    SMVS_K_REACTIVATE,    /* K9 */
+    SMVS_K_MISC,
+    SMVS_K_COUNT
+};
+int smvs_profile_enable(smvs_ctx *ctx, int on);
+int smvs_profile_reset(smvs_ctx *ctx);
+/* ms[SMVS_K_COUNT] accumulated kernel time, launches[SMVS_K_COUNT] */
+int smvs_profile_get(smvs_ctx *ctx, double *ms, long long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMVS_HIP_H */

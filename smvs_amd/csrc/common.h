@@ -1,0 +1,195 @@
+// Internal declarations shared by the HIP translation units of libsmvs_hip.so.
+// gfx950 only: no portability shims.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/smvs_hip.h"
+
+namespace smvs_hip {
+
+void set_error(const char *fmt, ...);
+
+#define SMVS_HIP_CHECK(expr)                                                  \
+    do {                                                                      \
+        hipError_t err__ = (expr);                                            \
+        if (err__ != hipSuccess) {                                            \
+            smvs_hip::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, \
+                hipGetErrorString(err__));                                    \
+            return SMVS_ERR_HIP;                                              \
+        }                                                                     \
+    } while (0)
+
+#define SMVS_REQUIRE(cond, msg)                                               \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            smvs_hip::set_error("%s: %s", __func__, msg);                     \
+            return SMVS_ERR_INVALID;                                          \
+        }                                                                     \
+    } while (0)
+
+// Number of double scalars kept on the device for the CG / GN loop.
+enum {
+    S_RR = 0,        // r_dot_r (z.r with preconditioner)
+    S_DAD,           // d . A d
+    S_RR_NEW,        // r . r after the update
+    S_Q0,
+    S_Q1,
+    S_ZR,            // z . r after the update
+    S_BETA,
+    S_ALPHA,
+    S_TOL,           // error tolerance
+    S_GNORM,         // ||g||
+    S_SUMDIFF,       // full_optimization: sum of reprojection deltas
+    S_COUNT_DIFF,    // number of terms in S_SUMDIFF
+    S_NUM = 16
+};
+
+// Integer status words on the device.
+enum {
+    I_DONE = 0,      // CG finished
+    I_INFO,          // smvs_cg_info
+    I_ITER,          // CG iteration counter (starts at 1)
+    I_NAN,           // delta[0] is NaN
+    I_NUM_ACTIVE,    // active nodes after re-activation
+    I_ACTIVE_PATCHES,
+    I_TICKET0,       // ticket counters for last-block reductions
+    I_TICKET1,
+    I_TICKET2,
+    I_TICKET3,
+    I_MAXITER,
+    I_NUM = 16
+};
+
+struct SubPlanes {
+    int width = 0, height = 0;
+    float2 *grad = nullptr;   // [h][w]  (I_x, I_y)
+    float4 *hess = nullptr;   // [h][w]  (I_xx, I_xy, I_yy, 0)
+};
+
+struct DeviceCameras {
+    double M[SMVS_MAX_SUBS][9];
+    double t[SMVS_MAX_SUBS][3];
+};
+
+struct Profile {
+    bool enabled = false;
+    double ms[SMVS_K_COUNT] = {0};
+    long long launches[SMVS_K_COUNT] = {0};
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+} // namespace smvs_hip
+
+struct smvs_ctx {
+    int device = 0;
+    int width = 0, height = 0, n_subs = 0;
+    hipStream_t stream = nullptr;
+    float flen = 0.f, inv_flen = 0.f;
+    bool has_cameras = false, has_surface = false, has_system = false;
+    bool has_shading = false;
+
+    // image planes
+    float2 *main_grad = nullptr;
+    float *main_shading = nullptr;
+    float2 *main_shading_grad = nullptr;
+    smvs_hip::SubPlanes subs[SMVS_MAX_SUBS];
+    smvs_hip::DeviceCameras *cams = nullptr;  // device copy
+    smvs_hip::SubPlanes *subs_dev = nullptr;  // device copy of subs[]
+
+    // surface
+    int scale = 0, patchsize = 0, npx = 0, npy = 0, start_x = 0, start_y = 0;
+    int num_nodes = 0, num_patches = 0, node_stride = 0;
+    size_t cap_nodes = 0, cap_patches = 0;
+    double *nodes = nullptr;        // [N][4]
+    uint8_t *node_valid = nullptr;
+    uint8_t *patch_valid = nullptr;
+    uint32_t *patch_vis = nullptr;
+    uint8_t *active = nullptr, *active_next = nullptr;
+    double *hermite_tab = nullptr;  // [ps][12] 1-D Hermite basis table
+    int hermite_tab_ps = 0;
+
+    // Gauss-Newton system
+    double *Hp = nullptr;           // [P][256] per-patch systems
+    double *gp = nullptr;           // [P][16]
+    double *H9 = nullptr;           // [9][N][16] slot-major block stencil
+    double *Pinv = nullptr;         // [N][16]
+    double *g = nullptr;            // [N][4]
+    double *lighting = nullptr;     // [16]
+
+    // CG vectors, [N][4] each
+    double *x = nullptr, *r = nullptr, *z = nullptr, *Ad = nullptr,
+        *d = nullptr, *b = nullptr;
+    double *partials = nullptr;     // [4][max_blocks] reduction partials
+    int max_blocks = 0;
+    double *scalars = nullptr;      // [S_NUM]
+    int *status = nullptr;          // [I_NUM]
+    int *status_host = nullptr;     // pinned
+    double *scalars_host = nullptr; // pinned
+    double *lightAb = nullptr;      // [272] lighting normal equations
+    float *stage = nullptr;         // upload staging (3-channel planes)
+    size_t stage_cap = 0;
+
+    smvs_hip::Profile prof;
+};
+
+namespace smvs_hip {
+
+// RAII helper that times one kernel class when profiling is enabled.
+struct ScopedKernelTimer {
+    smvs_ctx *ctx;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTimer(smvs_ctx *ctx, int cls);
+    ~ScopedKernelTimer();
+};
+int profile_collect(smvs_ctx *ctx);
+
+template <typename T>
+int device_alloc(T **ptr, size_t count)
+{
+    if (*ptr != nullptr) {
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+    }
+    if (count == 0)
+        return SMVS_OK;
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(ptr), count * sizeof(T));
+    if (err != hipSuccess) {
+        set_error("hipMalloc(%zu bytes): %s", count * sizeof(T),
+            hipGetErrorString(err));
+        return SMVS_ERR_NOMEM;
+    }
+    return SMVS_OK;
+}
+
+// Maps the hardware block index to a logical block so that the blocks that
+// land on one XCD (blockIdx % 8, MI355X_MICROARCH.md "Workgroup dispatch")
+// cover one contiguous band of patches: neighbouring patches sample
+// neighbouring texels, so each XCD's private L2 sees one image region.
+__device__ __forceinline__ unsigned
+xcd_band_block(unsigned bid, unsigned nblocks)
+{
+    unsigned const per = nblocks >> 3;
+    unsigned const body = per << 3;
+    if (bid >= body)
+        return bid;
+    return (bid & 7u) * per + (bid >> 3);
+}
+
+// internal entry points used by the fused loop
+int gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
+    bool use_lighting);
+int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
+    double q_tolerance, int *num_iterations, int *info);
+int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization);
+
+} // namespace smvs_hip

@@ -1,0 +1,528 @@
+// Context management, plane / surface uploads, profiling.
+#include "common.h"
+
+#include <cmath>
+
+namespace smvs_hip {
+
+static thread_local char g_error[512] = "";
+
+void
+set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+ScopedKernelTimer::ScopedKernelTimer(smvs_ctx *c, int k) : ctx(c), cls(k)
+{
+    if (!ctx->prof.enabled)
+        return;
+    auto take = [&]() {
+        hipEvent_t e = nullptr;
+        if (!ctx->prof.pool.empty()) {
+            e = ctx->prof.pool.back();
+            ctx->prof.pool.pop_back();
+        } else {
+            (void)hipEventCreate(&e);
+        }
+        return e;
+    };
+    a = take();
+    b = take();
+    (void)hipEventRecord(a, ctx->stream);
+}
+
+ScopedKernelTimer::~ScopedKernelTimer()
+{
+    if (a == nullptr)
+        return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof.pending.push_back({cls, a, b});
+    if (ctx->prof.pending.size() > 4096)
+        (void)profile_collect(ctx);
+}
+
+int
+profile_collect(smvs_ctx *ctx)
+{
+    if (ctx->prof.pending.empty())
+        return SMVS_OK;
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof.ms[p.cls] += ms;
+            ctx->prof.launches[p.cls] += 1;
+        }
+        ctx->prof.pool.push_back(p.a);
+        ctx->prof.pool.push_back(p.b);
+    }
+    ctx->prof.pending.clear();
+    return SMVS_OK;
+}
+
+__global__ void
+expand_hessian_kernel(const float *__restrict__ src, float4 *__restrict__ dst,
+    size_t count)
+{
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    dst[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
+}
+
+static int
+ensure_stage(smvs_ctx *ctx, size_t floats)
+{
+    if (ctx->stage_cap >= floats)
+        return SMVS_OK;
+    int rc = device_alloc(&ctx->stage, floats);
+    if (rc != SMVS_OK)
+        return rc;
+    ctx->stage_cap = floats;
+    return SMVS_OK;
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" const char *
+smvs_last_error(void)
+{
+    return g_error;
+}
+
+extern "C" int
+smvs_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+extern "C" int
+smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
+{
+    SMVS_REQUIRE(out != nullptr, "out must not be null");
+    SMVS_REQUIRE(width > 4 && height > 4, "image too small");
+    SMVS_REQUIRE(n_subs >= 1 && n_subs <= SMVS_MAX_SUBS,
+        "n_subs must be in [1, SMVS_MAX_SUBS]");
+    int count = 0;
+    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
+    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
+    SMVS_HIP_CHECK(hipSetDevice(device));
+
+    smvs_ctx *ctx = new smvs_ctx();
+    ctx->device = device;
+    ctx->width = width;
+    ctx->height = height;
+    ctx->n_subs = n_subs;
+    hipError_t err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        set_error("hipStreamCreate: %s", hipGetErrorString(err));
+        delete ctx;
+        return SMVS_ERR_HIP;
+    }
+    size_t const npix = (size_t)width * height;
+    int rc = SMVS_OK;
+    if ((rc = device_alloc(&ctx->main_grad, npix)) != SMVS_OK
+        || (rc = device_alloc(&ctx->cams, 1)) != SMVS_OK
+        || (rc = device_alloc(&ctx->subs_dev, SMVS_MAX_SUBS)) != SMVS_OK
+        || (rc = device_alloc(&ctx->scalars, S_NUM)) != SMVS_OK
+        || (rc = device_alloc(&ctx->status, I_NUM)) != SMVS_OK
+        || (rc = device_alloc(&ctx->lighting, 16)) != SMVS_OK
+        || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK) {
+        smvs_ctx_destroy(ctx);
+        return rc;
+    }
+    if (hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM) != hipSuccess
+        || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        smvs_ctx_destroy(ctx);
+        return SMVS_ERR_NOMEM;
+    }
+    (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
+    (void)hipMemsetAsync(ctx->status, 0, sizeof(int) * I_NUM, ctx->stream);
+    *out = ctx;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_destroy(smvs_ctx *ctx)
+{
+    if (ctx == nullptr)
+        return SMVS_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    void *bufs[] = { ctx->main_grad, ctx->main_shading, ctx->main_shading_grad,
+        ctx->cams, ctx->subs_dev, ctx->nodes, ctx->node_valid, ctx->patch_valid,
+        ctx->patch_vis, ctx->active, ctx->active_next, ctx->hermite_tab,
+        ctx->Hp, ctx->gp, ctx->H9, ctx->Pinv, ctx->g, ctx->lighting, ctx->x,
+        ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->b, ctx->partials, ctx->scalars,
+        ctx->status, ctx->lightAb, ctx->stage };
+    for (void *p : bufs)
+        if (p)
+            (void)hipFree(p);
+    for (int i = 0; i < SMVS_MAX_SUBS; ++i) {
+        if (ctx->subs[i].grad)
+            (void)hipFree(ctx->subs[i].grad);
+        if (ctx->subs[i].hess)
+            (void)hipFree(ctx->subs[i].hess);
+    }
+    if (ctx->status_host)
+        (void)hipHostFree(ctx->status_host);
+    if (ctx->scalars_host)
+        (void)hipHostFree(ctx->scalars_host);
+    for (auto &p : ctx->prof.pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : ctx->prof.pool)
+        (void)hipEventDestroy(e);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_synchronize(smvs_ctx *ctx)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_set_cameras(smvs_ctx *ctx, const double *Mi, const double *ti,
+    float flen, float inv_flen)
+{
+    SMVS_REQUIRE(ctx && Mi && ti, "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    DeviceCameras cams;
+    memset(&cams, 0, sizeof(cams));
+    for (int s = 0; s < ctx->n_subs; ++s) {
+        memcpy(cams.M[s], Mi + 9 * s, sizeof(double) * 9);
+        memcpy(cams.t[s], ti + 3 * s, sizeof(double) * 3);
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->cams, &cams, sizeof(cams),
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->flen = flen;
+    ctx->inv_flen = inv_flen;
+    ctx->has_cameras = true;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_upload_main(smvs_ctx *ctx, const float *grad2, const float *shading1,
+    const float *shading_grad2)
+{
+    SMVS_REQUIRE(ctx && grad2, "null argument");
+    SMVS_REQUIRE((shading1 == nullptr) == (shading_grad2 == nullptr),
+        "shading image and shading gradients come together");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const npix = (size_t)ctx->width * ctx->height;
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->main_grad, grad2, npix * sizeof(float2),
+        hipMemcpyHostToDevice, ctx->stream));
+    if (shading1 != nullptr) {
+        int rc;
+        if (ctx->main_shading == nullptr) {
+            if ((rc = device_alloc(&ctx->main_shading, npix)) != SMVS_OK)
+                return rc;
+            if ((rc = device_alloc(&ctx->main_shading_grad, npix)) != SMVS_OK)
+                return rc;
+        }
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->main_shading, shading1,
+            npix * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->main_shading_grad, shading_grad2,
+            npix * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+        ctx->has_shading = true;
+    }
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
+    const float *grad2, const float *hess3)
+{
+    SMVS_REQUIRE(ctx && grad2 && hess3, "null argument");
+    SMVS_REQUIRE(sub >= 0 && sub < ctx->n_subs, "sub view index out of range");
+    SMVS_REQUIRE(width > 1 && height > 1, "bad sub view size");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SubPlanes &sp = ctx->subs[sub];
+    size_t const npix = (size_t)width * height;
+    int rc;
+    if (sp.width != width || sp.height != height || sp.grad == nullptr) {
+        if ((rc = device_alloc(&sp.grad, npix)) != SMVS_OK)
+            return rc;
+        if ((rc = device_alloc(&sp.hess, npix)) != SMVS_OK)
+            return rc;
+        sp.width = width;
+        sp.height = height;
+    }
+    if ((rc = ensure_stage(ctx, npix * 3)) != SMVS_OK)
+        return rc;
+    SMVS_HIP_CHECK(hipMemcpyAsync(sp.grad, grad2, npix * sizeof(float2),
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->stage, hess3, npix * 3 * sizeof(float),
+        hipMemcpyHostToDevice, ctx->stream));
+    unsigned const blocks = (unsigned)((npix + 255) / 256);
+    hipLaunchKernelGGL(expand_hessian_kernel, dim3(blocks), dim3(256), 0,
+        ctx->stream, ctx->stage, sp.hess, npix);
+    SMVS_HIP_CHECK(hipGetLastError());
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->subs_dev, ctx->subs,
+        sizeof(SubPlanes) * SMVS_MAX_SUBS, hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+// 1-D cubic Hermite basis (value at node 0, value at node 1, slope at node 0,
+// slope at node 1) with derivatives 0..2 already divided by patchsize^k:
+// the bicubic patch basis (reference: bicubic_patch.cc:20-38, 258-316 and
+// surface.cc:929-955) is the tensor product of two rows of this table.
+static void
+build_hermite_table(int ps, std::vector<double> *tab)
+{
+    tab->assign((size_t)ps * 12, 0.0);
+    double const s1 = 1.0 / ps;
+    double const s2 = s1 / ps;
+    for (int c = 0; c < ps; ++c) {
+        double const t = ((double)c + 0.5) / ps;
+        double const t2 = t * t, t3 = t2 * t;
+        double *row = tab->data() + (size_t)c * 12;
+        // h00 = 1 - 3t^2 + 2t^3
+        row[0] = 1.0 - 3.0 * t2 + 2.0 * t3;
+        row[1] = (-6.0 * t + 6.0 * t2) * s1;
+        row[2] = (-6.0 + 12.0 * t) * s2;
+        // h01 = 3t^2 - 2t^3
+        row[3] = 3.0 * t2 - 2.0 * t3;
+        row[4] = (6.0 * t - 6.0 * t2) * s1;
+        row[5] = (6.0 - 12.0 * t) * s2;
+        // h10 = t - 2t^2 + t^3
+        row[6] = t - 2.0 * t2 + t3;
+        row[7] = (1.0 - 4.0 * t + 3.0 * t2) * s1;
+        row[8] = (-4.0 + 6.0 * t) * s2;
+        // h11 = -t^2 + t^3
+        row[9] = -t2 + t3;
+        row[10] = (-2.0 * t + 3.0 * t2) * s1;
+        row[11] = (-2.0 + 6.0 * t) * s2;
+    }
+}
+
+__global__ void
+init_active_kernel(const uint8_t *__restrict__ node_valid,
+    uint8_t *__restrict__ active, int n)
+{
+    int const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        active[i] = node_valid[i] ? 1 : 0;
+}
+
+extern "C" int
+smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
+    int start_y, const double *nodes, const uint8_t *node_valid,
+    const uint8_t *patch_valid, const uint32_t *patch_vis)
+{
+    SMVS_REQUIRE(ctx && nodes && node_valid && patch_valid && patch_vis,
+        "null argument");
+    SMVS_REQUIRE(scale >= 0 && scale <= 10, "scale out of range");
+    SMVS_REQUIRE(npx >= 1 && npy >= 1, "empty patch grid");
+    int const ps = 1 << scale;
+    SMVS_REQUIRE(start_x >= 0 && start_y >= 0
+        && start_x + npx * ps <= ctx->width && start_y + npy * ps <= ctx->height,
+        "patch grid does not fit the image");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+
+    size_t const N = (size_t)(npx + 1) * (npy + 1);
+    size_t const P = (size_t)npx * npy;
+    int rc = SMVS_OK;
+    if (N > ctx->cap_nodes) {
+        size_t const cap = N + N / 8;
+        if ((rc = device_alloc(&ctx->nodes, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->node_valid, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->active, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->active_next, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->H9, cap * 9 * 16)) != SMVS_OK
+            || (rc = device_alloc(&ctx->Pinv, cap * 16)) != SMVS_OK
+            || (rc = device_alloc(&ctx->g, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->x, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->r, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->z, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->Ad, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->d, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->b, cap * 4)) != SMVS_OK)
+            return rc;
+        ctx->max_blocks = (int)((cap * 4 + 255) / 256) + 8;
+        if ((rc = device_alloc(&ctx->partials, (size_t)ctx->max_blocks * 4)) != SMVS_OK)
+            return rc;
+        ctx->cap_nodes = cap;
+    }
+    if (P > ctx->cap_patches) {
+        size_t const cap = P + P / 8;
+        if ((rc = device_alloc(&ctx->patch_valid, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->patch_vis, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->Hp, cap * 256)) != SMVS_OK
+            || (rc = device_alloc(&ctx->gp, cap * 16)) != SMVS_OK)
+            return rc;
+        ctx->cap_patches = cap;
+    }
+    ctx->scale = scale;
+    ctx->patchsize = ps;
+    ctx->npx = npx;
+    ctx->npy = npy;
+    ctx->start_x = start_x;
+    ctx->start_y = start_y;
+    ctx->num_nodes = (int)N;
+    ctx->num_patches = (int)P;
+    ctx->node_stride = npx + 1;
+
+    if (ctx->hermite_tab_ps != ps) {
+        std::vector<double> tab;
+        build_hermite_table(ps, &tab);
+        if ((rc = device_alloc(&ctx->hermite_tab, tab.size())) != SMVS_OK)
+            return rc;
+        SMVS_HIP_CHECK(hipMemcpy(ctx->hermite_tab, tab.data(),
+            tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->hermite_tab_ps = ps;
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes, nodes, N * 4 * sizeof(double),
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->node_valid, node_valid, N,
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->patch_valid, patch_valid, P,
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->patch_vis, patch_vis,
+        P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(init_active_kernel, dim3((unsigned)((N + 255) / 256)),
+        dim3(256), 0, ctx->stream, ctx->node_valid, ctx->active, (int)N);
+    SMVS_HIP_CHECK(hipGetLastError());
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->has_surface = true;
+    ctx->has_system = false;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_set_active(smvs_ctx *ctx, const uint8_t *active)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface) {
+        set_error("smvs_ctx_set_active: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (active == nullptr) {
+        hipLaunchKernelGGL(init_active_kernel,
+            dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
+            ctx->stream, ctx->node_valid, ctx->active, ctx->num_nodes);
+        SMVS_HIP_CHECK(hipGetLastError());
+    } else {
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->active, active, ctx->num_nodes,
+            hipMemcpyHostToDevice, ctx->stream));
+    }
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_get_active(smvs_ctx *ctx, uint8_t *active, int *num_active)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface) {
+        set_error("smvs_get_active: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<uint8_t> tmp(ctx->num_nodes);
+    SMVS_HIP_CHECK(hipMemcpyAsync(tmp.data(), ctx->active, ctx->num_nodes,
+        hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (active != nullptr)
+        memcpy(active, tmp.data(), tmp.size());
+    if (num_active != nullptr) {
+        int n = 0;
+        for (uint8_t a : tmp)
+            n += (a == 1);
+        *num_active = n;
+    }
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_get_nodes(smvs_ctx *ctx, double *nodes)
+{
+    SMVS_REQUIRE(ctx && nodes, "null argument");
+    if (!ctx->has_surface) {
+        set_error("smvs_get_nodes: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(hipMemcpyAsync(nodes, ctx->nodes,
+        (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyDeviceToHost,
+        ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_set_nodes(smvs_ctx *ctx, const double *nodes)
+{
+    SMVS_REQUIRE(ctx && nodes, "null argument");
+    if (!ctx->has_surface) {
+        set_error("smvs_set_nodes: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes, nodes,
+        (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyHostToDevice,
+        ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_profile_enable(smvs_ctx *ctx, int on)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!on)
+        (void)profile_collect(ctx);
+    ctx->prof.enabled = on != 0;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_profile_reset(smvs_ctx *ctx)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    (void)profile_collect(ctx);
+    for (int i = 0; i < SMVS_K_COUNT; ++i) {
+        ctx->prof.ms[i] = 0.0;
+        ctx->prof.launches[i] = 0;
+    }
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_profile_get(smvs_ctx *ctx, double *ms, long long *launches)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    int rc = profile_collect(ctx);
+    if (rc != SMVS_OK)
+        return rc;
+    for (int i = 0; i < SMVS_K_COUNT; ++i) {
+        if (ms)
+            ms[i] = ctx->prof.ms[i];
+        if (launches)
+            launches[i] = ctx->prof.launches[i];
+    }
+    return SMVS_OK;
+}

@@ -1,0 +1,1113 @@
+// Gauss-Newton normal equations on gfx950.
+//
+// Replaces GaussNewtonStep::construct (reference: lib/gauss_newton_step.cc:33-143),
+// jacobian_entries_for_patch (:145-244) and fill_gradient_and_hessian_entries
+// (:246-518).
+//
+// Formulation.  For one pixel every Jacobian row the reference builds is a
+// linear combination of six rows of the bicubic basis table dn (the table
+// of lib/bicubic_patch.cc:302-316 / lib/surface.cc:929-955):
+//   photometric rows  jac_entries[j][col] = P_j * dn_w[col] + Q_j * dn_wx|wy[col]
+//                     (correspondence.cc:74-86, 102-187, gauss_newton_step.cc:202-207),
+//   regulariser rows  full_surface_div_deriv[v][col] = sum_a E[v][a] dn_a[col]
+//                     (surface_derivative.cc:109-190),
+//   shading rows      render_deriv[col] = sum_a rho[a] dn_a[col]
+//                     (gauss_newton_step.cc:468-499).
+// So the per-pixel contribution to the patch's 16x16 system is
+//   D6^T M6 D6  and  D6^T v6      with D6 = dn rows (w, w_x, w_y, w_xy, w_xx, w_yy)
+// and a 6x6 symmetric M6 / 6-vector v6 that carry all the view, IRLS-weight
+// and lighting dependence.  Phase 1 computes (M6, v6) with one lane per
+// sampled pixel (FP64 VALU); phase 2 contracts sum_pix D6^T (M6 D6) on the
+// matrix cores (v_mfma_f64_16x16x4_f64), K = 6 rows per pixel.
+// One wavefront owns 64 sampled pixels = 4 patches at the fine scales.
+#include "common.h"
+
+namespace smvs_hip {
+
+#define R_FACTOR 1e-4  // gauss_newton_step.cc:17
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct PatchKernelArgs {
+    const double *nodes;
+    const uint8_t *patch_valid;
+    const uint32_t *patch_vis;
+    const uint8_t *active;
+    const double *hermite_tab;   // [ps][12]
+    const float2 *main_grad;
+    const float *main_shading;
+    const float2 *main_shading_grad;
+    const SubPlanes *subs;
+    const DeviceCameras *cams;
+    const double *lighting;      // [16] or nullptr
+    double *Hp;
+    double *gp;
+    int W, H;
+    int npx, npy, stride;
+    int ps, start_x, start_y;
+    int sampling, spr, P;        // samples per row, samples per patch
+    int n_subs;
+    int num_patches;
+    double flen, inv_flen;
+    double reg, light_reg;
+    int use_lighting;
+};
+
+// 1 / x for x >= 1e-4 to ~1 ulp: hardware estimate + two Newton steps.
+__device__ __forceinline__ double
+fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// mve::Image<float>::linear_at in the reference's float operation order
+// (no FMA contraction) on the packed device planes. [MVE-unverified]
+struct Taps {
+    int o00, o10, o01, o11;
+    float w00, w10, w01, w11;
+};
+
+__device__ __forceinline__ Taps
+make_taps(float x, float y, int w, int h)
+{
+#pragma clang fp contract(off)
+    Taps t;
+    x = fmaxf(0.0f, fminf((float)(w - 1), x));
+    y = fmaxf(0.0f, fminf((float)(h - 1), y));
+    int const fx = (int)x;
+    int const fy = (int)y;
+    int const fx1 = min(fx + 1, w - 1);
+    int const fy1 = min(fy + 1, h - 1);
+    float const w1 = x - (float)fx;
+    float const w0 = 1.0f - w1;
+    float const w3 = y - (float)fy;
+    float const w2 = 1.0f - w3;
+    t.o00 = fy * w + fx;
+    t.o10 = fy * w + fx1;
+    t.o01 = fy1 * w + fx;
+    t.o11 = fy1 * w + fx1;
+    t.w00 = w0 * w2;
+    t.w10 = w1 * w2;
+    t.w01 = w0 * w3;
+    t.w11 = w1 * w3;
+    return t;
+}
+
+__device__ __forceinline__ float
+tap_mix(float v1, float v2, float v3, float v4, Taps const &t)
+{
+#pragma clang fp contract(off)
+    return v1 * t.w00 + v2 * t.w10 + v3 * t.w01 + v4 * t.w11;
+}
+
+// upper-triangular packed index of a symmetric 6x6
+__device__ __forceinline__ constexpr int
+sym6(int a, int b)
+{
+    return a <= b ? a * 6 - (a * (a - 1)) / 2 + (b - a)
+                  : b * 6 - (b * (b - 1)) / 2 + (a - b);
+}
+
+// Derivative of the six normal-divergence entries with respect to the six
+// pixel-space surface quantities, evaluated along `p`
+// (surface_derivative.cc:128-188 with the dn row replaced by p).
+struct DivState {
+    double x, y, f, f2inv;
+    double w, wx, wy, wxy, wxx, wyy;
+    double a, ax, ay, t, n, b, c, nx, ny;
+    double inv_n, inv_t, inv_t2, inv_t2f;
+};
+
+__device__ __forceinline__ void
+div_along(DivState const &s, double const p[6], double out[6])
+{
+    double const wp = p[0], dxp = p[1], dyp = p[2], dxyp = p[3],
+        dxxp = p[4], dyyp = p[5];
+    double const ap = wp + s.x * dxp + s.y * dyp;
+    double const axp = 2.0 * dxp + s.x * dxxp + s.y * dxyp;
+    double const ayp = 2.0 * dyp + s.y * dyyp + s.x * dxyp;
+    double const t2p = s.wx * dxp + s.wy * dyp + s.f2inv * s.a * ap;
+    double const np = t2p * s.inv_n;
+    double const bp = (dxp * s.wxx + s.wx * dxxp) + (dyp * s.wxy + s.wy * dxyp)
+        + s.f2inv * (ap * s.ax + s.a * axp);
+    double const cp = (dxp * s.wxy + s.wx * dxyp) + (dyp * s.wyy + s.wy * dyyp)
+        + s.f2inv * (ap * s.ay + s.a * ayp);
+    double const nxp = (bp * s.n - s.b * np) * s.inv_t;
+    double const nyp = (cp * s.n - s.c * np) * s.inv_t;
+    double const two_t2p = 2.0 * t2p;
+    double const xxp = ((dxxp * s.n + s.wxx * np - dxp * s.nx - s.wx * nxp) * s.t
+        - (s.wxx * s.n - s.wx * s.nx) * two_t2p) * s.inv_t2;
+    double const yyp = ((dyyp * s.n + s.wyy * np - dyp * s.ny - s.wy * nyp) * s.t
+        - (s.wyy * s.n - s.wy * s.ny) * two_t2p) * s.inv_t2;
+    double const xyp = ((dxyp * s.n + s.wxy * np - dxp * s.ny - s.wx * nyp) * s.t
+        - (s.wxy * s.n - s.wx * s.ny) * two_t2p) * s.inv_t2;
+    double const yxp = ((dxyp * s.n + s.wxy * np - dyp * s.nx - s.wy * nxp) * s.t
+        - (s.wxy * s.n - s.wy * s.nx) * two_t2p) * s.inv_t2;
+    double const zxp = ((axp * s.n + s.ax * np - ap * s.nx - s.a * nxp) * s.t
+        - (s.ax * s.n - s.a * s.nx) * two_t2p) * s.inv_t2f;
+    double const zyp = ((ayp * s.n + s.ay * np - ap * s.ny - s.a * nyp) * s.t
+        - (s.ay * s.n - s.a * s.ny) * two_t2p) * s.inv_t2f;
+    out[0] = xxp;
+    out[1] = -yxp;
+    out[2] = zxp;
+    out[3] = xyp;
+    out[4] = -yyp;
+    out[5] = zyp;
+}
+
+// surface_derivative.cc:42-63 along p (only w, w_x, w_y matter)
+__device__ __forceinline__ void
+normal_along(DivState const &s, double wp, double dxp, double dyp,
+    double out[3])
+{
+    double const ap = wp + s.x * dxp + s.y * dyp;
+    double const t2p = s.wx * dxp + s.wy * dyp + s.f2inv * s.a * ap;
+    double const np = t2p * s.inv_n;
+    out[0] = (dxp * s.n - s.wx * np) * s.inv_t;
+    out[1] = (-dyp * s.n + s.wy * np) * s.inv_t;
+    out[2] = (ap * s.n - s.a * np) * s.inv_t / s.f;
+}
+
+// spherical_harmonics.h:53-73,133-151 and :79-127,157-201 contracted with the
+// lighting parameters: shading = l . sh(n), G = sum_{l>=1} l_l dsh_l/dn.
+__device__ __forceinline__ void
+shading_and_gradient(const double *lp, const double n[3], double *shading,
+    double G[3])
+{
+    double const nx = n[0], ny = n[1], nz = n[2];
+    double const x2 = nx * nx, y2 = ny * ny, z2 = nz * nz;
+    double sh[16];
+    sh[0] = 1.0; sh[1] = ny; sh[2] = nz; sh[3] = nx;
+    sh[4] = nx * ny; sh[5] = ny * nz; sh[6] = -x2 - y2 + 2.0 * z2;
+    sh[7] = nx * nz; sh[8] = x2 - y2;
+    sh[9] = (3.0 * x2 - y2) * ny; sh[10] = nx * ny * nz;
+    sh[11] = (4.0 * z2 - x2 - y2) * ny;
+    sh[12] = (2.0 * z2 - 3.0 * x2 - 3.0 * y2) * nz;
+    sh[13] = (4.0 * z2 - x2 - y2) * nx;
+    sh[14] = (x2 - y2) * nz; sh[15] = (x2 - 3.0 * y2) * nx;
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l)
+        s += lp[l] * sh[l];
+    *shading = s;
+
+    double d[16][3];
+    d[0][0] = 0; d[0][1] = 0; d[0][2] = 0;
+    d[1][0] = 0; d[1][1] = 1; d[1][2] = 0;
+    d[2][0] = 0; d[2][1] = 0; d[2][2] = 1;
+    d[3][0] = 1; d[3][1] = 0; d[3][2] = 0;
+    d[4][0] = ny; d[4][1] = nx; d[4][2] = 0;
+    d[5][0] = 0; d[5][1] = nz; d[5][2] = ny;
+    d[6][0] = -2.0 * nx; d[6][1] = -2.0 * ny; d[6][2] = 4.0 * nz;
+    d[7][0] = nz; d[7][1] = 0; d[7][2] = nx;
+    d[8][0] = 2.0 * nx; d[8][1] = -2.0 * ny; d[8][2] = 0;
+    d[9][0] = 6.0 * nx * ny; d[9][1] = 3.0 * (x2 - y2); d[9][2] = 0;
+    d[10][0] = ny * nz; d[10][1] = nx * nz; d[10][2] = nx * ny;
+    d[11][0] = -2.0 * nx * ny; d[11][1] = 4.0 * z2 - x2 - 3.0 * y2;
+    d[11][2] = 8.0 * ny * nz;
+    d[12][0] = -6.0 * nx * nz; d[12][1] = -6.0 * ny * nz;
+    d[12][2] = 6.0 * z2 - 3.0 * (x2 + y2);
+    d[13][0] = 4.0 * z2 - 3.0 * x2 - y2; d[13][1] = -2.0 * nx * ny;
+    d[13][2] = 8.0 * nx * nz;
+    d[14][0] = 2.0 * nx * nz; d[14][1] = -2.0 * ny * nz; d[14][2] = x2 - y2;
+    d[15][0] = 3.0 * (x2 - y2); d[15][1] = -6.0 * nx * ny; d[15][2] = 0;
+    G[0] = G[1] = G[2] = 0.0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {  // sh0 is constant
+        G[0] += lp[l] * d[l][0];
+        G[1] += lp[l] * d[l][1];
+        G[2] += lp[l] * d[l][2];
+    }
+}
+
+// Column `col` (= 4*node + param, node = 2*b + a) of the basis table is the
+// product of the x-function ex and the y-function ey of the Hermite table.
+__device__ __forceinline__ void
+col_functions(int col, int *ex, int *ey)
+{
+    int const n = col >> 2, i = col & 3;
+    int const a = n & 1, b = n >> 1;
+    *ex = (i & 1) ? 2 + a : a;
+    *ey = (i & 2) ? 2 + b : b;
+}
+
+// ---------------------------------------------------------------------------
+// Phase 1: one lane = one sampled pixel -> (M6[21], v6[6])
+// ---------------------------------------------------------------------------
+template <int MAXS>
+__device__ __forceinline__ void
+pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
+    double const theta[16], int px, int py, int sx, int sy, uint32_t vis,
+    double M6[21], double v6[6])
+{
+#pragma unroll
+    for (int i = 0; i < 21; ++i)
+        M6[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        v6[i] = 0.0;
+
+    // ---- bicubic surface values at the pixel (surface_patch.cc:95-109) ----
+    double w, wx, wy, wxy, wxx, wyy;
+    {
+        const double *X = tabs + sx * 12;
+        const double *Y = tabs + sy * 12;
+        double G[4][3];
+#pragma unroll
+        for (int ey = 0; ey < 4; ++ey) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                G[ey][k] = 0.0;
+#pragma unroll
+            for (int ex = 0; ex < 4; ++ex) {
+                int const a = ex & 1, ix = ex >> 1, b = ey & 1, iy = ey >> 1;
+                double const c = theta[4 * (2 * b + a) + ix + 2 * iy];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    G[ey][k] = __builtin_fma(c, X[ex * 3 + k], G[ey][k]);
+            }
+        }
+        w = wx = wy = wxy = wxx = wyy = 0.0;
+#pragma unroll
+        for (int ey = 0; ey < 4; ++ey) {
+            double const y0 = Y[ey * 3 + 0], y1 = Y[ey * 3 + 1],
+                y2 = Y[ey * 3 + 2];
+            w = __builtin_fma(G[ey][0], y0, w);
+            wx = __builtin_fma(G[ey][1], y0, wx);
+            wy = __builtin_fma(G[ey][0], y1, wy);
+            wxy = __builtin_fma(G[ey][1], y1, wxy);
+            wxx = __builtin_fma(G[ey][2], y0, wxx);
+            wyy = __builtin_fma(G[ey][0], y2, wyy);
+        }
+    }
+
+    float2 const gm = A.main_grad[(size_t)py * A.W + px];
+    double const gm0 = gm.x, gm1 = gm.y;
+
+    // ---- neighbours (gauss_newton_step.cc:175-208) ----
+    double s0[MAXS], s1[MAXS], P0[MAXS], P1[MAXS], Q[MAXS];
+    int num_subs = 0;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        s0[j] = s1[j] = P0[j] = P1[j] = Q[j] = 0.0;
+        if (j >= A.n_subs || !((vis >> j) & 1u))
+            continue;
+        num_subs += 1;
+        const double *M = A.cams->M[j];
+        const double *t = A.cams->t[j];
+        SubPlanes const sp = A.subs[j];
+        double p, q, r, a, b, d, d2, proj0, proj1, jac0, jac1, jac2, jac3;
+        {
+            // correspondence.cc:36-51, 88-100 in the reference's operation
+            // order: the projection feeds float tap coordinates.
+#pragma clang fp contract(off)
+            double const u = (double)px + 0.5, v = (double)py + 0.5;
+            p = M[0] * u + M[1] * v + M[2];
+            q = M[3] * u + M[4] * v + M[5];
+            r = M[6] * u + M[7] * v + M[8];
+            a = w * p + t[0];
+            b = w * q + t[1];
+            d = w * r + t[2];
+            d2 = d * d;
+            proj0 = a / d;
+            proj1 = b / d;
+            proj0 -= 0.5;
+            proj1 -= 0.5;
+            jac0 = (wx * p + w * M[0]) / d;
+            jac2 = (wy * p + w * M[1]) / d;
+            jac0 -= a * (wx * r + w * M[6]) / d2;
+            jac2 -= a * (wy * r + w * M[7]) / d2;
+            jac1 = (wx * q + w * M[3]) / d;
+            jac3 = (wy * q + w * M[4]) / d;
+            jac1 -= b * (wx * r + w * M[6]) / d2;
+            jac3 -= b * (wy * r + w * M[7]) / d2;
+        }
+        Taps const tp = make_taps((float)proj0, (float)proj1, sp.width,
+            sp.height);
+        float2 const g00 = sp.grad[tp.o00], g10 = sp.grad[tp.o10],
+            g01 = sp.grad[tp.o01], g11 = sp.grad[tp.o11];
+        float4 const h00 = sp.hess[tp.o00], h10 = sp.hess[tp.o10],
+            h01 = sp.hess[tp.o01], h11 = sp.hess[tp.o11];
+        double const g0 = tap_mix(g00.x, g10.x, g01.x, g11.x, tp);
+        double const g1 = tap_mix(g00.y, g10.y, g01.y, g11.y, tp);
+        double const hxx = tap_mix(h00.x, h10.x, h01.x, h11.x, tp);
+        double const hxy = tap_mix(h00.y, h10.y, h01.y, h11.y, tp);
+        double const hyy = tap_mix(h00.z, h10.z, h01.z, h11.z, tp);
+
+        s0[j] = jac0 * g0 + jac1 * g1;
+        s1[j] = jac2 * g0 + jac3 * g1;
+
+        double const inv_d2 = 1.0 / d2;
+        double const du_w = (p * d - r * a) * inv_d2;
+        double const dv_w = (q * d - r * b) * inv_d2;
+        double const JH0 = jac0 * hxx + jac1 * hxy;
+        double const JH1 = jac0 * hxy + jac1 * hyy;
+        double const JH2 = jac2 * hxx + jac3 * hxy;
+        double const JH3 = jac2 * hxy + jac3 * hyy;
+
+        // correspondence.cc:102-168
+        double const d_prime_d4 = 2.0 * d * r * inv_d2 * inv_d2;
+        double const du_cp = p * t[2] - r * t[0];
+        double const dv_cp = q * t[2] - r * t[1];
+        double du_A[2], dv_A[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double const pp = M[k], qp = M[3 + k], rp = M[6 + k];
+            double const wk = k == 0 ? wx : wy;
+            double const du_at = w * (pp * r - p * rp);
+            double const dv_at = w * (qp * r - q * rp);
+            double const du_bp = pp * t[2] - rp * t[0];
+            double const dv_bp = qp * t[2] - rp * t[1];
+            double const du_abc = w * (du_at + du_bp) + wk * du_cp;
+            double const dv_abc = w * (dv_at + dv_bp) + wk * dv_cp;
+            du_A[k] = (2.0 * du_at + du_bp) * inv_d2 - du_abc * d_prime_d4;
+            dv_A[k] = (2.0 * dv_at + dv_bp) * inv_d2 - dv_abc * d_prime_d4;
+        }
+        double const cu = du_cp * inv_d2;
+        double const cv = dv_cp * inv_d2;
+        P0[j] = du_A[0] * g0 + dv_A[0] * g1 + JH0 * du_w + JH1 * dv_w;
+        P1[j] = du_A[1] * g0 + dv_A[1] * g1 + JH2 * du_w + JH3 * dv_w;
+        Q[j] = cu * g0 + cv * g1;
+    }
+
+    // ---- IRLS-weighted photometric terms (gauss_newton_step.cc:268-321):
+    // ref-neighbour residuals and all neighbour-neighbour pairs, expressed
+    // on the (w, w_x) / (w, w_y) rows of the basis table. ----
+    double m_ww = 0.0, m_wx = 0.0, m_xx = 0.0, m_wy = 0.0, m_yy = 0.0;
+    double v_w = 0.0, v_x = 0.0, v_y = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        if (j >= A.n_subs || !((vis >> j) & 1u))
+            continue;
+        {
+            double const diff0 = s0[j] - gm0, diff1 = s1[j] - gm1;
+            double const w0 = fast_rcp(fabs(diff0) + R_FACTOR);
+            double const w1 = fast_rcp(fabs(diff1) + R_FACTOR);
+            double const a0 = w0 * P0[j], b0 = w0 * Q[j];
+            double const a1 = w1 * P1[j], b1 = w1 * Q[j];
+            m_ww += a0 * P0[j] + a1 * P1[j];
+            m_wx += a0 * Q[j];
+            m_xx += b0 * Q[j];
+            m_wy += a1 * Q[j];
+            m_yy += b1 * Q[j];
+            v_w += a0 * diff0 + a1 * diff1;
+            v_x += b0 * diff0;
+            v_y += b1 * diff1;
+        }
+#pragma unroll
+        for (int j2 = j + 1; j2 < MAXS; ++j2) {
+            if (j2 >= A.n_subs || !((vis >> j2) & 1u))
+                continue;
+            double const sd0 = s0[j] - s0[j2], sd1 = s1[j] - s1[j2];
+            double const w0 = fast_rcp(fabs(sd0) + R_FACTOR);
+            double const w1 = fast_rcp(fabs(sd1) + R_FACTOR);
+            double const dP0 = P0[j] - P0[j2], dP1 = P1[j] - P1[j2];
+            double const dQ = Q[j] - Q[j2];
+            double const a0 = w0 * dP0, b0 = w0 * dQ;
+            double const a1 = w1 * dP1, b1 = w1 * dQ;
+            m_ww += a0 * dP0 + a1 * dP1;
+            m_wx += a0 * dQ;
+            m_xx += b0 * dQ;
+            m_wy += a1 * dQ;
+            m_yy += b1 * dQ;
+            v_w += a0 * sd0 + a1 * sd1;
+            v_x += b0 * sd0;
+            v_y += b1 * sd1;
+        }
+    }
+    M6[sym6(0, 0)] = m_ww;
+    M6[sym6(0, 1)] = m_wx;
+    M6[sym6(1, 1)] = m_xx;
+    M6[sym6(0, 2)] = m_wy;
+    M6[sym6(2, 2)] = m_yy;
+    v6[0] = v_w;
+    v6[1] = v_x;
+    v6[2] = v_y;
+
+    if (!(A.reg > 0.0))
+        return;
+
+    // ---- regulariser + shading (gauss_newton_step.cc:210-240, 385-517) ----
+    double const num_diffs = (double)((num_subs * (num_subs + 1)) / 2);
+    double const brw = A.reg * 0.005 / fmax(0.03, fabs(gm0) + fabs(gm1))
+        * num_diffs;
+
+    DivState s;
+    s.x = (double)px + 0.5 - (double)A.W / 2.0;
+    s.y = (double)py + 0.5 - (double)A.H / 2.0;
+    s.f = A.flen;
+    s.f2inv = 1.0 / (s.f * s.f);
+    s.w = w; s.wx = wx; s.wy = wy; s.wxy = wxy; s.wxx = wxx; s.wyy = wyy;
+    s.a = w + s.x * wx + s.y * wy;
+    s.ax = 2.0 * wx + s.x * wxx + s.y * wxy;
+    s.ay = 2.0 * wy + s.y * wyy + s.x * wxy;
+    double const a_f2 = s.a * s.f2inv;
+    s.t = wx * wx + wy * wy + s.a * a_f2;
+    s.n = sqrt(s.t);
+    s.b = wx * wxx + wy * wxy + a_f2 * s.ax;
+    s.c = wx * wxy + wy * wyy + a_f2 * s.ay;
+    s.inv_n = 1.0 / s.n;
+    s.inv_t = 1.0 / s.t;
+    s.inv_t2 = s.inv_t * s.inv_t;
+    s.inv_t2f = s.inv_t2 / s.f;
+    s.nx = s.b * s.inv_n;
+    s.ny = s.c * s.inv_n;
+
+    // normal divergence (surface_derivative.cc:69-107)
+    double div[6];
+    div[0] = (wxx * s.n - wx * s.nx) * s.inv_t;               // xx
+    div[1] = -((wxy * s.n - wy * s.nx) * s.inv_t);            // -yx
+    div[2] = (s.ax * s.n - s.a * s.nx) * s.inv_t / s.f;       // zx
+    div[3] = (wxy * s.n - wx * s.ny) * s.inv_t;               // xy
+    div[4] = -((wyy * s.n - wy * s.ny) * s.inv_t);            // -yy
+    div[5] = (s.ay * s.n - s.a * s.ny) * s.inv_t / s.f;       // zy
+
+    // E[v][a] = d div[v] / d (surface quantity a)
+    double E[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double unit[6] = { 0, 0, 0, 0, 0, 0 };
+        unit[a] = 1.0;
+        double out[6];
+        div_along(s, unit, out);
+#pragma unroll
+        for (int v = 0; v < 6; ++v)
+            E[v][a] = out[v];
+    }
+
+    bool const lit = A.use_lighting != 0;
+    if (!lit || A.light_reg > 0.0) {
+        double geom_weight = 1.0;
+        if (lit)
+            geom_weight *= A.light_reg / 100;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            double const wgt = geom_weight * brw
+                * fast_rcp(R_FACTOR + fabs(div[v]));
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double const wa = wgt * E[v][a];
+                v6[a] += wa * div[v];
+#pragma unroll
+                for (int b = a; b < 6; ++b)
+                    M6[sym6(a, b)] += wa * E[v][b];
+            }
+        }
+    }
+    if (!lit)
+        return;
+
+    // shading term (gauss_newton_step.cc:420-517)
+    double normal[3];
+    {
+        double nz = (s.x * wx + s.y * wy + w) * A.inv_flen;
+        double const len = sqrt(wx * wx + wy * wy + nz * nz);
+        normal[0] = wx / len;
+        normal[1] = -wy / len;
+        normal[2] = nz / len;
+    }
+    double shading, G[3];
+    shading_and_gradient(A.lighting, normal, &shading, G);
+    float2 const lgf = A.main_shading_grad[(size_t)py * A.W + px];
+    double lig0 = lgf.x, lig1 = lgf.y;
+    double const liv = A.main_shading[(size_t)py * A.W + px];
+    double const shading_weight = 0.001 * num_diffs
+        / (R_FACTOR + (fabs(lig0) + fabs(lig1)));
+    if (sqrt(lig0 * lig0 + lig1 * lig1) < 1e-10)
+        return;
+    if (shading * shading < 1e-10 || liv * liv < 1e-10)
+        return;
+
+    double sg[2];
+    sg[0] = G[0] * div[0] + G[1] * div[1] + G[2] * div[2];
+    sg[1] = G[0] * div[3] + G[1] * div[4] + G[2] * div[5];
+    double const inv_sh = 1.0 / shading;
+    double const inv_liv = 1.0 / liv;
+    double err[2];
+    err[0] = sg[0] * inv_sh - lig0 * inv_liv;
+    err[1] = sg[1] * inv_sh - lig1 * inv_liv;
+
+    // N[k][a]: d normal[k] / d (w, w_x, w_y)
+    double Nn[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double out[3];
+        normal_along(s, a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0,
+            a == 2 ? 1.0 : 0.0, out);
+        Nn[0][a] = out[0]; Nn[1][a] = out[1]; Nn[2][a] = out[2];
+    }
+    double const inv_sh2 = inv_sh * inv_sh;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double rho[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double const sgd = G[0] * E[3 * c + 0][a] + G[1] * E[3 * c + 1][a]
+                + G[2] * E[3 * c + 2][a];
+            double const sd = a < 3
+                ? G[0] * Nn[0][a] + G[1] * Nn[1][a] + G[2] * Nn[2][a] : 0.0;
+            rho[a] = (sgd * shading - sg[c] * sd) * inv_sh2;
+        }
+        double const wgt = shading_weight / (R_FACTOR + fabs(err[c]));
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double const wa = wgt * rho[a];
+            v6[a] += wa * err[c];
+#pragma unroll
+            for (int b = a; b < 6; ++b)
+                M6[sym6(a, b)] += wa * rho[b];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The patch kernel: one wavefront per block.
+//   PPW patches per wave (4 when a patch has <= 16 sampled pixels, else 1),
+//   SLOTS = 64 / PPW pixel slots per patch and chunk.
+// ---------------------------------------------------------------------------
+template <int PPW, int MAXS>
+__global__ void __launch_bounds__(64)
+gn_patch_kernel(PatchKernelArgs A)
+{
+    constexpr int SLOTS = 64 / PPW;
+    extern __shared__ double lds[];
+    double *Msh = lds;             // [27][64]
+    double *tabs = lds + 27 * 64;  // [spr][12] rows of the sampled coords
+
+    int const lane = threadIdx.x;
+    unsigned const wv = xcd_band_block(blockIdx.x, gridDim.x);
+    int const patch_base = (int)wv * PPW;
+
+    for (int i = lane; i < A.spr * 12; i += 64) {
+        int const row = i / 12, e = i - row * 12;
+        tabs[i] = A.hermite_tab[(size_t)(row * A.sampling) * 12 + e];
+    }
+
+    // the patch this lane works for in phase 1
+    int const q1 = lane / SLOTS;
+    int const sidx = lane - q1 * SLOTS;
+    int const patch1 = patch_base + q1;
+    bool live = false;
+    double theta[16];
+    uint32_t vis = 0;
+    int pox = 0, poy = 0;
+    if (patch1 < A.num_patches && A.patch_valid[patch1]) {
+        int const ix = patch1 % A.npx, iy = patch1 / A.npx;
+        int const n00 = iy * A.stride + ix;
+        int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+        live = (A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
+            | A.active[ids[3]]) != 0;
+        if (live) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const double *src = A.nodes + 4 * (size_t)ids[n];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    theta[4 * n + k] = src[k];
+            }
+            vis = A.patch_vis[patch1];
+            pox = A.start_x + ix * A.ps;
+            poy = A.start_y + iy * A.ps;
+        }
+    }
+    // wave-uniform early exit: nothing to do for any of the PPW patches
+    if (__ballot(live) == 0ull)
+        return;
+
+    // phase 2 roles
+    int const kg = lane >> 4, col = lane & 15;
+    int ex, ey;
+    col_functions(col, &ex, &ey);
+
+    double4_t acc[PPW];
+    double gacc[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        acc[q] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        gacc[q] = 0.0;
+    }
+
+    int const chunks = (A.P + SLOTS - 1) / SLOTS;
+    for (int c = 0; c < chunks; ++c) {
+        __syncthreads();
+        // ---- phase 1 ----
+        {
+            double M6[21], v6[6];
+            int const si = c * SLOTS + sidx;
+            if (live && si < A.P) {
+                int const sy = si / A.spr, sx = si - sy * A.spr;
+                pixel_system<MAXS>(A, tabs, theta, pox + sx * A.sampling,
+                    poy + sy * A.sampling, sx, sy, vis, M6, v6);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 21; ++i)
+                    M6[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    v6[i] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 21; ++i)
+                Msh[i * 64 + lane] = M6[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                Msh[(21 + i) * 64 + lane] = v6[i];
+        }
+        __syncthreads();
+        // ---- phase 2: H += sum_pix D6^T (M6 D6) on the matrix cores ----
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int const pl = 4 * t + kg;            // pixel slot in the wave
+            int const q = PPW == 1 ? 0 : (t >> 2);
+            int si = c * SLOTS + (pl & (SLOTS - 1));
+            si = min(si, A.P - 1);
+            int const sy = si / A.spr, sx = si - sy * A.spr;
+            const double *X = tabs + sx * 12 + ex * 3;
+            const double *Y = tabs + sy * 12 + ey * 3;
+            double const x0 = X[0], x1 = X[1], x2 = X[2];
+            double const y0 = Y[0], y1 = Y[1], y2 = Y[2];
+            double D[6];
+            D[0] = x0 * y0; D[1] = x1 * y0; D[2] = x0 * y1;
+            D[3] = x1 * y1; D[4] = x2 * y0; D[5] = x0 * y2;
+            double Mx[21];
+#pragma unroll
+            for (int i = 0; i < 21; ++i)
+                Mx[i] = Msh[i * 64 + pl];
+            double gsum = gacc[q];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double T = 0.0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                    T = __builtin_fma(Mx[sym6(a, b)], D[b], T);
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[a], T, acc[q],
+                    0, 0, 0);
+                gsum = __builtin_fma(Msh[(21 + a) * 64 + pl], D[a], gsum);
+            }
+            gacc[q] = gsum;
+        }
+    }
+
+    // ---- phase 3: store the per-patch systems ----
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        int const patch = patch_base + q;
+        double gv = gacc[q];
+        gv += __shfl_xor(gv, 16);
+        gv += __shfl_xor(gv, 32);
+        if (patch >= A.num_patches)
+            continue;
+        double *Hout = A.Hp + (size_t)patch * 256;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            Hout[(kg + 4 * rr) * 16 + col] = acc[q][rr];
+        if (lane < 16)
+            A.gp[(size_t)patch * 16 + lane] = gv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Assembly: gather form of gauss_newton_step.cc:88-142.  One thread per
+// (node, block row); the <= 4 incident patches are added in ascending patch
+// id, which is the order the reference's patch loop feeds its std::map.
+// Only upper-triangle entries of the per-patch system are used and mirrored
+// (gauss_newton_step.cc:103, 113-119).
+// ---------------------------------------------------------------------------
+struct AssembleArgs {
+    const double *Hp;
+    const double *gp;
+    const uint8_t *patch_valid;
+    const uint8_t *active;
+    double *H9;     // [9][N][16]
+    double *Pinv;   // [N][16]
+    double *g;      // [N][4]
+    int npx, npy, stride, num_nodes;
+};
+
+// lib/ldl_decomposition.h:43-92 for a 4x4 block, same operation order.
+__device__ __forceinline__ void
+ldl_inverse4(double A[16])
+{
+#pragma clang fp contract(off)
+    double L[16], D[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        L[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        D[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        D[j] = A[j * 4 + j];
+        L[j * 4 + j] = 1.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+            D[j] -= (L[j * 4 + k] * L[j * 4 + k]) * D[k];
+        if (D[j] == 0.0)
+            return;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            L[i * 4 + j] = A[i * 4 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k)
+                L[i * 4 + j] -= L[i * 4 + k] * D[k] * L[j * 4 + k];
+            L[i * 4 + j] /= D[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k = i; k < j; ++k)
+                sum -= L[j * 4 + k] * L[k * 4 + i];
+            L[j * 4 + i] = sum;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        D[i] = 1.0 / D[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        A[i] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2)
+                A[c1 * 4 + c2] += L[r * 4 + c2] * L[r * 4 + c1] * D[r];
+}
+
+__global__ void __launch_bounds__(256)
+gn_assemble_kernel(AssembleArgs A)
+{
+    int const gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int const n = gid >> 2, r = gid & 3;
+    bool const in_range = n < A.num_nodes;
+    int const ix = in_range ? n % A.stride : 0;
+    int const iy = in_range ? n / A.stride : 0;
+
+    double out[9][4];
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            out[s][c] = 0.0;
+    double gout = 0.0;
+
+    if (in_range && A.active[n]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int const pxq = ix - (1 - (q & 1));
+            int const pyq = iy - (1 - (q >> 1));
+            int const ln = 3 - q;  // local index of node n in that patch
+            if (pxq < 0 || pxq >= A.npx || pyq < 0 || pyq >= A.npy)
+                continue;
+            int const p = pyq * A.npx + pxq;
+            if (!A.patch_valid[p])
+                continue;
+            const double *Hl = A.Hp + (size_t)p * 256;
+            int const n00 = pyq * A.stride + pxq;
+#pragma unroll
+            for (int lm = 0; lm < 4; ++lm) {
+                int const m = n00 + (lm & 1) + (lm >> 1) * A.stride;
+                if (!A.active[m])
+                    continue;
+                int const dx = (lm & 1) - (1 - (q & 1));
+                int const dy = (lm >> 1) - (1 - (q >> 1));
+                int const slot = (dy + 1) * 3 + (dx + 1);
+                int const i = 4 * ln + r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int const j = 4 * lm + c;
+                    double const v = i <= j ? Hl[i * 16 + j] : Hl[j * 16 + i];
+                    out[slot][c] += v;
+                }
+            }
+            gout += A.gp[(size_t)p * 16 + 4 * ln + r];
+        }
+    }
+
+    if (in_range) {
+        size_t const N = (size_t)A.num_nodes;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            double *dst = A.H9 + ((size_t)s * N + n) * 16 + r * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                dst[c] = out[s][c];
+        }
+        A.g[(size_t)n * 4 + r] = gout;
+    }
+
+    // block-Jacobi preconditioner: the 4 row-lanes of a node hand their row
+    // of the diagonal block to lane r == 0 (block_sparse_matrix.h:300-316).
+    double blk[16];
+    int const base_lane = (threadIdx.x & 63) & ~3;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            blk[rr * 4 + c] = __shfl(out[4][c], base_lane + rr);
+    if (in_range && r == 0) {
+        double inv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            inv[i] = blk[i];
+        ldl_inverse4(inv);
+        bool nancheck = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            nancheck |= isnan(inv[i]);
+        double *dst = A.Pinv + (size_t)n * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            dst[i] = nancheck ? blk[i] : inv[i];
+    }
+}
+
+__global__ void
+count_active_patches_kernel(const uint8_t *__restrict__ patch_valid,
+    const uint8_t *__restrict__ active, int npx, int stride, int num_patches,
+    int *__restrict__ status)
+{
+    int const p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (p < num_patches && patch_valid[p]) {
+        int const n00 = (p / npx) * stride + (p % npx);
+        live = (active[n00] | active[n00 + 1] | active[n00 + stride]
+            | active[n00 + stride + 1]) != 0;
+    }
+    unsigned long long const m = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && m != 0ull)
+        atomicAdd(&status[I_ACTIVE_PATCHES], __popcll(m));
+}
+
+static int
+sampling_for_scale(int scale)
+{
+    // gauss_newton_step.cc:157-161
+    int sampling = 4;
+    if (scale < 5)
+        sampling = 2;
+    if (scale < 3)
+        sampling = 1;
+    return sampling;
+}
+
+int
+gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
+    bool use_lighting)
+{
+    PatchKernelArgs A;
+    A.nodes = ctx->nodes;
+    A.patch_valid = ctx->patch_valid;
+    A.patch_vis = ctx->patch_vis;
+    A.active = ctx->active;
+    A.hermite_tab = ctx->hermite_tab;
+    A.main_grad = ctx->main_grad;
+    A.main_shading = ctx->main_shading;
+    A.main_shading_grad = ctx->main_shading_grad;
+    A.subs = ctx->subs_dev;
+    A.cams = ctx->cams;
+    A.lighting = ctx->lighting;
+    A.Hp = ctx->Hp;
+    A.gp = ctx->gp;
+    A.W = ctx->width;
+    A.H = ctx->height;
+    A.npx = ctx->npx;
+    A.npy = ctx->npy;
+    A.stride = ctx->node_stride;
+    A.ps = ctx->patchsize;
+    A.start_x = ctx->start_x;
+    A.start_y = ctx->start_y;
+    A.sampling = sampling_for_scale(ctx->scale);
+    if (A.sampling > A.ps)
+        A.sampling = A.ps;
+    A.spr = A.ps / A.sampling;
+    A.P = A.spr * A.spr;
+    A.n_subs = ctx->n_subs;
+    A.num_patches = ctx->num_patches;
+    A.flen = (double)ctx->flen;
+    A.inv_flen = (double)ctx->inv_flen;
+    A.reg = reg;
+    A.light_reg = light_reg;
+    A.use_lighting = use_lighting ? 1 : 0;
+
+    SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_ACTIVE_PATCHES, 0,
+        sizeof(int), ctx->stream));
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+        hipLaunchKernelGGL(count_active_patches_kernel,
+            dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0,
+            ctx->stream, ctx->patch_valid, ctx->active, ctx->npx,
+            ctx->node_stride, ctx->num_patches, ctx->status);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+
+    size_t const lds = (size_t)(27 * 64 + A.spr * 12) * sizeof(double);
+    bool const four = A.P <= 16;
+    int const ppw = four ? 4 : 1;
+    unsigned const blocks = (unsigned)((ctx->num_patches + ppw - 1) / ppw);
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_PATCH);
+        if (ctx->n_subs <= 8) {
+            if (four)
+                hipLaunchKernelGGL((gn_patch_kernel<4, 8>), dim3(blocks),
+                    dim3(64), lds, ctx->stream, A);
+            else
+                hipLaunchKernelGGL((gn_patch_kernel<1, 8>), dim3(blocks),
+                    dim3(64), lds, ctx->stream, A);
+        } else {
+            if (four)
+                hipLaunchKernelGGL((gn_patch_kernel<4, 16>), dim3(blocks),
+                    dim3(64), lds, ctx->stream, A);
+            else
+                hipLaunchKernelGGL((gn_patch_kernel<1, 16>), dim3(blocks),
+                    dim3(64), lds, ctx->stream, A);
+        }
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+
+    AssembleArgs B;
+    B.Hp = ctx->Hp;
+    B.gp = ctx->gp;
+    B.patch_valid = ctx->patch_valid;
+    B.active = ctx->active;
+    B.H9 = ctx->H9;
+    B.Pinv = ctx->Pinv;
+    B.g = ctx->g;
+    B.npx = ctx->npx;
+    B.npy = ctx->npy;
+    B.stride = ctx->node_stride;
+    B.num_nodes = ctx->num_nodes;
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_ASSEMBLE);
+        hipLaunchKernelGGL(gn_assemble_kernel,
+            dim3((unsigned)(((size_t)ctx->num_nodes * 4 + 255) / 256)),
+            dim3(256), 0, ctx->stream, B);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    ctx->has_system = true;
+    return SMVS_OK;
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_gn_construct(smvs_ctx *ctx, double regularization,
+    double light_surf_regularization, const double *lighting16,
+    int *num_active_patches)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface || !ctx->has_cameras) {
+        set_error("smvs_gn_construct: cameras and surface must be set first");
+        return SMVS_ERR_STATE;
+    }
+    for (int j = 0; j < ctx->n_subs; ++j)
+        if (ctx->subs[j].grad == nullptr) {
+            set_error("smvs_gn_construct: sub view %d has no planes", j);
+            return SMVS_ERR_STATE;
+        }
+    if (lighting16 != nullptr && !ctx->has_shading) {
+        set_error("smvs_gn_construct: lighting given but no shading planes");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (lighting16 != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->lighting, lighting16,
+            16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = gn_construct_launch(ctx, regularization,
+        light_surf_regularization, lighting16 != nullptr);
+    if (rc != SMVS_OK)
+        return rc;
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
+        sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (num_active_patches != nullptr)
+        *num_active_patches = ctx->status_host[I_ACTIVE_PATCHES];
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_gn_download(smvs_ctx *ctx, double *H9, double *g, double *P)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_system) {
+        set_error("smvs_gn_download: no system constructed");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const N = (size_t)ctx->num_nodes;
+    if (H9 != nullptr) {
+        std::vector<double> tmp(N * 9 * 16);
+        SMVS_HIP_CHECK(hipMemcpyAsync(tmp.data(), ctx->H9,
+            tmp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (size_t s = 0; s < 9; ++s)
+            for (size_t n = 0; n < N; ++n)
+                memcpy(H9 + (n * 9 + s) * 16, tmp.data() + (s * N + n) * 16,
+                    16 * sizeof(double));
+    }
+    if (g != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(g, ctx->g, N * 4 * sizeof(double),
+            hipMemcpyDeviceToHost, ctx->stream));
+    if (P != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(P, ctx->Pinv, N * 16 * sizeof(double),
+            hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
+    const double *P)
+{
+    SMVS_REQUIRE(ctx && H9 && g && P, "null argument");
+    if (!ctx->has_surface) {
+        set_error("smvs_gn_upload: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const N = (size_t)ctx->num_nodes;
+    std::vector<double> tmp(N * 9 * 16);
+    for (size_t s = 0; s < 9; ++s)
+        for (size_t n = 0; n < N; ++n)
+            memcpy(tmp.data() + (s * N + n) * 16, H9 + (n * 9 + s) * 16,
+                16 * sizeof(double));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->H9, tmp.data(),
+        tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->g, g, N * 4 * sizeof(double),
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->Pinv, P, N * 16 * sizeof(double),
+        hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->has_system = true;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_system) {
+        set_error("smvs_gn_download_patch_systems: no system constructed");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const P = (size_t)ctx->num_patches;
+    if (Hp != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(Hp, ctx->Hp, P * 256 * sizeof(double),
+            hipMemcpyDeviceToHost, ctx->stream));
+    if (gp != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(gp, ctx->gp, P * 16 * sizeof(double),
+            hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}

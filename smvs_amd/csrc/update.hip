@@ -1,0 +1,636 @@
+// Node update + re-activation, surface outputs, lighting normal equations and
+// the fused Newton loop.
+//
+// Replaces DepthOptimizer::fill_node_reprojections (reference:
+// lib/depth_optimizer.cc:647-677), Surface::update_nodes (lib/surface.cc:957-981),
+// the active-set test (lib/depth_optimizer.cc:275-303), Surface::get_depth_map /
+// get_normal_map (lib/surface.cc:155-183) and the accumulation loop of
+// LightOptimizer::fit_lighting_to_image (lib/light_optimizer.cc:32-49).
+#include "common.h"
+
+#include <cmath>
+
+namespace smvs_hip {
+
+// bicubic value / first derivatives at pixel (ci, cj) of a patch from the
+// 1-D Hermite table rows (global memory, [ps][12]).
+__device__ __forceinline__ void
+eval_patch(const double *tab, int ci, int cj, double const theta[16],
+    double *w, double *wx, double *wy)
+{
+    const double *X = tab + (size_t)ci * 12;
+    const double *Y = tab + (size_t)cj * 12;
+    double v = 0.0, vx = 0.0, vy = 0.0;
+#pragma unroll
+    for (int ey = 0; ey < 4; ++ey) {
+        double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+        for (int ex = 0; ex < 4; ++ex) {
+            int const a = ex & 1, ix = ex >> 1, b = ey & 1, iy = ey >> 1;
+            double const c = theta[4 * (2 * b + a) + ix + 2 * iy];
+            g0 = __builtin_fma(c, X[ex * 3 + 0], g0);
+            g1 = __builtin_fma(c, X[ex * 3 + 1], g1);
+        }
+        v = __builtin_fma(g0, Y[ey * 3 + 0], v);
+        vx = __builtin_fma(g1, Y[ey * 3 + 0], vx);
+        vy = __builtin_fma(g0, Y[ey * 3 + 1], vy);
+    }
+    *w = v;
+    *wx = vx;
+    *wy = vy;
+}
+
+struct ReactivateArgs {
+    const double *nodes;
+    const double *x;            // delta
+    const uint8_t *patch_valid;
+    const uint32_t *patch_vis;
+    const uint8_t *active;
+    uint8_t *active_next;
+    const double *hermite_tab;
+    const DeviceCameras *cams;
+    double *partials;
+    double *scalars;
+    int *status;
+    int npx, stride, ps, start_x, start_y, n_subs, num_patches, max_blocks;
+    double threshold;
+    int full_optimization;
+};
+
+// One thread per (patch, full-resolution pixel): project with the old and
+// the updated nodes into every visible neighbour (pixel coordinates WITHOUT
+// the +0.5 convention, depth_optimizer.cc:669-672).
+__global__ void __launch_bounds__(256)
+reactivate_kernel(ReactivateArgs A)
+{
+    if (A.status[I_NAN])
+        return;
+    int const pp = A.ps * A.ps;
+    long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int const patch = (int)(gid / pp);
+    int const pid = (int)(gid - (long long)patch * pp);
+    double sum = 0.0, cnt = 0.0;
+    if (patch < A.num_patches && A.patch_valid[patch]) {
+        int const ix = patch % A.npx, iy = patch / A.npx;
+        int const n00 = iy * A.stride + ix;
+        int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+        if ((A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
+            | A.active[ids[3]]) != 0) {
+            double th0[16], th1[16];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double const v = A.nodes[4 * (size_t)ids[n] + k];
+                    th0[4 * n + k] = v;
+                    th1[4 * n + k] = v + A.x[4 * (size_t)ids[n] + k];
+                }
+            int const ci = pid % A.ps, cj = pid / A.ps;
+            double w0, w1, dum0, dum1;
+            eval_patch(A.hermite_tab, ci, cj, th0, &w0, &dum0, &dum1);
+            eval_patch(A.hermite_tab, ci, cj, th1, &w1, &dum0, &dum1);
+            double const u = (double)(A.start_x + ix * A.ps + ci);
+            double const v = (double)(A.start_y + iy * A.ps + cj);
+            uint32_t const vis = A.patch_vis[patch];
+            bool moved = false;
+            for (int j = 0; j < A.n_subs; ++j) {
+                if (!((vis >> j) & 1u))
+                    continue;
+                const double *M = A.cams->M[j];
+                const double *t = A.cams->t[j];
+                double const p = M[0] * u + M[1] * v + M[2];
+                double const q = M[3] * u + M[4] * v + M[5];
+                double const r = M[6] * u + M[7] * v + M[8];
+                double const d0 = w0 * r + t[2], d1 = w1 * r + t[2];
+                double const ex = (w0 * p + t[0]) / d0 - (w1 * p + t[0]) / d1;
+                double const ey = (w0 * q + t[1]) / d0 - (w1 * q + t[1]) / d1;
+                double const diff = sqrt(ex * ex + ey * ey);
+                sum += diff;
+                cnt += 1.0;
+                moved |= diff > A.threshold;
+            }
+            if (moved && !A.full_optimization) {
+                A.active_next[ids[0]] = 1;
+                A.active_next[ids[1]] = 1;
+                A.active_next[ids[2]] = 1;
+                A.active_next[ids[3]] = 1;
+            }
+        }
+    }
+    if (!A.full_optimization)
+        return;
+    // mean reprojection delta (depth_optimizer.cc:277-282)
+    __shared__ double red[2][4];
+    __shared__ bool is_last;
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        cnt += __shfl_xor(cnt, off);
+    }
+    if (lane == 0) {
+        red[0][wave] = sum;
+        red[1][wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0, c = 0.0;
+        for (int wv = 0; wv < 4; ++wv) {
+            s += red[0][wv];
+            c += red[1][wv];
+        }
+        // the number of blocks can exceed the CG partial buffer: accumulate
+        // with atomics (order-dependent in the last bits; only compared
+        // against the 0.01 threshold).
+        atomicAdd(&A.scalars[S_SUMDIFF], s);
+        atomicAdd(&A.scalars[S_COUNT_DIFF], c);
+    }
+    (void)is_last;
+}
+
+// delta[0] NaN guard (depth_optimizer.cc:267-268) and reset of the next set
+__global__ void
+prepare_update_kernel(const double *x, uint8_t *active_next, int num_nodes,
+    double *scalars, int *status)
+{
+    int const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < num_nodes)
+        active_next[i] = 0;
+    if (i == 0) {
+        status[I_NAN] = isnan(x[0]) ? 1 : 0;
+        status[I_NUM_ACTIVE] = 0;
+        scalars[S_SUMDIFF] = 0.0;
+        scalars[S_COUNT_DIFF] = 0.0;
+    }
+}
+
+// nodes += delta for valid nodes (surface.cc:964-975); adopt the new active
+// set and count it (depth_optimizer.cc:291-303).
+__global__ void
+apply_update_kernel(double *nodes, const double *x, const uint8_t *node_valid,
+    uint8_t *active, const uint8_t *active_next, int num_nodes,
+    int full_optimization, int *status)
+{
+    if (status[I_NAN])
+        return;
+    int const i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool on = false;
+    if (i < num_nodes) {
+        if (node_valid[i]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                nodes[4 * (size_t)i + k] += x[4 * (size_t)i + k];
+        }
+        if (!full_optimization) {
+            active[i] = active_next[i];
+            on = active_next[i] == 1;
+        } else {
+            on = active[i] == 1;
+        }
+    }
+    unsigned long long const m = __ballot(on);
+    if ((threadIdx.x & 63) == 0 && m != 0ull)
+        atomicAdd(&status[I_NUM_ACTIVE], __popcll(m));
+}
+
+int
+reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization)
+{
+    int const N = ctx->num_nodes;
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+        hipLaunchKernelGGL(prepare_update_kernel, dim3((unsigned)((N + 255) / 256)),
+            dim3(256), 0, ctx->stream, ctx->x, ctx->active_next, N,
+            ctx->scalars, ctx->status);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    ReactivateArgs A;
+    A.nodes = ctx->nodes;
+    A.x = ctx->x;
+    A.patch_valid = ctx->patch_valid;
+    A.patch_vis = ctx->patch_vis;
+    A.active = ctx->active;
+    A.active_next = ctx->active_next;
+    A.hermite_tab = ctx->hermite_tab;
+    A.cams = ctx->cams;
+    A.partials = ctx->partials;
+    A.scalars = ctx->scalars;
+    A.status = ctx->status;
+    A.npx = ctx->npx;
+    A.stride = ctx->node_stride;
+    A.ps = ctx->patchsize;
+    A.start_x = ctx->start_x;
+    A.start_y = ctx->start_y;
+    A.n_subs = ctx->n_subs;
+    A.num_patches = ctx->num_patches;
+    A.max_blocks = ctx->max_blocks;
+    A.threshold = threshold;
+    A.full_optimization = full_optimization;
+    long long const items = (long long)ctx->num_patches * ctx->patchsize
+        * ctx->patchsize;
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_REACTIVATE);
+        hipLaunchKernelGGL(reactivate_kernel, dim3((unsigned)((items + 255) / 256)),
+            dim3(256), 0, ctx->stream, A);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+        hipLaunchKernelGGL(apply_update_kernel, dim3((unsigned)((N + 255) / 256)),
+            dim3(256), 0, ctx->stream, ctx->nodes, ctx->x, ctx->node_valid,
+            ctx->active, ctx->active_next, N, full_optimization, ctx->status);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// depth / normal maps
+// ---------------------------------------------------------------------------
+struct MapArgs {
+    const double *nodes;
+    const uint8_t *patch_valid;
+    const double *hermite_tab;
+    float *depth;     // [H][W] or nullptr
+    float *normals;   // [H][W][3] or nullptr
+    int W, H, npx, stride, ps, start_x, start_y, num_patches;
+    double inv_flen;
+};
+
+__global__ void __launch_bounds__(256)
+surface_maps_kernel(MapArgs A)
+{
+    int const pp = A.ps * A.ps;
+    long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int const patch = (int)(gid / pp);
+    int const pid = (int)(gid - (long long)patch * pp);
+    if (patch >= A.num_patches || !A.patch_valid[patch])
+        return;
+    int const ix = patch % A.npx, iy = patch / A.npx;
+    int const n00 = iy * A.stride + ix;
+    int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+    double th[16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            th[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
+    int const ci = pid % A.ps, cj = pid / A.ps;
+    double w, wx, wy;
+    eval_patch(A.hermite_tab, ci, cj, th, &w, &wx, &wy);
+    int const px = A.start_x + ix * A.ps + ci;
+    int const py = A.start_y + iy * A.ps + cj;
+    size_t const o = (size_t)py * A.W + px;
+    if (A.depth != nullptr)
+        A.depth[o] = (float)w;
+    if (A.normals != nullptr) {
+        // surface_derivative.cc:17-28
+        double const x = (double)px + 0.5 - (double)A.W / 2.0;
+        double const y = (double)py + 0.5 - (double)A.H / 2.0;
+        double const nz = (x * wx + y * wy + w) * A.inv_flen;
+        double const len = sqrt(wx * wx + wy * wy + nz * nz);
+        A.normals[3 * o + 0] = (float)(wx / len);
+        A.normals[3 * o + 1] = (float)(-wy / len);
+        A.normals[3 * o + 2] = (float)(nz / len);
+    }
+}
+
+static int
+launch_maps(smvs_ctx *ctx, float *depth_dev, float *normals_dev)
+{
+    MapArgs A;
+    A.nodes = ctx->nodes;
+    A.patch_valid = ctx->patch_valid;
+    A.hermite_tab = ctx->hermite_tab;
+    A.depth = depth_dev;
+    A.normals = normals_dev;
+    A.W = ctx->width;
+    A.H = ctx->height;
+    A.npx = ctx->npx;
+    A.stride = ctx->node_stride;
+    A.ps = ctx->patchsize;
+    A.start_x = ctx->start_x;
+    A.start_y = ctx->start_y;
+    A.num_patches = ctx->num_patches;
+    A.inv_flen = (double)ctx->inv_flen;
+    long long const items = (long long)ctx->num_patches * ctx->patchsize
+        * ctx->patchsize;
+    ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+    hipLaunchKernelGGL(surface_maps_kernel, dim3((unsigned)((items + 255) / 256)),
+        dim3(256), 0, ctx->stream, A);
+    SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// lighting normal equations: A += sh sh^T, b += sh I over valid pixels
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void
+sh_basis_4_band(const double n[3], double sh[16])
+{
+    double const nx = n[0], ny = n[1], nz = n[2];
+    double const x2 = nx * nx, y2 = ny * ny, z2 = nz * nz;
+    sh[0] = 1.0; sh[1] = ny; sh[2] = nz; sh[3] = nx;
+    sh[4] = nx * ny; sh[5] = ny * nz; sh[6] = -x2 - y2 + 2.0 * z2;
+    sh[7] = nx * nz; sh[8] = x2 - y2;
+    sh[9] = (3.0 * x2 - y2) * ny; sh[10] = nx * ny * nz;
+    sh[11] = (4.0 * z2 - x2 - y2) * ny;
+    sh[12] = (2.0 * z2 - 3.0 * x2 - 3.0 * y2) * nz;
+    sh[13] = (4.0 * z2 - x2 - y2) * nx;
+    sh[14] = (x2 - y2) * nz; sh[15] = (x2 - 3.0 * y2) * nx;
+}
+
+constexpr int LIGHT_BLOCKS = 512;
+
+// partial[block][152]: upper triangle of A (136) then b (16)
+__global__ void __launch_bounds__(256)
+light_accumulate_kernel(const float *__restrict__ normals,
+    const float *__restrict__ image, size_t num_pixels,
+    double *__restrict__ partial)
+{
+    double acc[152];
+#pragma unroll
+    for (int i = 0; i < 152; ++i)
+        acc[i] = 0.0;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+         p < num_pixels; p += (size_t)gridDim.x * blockDim.x) {
+        double const n[3] = { (double)normals[3 * p], (double)normals[3 * p + 1],
+            (double)normals[3 * p + 2] };
+        double const len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        float const iv = image[p];
+        if (fabs(len - 1.0) > 1e-6 || iv < 0.05f)
+            continue;
+        double sh[16];
+        sh_basis_4_band(n, sh);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int j = i; j < 16; ++j)
+                acc[k++] += sh[i] * sh[j];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[136 + i] += sh[i] * (double)iv;
+    }
+    __shared__ double red[4][152];
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 152; ++i) {
+        double s = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            s += __shfl_xor(s, off);
+        if (lane == 0)
+            red[wave][i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 152; i += blockDim.x)
+        partial[(size_t)blockIdx.x * 152 + i] = red[0][i] + red[1][i]
+            + red[2][i] + red[3][i];
+}
+
+__global__ void
+light_finalize_kernel(const double *__restrict__ partial, int blocks,
+    double *__restrict__ Ab)
+{
+    int const i = threadIdx.x;
+    if (i >= 152)
+        return;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b)
+        s += partial[(size_t)b * 152 + i];
+    if (i >= 136) {
+        Ab[256 + (i - 136)] = s;
+        return;
+    }
+    // unpack upper-triangle index
+    int r = 0, k = i;
+    while (k >= 16 - r) {
+        k -= 16 - r;
+        r += 1;
+    }
+    int const c = r + k;
+    Ab[r * 16 + c] = s;
+    Ab[c * 16 + r] = s;
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_update_and_reactivate(smvs_ctx *ctx, double threshold,
+    int full_optimization, int *num_active, double *mean_delta, int *nan_flag)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface || !ctx->has_cameras) {
+        set_error("smvs_update_and_reactivate: no surface / cameras");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = reactivate_launch(ctx, threshold, full_optimization);
+    if (rc != SMVS_OK)
+        return rc;
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
+        sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->scalars_host, ctx->scalars,
+        sizeof(double) * S_NUM, hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (num_active != nullptr)
+        *num_active = ctx->status_host[I_NUM_ACTIVE];
+    if (nan_flag != nullptr)
+        *nan_flag = ctx->status_host[I_NAN];
+    if (mean_delta != nullptr)
+        *mean_delta = ctx->scalars_host[S_COUNT_DIFF] > 0.0
+            ? ctx->scalars_host[S_SUMDIFF] / ctx->scalars_host[S_COUNT_DIFF]
+            : 0.0;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
+    smvs_gn_loop_stats *stats)
+{
+    SMVS_REQUIRE(ctx && prm && stats, "null argument");
+    if (!ctx->has_surface || !ctx->has_cameras) {
+        set_error("smvs_gn_run_loop: no surface / cameras");
+        return SMVS_ERR_STATE;
+    }
+    if (prm->use_lighting && !ctx->has_shading) {
+        set_error("smvs_gn_run_loop: lighting requested without shading planes");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    memset(stats, 0, sizeof(*stats));
+    int rc;
+    if (prm->reset_active)
+        if ((rc = smvs_ctx_set_active(ctx, nullptr)) != SMVS_OK)
+            return rc;
+    if (prm->use_lighting)
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->lighting, prm->lighting,
+            16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+
+    int num_initial = 0;
+    if ((rc = smvs_get_active(ctx, nullptr, &num_initial)) != SMVS_OK)
+        return rc;
+    int num_active = num_initial;
+    int newton_step = 0;
+    // depth_optimizer.cc:219-220
+    while (newton_step < prm->max_newton_steps
+        && num_active > num_initial / 20) {
+        newton_step += 1;
+        if ((rc = gn_construct_launch(ctx, prm->regularization,
+                prm->light_surf_regularization, prm->use_lighting != 0)) != SMVS_OK)
+            return rc;
+        int iters = 0, info = 0;
+        if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
+                prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
+            return rc;
+        stats->linear_iterations += iters;
+        stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
+        if ((rc = reactivate_launch(ctx, prm->active_threshold,
+                prm->full_optimization)) != SMVS_OK)
+            return rc;
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
+            sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->scalars_host, ctx->scalars,
+            sizeof(double) * S_NUM, hipMemcpyDeviceToHost, ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->status_host[I_NAN]) {
+            stats->nan_break = 1;
+            break;
+        }
+        if (prm->full_optimization) {
+            double const cnt = ctx->scalars_host[S_COUNT_DIFF];
+            double const update = cnt > 0.0
+                ? ctx->scalars_host[S_SUMDIFF] / cnt : 0.0;
+            if (update < prm->full_opt_threshold)
+                break;
+            continue;
+        }
+        num_active = ctx->status_host[I_NUM_ACTIVE];
+    }
+    stats->newton_steps = newton_step;
+    stats->final_active_nodes = num_active;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_get_depth_map(smvs_ctx *ctx, float *depth)
+{
+    SMVS_REQUIRE(ctx && depth, "null argument");
+    if (!ctx->has_surface) {
+        set_error("smvs_get_depth_map: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const npix = (size_t)ctx->width * ctx->height;
+    float *buf = nullptr;
+    int rc = device_alloc(&buf, npix);
+    if (rc != SMVS_OK)
+        return rc;
+    hipError_t e = hipMemsetAsync(buf, 0, npix * sizeof(float), ctx->stream);
+    if (e == hipSuccess)
+        rc = launch_maps(ctx, buf, nullptr);
+    if (e == hipSuccess && rc == SMVS_OK)
+        e = hipMemcpyAsync(depth, buf, npix * sizeof(float),
+            hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) {
+        set_error("smvs_get_depth_map: %s", hipGetErrorString(e));
+        return SMVS_ERR_HIP;
+    }
+    return rc;
+}
+
+extern "C" int
+smvs_get_normal_map(smvs_ctx *ctx, float *normals)
+{
+    SMVS_REQUIRE(ctx && normals, "null argument");
+    if (!ctx->has_surface) {
+        set_error("smvs_get_normal_map: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const n = (size_t)ctx->width * ctx->height * 3;
+    float *buf = nullptr;
+    int rc = device_alloc(&buf, n);
+    if (rc != SMVS_OK)
+        return rc;
+    hipError_t e = hipMemsetAsync(buf, 0, n * sizeof(float), ctx->stream);
+    if (e == hipSuccess)
+        rc = launch_maps(ctx, nullptr, buf);
+    if (e == hipSuccess && rc == SMVS_OK)
+        e = hipMemcpyAsync(normals, buf, n * sizeof(float),
+            hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) {
+        set_error("smvs_get_normal_map: %s", hipGetErrorString(e));
+        return SMVS_ERR_HIP;
+    }
+    return rc;
+}
+
+extern "C" int
+smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface || !ctx->has_shading) {
+        set_error("smvs_light_accumulate: needs a surface and a shading image");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const npix = (size_t)ctx->width * ctx->height;
+    float *normals = nullptr;
+    double *partial = nullptr;
+    int rc = device_alloc(&normals, npix * 3);
+    if (rc != SMVS_OK)
+        return rc;
+    if ((rc = device_alloc(&partial, (size_t)LIGHT_BLOCKS * 152)) != SMVS_OK) {
+        (void)hipFree(normals);
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(normals, 0, npix * 3 * sizeof(float),
+        ctx->stream);
+    if (e == hipSuccess)
+        rc = launch_maps(ctx, nullptr, normals);
+    if (e == hipSuccess && rc == SMVS_OK) {
+        ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+        hipLaunchKernelGGL(light_accumulate_kernel, dim3(LIGHT_BLOCKS),
+            dim3(256), 0, ctx->stream, normals, ctx->main_shading, npix,
+            partial);
+        hipLaunchKernelGGL(light_finalize_kernel, dim3(1), dim3(256), 0,
+            ctx->stream, partial, LIGHT_BLOCKS, ctx->lightAb);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(normals);
+    (void)hipFree(partial);
+    if (e != hipSuccess) {
+        set_error("smvs_light_accumulate: %s", hipGetErrorString(e));
+        return SMVS_ERR_HIP;
+    }
+    if (Ab272_dev != nullptr)
+        *Ab272_dev = ctx->lightAb;
+    return rc;
+}
+
+extern "C" int
+smvs_light_accumulate(smvs_ctx *ctx, double *A256, double *b16)
+{
+    SMVS_REQUIRE(ctx && A256 && b16, "null argument");
+    int rc = smvs_light_accumulate_dev(ctx, nullptr);
+    if (rc != SMVS_OK)
+        return rc;
+    double host[272];
+    SMVS_HIP_CHECK(hipMemcpy(host, ctx->lightAb, sizeof(host),
+        hipMemcpyDeviceToHost));
+    memcpy(A256, host, 256 * sizeof(double));
+    memcpy(b16, host + 256, 16 * sizeof(double));
+    return SMVS_OK;
+}

@@ -1,0 +1,242 @@
+"""Thin Python handle on one smvs_ctx (one reference view on one GPU).
+
+All arithmetic happens in libsmvs_hip.so; this module only marshals numpy
+buffers across the C ABI of include/smvs_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import LoopParams, LoopStats, check
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count():
+    return _capi.load().smvs_device_count()
+
+
+class ViewContext:
+    """One reference view + its neighbours on one GPU."""
+
+    def __init__(self, width, height, n_subs, device=0):
+        self.lib = _capi.load()
+        self.width, self.height, self.n_subs = width, height, n_subs
+        self.handle = C.c_void_p()
+        check(self.lib.smvs_ctx_create(device, width, height, n_subs,
+                                       C.byref(self.handle)))
+        self.num_nodes = 0
+        self.num_patches = 0
+
+    def close(self):
+        if self.handle:
+            self.lib.smvs_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ uploads
+    def set_views(self, views):
+        """views: dict as produced by smvs_amd.synth.make_problem."""
+        M = _f64(views["M"]).reshape(-1, 9); t = _f64(views["t"]).reshape(-1, 3)
+        assert M.shape[0] == self.n_subs
+        check(self.lib.smvs_ctx_set_cameras(self.handle, _p(M, _dp), _p(t, _dp),
+              C.c_float(views["flen"]), C.c_float(views["inv_flen"])))
+        grad = _f32(views["grad"])
+        assert grad.shape == (self.height, self.width, 2)
+        sh = _f32(views["shading"]) if views.get("shading") is not None else None
+        shg = _f32(views["shading_grad"]) if views.get("shading_grad") is not None else None
+        check(self.lib.smvs_ctx_upload_main(self.handle, _p(grad, _fp),
+                                            _p(sh, _fp), _p(shg, _fp)))
+        for j, (g, h) in enumerate(views["subs"]):
+            g = _f32(g); h = _f32(h)
+            check(self.lib.smvs_ctx_upload_sub(self.handle, j, g.shape[1],
+                  g.shape[0], _p(g, _fp), _p(h, _fp)))
+
+    def set_surface(self, surf):
+        nodes = _f64(surf["nodes"]).reshape(-1, 4)
+        nv = np.ascontiguousarray(surf["node_valid"], dtype=np.uint8)
+        pv = np.ascontiguousarray(surf["patch_valid"], dtype=np.uint8)
+        vis = np.ascontiguousarray(surf["patch_vis"], dtype=np.uint32)
+        self.num_nodes = (surf["npx"] + 1) * (surf["npy"] + 1)
+        self.num_patches = surf["npx"] * surf["npy"]
+        assert nodes.shape[0] == self.num_nodes and pv.size == self.num_patches
+        check(self.lib.smvs_ctx_set_surface(self.handle, surf["scale"],
+              surf["npx"], surf["npy"], surf["start_x"], surf["start_y"],
+              _p(nodes, _dp), _p(nv, _u8p), _p(pv, _u8p), _p(vis, _u32p)))
+
+    def set_active(self, active=None):
+        a = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        check(self.lib.smvs_ctx_set_active(self.handle, _p(a, _u8p)))
+
+    def get_active(self):
+        a = np.zeros(self.num_nodes, dtype=np.uint8); n = C.c_int(0)
+        check(self.lib.smvs_get_active(self.handle, _p(a, _u8p), C.byref(n)))
+        return a, n.value
+
+    def get_nodes(self):
+        nodes = np.zeros((self.num_nodes, 4))
+        check(self.lib.smvs_get_nodes(self.handle, _p(nodes, _dp)))
+        return nodes
+
+    def set_nodes(self, nodes):
+        nodes = _f64(nodes).reshape(-1, 4)
+        assert nodes.shape[0] == self.num_nodes
+        check(self.lib.smvs_set_nodes(self.handle, _p(nodes, _dp)))
+
+    # ------------------------------------------------------------ GN step
+    def gn_construct(self, regularization, light_reg=0.0, lighting=None):
+        lt = _f64(lighting) if lighting is not None else None
+        n = C.c_int(0)
+        check(self.lib.smvs_gn_construct(self.handle, C.c_double(regularization),
+              C.c_double(light_reg), _p(lt, _dp), C.byref(n)))
+        return n.value
+
+    def gn_download(self):
+        N = self.num_nodes
+        H9 = np.zeros((N, 9, 16)); g = np.zeros(4 * N); P = np.zeros((N, 16))
+        check(self.lib.smvs_gn_download(self.handle, _p(H9, _dp), _p(g, _dp),
+                                        _p(P, _dp)))
+        return H9, g, P
+
+    def gn_upload(self, H9, g, P):
+        H9 = _f64(H9); g = _f64(g); P = _f64(P)
+        check(self.lib.smvs_gn_upload(self.handle, _p(H9, _dp), _p(g, _dp),
+                                      _p(P, _dp)))
+
+    def gn_patch_systems(self):
+        Hp = np.zeros((self.num_patches, 16, 16)); gp = np.zeros((self.num_patches, 16))
+        check(self.lib.smvs_gn_download_patch_systems(self.handle, _p(Hp, _dp),
+                                                      _p(gp, _dp)))
+        return Hp, gp
+
+    def cg_solve(self, max_iterations=200, error_tolerance=-1.0, q_tolerance=1e-3):
+        it = C.c_int(0); info = C.c_int(0)
+        check(self.lib.smvs_cg_solve(self.handle, max_iterations,
+              C.c_double(error_tolerance), C.c_double(q_tolerance),
+              C.byref(it), C.byref(info)))
+        return it.value, info.value
+
+    def cg_x(self):
+        x = np.zeros(4 * self.num_nodes)
+        check(self.lib.smvs_cg_download_x(self.handle, _p(x, _dp)))
+        return x
+
+    def cg_set_x(self, x):
+        x = _f64(x)
+        check(self.lib.smvs_cg_upload_x(self.handle, _p(x, _dp)))
+
+    def update_and_reactivate(self, threshold=0.15, full_optimization=False):
+        n = C.c_int(0); mean = C.c_double(0.0); nan = C.c_int(0)
+        check(self.lib.smvs_update_and_reactivate(self.handle, C.c_double(threshold),
+              1 if full_optimization else 0, C.byref(n), C.byref(mean), C.byref(nan)))
+        return n.value, mean.value, nan.value
+
+    def run_loop(self, regularization, light_reg=0.0, lighting=None,
+                 full_optimization=False, max_newton_steps=200,
+                 cg_max_iterations=200, reset_active=True):
+        p = LoopParams()
+        p.regularization = regularization
+        p.light_surf_regularization = light_reg
+        p.full_optimization = 1 if full_optimization else 0
+        p.max_newton_steps = max_newton_steps
+        p.cg_max_iterations = cg_max_iterations
+        p.cg_q_tolerance = 1e-3
+        p.active_threshold = 0.15
+        p.full_opt_threshold = 0.01
+        p.use_lighting = 1 if lighting is not None else 0
+        if lighting is not None:
+            for i in range(16):
+                p.lighting[i] = float(lighting[i])
+        p.reset_active = 1 if reset_active else 0
+        s = LoopStats()
+        check(self.lib.smvs_gn_run_loop(self.handle, C.byref(p), C.byref(s)))
+        return dict(newton_steps=s.newton_steps,
+                    linear_iterations=s.linear_iterations,
+                    active_patch_steps=s.active_patch_steps,
+                    final_active_nodes=s.final_active_nodes,
+                    nan_break=s.nan_break)
+
+    # ------------------------------------------------------------ outputs
+    def depth_map(self):
+        out = np.zeros((self.height, self.width), dtype=np.float32)
+        check(self.lib.smvs_get_depth_map(self.handle, _p(out, _fp)))
+        return out
+
+    def normal_map(self):
+        out = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        check(self.lib.smvs_get_normal_map(self.handle, _p(out, _fp)))
+        return out
+
+    def light_accumulate(self):
+        A = np.zeros((16, 16)); b = np.zeros(16)
+        check(self.lib.smvs_light_accumulate(self.handle, _p(A, _dp), _p(b, _dp)))
+        return A, b
+
+    def synchronize(self):
+        check(self.lib.smvs_ctx_synchronize(self.handle))
+
+    # ---------------------------------------------------------- profiling
+    def profile(self, on=True):
+        check(self.lib.smvs_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.smvs_profile_reset(self.handle))
+
+    def profile_get(self):
+        ms = (C.c_double * 8)(); cnt = (C.c_longlong * 8)()
+        check(self.lib.smvs_profile_get(self.handle, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(_capi.K_NAMES)}
+
+
+def sgm_run(main_img, neighbor_img, M, t, min_depth, max_depth, num_steps=128,
+            p1=6, p2=96, device=0, want_volumes=False):
+    lib = _capi.load()
+    main_img = np.ascontiguousarray(main_img, dtype=np.uint8)
+    neighbor_img = np.ascontiguousarray(neighbor_img, dtype=np.uint8)
+    M = _f32(M).reshape(9); t = _f32(t).reshape(3)
+    h, w = main_img.shape; nh, nw = neighbor_img.shape
+    depth = np.zeros((h, w), dtype=np.float32)
+    argmin = np.zeros((h, w), dtype=np.int32)
+    cost = np.zeros((h, w, num_steps), dtype=np.uint16) if want_volumes else None
+    sgm = np.zeros((h, w, num_steps), dtype=np.uint16) if want_volumes else None
+    check(lib.smvs_sgm_run(device, _p(main_img, _u8p), w, h,
+          _p(neighbor_img, _u8p), nw, nh, _p(M, _fp), _p(t, _fp),
+          C.c_float(min_depth), C.c_float(max_depth), num_steps,
+          C.c_uint16(p1), C.c_uint16(p2), _p(depth, _fp), _p(argmin, _i32p),
+          _p(cost, _u16p), _p(sgm, _u16p)))
+    return dict(depth=depth, argmin=argmin, cost=cost, sgm=sgm)
+
+
+def bilateral_upsample(dm, ci, sigma=5.0, kernel_size=5, device=0):
+    lib = _capi.load()
+    dm = _f32(dm); ci = _f32(ci)
+    if ci.ndim == 2:
+        ci = ci[:, :, None]
+    h, w, c = ci.shape; dh, dw = dm.shape
+    out = np.zeros((h, w), dtype=np.float32)
+    check(lib.smvs_bilateral_upsample(device, _p(dm, _fp), dw, dh, _p(ci, _fp),
+          w, h, c, C.c_float(sigma), kernel_size, _p(out, _fp)))
+    return out

@@ -1,0 +1,183 @@
+"""Parity of the HIP hot path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  FP64 path: tolerances are written at each assert;
+integer / index outputs (active sets, iteration counts) must match exactly.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import smvs_amd
+    if smvs_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on a GPU")
+    return smvs_amd
+
+
+def _setup(hip, oracle, width, height, n_subs, scale, shading=False, noise=0.004):
+    from smvs_amd import synth
+    prob = synth.make_problem(width, height, n_subs, scale, shading=shading,
+                              noise=noise)
+    ctx = hip.ViewContext(width, height, n_subs)
+    ctx.set_views(prob["views"])
+    ctx.set_surface(prob["surf"])
+    orc = oracle.OracleProblem(prob["surf"], prob["views"])
+    return prob, ctx, orc
+
+
+@pytest.mark.parametrize("scale,size,n_subs", [(2, (192, 128), 3),
+                                                (3, (256, 192), 4),
+                                                (4, (320, 256), 2),
+                                                (5, (512, 384), 8)])
+def test_patch_systems_match_oracle(hip, oracle, scale, size, n_subs):
+    """per-patch 16x16 J^T W J and 16-gradient (gauss_newton_step.cc:145-518)."""
+    prob, ctx, orc = _setup(hip, oracle, size[0], size[1], n_subs, scale)
+    reg = 0.01
+    ctx.gn_construct(reg)
+    Hp, gp = ctx.gn_patch_systems()
+    valid = np.flatnonzero(prob["surf"]["patch_valid"])
+    rng = np.random.default_rng(0)
+    pick = rng.choice(valid, size=min(40, valid.size), replace=False)
+    worst_H = worst_g = 0.0
+    for p in pick:
+        g_ref, H_ref = orc.gn_patch(int(p), reg)
+        H_gpu = np.triu(Hp[p])
+        worst_H = max(worst_H, _rel(H_gpu, np.triu(H_ref)))
+        worst_g = max(worst_g, _rel(gp[p], g_ref))
+    # FP64, different (factored) summation order: 1e-10 relative
+    assert worst_H < 1e-10, worst_H
+    assert worst_g < 1e-10, worst_g
+    ctx.close()
+
+
+@pytest.mark.parametrize("shading,light_reg", [(False, 0.0), (True, 0.0), (True, 0.5)])
+def test_assembled_system_matches_oracle(hip, oracle, shading, light_reg):
+    """H (block stencil), g and the inverted diagonal blocks, incl. the
+    shading term and the inactive-node rule (gauss_newton_step.cc:88-142)."""
+    prob, ctx, orc = _setup(hip, oracle, 192, 128, 3, 2, shading=shading)
+    lighting = prob["lighting"] if shading else None
+    reg = 0.01
+    surf = prob["surf"]
+    rng = np.random.default_rng(1)
+    active = surf["node_valid"].copy()
+    active[rng.random(active.size) < 0.3] = 0  # partially active set
+    ctx.set_active(active)
+    n_gpu = ctx.gn_construct(reg, light_reg, lighting)
+    H9, g, P = ctx.gn_download()
+    ref = orc.gn_construct(active, reg, light_reg, lighting)
+    assert n_gpu == ref["active_patches"]
+    assert _rel(H9, ref["H9"]) < 1e-10
+    assert _rel(g, ref["g"]) < 1e-10
+    # blocks the reference does not hold are exactly zero
+    assert np.all(H9[ref["present"] == 0] == 0.0)
+    # inverted 4x4 blocks amplify by the block condition number
+    assert _rel(P, ref["P"]) < 1e-7
+    ctx.close()
+
+
+def test_spmv_and_cg_match_oracle(hip, oracle):
+    """ConjugateGradient::solve on identical systems: same iteration count,
+    same return info, x within 1e-9 (conjugate_gradient.h:72-202)."""
+    prob, ctx, orc = _setup(hip, oracle, 256, 192, 4, 2)
+    active = prob["surf"]["node_valid"]
+    ref = orc.gn_construct(active, 0.01)
+    # feed the ORACLE's system to the GPU solver so only the solver differs
+    ctx.gn_upload(ref["H9"], ref["g"], ref["P"])
+    tol = 0.01 * np.linalg.norm(ref["g"])
+    for max_it, q_tol, etol in [(200, 1e-3, -1.0), (200, 1e-9, 1e-20), (6, 1e-9, 1e-30)]:
+        it, info = ctx.cg_solve(max_it, etol, q_tol)
+        x = ctx.cg_x()
+        xr, itr, infor = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"],
+                                      max_it, tol if etol < 0 else etol, q_tol)
+        assert (it, info) == (itr, infor), (max_it, q_tol, it, info, itr, infor)
+        assert _rel(x, xr) < 1e-9
+    ctx.close()
+
+
+def test_update_and_reactivate_matches_oracle(hip, oracle):
+    """Surface::update_nodes + reprojection-based active set
+    (depth_optimizer.cc:271-303): identical sets, identical node values."""
+    prob, ctx, orc = _setup(hip, oracle, 256, 192, 4, 3, noise=0.02)
+    active = prob["surf"]["node_valid"].copy()
+    ref = orc.gn_construct(active, 0.01)
+    x, _, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
+                           0.01 * np.linalg.norm(ref["g"]), 1e-3)
+    ctx.cg_set_x(x)
+    n_gpu, _, nan = ctx.update_and_reactivate(0.15, False)
+    new_active, n_ref, _ = orc.update_and_reactivate(x, active)
+    a_gpu, cnt = ctx.get_active()
+    assert nan == 0
+    assert n_gpu == n_ref == cnt
+    assert np.array_equal(a_gpu, new_active)
+    assert 0 < n_ref < active.sum()  # the test actually exercises both outcomes
+    assert np.max(np.abs(ctx.get_nodes() - orc.nodes)) == 0.0
+    # full_optimization variant: mean reprojection delta
+    ctx.set_active(active); orc2 = oracle.OracleProblem(prob["surf"], prob["views"])
+    ctx.set_nodes(prob["surf"]["nodes"]); ctx.cg_set_x(x)
+    _, mean_gpu, _ = ctx.update_and_reactivate(0.15, True)
+    _, _, mean_ref = orc2.update_and_reactivate(x, active, full_optimization=True)
+    assert abs(mean_gpu - mean_ref) < 1e-9 * max(1.0, mean_ref)
+    ctx.close()
+
+
+def test_nan_guard(hip, oracle):
+    """delta[0] NaN leaves the surface untouched (depth_optimizer.cc:267-268)."""
+    prob, ctx, orc = _setup(hip, oracle, 192, 128, 2, 2)
+    x = np.zeros(4 * ctx.num_nodes); x[0] = np.nan
+    before = ctx.get_nodes()
+    ctx.cg_set_x(x)
+    _, _, nan = ctx.update_and_reactivate(0.15, False)
+    assert nan == 1
+    assert np.array_equal(ctx.get_nodes(), before, equal_nan=True)
+    ctx.close()
+
+
+def test_depth_and_normal_maps_match_oracle(hip, oracle):
+    """Surface::get_depth_map / get_normal_map (surface.cc:155-183)."""
+    prob, ctx, orc = _setup(hip, oracle, 256, 192, 2, 3)
+    d_gpu, d_ref = ctx.depth_map(), orc.depth_map()
+    n_gpu, n_ref = ctx.normal_map(), orc.normal_map()
+    assert np.array_equal(d_gpu == 0, d_ref == 0)
+    assert _rel(d_gpu, d_ref) < 1e-6       # float32 outputs
+    assert np.max(np.abs(n_gpu - n_ref)) < 1e-6
+    ctx.close()
+
+
+def test_light_fit_matches_oracle(hip, oracle):
+    """LightOptimizer accumulation (light_optimizer.cc:32-49)."""
+    prob, ctx, orc = _setup(hip, oracle, 256, 192, 2, 2, shading=True)
+    A_gpu, b_gpu = ctx.light_accumulate()
+    A_ref, b_ref = oracle.light_accumulate(orc.normal_map(), prob["views"]["shading"])
+    assert _rel(A_gpu, A_ref) < 1e-10
+    assert _rel(b_gpu, b_ref) < 1e-10
+    ctx.close()
+
+
+def test_gn_loop_tracks_oracle_loop(hip, oracle):
+    """The fused Newton loop (depth_optimizer.cc:219-304) against the same
+    loop run step by step on the oracle: same step count, same active-set
+    sizes, depth relative L2 <= 1e-4 (north_star tolerance)."""
+    prob, ctx, orc = _setup(hip, oracle, 256, 192, 4, 2, noise=0.01)
+    reg = 0.01
+    stats = ctx.run_loop(reg, max_newton_steps=6)
+    active = prob["surf"]["node_valid"].copy()
+    n_init = int(active.sum()); n_act = n_init; steps = 0; patch_steps = 0
+    while steps < 6 and n_act > n_init // 20:
+        steps += 1
+        ref = orc.gn_construct(active, reg)
+        patch_steps += ref["active_patches"]
+        x, _, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
+                               0.01 * np.linalg.norm(ref["g"]), 1e-3)
+        active, n_act, _ = orc.update_and_reactivate(x, active)
+    assert stats["newton_steps"] == steps
+    assert stats["active_patch_steps"] == patch_steps
+    assert stats["final_active_nodes"] == n_act
+    d_gpu, d_ref = ctx.depth_map(), orc.depth_map()
+    assert _rel(d_gpu, d_ref) <= 1e-4
+    ctx.close()
