@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gauss-Newton iterations/s x active patches on a
+1920x1080 reference view with 8 neighbours (BASELINE.json configs[1]:
+synthetic textured sphere, -o2, basic photometric optimizer).
+
+A "step" is one pass of the Newton loop of lib/depth_optimizer.cc:219-304
+(construct + PCG solve + node update + re-activation) at scale 2 over the
+evolving active set; when the loop ends (active <= initial/20, :220) the
+surface is reset to the same perturbed start and the loop restarts.
+value = sum over timed steps of active patches / wall time, inputs resident
+in HBM.  One process per GPU; ranks work on independent reference views
+(weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NSUBS, SCALE = 1920, 1080, 8, 2
+REG = 0.01            # 0.01 * alpha (app/smvsrecon.cc:712), alpha = 1
+NOISE = 0.002
+
+
+def make_problem(rank, small=False):
+    from smvs_amd import synth
+    if small:
+        return synth.make_problem(480, 270, NSUBS, SCALE, noise=NOISE, seed=2000 + rank)
+    return synth.make_problem(W, H, NSUBS, SCALE, noise=NOISE, seed=2000 + rank)
+
+
+def run_steps(ctx, prob, steps):
+    """Run exactly `steps` Newton steps; returns (active patch-steps, CG its)."""
+    done = 0
+    patch_steps = 0
+    cg_its = 0
+    need_reset = False
+    while done < steps:
+        if need_reset:
+            ctx.set_nodes(prob["surf"]["nodes"])
+        st = ctx.run_loop(REG, max_newton_steps=min(200, steps - done),
+                          reset_active=True)
+        done += st["newton_steps"]
+        patch_steps += st["active_patch_steps"]
+        cg_its += st["linear_iterations"]
+        need_reset = True
+        if st["newton_steps"] == 0:
+            raise RuntimeError("Newton loop made no progress")
+    return patch_steps, cg_its
+
+
+def cpu_baseline(prob):
+    """Oracle (CPU restatement, 1 thread) on a bounded window of the same
+    workload: one Newton step with ~1/4 of the nodes active."""
+    from oracle import pyoracle
+    surf = prob["surf"]
+    stride = surf["npx"] + 1
+    rows = surf["npy"] + 1
+    active = np.zeros((rows, stride), np.uint8)
+    r0, c0 = rows // 4, stride // 4
+    active[r0:r0 + rows // 2, c0:c0 + stride // 2] = 1
+    active = (active.reshape(-1) & surf["node_valid"]).astype(np.uint8)
+    orc = pyoracle.OracleProblem(surf, prob["views"])
+    t0 = time.perf_counter()
+    ref = orc.gn_construct(active, REG)
+    t1 = time.perf_counter()
+    x, it, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
+                            0.01 * np.linalg.norm(ref["g"]), 1e-3)
+    t2 = time.perf_counter()
+    orc.update_and_reactivate(x, active)
+    t3 = time.perf_counter()
+    return dict(value=ref["active_patches"] / (t3 - t0),
+                unit="active-patch-steps/s", cores=1, kind="port",
+                sample="1 Newton step, %d active patches (central 1/4 window of "
+                       "the %dx%d / %d-neighbour workload): construct %.2fs, "
+                       "PCG %d it %.2fs, update %.2fs"
+                       % (ref["active_patches"], W, H, NSUBS, t1 - t0, it,
+                          t2 - t1, t3 - t2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--small", action="store_true", help="480x270 debug size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch  # device plumbing + torch.distributed only
+    import smvs_amd
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if smvs_amd.device_count() < 1:
+        raise RuntimeError("bench.py needs a GPU")
+
+    prob = make_problem(rank, args.small)
+    surf = prob["surf"]
+    w, h = surf["width"], surf["height"]
+    ctx = smvs_amd.ViewContext(w, h, NSUBS, device=local_rank)
+    ctx.set_views(prob["views"])
+    ctx.set_surface(surf)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    run_steps(ctx, prob, args.warmup)
+    ctx.set_nodes(surf["nodes"])
+    barrier()
+    t0 = time.perf_counter()
+    patch_steps, cg_its = run_steps(ctx, prob, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        p = torch.tensor([patch_steps, cg_its], dtype=torch.float64, device="cuda")
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        patch_steps, cg_its = int(p[0].item()), int(p[1].item())
+
+    # ---- roofline of the dominant kernel: same steps, HIP-event timed ----
+    roof = None
+    cpu = None
+    if rank == 0:
+        ctx.set_nodes(surf["nodes"])
+        ctx.profile(True)
+        ctx.profile_reset()
+        run_steps(ctx, prob, args.steps)
+        prof = ctx.profile_get()
+        ctx.profile(False)
+        name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        n_nodes = ctx.num_nodes
+        # algorithmic bytes per launch (DESIGN.md "Kernels"):
+        per_node = {"cg_spmv": 9 * 128 + 32 + 32, "cg_update": 5 * 32 + 3 * 32 + 128,
+                    "cg_dir": 3 * 32}
+        kernels = {k: dict(ms=round(v[0], 3), launches=int(v[1]),
+                           avg_us=round(1e3 * v[0] / max(v[1], 1), 2))
+                   for k, v in prof.items()}
+        if name in per_node:
+            bytes_per_launch = per_node[name] * n_nodes
+            avg_s = ms * 1e-3 / cnt
+            achieved = bytes_per_launch / avg_s / 1e9
+            roof = dict(kernel=name, bound="hbm", achieved=round(achieved, 1),
+                        peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
+                        traffic=None, bytes_per_launch=bytes_per_launch,
+                        avg_us=round(avg_s * 1e6, 2), kernels=kernels)
+        else:
+            # construct kernels: FP64; algorithmic flops per active patch
+            # (~0.50 MFLOP at S = 8, P = 16) x patches per launch
+            flops = 0.50e6 * (patch_steps / max(args.steps, 1)) / max(world, 1)
+            avg_s = ms * 1e-3 / cnt
+            achieved = flops / avg_s / 1e12
+            roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 3),
+                        peak=78.6, unit="TFLOP/s", frac=round(achieved / 78.6, 4),
+                        traffic=None, avg_us=round(avg_s * 1e6, 2), kernels=kernels)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(prob)
+
+    if rank == 0:
+        value = patch_steps / elapsed
+        out = {
+            "metric": "Gauss-Newton iters/sec x active patches, 1920x1080 ref view, 8 neighbours",
+            "value": value, "unit": "active-patch-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %dx%d synthetic textured sphere, 1 ref + %d "
+                                   "neighbours, -o2 (scale 2, %d patches), basic photometric "
+                                   "optimizer, one reference view per GPU"
+                                   % (w, h, NSUBS, int(surf["patch_valid"].sum())),
+                       "regularization": REG, "cg_iterations_per_step": cg_its / max(args.steps * world, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
