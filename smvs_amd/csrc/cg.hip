@@ -5,8 +5,17 @@
 // SSEVector kernels (lib/sse_vector.cc).  The node grid is regular, so the
 // block-CSC matrix of the reference becomes a 9-point stencil of 4x4 blocks,
 // stored slot-major H9[slot][node][16]: no index arrays, fully coalesced.
-// All scalars (alpha, beta, residual norms, the quadratic-model test) live on
-// the device; the host only polls a "done" word once per chunk of iterations.
+//
+// Two kernels per iteration, no atomics, no intra-kernel fences:
+//   A_k  finishes iteration k-1 (termination tests, beta), forms
+//        d_k = z + beta d_{k-1} on the fly, computes Ad_k and the d.Ad partials;
+//   B_k  alpha = rr / d.Ad; x += alpha d; r -= alpha Ad; z = P r; partials of
+//        r.r, x.(b + r), z.r.
+// Every block re-reduces the (<= 1024) per-block partials of the previous
+// kernel in the same fixed order, so all blocks derive bit-identical scalars
+// and the result is independent of scheduling.  The CG state (rr, Q0, iter,
+// done) is double-buffered: block 0 of A_k writes bank k&1 while the other
+// blocks read bank (k-1)&1.  The host only polls a "done" word per chunk.
 #include "common.h"
 
 #include <cmath>
@@ -14,17 +23,72 @@
 namespace smvs_hip {
 
 constexpr int CG_THREADS = 256;
+constexpr int CG_MAX_BLOCKS = 1024;
 
-// ---- deterministic grid reductions --------------------------------------
-// Every block stores its partial sums; the last block to arrive (ticket)
-// adds the partials in block order, so results do not depend on scheduling.
+struct CgState {
+    double rr;       // z.r (r_dot_r of the reference)
+    double q0;
+    double tol;
+    double gnorm;
+    int iter;        // iteration this state belongs to
+    int done;
+    int info;
+    int pad;
+};
+
+struct CgArgs {
+    const double *H9;
+    const double *Pinv;
+    const double *g;
+    double *x, *r, *z, *Ad, *b;
+    double *dbuf[2];
+    double *partials;      // [4][CG_MAX_BLOCKS]
+    CgState *state;        // [2]
+    int *status;
+    int num_nodes, stride;
+    int k;                 // iteration index of this launch
+    int max_iterations;
+    double q_tolerance;
+    double fixed_tolerance;  // < 0: 0.01 * ||g||
+};
+
+// Sum NV arrays of `nb` per-block partials in a fixed order; every thread of
+// every block gets the same values.
 template <int NV>
-__device__ __forceinline__ bool
-block_reduce_and_ticket(double (&v)[NV], double *partials, int max_blocks,
-    int *ticket)
+__device__ __forceinline__ void
+reduce_partials(const double *partials, int nb, double (&out)[NV])
 {
     __shared__ double red[NV][CG_THREADS / 64];
-    __shared__ bool is_last;
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nb; i += CG_THREADS)
+            s += partials[(size_t)k * CG_MAX_BLOCKS + i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            s += __shfl_xor(s, off);
+        if (lane == 0)
+            red[k][wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < CG_THREADS / 64; ++wv)
+            s += red[k][wv];
+        out[k] = s;
+    }
+    __syncthreads();
+}
+
+// Block-level sum of per-thread values -> partials[k][blockIdx.x]
+template <int NV>
+__device__ __forceinline__ void
+store_partials(double (&v)[NV], double *partials)
+{
+    __shared__ double red[NV][CG_THREADS / 64];
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -43,90 +107,30 @@ block_reduce_and_ticket(double (&v)[NV], double *partials, int max_blocks,
 #pragma unroll
             for (int wv = 0; wv < CG_THREADS / 64; ++wv)
                 s += red[k][wv];
-            partials[(size_t)k * max_blocks + blockIdx.x] = s;
-        }
-        __threadfence();  // release the partials before taking the ticket
-        int const t = atomicAdd(ticket, 1);
-        is_last = (t == (int)gridDim.x - 1);
-        if (is_last)
-            *ticket = 0;
-    }
-    __syncthreads();
-    if (!is_last)
-        return false;
-    __threadfence();      // acquire the other blocks' partials
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += CG_THREADS)
-            s += __hip_atomic_load(&partials[(size_t)k * max_blocks + i],
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            s += __shfl_xor(s, off);
-        if (lane == 0)
-            red[k][wave] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            double s = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < CG_THREADS / 64; ++wv)
-                s += red[k][wv];
-            v[k] = s;
+            partials[(size_t)k * CG_MAX_BLOCKS + blockIdx.x] = s;
         }
     }
-    return threadIdx.x == 0;
 }
 
-struct CgArgs {
-    const double *H9;
-    const double *Pinv;
-    const double *g;
-    double *x, *r, *z, *Ad, *d, *b;
-    double *partials;
-    double *scalars;
-    int *status;
-    int num_nodes, stride, max_blocks;
-    double q_tolerance;
-    double fixed_tolerance;  // < 0: 0.01 * ||g||
-};
-
-// z = P r for one (node, row): block_sparse_matrix.h:289-295 accumulation order
-__device__ __forceinline__ double
-precond_row(const double *Pinv, const double *r, int n, int row)
-{
-#pragma clang fp contract(off)
-    const double *v = Pinv + (size_t)n * 16 + row * 4;
-    const double *rn = r + (size_t)n * 4;
-    double s = 0.0;
-    s += v[0] * rn[0];
-    s += v[1] * rn[1];
-    s += v[2] * rn[2];
-    s += v[3] * rn[3];
-    return s;
-}
-
-// b = -g, x = 0, r = b, z = P r, d = z; rr = z.r; tol from ||g||
+// b = -g, x = 0, r = b, z = P r, d_1 = z; partials of z.r and g.g
 __global__ void __launch_bounds__(CG_THREADS)
 cg_init_kernel(CgArgs A)
 {
-    int const gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int const n = gid >> 2, row = gid & 3;
+    int const items = A.num_nodes * 4;
     double v[2] = { 0.0, 0.0 };
-    if (n < A.num_nodes) {
+    for (int gid = blockIdx.x * CG_THREADS + threadIdx.x; gid < items;
+         gid += gridDim.x * CG_THREADS) {
+        int const n = gid >> 2, row = gid & 3;
         double const gi = A.g[gid];
         double const bi = -gi;
         A.b[gid] = bi;
         A.x[gid] = 0.0;
         A.r[gid] = bi;
-        // z needs the whole r of the node: read g directly
         const double *gn = A.g + (size_t)n * 4;
         const double *P = A.Pinv + (size_t)n * 16 + row * 4;
         double zi;
         {
+            // block_sparse_matrix.h:289-295 accumulation order
 #pragma clang fp contract(off)
             zi = 0.0;
             zi += P[0] * (-gn[0]);
@@ -135,45 +139,103 @@ cg_init_kernel(CgArgs A)
             zi += P[3] * (-gn[3]);
         }
         A.z[gid] = zi;
-        A.d[gid] = zi;
-        v[0] = zi * bi;
-        v[1] = gi * gi;
+        A.dbuf[1][gid] = zi;
+        v[0] += zi * bi;
+        v[1] += gi * gi;
     }
-    if (block_reduce_and_ticket<2>(v, A.partials, A.max_blocks,
-            &A.status[I_TICKET0])) {
-        A.scalars[S_RR] = v[0];
-        double const gnorm = sqrt(v[1]);
-        A.scalars[S_GNORM] = gnorm;
-        A.scalars[S_TOL] = A.fixed_tolerance < 0.0 ? gnorm * 0.01
-            : A.fixed_tolerance;
-        A.scalars[S_Q0] = -0.0;
-        A.status[I_DONE] = 0;
-        A.status[I_INFO] = SMVS_CG_MAX_ITERATIONS;
-        A.status[I_ITER] = 1;
-        // loop condition `num_iterations < max_iterations` fails at once
-        if (A.status[I_MAXITER] <= 1)
-            A.status[I_DONE] = 1;
-        __threadfence();
-    }
+    store_partials<2>(v, A.partials);
 }
 
-// Ad = A d (9-point block stencil), dAd partial sums.  One thread per
-// (node, row); a wave reads 16 consecutive nodes' rows of one slot as one
-// contiguous 2 KiB segment.  Accumulation follows the reference's order
-// (ascending block column, then column inside the block, separate mul/add)
-// so the product is bit-identical to BlockSparseMatrix::multiply.
 __global__ void __launch_bounds__(CG_THREADS)
-cg_spmv_kernel(CgArgs A)
+cg_init_finalize_kernel(CgArgs A, int nb)
 {
-    if (A.status[I_DONE])
+    double v[2];
+    reduce_partials<2>(A.partials, nb, v);
+    if (threadIdx.x != 0)
         return;
-    int const gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int const n = gid >> 2, row = gid & 3;
+    CgState s;
+    s.rr = v[0];
+    s.q0 = -0.0;  // -1.0 * x.(b + r) with x = 0
+    s.gnorm = sqrt(v[1]);
+    s.tol = A.fixed_tolerance < 0.0 ? s.gnorm * 0.01 : A.fixed_tolerance;
+    s.iter = 1;
+    // loop condition `num_iterations < max_iterations` fails at once
+    s.done = A.max_iterations <= 1 ? 1 : 0;
+    s.info = SMVS_CG_MAX_ITERATIONS;
+    s.pad = 0;
+    A.state[1] = s;
+    A.state[0] = s;
+    A.status[I_DONE] = s.done;
+    A.status[I_INFO] = s.info;
+    A.status[I_ITER] = 1;
+}
+
+// A_k: finish iteration k-1, form d_k, Ad_k = A d_k, partial d.Ad.
+// One thread per (node, row); a wave reads 16 consecutive nodes' rows of one
+// slot as one contiguous 2 KiB segment.  The product follows the reference's
+// accumulation order (ascending block column, then column inside the block,
+// separate mul/add) and is bit-identical to BlockSparseMatrix::multiply.
+__global__ void __launch_bounds__(CG_THREADS)
+cg_spmv_kernel(CgArgs A, int nb)
+{
+    CgState const prev = A.state[(A.k - 1) & 1];
+    if (prev.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            A.state[A.k & 1] = prev;
+        return;
+    }
+    double beta = 0.0;
+    if (A.k > 1) {
+        // termination tests of iteration k-1 (conjugate_gradient.h:136-198)
+        double v[3];
+        reduce_partials<3>(A.partials + CG_MAX_BLOCKS, nb, v);
+        double const new_rr = v[0];
+        double const Q1 = -1.0 * v[1];
+        int const it = prev.iter;  // == k - 1
+        int done = 0, info = SMVS_CG_MAX_ITERATIONS, iter_out = it + 1;
+        if (new_rr < prev.tol) {
+            done = 1; info = SMVS_CG_CONVERGENCE; iter_out = it;
+        } else {
+            double const zeta = it * (Q1 - prev.q0) / Q1;
+            if (zeta < A.q_tolerance) {
+                done = 1; info = SMVS_CG_CONVERGENCE; iter_out = it;
+            } else if (it + 1 >= A.max_iterations) {
+                done = 1;  // loop ran out: CG_MAX_ITERATIONS, count = max
+            }
+        }
+        beta = v[2] / prev.rr;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            CgState s = prev;
+            s.rr = v[2];
+            s.q0 = Q1;
+            s.iter = iter_out;
+            s.done = done;
+            s.info = info;
+            A.state[A.k & 1] = s;
+            if (done) {
+                A.status[I_DONE] = 1;
+                A.status[I_INFO] = info;
+                A.status[I_ITER] = iter_out;
+            }
+        }
+        if (done)
+            return;
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.state[A.k & 1] = prev;
+    }
+
+    const double *d_old = A.dbuf[(A.k - 1) & 1];
+    double *d_new = A.dbuf[A.k & 1];
+    bool const first = A.k == 1;
+    int const items = A.num_nodes * 4;
+    size_t const N = (size_t)A.num_nodes;
     double v[1] = { 0.0 };
-    if (n < A.num_nodes) {
-        int const ix = n % A.stride, iy = n / A.stride;
-        size_t const N = (size_t)A.num_nodes;
+    for (int gid = blockIdx.x * CG_THREADS + threadIdx.x; gid < items;
+         gid += gridDim.x * CG_THREADS) {
+        int const n = gid >> 2, row = gid & 3;
+        int const ix = n % A.stride;
         double acc = 0.0;
+        double d_own = 0.0;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             int const dx = s % 3 - 1, dy = s / 3 - 1;
@@ -182,7 +244,21 @@ cg_spmv_kernel(CgArgs A)
             if (mx < 0 || mx >= A.stride || m < 0 || m >= A.num_nodes)
                 continue;
             const double *blk = A.H9 + ((size_t)s * N + n) * 16 + row * 4;
-            const double *dm = A.d + (size_t)m * 4;
+            double dm[4];
+            if (first) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    dm[c] = d_new[(size_t)m * 4 + c];
+            } else {
+#pragma clang fp contract(off)
+                const double *zm = A.z + (size_t)m * 4;
+                const double *om = d_old + (size_t)m * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    dm[c] = zm[c] + beta * om[c];
+            }
+            if (s == 4)
+                d_own = dm[row];
             double const h0 = blk[0], h1 = blk[1], h2 = blk[2], h3 = blk[3];
             {
 #pragma clang fp contract(off)
@@ -193,107 +269,68 @@ cg_spmv_kernel(CgArgs A)
             }
         }
         A.Ad[gid] = acc;
-        v[0] = A.d[gid] * acc;
+        if (!first)
+            d_new[gid] = d_own;
+        v[0] += d_own * acc;
     }
-    if (block_reduce_and_ticket<1>(v, A.partials, A.max_blocks,
-            &A.status[I_TICKET1])) {
-        A.scalars[S_DAD] = v[0];
-        __threadfence();
-    }
+    store_partials<1>(v, A.partials);
 }
 
-// x += alpha d; r -= alpha Ad; z = P r; partial sums of r.r, x.(b + r), z.r;
-// then the termination tests of conjugate_gradient.h:136-198.
+// B_k: x += alpha d; r -= alpha Ad; z = P r; partials of r.r, x.(b + r), z.r
 __global__ void __launch_bounds__(CG_THREADS)
-cg_update_kernel(CgArgs A)
+cg_update_kernel(CgArgs A, int nb)
 {
-    if (A.status[I_DONE])
+    CgState const st = A.state[A.k & 1];
+    if (st.done)
         return;
-    int const gid = blockIdx.x * blockDim.x + threadIdx.x;
-    int const n = gid >> 2, row = gid & 3;
-    double const alpha = A.scalars[S_RR] / A.scalars[S_DAD];
+    double dad[1];
+    reduce_partials<1>(A.partials, nb, dad);
+    double const alpha = st.rr / dad[0];
+    const double *d = A.dbuf[A.k & 1];
+    int const items = A.num_nodes * 4;
+    // every thread runs the same number of rounds so the shuffles stay
+    // convergent
+    int const rounds = (items + gridDim.x * CG_THREADS - 1)
+        / (gridDim.x * CG_THREADS);
     double v[3] = { 0.0, 0.0, 0.0 };
-    bool const in_range = n < A.num_nodes;
-    double xi = 0.0, ri = 0.0;
-    if (in_range) {
+    for (int round = 0; round < rounds; ++round) {
+        int const gid = (round * gridDim.x + blockIdx.x) * CG_THREADS
+            + threadIdx.x;
+        bool const in_range = gid < items;
+        int const n = gid >> 2, row = gid & 3;
+        double xi = 0.0, ri = 0.0;
+        if (in_range) {
 #pragma clang fp contract(off)
-        xi = A.x[gid] + alpha * A.d[gid];
-        ri = A.r[gid] - alpha * A.Ad[gid];
-    }
-    // z = P r needs the node's whole residual: the four row-lanes of a node
-    // are neighbours in the wave.
-    int const base_lane = (threadIdx.x & 63) & ~3;
-    double rn[4];
+            xi = A.x[gid] + alpha * d[gid];
+            ri = A.r[gid] - alpha * A.Ad[gid];
+        }
+        // z = P r needs the node's whole residual: the four row-lanes of a
+        // node are neighbours in the wave.
+        int const base_lane = (threadIdx.x & 63) & ~3;
+        double rn[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        rn[k] = __shfl(ri, base_lane + k);
-    if (in_range) {
-        A.x[gid] = xi;
-        A.r[gid] = ri;
-        const double *P = A.Pinv + (size_t)n * 16 + row * 4;
-        double zi;
-        {
+        for (int c = 0; c < 4; ++c)
+            rn[c] = __shfl(ri, base_lane + c);
+        if (in_range) {
+            A.x[gid] = xi;
+            A.r[gid] = ri;
+            const double *P = A.Pinv + (size_t)n * 16 + row * 4;
+            double zi;
+            {
 #pragma clang fp contract(off)
-            zi = 0.0;
-            zi += P[0] * rn[0];
-            zi += P[1] * rn[1];
-            zi += P[2] * rn[2];
-            zi += P[3] * rn[3];
-        }
-        A.z[gid] = zi;
-        v[0] = ri * ri;
-        v[1] = xi * (A.b[gid] + ri);
-        v[2] = zi * ri;
-    }
-    if (block_reduce_and_ticket<3>(v, A.partials, A.max_blocks,
-            &A.status[I_TICKET2])) {
-        double const new_rr = v[0];
-        double const Q1 = -1.0 * v[1];
-        int const it = A.status[I_ITER];
-        bool done = false;
-        if (new_rr < A.scalars[S_TOL]) {
-            A.status[I_INFO] = SMVS_CG_CONVERGENCE;
-            done = true;
-        } else {
-            double const Q0 = A.scalars[S_Q0];
-            double const zeta = it * (Q1 - Q0) / Q1;
-            if (zeta < A.q_tolerance) {
-                A.status[I_INFO] = SMVS_CG_CONVERGENCE;
-                done = true;
+                zi = 0.0;
+                zi += P[0] * rn[0];
+                zi += P[1] * rn[1];
+                zi += P[2] * rn[2];
+                zi += P[3] * rn[3];
             }
+            A.z[gid] = zi;
+            v[0] += ri * ri;
+            v[1] += xi * (A.b[gid] + ri);
+            v[2] += zi * ri;
         }
-        A.scalars[S_RR_NEW] = new_rr;
-        A.scalars[S_Q1] = Q1;
-        if (!done) {
-            A.scalars[S_Q0] = Q1;
-            A.scalars[S_BETA] = v[2] / A.scalars[S_RR];
-            A.scalars[S_RR] = v[2];
-            A.status[I_ITER] = it + 1;
-            if (it + 1 >= A.status[I_MAXITER]) {
-                A.status[I_INFO] = SMVS_CG_MAX_ITERATIONS;
-                done = true;
-            }
-        }
-        if (done)
-            A.status[I_DONE] = 1;
-        __threadfence();
     }
-}
-
-// d = z + beta d
-__global__ void __launch_bounds__(CG_THREADS)
-cg_direction_kernel(CgArgs A)
-{
-    if (A.status[I_DONE])
-        return;
-    int const gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= A.num_nodes * 4)
-        return;
-    double const beta = A.scalars[S_BETA];
-    {
-#pragma clang fp contract(off)
-        A.d[gid] = A.z[gid] + beta * A.d[gid];
-    }
+    store_partials<3>(v, A.partials + CG_MAX_BLOCKS);
 }
 
 int
@@ -308,63 +345,60 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.r = ctx->r;
     A.z = ctx->z;
     A.Ad = ctx->Ad;
-    A.d = ctx->d;
     A.b = ctx->b;
+    A.dbuf[0] = ctx->d;
+    A.dbuf[1] = ctx->d2;
     A.partials = ctx->partials;
-    A.scalars = ctx->scalars;
+    A.state = reinterpret_cast<CgState *>(ctx->cg_state);
     A.status = ctx->status;
     A.num_nodes = ctx->num_nodes;
     A.stride = ctx->node_stride;
-    A.max_blocks = ctx->max_blocks;
+    A.k = 0;
+    A.max_iterations = max_iterations;
     A.q_tolerance = q_tolerance;
     A.fixed_tolerance = error_tolerance;
 
-    unsigned const blocks =
-        (unsigned)(((size_t)ctx->num_nodes * 4 + CG_THREADS - 1) / CG_THREADS);
-    if ((int)blocks > ctx->max_blocks) {
-        set_error("cg_solve_launch: reduction buffer too small");
-        return SMVS_ERR_STATE;
-    }
-    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status + I_MAXITER, &max_iterations,
-        sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    size_t const items = (size_t)ctx->num_nodes * 4;
+    int nb = (int)((items + CG_THREADS - 1) / CG_THREADS);
+    if (nb > CG_MAX_BLOCKS)
+        nb = CG_MAX_BLOCKS;
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_INIT);
-        hipLaunchKernelGGL(cg_init_kernel, dim3(blocks), dim3(CG_THREADS), 0,
+        hipLaunchKernelGGL(cg_init_kernel, dim3(nb), dim3(CG_THREADS), 0,
             ctx->stream, A);
+        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(CG_THREADS),
+            0, ctx->stream, A, nb);
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
+    // A_k for k = 1 .. max_iterations (A_max only finishes iteration max-1),
+    // B_k for k = 1 .. max_iterations - 1.
     int const chunk = 8;
-    int issued = 1;  // iteration counter of the next iteration to enqueue
-    bool done = max_iterations <= 1;
+    int k = 1;
+    bool done = false;
     while (!done) {
-        for (int k = 0; k < chunk && issued < max_iterations; ++k, ++issued) {
+        for (int c = 0; c < chunk && k <= max_iterations; ++c, ++k) {
+            A.k = k;
             {
                 ScopedKernelTimer timer(ctx, SMVS_K_CG_SPMV);
-                hipLaunchKernelGGL(cg_spmv_kernel, dim3(blocks),
-                    dim3(CG_THREADS), 0, ctx->stream, A);
+                hipLaunchKernelGGL(cg_spmv_kernel, dim3(nb), dim3(CG_THREADS),
+                    0, ctx->stream, A, nb);
             }
-            {
+            if (k < max_iterations) {
                 ScopedKernelTimer timer(ctx, SMVS_K_CG_UPDATE);
-                hipLaunchKernelGGL(cg_update_kernel, dim3(blocks),
-                    dim3(CG_THREADS), 0, ctx->stream, A);
-            }
-            {
-                ScopedKernelTimer timer(ctx, SMVS_K_CG_DIR);
-                hipLaunchKernelGGL(cg_direction_kernel, dim3(blocks),
-                    dim3(CG_THREADS), 0, ctx->stream, A);
+                hipLaunchKernelGGL(cg_update_kernel, dim3(nb),
+                    dim3(CG_THREADS), 0, ctx->stream, A, nb);
             }
         }
         SMVS_HIP_CHECK(hipGetLastError());
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
             sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        done = ctx->status_host[I_DONE] != 0 || issued >= max_iterations;
+        done = ctx->status_host[I_DONE] != 0 || k > max_iterations;
     }
-    if (max_iterations <= 1) {
-        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
-            sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
-        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->status_host[I_DONE] == 0) {
+        set_error("cg_solve_launch: solver did not report completion");
+        return SMVS_ERR_STATE;
     }
     if (num_iterations != nullptr)
         *num_iterations = ctx->status_host[I_ITER];

@@ -127,9 +127,10 @@ struct smvs_ctx {
 
     // CG vectors, [N][4] each
     double *x = nullptr, *r = nullptr, *z = nullptr, *Ad = nullptr,
-        *d = nullptr, *b = nullptr;
-    double *partials = nullptr;     // [4][max_blocks] reduction partials
+        *d = nullptr, *d2 = nullptr, *b = nullptr;
+    double *partials = nullptr;     // [4][1024] per-block reduction partials
     int max_blocks = 0;
+    void *cg_state = nullptr;       // CgState[2] (cg.hip)
     double *scalars = nullptr;      // [S_NUM]
     int *status = nullptr;          // [I_NUM]
     int *status_host = nullptr;     // pinned

@@ -136,7 +136,9 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || (rc = device_alloc(&ctx->scalars, S_NUM)) != SMVS_OK
         || (rc = device_alloc(&ctx->status, I_NUM)) != SMVS_OK
         || (rc = device_alloc(&ctx->lighting, 16)) != SMVS_OK
-        || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK) {
+        || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK
+        || (rc = device_alloc(&ctx->partials, 4 * 1024)) != SMVS_OK
+        || (rc = device_alloc(reinterpret_cast<char **>(&ctx->cg_state), 256)) != SMVS_OK) {
         smvs_ctx_destroy(ctx);
         return rc;
     }
@@ -164,7 +166,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->cams, ctx->subs_dev, ctx->nodes, ctx->node_valid, ctx->patch_valid,
         ctx->patch_vis, ctx->active, ctx->active_next, ctx->hermite_tab,
         ctx->Hp, ctx->gp, ctx->H9, ctx->Pinv, ctx->g, ctx->lighting, ctx->x,
-        ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->b, ctx->partials, ctx->scalars,
+        ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->d2, ctx->b, ctx->partials,
+        ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage };
     for (void *p : bufs)
         if (p)
@@ -359,10 +362,8 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
             || (rc = device_alloc(&ctx->z, cap * 4)) != SMVS_OK
             || (rc = device_alloc(&ctx->Ad, cap * 4)) != SMVS_OK
             || (rc = device_alloc(&ctx->d, cap * 4)) != SMVS_OK
+            || (rc = device_alloc(&ctx->d2, cap * 4)) != SMVS_OK
             || (rc = device_alloc(&ctx->b, cap * 4)) != SMVS_OK)
-            return rc;
-        ctx->max_blocks = (int)((cap * 4 + 255) / 256) + 8;
-        if ((rc = device_alloc(&ctx->partials, (size_t)ctx->max_blocks * 4)) != SMVS_OK)
             return rc;
         ctx->cap_nodes = cap;
     }

@@ -882,9 +882,9 @@ count_active_patches_kernel(const uint8_t *__restrict__ patch_valid,
         live = (active[n00] | active[n00 + 1] | active[n00 + stride]
             | active[n00 + stride + 1]) != 0;
     }
-    unsigned long long const m = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && m != 0ull)
-        atomicAdd(&status[I_ACTIVE_PATCHES], __popcll(m));
+    int const cnt = __syncthreads_count(live);
+    if (threadIdx.x == 0 && cnt != 0)
+        atomicAdd(&status[I_ACTIVE_PATCHES], cnt);
 }
 
 static int

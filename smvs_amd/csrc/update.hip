@@ -171,11 +171,10 @@ apply_update_kernel(double *nodes, const double *x, const uint8_t *node_valid,
     uint8_t *active, const uint8_t *active_next, int num_nodes,
     int full_optimization, int *status)
 {
-    if (status[I_NAN])
-        return;
+    bool const skip = status[I_NAN] != 0;
     int const i = blockIdx.x * blockDim.x + threadIdx.x;
     bool on = false;
-    if (i < num_nodes) {
+    if (!skip && i < num_nodes) {
         if (node_valid[i]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -188,9 +187,9 @@ apply_update_kernel(double *nodes, const double *x, const uint8_t *node_valid,
             on = active[i] == 1;
         }
     }
-    unsigned long long const m = __ballot(on);
-    if ((threadIdx.x & 63) == 0 && m != 0ull)
-        atomicAdd(&status[I_NUM_ACTIVE], __popcll(m));
+    int const cnt = __syncthreads_count(on);
+    if (threadIdx.x == 0 && cnt != 0)
+        atomicAdd(&status[I_NUM_ACTIVE], cnt);
 }
 
 int
