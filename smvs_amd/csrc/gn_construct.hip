@@ -49,6 +49,7 @@ struct PatchKernelArgs {
     int n_subs;
     int num_patches;
     double flen, inv_flen;
+    double inv_f, f2inv;         // 1 / flen, 1 / flen^2 (double)
     double reg, light_reg;
     int use_lighting;
 };
@@ -118,7 +119,7 @@ struct DivState {
     double x, y, f, f2inv;
     double w, wx, wy, wxy, wxx, wyy;
     double a, ax, ay, t, n, b, c, nx, ny;
-    double inv_n, inv_t, inv_t2, inv_t2f;
+    double inv_n, inv_t, inv_t2, inv_t2f, inv_f;
 };
 
 __device__ __forceinline__ void
@@ -168,7 +169,7 @@ normal_along(DivState const &s, double wp, double dxp, double dyp,
     double const np = t2p * s.inv_n;
     out[0] = (dxp * s.n - s.wx * np) * s.inv_t;
     out[1] = (-dyp * s.n + s.wy * np) * s.inv_t;
-    out[2] = (ap * s.n - s.a * np) * s.inv_t / s.f;
+    out[2] = (ap * s.n - s.a * np) * s.inv_t * s.inv_f;
 }
 
 // spherical_harmonics.h:53-73,133-151 and :79-127,157-201 contracted with the
@@ -299,10 +300,11 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         const double *M = A.cams->M[j];
         const double *t = A.cams->t[j];
         SubPlanes const sp = A.subs[j];
-        double p, q, r, a, b, d, d2, proj0, proj1, jac0, jac1, jac2, jac3;
+        double p, q, r, a, b, d, proj0, proj1;
         {
-            // correspondence.cc:36-51, 88-100 in the reference's operation
-            // order: the projection feeds float tap coordinates.
+            // correspondence.cc:36-51 in the reference's operation order
+            // (true divisions, no contraction): the projection feeds the
+            // float tap coordinates.
 #pragma clang fp contract(off)
             double const u = (double)px + 0.5, v = (double)py + 0.5;
             p = M[0] * u + M[1] * v + M[2];
@@ -311,20 +313,19 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
             a = w * p + t[0];
             b = w * q + t[1];
             d = w * r + t[2];
-            d2 = d * d;
             proj0 = a / d;
             proj1 = b / d;
             proj0 -= 0.5;
             proj1 -= 0.5;
-            jac0 = (wx * p + w * M[0]) / d;
-            jac2 = (wy * p + w * M[1]) / d;
-            jac0 -= a * (wx * r + w * M[6]) / d2;
-            jac2 -= a * (wy * r + w * M[7]) / d2;
-            jac1 = (wx * q + w * M[3]) / d;
-            jac3 = (wy * q + w * M[4]) / d;
-            jac1 -= b * (wx * r + w * M[6]) / d2;
-            jac3 -= b * (wy * r + w * M[7]) / d2;
         }
+        // correspondence.cc:88-100 with reciprocals
+        double const inv_d = fast_rcp(d);
+        double const inv_d2 = inv_d * inv_d;
+        double const rx = wx * r + w * M[6], ry = wy * r + w * M[7];
+        double const jac0 = (wx * p + w * M[0]) * inv_d - a * rx * inv_d2;
+        double const jac2 = (wy * p + w * M[1]) * inv_d - a * ry * inv_d2;
+        double const jac1 = (wx * q + w * M[3]) * inv_d - b * rx * inv_d2;
+        double const jac3 = (wy * q + w * M[4]) * inv_d - b * ry * inv_d2;
         Taps const tp = make_taps((float)proj0, (float)proj1, sp.width,
             sp.height);
         float2 const g00 = sp.grad[tp.o00], g10 = sp.grad[tp.o10],
@@ -340,7 +341,6 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         s0[j] = jac0 * g0 + jac1 * g1;
         s1[j] = jac2 * g0 + jac3 * g1;
 
-        double const inv_d2 = 1.0 / d2;
         double const du_w = (p * d - r * a) * inv_d2;
         double const dv_w = (q * d - r * b) * inv_d2;
         double const JH0 = jac0 * hxx + jac1 * hxy;
@@ -432,14 +432,14 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
 
     // ---- regulariser + shading (gauss_newton_step.cc:210-240, 385-517) ----
     double const num_diffs = (double)((num_subs * (num_subs + 1)) / 2);
-    double const brw = A.reg * 0.005 / fmax(0.03, fabs(gm0) + fabs(gm1))
+    double const brw = A.reg * 0.005 * fast_rcp(fmax(0.03, fabs(gm0) + fabs(gm1)))
         * num_diffs;
 
     DivState s;
     s.x = (double)px + 0.5 - (double)A.W / 2.0;
     s.y = (double)py + 0.5 - (double)A.H / 2.0;
     s.f = A.flen;
-    s.f2inv = 1.0 / (s.f * s.f);
+    s.f2inv = A.f2inv;
     s.w = w; s.wx = wx; s.wy = wy; s.wxy = wxy; s.wxx = wxx; s.wyy = wyy;
     s.a = w + s.x * wx + s.y * wy;
     s.ax = 2.0 * wx + s.x * wxx + s.y * wxy;
@@ -449,10 +449,11 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
     s.n = sqrt(s.t);
     s.b = wx * wxx + wy * wxy + a_f2 * s.ax;
     s.c = wx * wxy + wy * wyy + a_f2 * s.ay;
-    s.inv_n = 1.0 / s.n;
-    s.inv_t = 1.0 / s.t;
+    s.inv_n = fast_rcp(s.n);
+    s.inv_t = s.inv_n * s.inv_n;
     s.inv_t2 = s.inv_t * s.inv_t;
-    s.inv_t2f = s.inv_t2 / s.f;
+    s.inv_t2f = s.inv_t2 * A.inv_f;
+    s.inv_f = A.inv_f;
     s.nx = s.b * s.inv_n;
     s.ny = s.c * s.inv_n;
 
@@ -460,10 +461,10 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
     double div[6];
     div[0] = (wxx * s.n - wx * s.nx) * s.inv_t;               // xx
     div[1] = -((wxy * s.n - wy * s.nx) * s.inv_t);            // -yx
-    div[2] = (s.ax * s.n - s.a * s.nx) * s.inv_t / s.f;       // zx
+    div[2] = (s.ax * s.n - s.a * s.nx) * s.inv_t * s.inv_f;   // zx
     div[3] = (wxy * s.n - wx * s.ny) * s.inv_t;               // xy
     div[4] = -((wyy * s.n - wy * s.ny) * s.inv_t);            // -yy
-    div[5] = (s.ay * s.n - s.a * s.ny) * s.inv_t / s.f;       // zy
+    div[5] = (s.ay * s.n - s.a * s.ny) * s.inv_t * s.inv_f;   // zy
 
     // E[v][a] = d div[v] / d (surface quantity a)
     double E[6][6];
@@ -934,6 +935,8 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     A.num_patches = ctx->num_patches;
     A.flen = (double)ctx->flen;
     A.inv_flen = (double)ctx->inv_flen;
+    A.inv_f = 1.0 / A.flen;
+    A.f2inv = 1.0 / (A.flen * A.flen);
     A.reg = reg;
     A.light_reg = light_reg;
     A.use_lighting = use_lighting ? 1 : 0;

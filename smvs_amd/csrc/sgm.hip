@@ -1,18 +1,529 @@
-// SGM entry points (implemented in a later commit of this round).
+// Census / plane-sweep cost volume, 8-path SGM aggregation, WTA and the joint
+// bilateral upsample on gfx950.
+//
+// Replaces SGMStereo::run_sgm (reference: lib/sgm_stereo.cc:98-124):
+// census_filter (:126-148), warped_neighbors_for_depth (:150-190),
+// create_cost_volume (:192-244), aggregate_sgm_costs (:429-667, the SSE
+// branch with constant penalty2, :361-406), depth_from_sgm_volume (:274-306);
+// and DepthOptimizer::depthmap_bilateral_filter (lib/depth_optimizer.cc:957-1004).
+//
+// Integer path: results are bit-exact with the reference semantics.  The
+// float warp is evaluated in the reference's operation order with FMA
+// contraction off.  Volumes are [y][x][d], d fastest (sgm_stereo.cc:436-437);
+// the cost volume is kept as u8 (values <= 255), S as u16.
+//
+// Aggregation: every path direction is an independent 1-D recurrence along a
+// row, a column or a diagonal line of the image, so one wavefront walks one
+// line (lane l owns planes 2l, 2l+1), with the loads of the next pixels
+// issued ahead of the dependent chain.  The eight directions run as eight
+// launches that read C once and read-modify-write S once each:
+// 5 bytes per (pixel, plane, path), the algorithmic traffic of SURVEY.md 8(d).
 #include "common.h"
-using namespace smvs_hip;
-extern "C" int
-smvs_sgm_run(int, const uint8_t *, int, int, const uint8_t *, int, int,
-    const float *, const float *, float, float, int, uint16_t, uint16_t,
-    float *, int32_t *, uint16_t *, uint16_t *)
+
+#include <cmath>
+#include <vector>
+
+namespace smvs_hip {
+
+// ------------------------------------------------------------------ census
+// sgm_stereo.cc:126-148: 9x7 window, x in [4, w-5), y in [3, h-4); bit = centre
+// < neighbour, MSB first in (i outer, j inner) order; centre 0 -> census 0.
+__global__ void __launch_bounds__(256)
+census_main_kernel(const uint8_t *__restrict__ img, int w, int h,
+    unsigned long long *__restrict__ out)
 {
-    set_error("smvs_sgm_run: not implemented yet");
-    return SMVS_ERR_STATE;
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= w)
+        return;
+    unsigned long long census = 0;
+    if (x >= 4 && x < w - 5 && y >= 3 && y < h - 4) {
+        uint8_t const thr = img[(size_t)y * w + x];
+        if (thr != 0) {
+            for (int i = x - 4; i < x + 5; ++i)
+                for (int j = y - 3; j < y + 4; ++j) {
+                    census <<= 1;
+                    if (thr < img[(size_t)j * w + i])
+                        census |= 1ull;
+                }
+        }
+    }
+    out[(size_t)y * w + x] = census;
 }
-extern "C" int
-smvs_bilateral_upsample(int, const float *, int, int, const float *, int, int,
-    int, float, int, float *)
+
+struct WarpArgs {
+    const uint8_t *neighbor;
+    int nw, nh;
+    float M[9], t[3];
+    const float *depths;
+    int D, w, h;
+    uint8_t *warped;   // [h][w][D]
+};
+
+// sgm_stereo.cc:150-190, one thread per (pixel, plane)
+__global__ void __launch_bounds__(256)
+warp_kernel(WarpArgs A)
 {
-    set_error("smvs_bilateral_upsample: not implemented yet");
-    return SMVS_ERR_STATE;
+#pragma clang fp contract(off)
+    size_t const gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t const total = (size_t)A.w * A.h * A.D;
+    if (gid >= total)
+        return;
+    int const d = (int)(gid % A.D);
+    size_t const p = gid / A.D;
+    int const x = (int)(p % A.w), y = (int)(p / A.w);
+    float const px = 0.5f + (float)x, py = 0.5f + (float)y;
+    float tp[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float s = 0.0f;
+        s += A.M[3 * r + 0] * px;
+        s += A.M[3 * r + 1] * py;
+        s += A.M[3 * r + 2] * 1.f;
+        tp[r] = s;
+    }
+    float const depth = A.depths[d];
+    float p0 = tp[0] * depth + A.t[0];
+    float p1 = tp[1] * depth + A.t[1];
+    float const p2 = tp[2] * depth + A.t[2];
+    uint8_t out = 0;
+    if (!(p2 < 0)) {
+        p0 /= p2;
+        p1 /= p2;
+        p0 -= 0.5f;
+        p1 -= 0.5f;
+        if (!(p0 < 0 || p1 < 0 || p0 > (float)(A.nw - 1)
+                || p1 > (float)(A.nh - 1))) {
+            // mve::Image<uint8_t>::linear_at [MVE-unverified]
+            float fx = fmaxf(0.0f, fminf((float)(A.nw - 1), p0));
+            float fy = fmaxf(0.0f, fminf((float)(A.nh - 1), p1));
+            int const ix = (int)fx, iy = (int)fy;
+            int const ix1 = min(ix + 1, A.nw - 1), iy1 = min(iy + 1, A.nh - 1);
+            float const w1 = fx - (float)ix, w0 = 1.0f - w1;
+            float const w3 = fy - (float)iy, w2 = 1.0f - w3;
+            float const v1 = (float)A.neighbor[(size_t)iy * A.nw + ix];
+            float const v2 = (float)A.neighbor[(size_t)iy * A.nw + ix1];
+            float const v3 = (float)A.neighbor[(size_t)iy1 * A.nw + ix];
+            float const v4 = (float)A.neighbor[(size_t)iy1 * A.nw + ix1];
+            out = (uint8_t)(v1 * (w0 * w2) + v2 * (w1 * w2) + v3 * (w0 * w3)
+                + v4 * (w1 * w3) + 0.5f);
+        }
+    }
+    A.warped[gid] = out;
+}
+
+// census of every warped plane + Hamming distance to the main census
+// (sgm_stereo.cc:224-243): cost 255 where nothing was warped.
+__global__ void __launch_bounds__(256)
+cost_kernel(const uint8_t *__restrict__ warped,
+    const unsigned long long *__restrict__ main_census, int w, int h, int D,
+    uint8_t *__restrict__ cost)
+{
+    size_t const gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t const total = (size_t)w * h * D;
+    if (gid >= total)
+        return;
+    int const d = (int)(gid % D);
+    size_t const p = gid / D;
+    int const x = (int)(p % w), y = (int)(p / w);
+    uint8_t const thr = warped[gid];
+    uint8_t c = 255;
+    if (thr != 0) {
+        unsigned long long census = 0;
+        if (x >= 4 && x < w - 5 && y >= 3 && y < h - 4) {
+            for (int i = x - 4; i < x + 5; ++i)
+                for (int j = y - 3; j < y + 4; ++j) {
+                    census <<= 1;
+                    if (thr < warped[((size_t)j * w + i) * D + d])
+                        census |= 1ull;
+                }
+        }
+        c = (uint8_t)__popcll(main_census[p] ^ census);
+    }
+    cost[gid] = c;
+}
+
+// ------------------------------------------------------------- aggregation
+struct PathArgs {
+    const uint8_t *cost;
+    uint16_t *sgm;
+    int w, h, D;
+    int dx, dy;        // direction of travel
+    uint32_t p1, p2;
+    int first;         // 1: S is written, not accumulated
+};
+
+__device__ __forceinline__ uint32_t
+wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = min(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+
+// One wavefront per line.  Lines: for a horizontal path the rows, for a
+// vertical path the columns, for a diagonal path all diagonals that start on
+// the entry row or the entry column.
+//
+// Seeding follows the reference exactly (sgm_stereo.cc:457-464, 511-534,
+// 589-612): the first pixel of a line copies C and adds it to S; for a
+// diagonal path the corner pixel that lies on both the entry row and the
+// entry column is added twice.
+__global__ void __launch_bounds__(64)
+sgm_path_kernel(PathArgs A)
+{
+    int const lane = threadIdx.x;
+    int const line = blockIdx.x;
+    int const w = A.w, h = A.h, D = A.D;
+    int x, y, len;
+    int extra_seed = 0;
+    if (A.dy == 0) {            // horizontal: one line per row
+        if (line >= h)
+            return;
+        y = line;
+        x = A.dx > 0 ? 0 : w - 1;
+        len = w;
+    } else if (A.dx == 0) {     // vertical: one line per column
+        if (line >= w)
+            return;
+        x = line;
+        y = A.dy > 0 ? 0 : h - 1;
+        len = h;
+    } else {                    // diagonal
+        if (line >= w + h - 1)
+            return;
+        int const y_entry = A.dy > 0 ? 0 : h - 1;
+        int const x_entry = A.dx > 0 ? 0 : w - 1;
+        if (line < w) {         // starts on the entry row
+            x = line;
+            y = y_entry;
+            if (x == x_entry)
+                extra_seed = 1; // corner: row seed + column seed
+        } else {                // starts on the entry column, off the corner
+            int const k = line - w + 1;
+            x = x_entry;
+            y = A.dy > 0 ? k : h - 1 - k;
+        }
+        int const nx = A.dx > 0 ? w - x : x + 1;
+        int const ny = A.dy > 0 ? h - y : y + 1;
+        len = min(nx, ny);
+    }
+
+    int const d0 = 2 * lane, d1 = 2 * lane + 1;
+    bool const ok0 = d0 < D, ok1 = d1 < D;
+    uint32_t const BIG = 0xFFFFu;
+    uint32_t prev0 = BIG, prev1 = BIG;
+
+    for (int s = 0; s < len; ++s, x += A.dx, y += A.dy) {
+        size_t const base = ((size_t)y * w + x) * D;
+        uint32_t c0 = ok0 ? A.cost[base + d0] : 0u;
+        uint32_t c1 = ok1 ? A.cost[base + d1] : 0u;
+        uint32_t l0, l1;
+        if (s == 0) {
+            l0 = c0;
+            l1 = c1;
+        } else {
+            uint32_t const mn = wave_min_u32(min(prev0, prev1));
+            uint32_t const left = (uint32_t)__shfl_up((int)prev1, 1);
+            uint32_t const right = (uint32_t)__shfl_down((int)prev0, 1);
+            bool const has_left = lane > 0;
+            bool const has_right = lane < 63 && d1 + 1 < D;
+            uint32_t const far = (mn + A.p2) & 0xFFFFu;
+            // u16 wrapping arithmetic of the SSE code (_mm_add_epi16)
+            uint32_t u0 = prev0;
+            u0 = min(u0, has_left ? ((left + A.p1) & 0xFFFFu) : BIG);
+            u0 = min(u0, ok1 ? ((prev1 + A.p1) & 0xFFFFu) : BIG);
+            u0 = min(u0, far);
+            uint32_t u1 = prev1;
+            u1 = min(u1, (prev0 + A.p1) & 0xFFFFu);
+            u1 = min(u1, has_right ? ((right + A.p1) & 0xFFFFu) : BIG);
+            u1 = min(u1, far);
+            l0 = (c0 + u0 - mn) & 0xFFFFu;
+            l1 = (c1 + u1 - mn) & 0xFFFFu;
+        }
+        uint32_t add0 = l0, add1 = l1;
+        if (s == 0 && extra_seed) {
+            add0 = (2 * c0) & 0xFFFFu;
+            add1 = (2 * c1) & 0xFFFFu;
+        }
+        if (ok0) {
+            uint32_t const old = A.first ? 0u : A.sgm[base + d0];
+            A.sgm[base + d0] = (uint16_t)(old + add0);
+        }
+        if (ok1) {
+            uint32_t const old = A.first ? 0u : A.sgm[base + d1];
+            A.sgm[base + d1] = (uint16_t)(old + add1);
+        }
+        prev0 = ok0 ? l0 : BIG;
+        prev1 = ok1 ? l1 : BIG;
+    }
+}
+
+// The reference seeds the whole entry column of the diagonal passes
+// (sgm_stereo.cc:523-534), also where a diagonal does not start: those pixels
+// lie on lines that start on the entry row.  For such a pixel the seed only
+// adds C to S and overwrites the path volume with C *before* the sweep; the
+// sweep then overwrites the path value again (x > 0 branch never runs for the
+// entry column, so the path value stays C there).  Net effect on the entry
+// column: L = C (a line start) and S += C.  Lines that start on the entry
+// column are handled in sgm_path_kernel; nothing else is needed because every
+// entry-column pixel IS the start of its own diagonal.
+
+// WTA (sgm_stereo.cc:274-306): first minimum wins; invalid if index < 2 or
+// main intensity < 25.
+__global__ void __launch_bounds__(256)
+wta_kernel(const uint16_t *__restrict__ sgm, const uint8_t *__restrict__ main_img,
+    const float *__restrict__ depths, size_t npix, int D,
+    float *__restrict__ depth, int32_t *__restrict__ argmin)
+{
+    size_t const p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix)
+        return;
+    uint32_t min_error = 0xFFFFu;
+    int min_index = 0;
+    for (int i = 0; i < D; ++i) {
+        uint32_t const v = sgm[p * D + i];
+        if (v < min_error) {
+            min_error = v;
+            min_index = i;
+        }
+    }
+    if (argmin != nullptr)
+        argmin[p] = min_index;
+    if (depth != nullptr)
+        depth[p] = (min_index < 2 || main_img[p] < 25) ? 0.0f : depths[min_index];
+}
+
+__global__ void __launch_bounds__(256)
+widen_u8_kernel(const uint8_t *__restrict__ src, uint16_t *__restrict__ dst,
+    size_t n)
+{
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] = src[i];
+}
+
+// depth_optimizer.cc:957-1004
+struct BilateralArgs {
+    const float *dm;
+    const float *ci;
+    float *out;
+    int dm_w, dm_h, w, h, channels, kernel_size;
+    float sigma;
+};
+
+__global__ void __launch_bounds__(256)
+bilateral_kernel(BilateralArgs A)
+{
+#pragma clang fp contract(off)
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= A.w)
+        return;
+    float const scale_x = (float)A.dm_w / (float)A.w;
+    float const scale_y = (float)A.dm_h / (float)A.h;
+    float acc_v = 0.0f, acc_w = 0.0f;
+    for (int ky = -A.kernel_size; ky <= A.kernel_size; ++ky)
+        for (int kx = -A.kernel_size; kx <= A.kernel_size; ++kx) {
+            int const ci_x = min(max(x + kx, 0), A.w - 1);
+            int const ci_y = min(max(y + ky, 0), A.h - 1);
+            float fx = scale_x * (float)ci_x, fy = scale_y * (float)ci_y;
+            fx = fminf(fmaxf(fx, 0.f), (float)A.dm_w - 1.f);
+            fy = fminf(fmaxf(fy, 0.f), (float)A.dm_h - 1.f);
+            int const dm_x = (int)fx, dm_y = (int)fy;
+            float const dv = A.dm[(size_t)dm_y * A.dm_w + dm_x];
+            if (dv == 0.0f)
+                continue;
+            float weight = 1.0f;
+            weight *= expf(-((float)kx * (float)kx / (2.0f * A.sigma * A.sigma)
+                + (float)ky * (float)ky / (2.0f * A.sigma * A.sigma)));
+            for (int c = 0; c < A.channels; ++c) {
+                float const diff =
+                    A.ci[((size_t)ci_y * A.w + ci_x) * A.channels + c]
+                    - A.ci[((size_t)y * A.w + x) * A.channels + c];
+                weight *= expf(-(diff * diff) / (2.0f * 0.1f * 0.1f));
+            }
+            acc_v += dv * weight;
+            acc_w += weight;
+        }
+    A.out[(size_t)y * A.w + x] = acc_w > 0 ? acc_v / acc_w : 0.0f;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+            p = nullptr;
+            return SMVS_ERR_NOMEM;
+        }
+        return SMVS_OK;
+    }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
+    const uint8_t *neighbor_img, int nw, int nh, const float *M,
+    const float *t, float min_depth, float max_depth, int num_steps,
+    uint16_t penalty1, uint16_t penalty2, float *depth, int32_t *argmin,
+    uint16_t *cost, uint16_t *sgm)
+{
+    SMVS_REQUIRE(main_img && neighbor_img && M && t, "null argument");
+    SMVS_REQUIRE(w > 10 && h > 8 && nw > 1 && nh > 1, "image too small");
+    SMVS_REQUIRE(num_steps >= 2 && num_steps <= 128,
+        "num_steps must be in [2, 128]");
+    SMVS_REQUIRE(min_depth > 0.f && max_depth > min_depth, "bad depth range");
+    SMVS_REQUIRE(penalty2 >= penalty1, "penalty2 must not be below penalty1");
+    int count = 0;
+    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
+    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
+    SMVS_HIP_CHECK(hipSetDevice(device));
+
+    // sgm_stereo.cc:195-203: inverse-depth planes by repeated float addition
+    std::vector<float> depths(num_steps);
+    {
+        float inv_depth = 1.0f / max_depth;
+        float const increment = (1.0f / min_depth - inv_depth) / (num_steps - 1);
+        for (int i = 0; i < num_steps; ++i) {
+            depths[i] = 1.0f / inv_depth;
+            inv_depth += increment;
+        }
+    }
+    size_t const npix = (size_t)w * h, nnpix = (size_t)nw * nh;
+    size_t const vol = npix * num_steps;
+    DevBuf d_main, d_nbr, d_depths, d_census, d_warped, d_cost, d_sgm, d_depth,
+        d_argmin, d_cost16;
+    int rc;
+    if ((rc = d_main.alloc(npix)) || (rc = d_nbr.alloc(nnpix))
+        || (rc = d_depths.alloc(sizeof(float) * num_steps))
+        || (rc = d_census.alloc(sizeof(unsigned long long) * npix))
+        || (rc = d_warped.alloc(vol)) || (rc = d_cost.alloc(vol))
+        || (rc = d_sgm.alloc(sizeof(uint16_t) * vol))
+        || (rc = d_depth.alloc(sizeof(float) * npix))
+        || (rc = d_argmin.alloc(sizeof(int32_t) * npix)))
+        return rc;
+    hipStream_t stream = nullptr;  // default stream: one-shot entry point
+    SMVS_HIP_CHECK(hipMemcpy(d_main.p, main_img, npix, hipMemcpyHostToDevice));
+    SMVS_HIP_CHECK(hipMemcpy(d_nbr.p, neighbor_img, nnpix, hipMemcpyHostToDevice));
+    SMVS_HIP_CHECK(hipMemcpy(d_depths.p, depths.data(),
+        sizeof(float) * num_steps, hipMemcpyHostToDevice));
+
+    hipLaunchKernelGGL(census_main_kernel, dim3((w + 255) / 256, h), dim3(256),
+        0, stream, d_main.as<uint8_t>(), w, h,
+        d_census.as<unsigned long long>());
+    WarpArgs W;
+    W.neighbor = d_nbr.as<uint8_t>();
+    W.nw = nw;
+    W.nh = nh;
+    memcpy(W.M, M, sizeof(float) * 9);
+    memcpy(W.t, t, sizeof(float) * 3);
+    W.depths = d_depths.as<float>();
+    W.D = num_steps;
+    W.w = w;
+    W.h = h;
+    W.warped = d_warped.as<uint8_t>();
+    unsigned const vblocks = (unsigned)((vol + 255) / 256);
+    hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
+    hipLaunchKernelGGL(cost_kernel, dim3(vblocks), dim3(256), 0, stream,
+        d_warped.as<uint8_t>(), d_census.as<unsigned long long>(), w, h,
+        num_steps, d_cost.as<uint8_t>());
+    SMVS_HIP_CHECK(hipGetLastError());
+
+    // the eight paths in the reference's order: ->, <-, then the three
+    // top-to-bottom paths, then the three bottom-to-top paths
+    static const int dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 },
+        { -1, 1 }, { 0, -1 }, { 1, -1 }, { -1, -1 } };
+    for (int k = 0; k < 8; ++k) {
+        PathArgs P;
+        P.cost = d_cost.as<uint8_t>();
+        P.sgm = d_sgm.as<uint16_t>();
+        P.w = w;
+        P.h = h;
+        P.D = num_steps;
+        P.dx = dirs[k][0];
+        P.dy = dirs[k][1];
+        P.p1 = penalty1;
+        P.p2 = penalty2;
+        P.first = k == 0 ? 1 : 0;
+        int lines = P.dy == 0 ? h : (P.dx == 0 ? w : w + h - 1);
+        hipLaunchKernelGGL(sgm_path_kernel, dim3(lines), dim3(64), 0, stream, P);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(wta_kernel, dim3((unsigned)((npix + 255) / 256)),
+        dim3(256), 0, stream, d_sgm.as<uint16_t>(), d_main.as<uint8_t>(),
+        d_depths.as<float>(), npix, num_steps, d_depth.as<float>(),
+        d_argmin.as<int32_t>());
+    SMVS_HIP_CHECK(hipGetLastError());
+    SMVS_HIP_CHECK(hipDeviceSynchronize());
+
+    if (depth != nullptr)
+        SMVS_HIP_CHECK(hipMemcpy(depth, d_depth.p, sizeof(float) * npix,
+            hipMemcpyDeviceToHost));
+    if (argmin != nullptr)
+        SMVS_HIP_CHECK(hipMemcpy(argmin, d_argmin.p, sizeof(int32_t) * npix,
+            hipMemcpyDeviceToHost));
+    if (sgm != nullptr)
+        SMVS_HIP_CHECK(hipMemcpy(sgm, d_sgm.p, sizeof(uint16_t) * vol,
+            hipMemcpyDeviceToHost));
+    if (cost != nullptr) {
+        if ((rc = d_cost16.alloc(sizeof(uint16_t) * vol)))
+            return rc;
+        hipLaunchKernelGGL(widen_u8_kernel, dim3(vblocks), dim3(256), 0, stream,
+            d_cost.as<uint8_t>(), d_cost16.as<uint16_t>(), vol);
+        SMVS_HIP_CHECK(hipGetLastError());
+        SMVS_HIP_CHECK(hipMemcpy(cost, d_cost16.p, sizeof(uint16_t) * vol,
+            hipMemcpyDeviceToHost));
+    }
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
+    const float *ci, int w, int h, int channels, float sigma, int kernel_size,
+    float *out)
+{
+    SMVS_REQUIRE(dm && ci && out, "null argument");
+    SMVS_REQUIRE(dm_w > 0 && dm_h > 0 && w > 0 && h > 0 && channels > 0
+        && kernel_size >= 0 && sigma > 0.f, "bad argument");
+    int count = 0;
+    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
+    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
+    SMVS_HIP_CHECK(hipSetDevice(device));
+    DevBuf d_dm, d_ci, d_out;
+    int rc;
+    size_t const n = (size_t)w * h;
+    if ((rc = d_dm.alloc(sizeof(float) * dm_w * dm_h))
+        || (rc = d_ci.alloc(sizeof(float) * n * channels))
+        || (rc = d_out.alloc(sizeof(float) * n)))
+        return rc;
+    SMVS_HIP_CHECK(hipMemcpy(d_dm.p, dm, sizeof(float) * dm_w * dm_h,
+        hipMemcpyHostToDevice));
+    SMVS_HIP_CHECK(hipMemcpy(d_ci.p, ci, sizeof(float) * n * channels,
+        hipMemcpyHostToDevice));
+    BilateralArgs A;
+    A.dm = d_dm.as<float>();
+    A.ci = d_ci.as<float>();
+    A.out = d_out.as<float>();
+    A.dm_w = dm_w;
+    A.dm_h = dm_h;
+    A.w = w;
+    A.h = h;
+    A.channels = channels;
+    A.kernel_size = kernel_size;
+    A.sigma = sigma;
+    hipLaunchKernelGGL(bilateral_kernel, dim3((w + 255) / 256, h), dim3(256), 0,
+        nullptr, A);
+    SMVS_HIP_CHECK(hipGetLastError());
+    SMVS_HIP_CHECK(hipMemcpy(out, d_out.p, sizeof(float) * n,
+        hipMemcpyDeviceToHost));
+    return SMVS_OK;
 }

@@ -181,3 +181,58 @@ def test_gn_loop_tracks_oracle_loop(hip, oracle):
     d_gpu, d_ref = ctx.depth_map(), orc.depth_map()
     assert _rel(d_gpu, d_ref) <= 1e-4
     ctx.close()
+
+
+# ---------------------------------------------------------------------- SGM
+def _sgm_pair(w, h, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(20, 235, size=(h + 8, w + 40)).astype(np.float32)
+    base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, -1, 1)) / 4
+    base[5:9, 20:30] = 0  # zero intensities exercise the census special case
+    main = base[4:4 + h, 16:16 + w].astype(np.uint8)
+    nbr = base[4:4 + h, 19:19 + w].astype(np.uint8)
+    M = np.array([1.001, 0.002, 0.1, -0.001, 0.999, 0.2, 1e-6, -2e-6, 1.0], np.float32)
+    t = np.array([-6.0, 0.3, 0.01], np.float32)
+    return main, nbr, M, t
+
+
+@pytest.mark.parametrize("w,h,D", [(96, 64, 128), (71, 45, 128), (64, 40, 37)])
+def test_sgm_bit_exact(hip, oracle, w, h, D):
+    """cost volume, aggregated volume, argmin and depth map are bit-exact
+    with the oracle (sgm_stereo.cc:98-306), ragged sizes and odd plane counts
+    included."""
+    main, nbr, M, t = _sgm_pair(w, h, seed=w)
+    out = hip.sgm_run(main, nbr, M, t, 1.0, 12.0, D, 6, 96, want_volumes=True)
+    depths = oracle.sgm_depths(1.0, 12.0, D)
+    cost = oracle.sgm_cost_volume(main, nbr, M, t, depths)
+    assert np.array_equal(out["cost"], cost)
+    sgm = oracle.sgm_aggregate(cost, 6, 96)
+    assert np.array_equal(out["sgm"], sgm)
+    depth, argmin = oracle.sgm_depth_from_volume(sgm, main, depths)
+    assert np.array_equal(out["argmin"], argmin)
+    assert np.array_equal(out["depth"], depth)
+    assert (depth > 0).sum() > 0
+
+
+def test_sgm_rejects_bad_arguments(hip):
+    from smvs_amd._capi import SmvsError
+    main, nbr, M, t = _sgm_pair(64, 40, 1)
+    with pytest.raises(SmvsError):
+        hip.sgm_run(main, nbr, M, t, 1.0, 12.0, 300)     # too many planes
+    with pytest.raises(SmvsError):
+        hip.sgm_run(main, nbr, M, t, 5.0, 2.0, 64)       # inverted range
+    with pytest.raises(SmvsError):
+        hip.sgm_run(main, nbr, M, t, 1.0, 12.0, 64, p1=50, p2=10)
+
+
+def test_bilateral_upsample_matches_oracle(hip, oracle):
+    """depthmap_bilateral_filter (depth_optimizer.cc:957-1004); float path with
+    device expf: 1e-5 relative."""
+    rng = np.random.default_rng(9)
+    dm = (2.0 + rng.random((24, 32))).astype(np.float32)
+    dm[rng.random(dm.shape) < 0.2] = 0.0
+    ci = rng.random((48, 64, 3)).astype(np.float32)
+    got = hip.bilateral_upsample(dm, ci)
+    want = oracle.bilateral_upsample(dm, ci)
+    assert np.array_equal(got == 0, want == 0)
+    assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
