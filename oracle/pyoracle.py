@@ -452,3 +452,110 @@ def bilateral_upsample(dm, ci, sigma=5.0, kernel_size=5):
     lib().orc_bilateral_upsample(_p(dm, c_float_p), dw, dh, _p(ci, c_float_p),
         w, h, c, C.c_float(sigma), C.c_int(kernel_size), _p(out, c_float_p))
     return out
+
+
+# ----------------------------------------------------------- whole optimizer
+class ViewInput(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("channels", C.c_int),
+                ("bytes", c_u8_p), ("flen", C.c_float), ("rot", C.c_float * 9),
+                ("trans", C.c_float * 3), ("view_id", C.c_int)]
+
+
+class Bundle(C.Structure):
+    _fields_ = [("num_features", C.c_int), ("positions", c_float_p),
+                ("ref_offsets", c_i32_p), ("ref_views", c_i32_p)]
+
+
+class OptOptions(C.Structure):
+    _fields_ = [("regularization", C.c_double),
+                ("light_surf_regularization", C.c_double),
+                ("num_iterations", C.c_int), ("min_scale", C.c_int),
+                ("use_shading", C.c_int), ("use_sgm", C.c_int),
+                ("full_optimization", C.c_int), ("sgm_width", C.c_int),
+                ("sgm_height", C.c_int)]
+
+
+class OptLog(C.Structure):
+    _fields_ = [("count", C.c_int), ("scale", C.c_int * 256),
+                ("iter", C.c_int * 256), ("newton_steps", C.c_int * 256),
+                ("valid_patches", C.c_int * 256), ("cg_iterations", C.c_int * 256),
+                ("final_scale", C.c_int), ("final_patches", C.c_int),
+                ("has_lighting", C.c_int), ("lighting", C.c_double * 16)]
+
+
+def _view_input(img, cam, view_id, keep):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    keep.append(img)
+    v = ViewInput()
+    v.height, v.width, v.channels = img.shape
+    v.bytes = _p(img, c_u8_p)
+    v.flen = cam.flen
+    for i, x in enumerate(np.asarray(cam.R, dtype=np.float32).reshape(9)):
+        v.rot[i] = float(x)
+    for i, x in enumerate(np.asarray(cam.t, dtype=np.float32).reshape(3)):
+        v.trans[i] = float(x)
+    v.view_id = view_id
+    return v
+
+
+def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
+             min_scale=2, use_shading=False, sgm_depth=None,
+             full_optimization=False):
+    """orc_optimize on the dict of smvs_amd.synth.pipeline_inputs()."""
+    keep = []
+    cams, images = inputs["cams"], inputs["images"]
+    main = _view_input(images[0], cams[0], inputs["view_ids"][0], keep)
+    n_subs = len(cams) - 1
+    subs = (ViewInput * n_subs)()
+    for j in range(n_subs):
+        subs[j] = _view_input(images[j + 1], cams[j + 1], inputs["view_ids"][j + 1], keep)
+    feats = f32(inputs["features"]).reshape(-1, 3)
+    nf = feats.shape[0]
+    nviews = len(cams)
+    offsets = (np.arange(nf + 1) * nviews).astype(np.int32)
+    refs = np.tile(np.asarray(inputs["view_ids"], dtype=np.int32), nf)
+    b = Bundle(nf, _p(feats, c_float_p), _p(offsets, c_i32_p), _p(refs, c_i32_p))
+    o = OptOptions()
+    o.regularization = regularization; o.light_surf_regularization = light_reg
+    o.num_iterations = num_iterations; o.min_scale = min_scale
+    o.use_shading = 1 if use_shading else 0
+    o.use_sgm = 1 if sgm_depth is not None else 0
+    o.full_optimization = 1 if full_optimization else 0
+    sd = None
+    if sgm_depth is not None:
+        sd = f32(sgm_depth)
+        o.sgm_height, o.sgm_width = sd.shape
+    h, w = main.height, main.width
+    depth = np.zeros((h, w), dtype=np.float32)
+    normals = np.zeros((h, w, 3), dtype=np.float32)
+    log = OptLog()
+    rc = lib().orc_optimize(C.byref(main), subs, n_subs, C.byref(b),
+        _p(sd, c_float_p), C.byref(o), _p(depth, c_float_p),
+        _p(normals, c_float_p), C.byref(log))
+    if rc != 0:
+        raise RuntimeError("orc_optimize failed: %d" % rc)
+    steps = [dict(scale=log.scale[i], iter=log.iter[i],
+                  newton_steps=log.newton_steps[i],
+                  valid_patches=log.valid_patches[i],
+                  cg_iterations=log.cg_iterations[i]) for i in range(log.count)]
+    return dict(depth=depth, normals=normals, log=steps,
+                final_patches=log.final_patches,
+                lighting=np.array(log.lighting[:]) if log.has_lighting else None)
+
+
+def rescale_half_size_u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), dtype=np.uint8)
+    lib().orc_rescale_half_size_u8(_p(img, c_u8_p), w, h, _p(out, c_u8_p))
+    return out
+
+
+def gradients_and_hessian(img):
+    img = f32(img); h, w = img.shape
+    g = np.zeros((h, w, 2), np.float32); hs = np.zeros((h, w, 3), np.float32)
+    lib().orc_gradients_and_hessian(_p(img, c_float_p), w, h, _p(g, c_float_p),
+                                    _p(hs, c_float_p))
+    return g, hs

@@ -20,7 +20,45 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_LIB = os.path.join(HOST_DIR, "libsmvs_host.so")
+HOST_SOURCES = ["camera.cc", "stereo_view.cc", "surface.cc", "sgm_stereo.cc",
+                "depth_optimizer.cc", "host_capi.cc"]
+
+
+def _host_stale():
+    if not os.path.exists(HOST_LIB):
+        return True
+    t = os.path.getmtime(HOST_LIB)
+    deps = [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR)
+            if f.endswith((".cc", ".h"))]
+    deps += [LIB, os.path.join(HERE, "..", "include", "smvs_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_host(force=False, verbose=False):
+    """C++ host mirror (DepthOptimizer / Surface / StereoView / SGMStereo)
+    on top of the C ABI."""
+    if not force and not _host_stale():
+        return HOST_LIB
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-shared", "-o", HOST_LIB] \
+        + [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] \
+        + ["-L" + CSRC, "-lsmvs_hip", "-Wl,-rpath,$ORIGIN/..",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def build(force=False, verbose=False):
+    lib = _build_hip(force, verbose)
+    build_host(force, verbose)
+    return lib
+
+
+def _build_hip(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,89 @@
+// Host mirror of smvs::DepthOptimizer (reference: lib/depth_optimizer.h:27-122).
+// Same Options, constructor and optimize() / get_depth() / get_normals()
+// surface; the Newton loop (lib/depth_optimizer.cc:219-304), the lighting
+// accumulation and the bilateral upsample run on the GPU through the C ABI of
+// include/smvs_hip.h, topology operations stay on the host.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "image.h"
+#include "stereo_view.h"
+#include "surface.h"
+
+struct smvs_ctx;
+
+namespace smvs_amd {
+
+class DepthOptimizer
+{
+public:
+    struct Options  // lib/depth_optimizer.h:30-42
+    {
+        double regularization = 0.001;
+        double light_surf_regularization = 0.0;
+        int num_iterations = 10;
+        int min_scale = 1;
+        int debug_lvl = 0;
+        bool use_shading = false;
+        bool use_sgm = false;
+        bool full_optimization = false;
+        std::string output_name = "smvs";
+        int device = 0;  // HIP device (not in the reference)
+    };
+
+    struct IterationLog
+    {
+        int scale, iter, newton_steps, valid_patches, cg_iterations;
+    };
+
+public:
+    DepthOptimizer(StereoView::Ptr main_view,
+        std::vector<StereoView::Ptr> const& sub_views,
+        Bundle::ConstPtr bundle, Options const& options);
+    ~DepthOptimizer(void);
+    DepthOptimizer(DepthOptimizer const&) = delete;
+    DepthOptimizer& operator=(DepthOptimizer const&) = delete;
+
+    void optimize(void);
+
+    FloatImage::Ptr get_depth(void);
+    FloatImage::Ptr get_normals(void);
+
+    std::vector<IterationLog> const& get_log(void) const { return log; }
+    bool has_lighting(void) const { return lit; }
+    double const* get_lighting(void) const { return lighting; }
+
+private:
+    void prepare_correspondences(void);
+    void create_initial_surface(void);
+    void create_subview_surfaces(void);
+    void run_newton_iterations(int num_iters);
+    int cut_boundaries(void);
+    double mse_for_patch(std::size_t patch_id);
+    double ncc_for_patch(std::size_t patch_id, std::size_t sub_id);
+    FloatImage::Ptr depthmap_bilateral_filter(FloatImage::ConstPtr dm,
+        FloatImage::ConstPtr ci, float sigma = 5, int kernel_size = 5);
+    void fit_lighting(void);
+
+    void set_scale_everywhere(int scale);
+    void upload_surface(void);
+    void check(int status, char const* what) const;
+
+private:
+    Options const& opts;
+    Bundle::ConstPtr bundle;
+    StereoView::Ptr main_view;
+    std::vector<StereoView::Ptr> const& sub_views;
+    std::vector<double> Mi, ti;          // 9 / 3 per neighbour
+    FloatImage::ConstPtr sgm_depth;
+    Surface::Ptr surface;
+    std::vector<uint32_t> subsurfaces;   // bit j: neighbour j sees the patch
+    bool lit = false;
+    double lighting[16];
+    smvs_ctx* ctx = nullptr;
+    std::vector<IterationLog> log;
+};
+
+} // namespace smvs_amd

@@ -1,0 +1,144 @@
+#include "host_capi.h"
+
+#include <algorithm>
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "depth_optimizer.h"
+#include "sgm_stereo.h"
+
+using namespace smvs_amd;
+
+static thread_local std::string g_host_error;
+
+extern "C" const char *
+smvs_host_last_error(void)
+{
+    return g_host_error.c_str();
+}
+
+static StereoView::Ptr
+make_view(smvs_host_view const& v, bool linear)
+{
+    ByteImage::Ptr img = ByteImage::create(v.width, v.height, v.channels);
+    std::memcpy(img->begin(), v.bytes, (size_t)v.width * v.height * v.channels);
+    CameraInfo cam;
+    cam.flen = v.flen;
+    std::copy(v.rot, v.rot + 9, cam.rot);
+    std::copy(v.trans, v.trans + 3, cam.trans);
+    return StereoView::create(v.view_id, img, cam, linear, false);
+}
+
+static Bundle::Ptr
+make_bundle(smvs_host_bundle const* b)
+{
+    if (b == nullptr)
+        return nullptr;
+    Bundle::Ptr bundle(new Bundle());
+    bundle->features.resize(b->num_features);
+    for (int i = 0; i < b->num_features; ++i) {
+        std::copy(b->positions + 3 * i, b->positions + 3 * i + 3,
+            bundle->features[i].pos);
+        bundle->features[i].view_ids.assign(b->ref_views + b->ref_offsets[i],
+            b->ref_views + b->ref_offsets[i + 1]);
+    }
+    return bundle;
+}
+
+extern "C" int
+smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
+    int n_subs, const smvs_host_bundle *bundle_in, const float *sgm_depth,
+    int sgm_w, int sgm_h, float *sgm_roundtrip, const smvs_host_options *o,
+    float *depth_out, float *normals_out, smvs_host_log *log)
+{
+    try {
+        StereoView::Ptr main_view = make_view(*main_in, o->use_shading != 0);
+        std::vector<StereoView::Ptr> subs;
+        for (int j = 0; j < n_subs; ++j)
+            subs.push_back(make_view(subs_in[j], false));
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        if (sgm_depth != nullptr) {
+            FloatImage::Ptr d = FloatImage::create(sgm_w, sgm_h, 1);
+            std::memcpy(d->begin(), sgm_depth, sizeof(float) * sgm_w * sgm_h);
+            main_view->write_depth_to_view(d, "smvs-sgm");
+            if (sgm_roundtrip != nullptr) {
+                FloatImage::Ptr back = main_view->get_sgm_depth();
+                std::memcpy(sgm_roundtrip, back->begin(),
+                    sizeof(float) * sgm_w * sgm_h);
+            }
+        }
+        DepthOptimizer::Options opts;
+        opts.regularization = o->regularization;
+        opts.light_surf_regularization = o->light_surf_regularization;
+        opts.num_iterations = o->num_iterations;
+        opts.min_scale = o->min_scale;
+        opts.use_shading = o->use_shading != 0;
+        opts.use_sgm = o->use_sgm != 0;
+        opts.full_optimization = o->full_optimization != 0;
+        opts.device = o->device;
+        DepthOptimizer optimizer(main_view, subs, bundle, opts);
+        optimizer.optimize();
+        size_t const npix = (size_t)main_in->width * main_in->height;
+        if (depth_out != nullptr)
+            std::memcpy(depth_out, optimizer.get_depth()->begin(),
+                sizeof(float) * npix);
+        if (normals_out != nullptr)
+            std::memcpy(normals_out, optimizer.get_normals()->begin(),
+                sizeof(float) * 3 * npix);
+        if (log != nullptr) {
+            log->count = 0;
+            for (auto const& e : optimizer.get_log()) {
+                if (log->count >= SMVS_HOST_LOG_MAX)
+                    break;
+                int const i = log->count++;
+                log->scale[i] = e.scale;
+                log->iter[i] = e.iter;
+                log->newton_steps[i] = e.newton_steps;
+                log->valid_patches[i] = e.valid_patches;
+                log->cg_iterations[i] = e.cg_iterations;
+            }
+            log->has_lighting = optimizer.has_lighting() ? 1 : 0;
+            std::copy(optimizer.get_lighting(), optimizer.get_lighting() + 16,
+                log->lighting);
+        }
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_sgm_depth(const smvs_host_view *main_in, const smvs_host_view *subs_in,
+    int n_subs, const smvs_host_bundle *bundle_in, int sgm_scale,
+    float min_depth, float max_depth, int device, float *depth_out, int *out_w,
+    int *out_h)
+{
+    try {
+        StereoView::Ptr main_view = make_view(*main_in, false);
+        std::vector<StereoView::Ptr> subs;
+        for (int j = 0; j < n_subs; ++j)
+            subs.push_back(make_view(subs_in[j], false));
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        SGMStereo::Options opts;
+        opts.scale = sgm_scale;
+        opts.num_steps = 128;
+        opts.min_depth = min_depth;
+        opts.max_depth = max_depth;
+        opts.device = device;
+        FloatImage::Ptr d = reconstruct_sgm_depth_for_view(opts, main_view, subs,
+            bundle);
+        if (out_w != nullptr)
+            *out_w = d->width();
+        if (out_h != nullptr)
+            *out_h = d->height();
+        if (depth_out != nullptr)
+            std::memcpy(depth_out, d->begin(),
+                sizeof(float) * d->get_pixel_amount());
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}

@@ -1,0 +1,73 @@
+/* C entry points of the host mirror (libsmvs_host.so): lets tests / tools
+ * drive smvs_amd::DepthOptimizer and smvs_amd::SGMStereo without a C++
+ * toolchain.  Not part of the device boundary (that is include/smvs_hip.h). */
+#ifndef SMVS_HOST_CAPI_H
+#define SMVS_HOST_CAPI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int width, height, channels;
+    const uint8_t *bytes;       /* interleaved u8 image */
+    float flen;                 /* CameraInfo::flen */
+    float rot[9], trans[3];
+    int view_id;
+} smvs_host_view;
+
+typedef struct {
+    int num_features;
+    const float *positions;     /* num_features * 3 */
+    const int *ref_offsets;     /* num_features + 1 */
+    const int *ref_views;
+} smvs_host_bundle;
+
+typedef struct {                /* DepthOptimizer::Options */
+    double regularization;
+    double light_surf_regularization;
+    int num_iterations;
+    int min_scale;
+    int use_shading;
+    int use_sgm;
+    int full_optimization;
+    int device;
+} smvs_host_options;
+
+#define SMVS_HOST_LOG_MAX 256
+typedef struct {
+    int count;
+    int scale[SMVS_HOST_LOG_MAX];
+    int iter[SMVS_HOST_LOG_MAX];
+    int newton_steps[SMVS_HOST_LOG_MAX];
+    int valid_patches[SMVS_HOST_LOG_MAX];
+    int cg_iterations[SMVS_HOST_LOG_MAX];
+    int has_lighting;
+    double lighting[16];
+} smvs_host_log;
+
+const char *smvs_host_last_error(void);
+
+/* DepthOptimizer(main, subs, bundle, opts).optimize().
+ * sgm_depth: optional z-depth map (sgm_w x sgm_h) stored as the "smvs-sgm"
+ * embedding; sgm_depth_roundtrip (optional, same size) receives what
+ * StereoView::get_sgm_depth() hands to the optimizer. */
+int smvs_host_optimize(const smvs_host_view *main_view,
+    const smvs_host_view *subs, int n_subs, const smvs_host_bundle *bundle,
+    const float *sgm_depth, int sgm_w, int sgm_h, float *sgm_depth_roundtrip,
+    const smvs_host_options *opts, float *depth_out, float *normals_out,
+    smvs_host_log *log);
+
+/* reconstruct_sgm_depth_for_view (app/smvsrecon.cc:346-384): returns the
+ * merged z-depth map at SGM resolution ((w+1)>>scale ...). */
+int smvs_host_sgm_depth(const smvs_host_view *main_view,
+    const smvs_host_view *subs, int n_subs, const smvs_host_bundle *bundle,
+    int sgm_scale, float min_depth, float max_depth, int device,
+    float *depth_out, int *out_w, int *out_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

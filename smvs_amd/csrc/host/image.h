@@ -1,0 +1,105 @@
+// Minimal image / camera / bundle containers of the host mirror.
+// With MVE present these would be mve::Image<T>, mve::CameraInfo and
+// mve::Bundle; the layout is MVE's: interleaved
+// channels, row-major, index (y*w + x)*c + ch.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+namespace smvs_amd {
+
+template <typename T>
+class Image
+{
+public:
+    typedef std::shared_ptr<Image<T>> Ptr;
+    typedef std::shared_ptr<Image<T> const> ConstPtr;
+
+    static Ptr create(int width, int height, int channels)
+    {
+        Ptr img(new Image<T>());
+        img->w = width;
+        img->h = height;
+        img->c = channels;
+        img->data.assign((size_t)width * height * channels, T(0));
+        return img;
+    }
+    Ptr duplicate(void) const { return Ptr(new Image<T>(*this)); }
+
+    int width(void) const { return w; }
+    int height(void) const { return h; }
+    int channels(void) const { return c; }
+    int get_pixel_amount(void) const { return w * h; }
+    void fill(T const& v) { std::fill(data.begin(), data.end(), v); }
+
+    T& at(int64_t i) { return data[i]; }
+    T const& at(int64_t i) const { return data[i]; }
+    T& at(int64_t p, int64_t ch) { return data[p * c + ch]; }
+    T const& at(int64_t p, int64_t ch) const { return data[p * c + ch]; }
+    T& at(int64_t x, int64_t y, int64_t ch) { return data[(y * w + x) * c + ch]; }
+    T const& at(int64_t x, int64_t y, int64_t ch) const
+    {
+        return data[(y * w + x) * c + ch];
+    }
+    T* begin(void) { return data.data(); }
+    T const* begin(void) const { return data.data(); }
+
+    // bilinear sample with clamping; float weights [MVE-unverified]
+    T linear_at(float x, float y, int64_t ch) const;
+
+private:
+    int w = 0, h = 0, c = 0;
+    std::vector<T> data;
+};
+
+typedef Image<float> FloatImage;
+typedef Image<uint8_t> ByteImage;
+
+template <>
+inline float
+Image<float>::linear_at(float x, float y, int64_t ch) const
+{
+    x = x < 0.0f ? 0.0f : (x > (float)(w - 1) ? (float)(w - 1) : x);
+    y = y < 0.0f ? 0.0f : (y > (float)(h - 1) ? (float)(h - 1) : y);
+    int const fx = (int)x, fy = (int)y;
+    int const fx1 = fx + 1 < w - 1 ? fx + 1 : w - 1;
+    int const fy1 = fy + 1 < h - 1 ? fy + 1 : h - 1;
+    float const w1 = x - (float)fx, w0 = 1.0f - w1;
+    float const w3 = y - (float)fy, w2 = 1.0f - w3;
+    return at(fx, fy, ch) * (w0 * w2) + at(fx1, fy, ch) * (w1 * w2)
+        + at(fx, fy1, ch) * (w0 * w3) + at(fx1, fy1, ch) * (w1 * w3);
+}
+
+// mve::CameraInfo subset
+struct CameraInfo
+{
+    float flen = 0.0f;           // normalised by max(width, height)
+    float ppoint[2] = { 0.5f, 0.5f };
+    float paspect = 1.0f;
+    float trans[3] = { 0, 0, 0 };
+    float rot[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+
+    void fill_calibration(float* mat, float width, float height) const;
+    void fill_inverse_calibration(float* mat, float width, float height) const;
+    // M = K_d R_d R_s^T K_s^-1, t = K_d (t_d - R_d R_s^T t_s)  (this = source)
+    void fill_reprojection(CameraInfo const& destination, float src_width,
+        float src_height, float dst_width, float dst_height, float* mat,
+        float* vec) const;
+};
+
+// mve::Bundle subset: sparse SfM points with the views that see them
+struct Bundle
+{
+    typedef std::shared_ptr<Bundle> Ptr;
+    typedef std::shared_ptr<Bundle const> ConstPtr;
+    struct Feature3D
+    {
+        float pos[3];
+        std::vector<int> view_ids;
+    };
+    std::vector<Feature3D> features;
+};
+
+} // namespace smvs_amd

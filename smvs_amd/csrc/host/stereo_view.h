@@ -1,0 +1,78 @@
+// Host mirror of smvs::StereoView (reference: lib/stereo_view.h:21-79): the
+// per-view image bundle consumed by DepthOptimizer / SGMStereo.  The MVE view
+// + embedding name of the reference is replaced by an in-memory byte image
+// and camera; named embeddings written by the optimizer are kept in a map.
+#pragma once
+
+#include <map>
+#include <string>
+
+#include "image.h"
+
+namespace smvs_amd {
+
+class StereoView
+{
+public:
+    typedef std::shared_ptr<StereoView> Ptr;
+    typedef std::shared_ptr<const StereoView> ConstPtr;
+
+    // lib/stereo_view.h:28-30
+    static Ptr create(int view_id, ByteImage::ConstPtr image,
+        CameraInfo const& camera, bool initialize_linear = false,
+        bool gamma_correction = false);
+
+    void set_scale(int scale, bool debug = false);
+
+    int get_width(void) const { return image->width(); }
+    int get_height(void) const { return image->height(); }
+    int get_view_id(void) const { return view_id; }
+    CameraInfo const& get_camera(void) const { return camera; }
+    float get_flen(void) const;
+    float get_inverse_flen(void) const;
+    ByteImage::ConstPtr get_byte_image(void) const;
+    FloatImage::ConstPtr get_image(void) const { return image; }
+    FloatImage::ConstPtr get_scaleimage(void) const { return scaleimage; }
+    FloatImage::ConstPtr get_image_gradients(void) const { return image_grad; }
+    FloatImage::ConstPtr get_image_hessian(void) const { return image_hessian; }
+    FloatImage::ConstPtr get_shading_image(void) const { return shading; }
+    FloatImage::ConstPtr get_shading_gradients(void) const { return shading_grad; }
+    FloatImage::ConstPtr get_linear_image(void) const { return linear_image; }
+
+    // "smvs-sgm" embedding: stored in MVE convention (ray length); the getter
+    // converts to z-depth (lib/stereo_view.h:121-130)
+    FloatImage::Ptr get_sgm_depth(void) const;
+    bool has_embedding(std::string const& name) const;
+    FloatImage::Ptr get_embedding(std::string const& name) const;
+
+    void write_image_to_view(FloatImage::Ptr image, std::string const& name);
+    void write_depth_to_view(FloatImage::Ptr depth, std::string const& name);
+
+private:
+    StereoView(void) = default;
+    void initialize_linear(bool gamma_correction);
+
+private:
+    int view_id = 0;
+    CameraInfo camera;
+    ByteImage::ConstPtr bytes;
+    FloatImage::ConstPtr image;
+    FloatImage::Ptr scaleimage, image_grad, image_hessian;
+    FloatImage::Ptr linear_image, shading, shading_grad;
+    std::map<std::string, FloatImage::Ptr> embeddings;
+};
+
+// image helpers shared with SGMStereo / DepthOptimizer
+namespace imgtools {
+FloatImage::Ptr blur_gaussian(FloatImage::ConstPtr in, float sigma);
+FloatImage::Ptr desaturate(FloatImage::ConstPtr in);
+ByteImage::Ptr desaturate(ByteImage::ConstPtr in);
+ByteImage::Ptr rescale_half_size(ByteImage::ConstPtr in);
+void gradients_and_hessian(FloatImage::ConstPtr input, FloatImage::Ptr gradient,
+    FloatImage::Ptr hessian);
+// z-depth <-> ray length (mve::image::depthmap_convert_conventions)
+void depthmap_convert_conventions(FloatImage::Ptr dm, float const* invproj,
+    bool to_mve);
+}
+
+} // namespace smvs_amd

@@ -1,0 +1,484 @@
+// Host mirror of lib/surface.cc + the evaluation part of lib/bicubic_patch.cc
+// and lib/surface_patch.cc.  Topology operations run on the host between
+// Newton batches.
+#include "surface.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace smvs_amd {
+
+namespace {
+
+// 1-D cubic Hermite basis and derivatives: value@0, value@1, slope@0, slope@1
+inline void
+hermite(double t, int k, double* b)
+{
+    double const t2 = t * t, t3 = t2 * t;
+    switch (k) {
+    case 0:
+        b[0] = 1.0 - 3.0 * t2 + 2.0 * t3; b[1] = 3.0 * t2 - 2.0 * t3;
+        b[2] = t - 2.0 * t2 + t3;         b[3] = t3 - t2;
+        break;
+    case 1:
+        b[0] = -6.0 * t + 6.0 * t2;       b[1] = 6.0 * t - 6.0 * t2;
+        b[2] = 1.0 - 4.0 * t + 3.0 * t2;  b[3] = 3.0 * t2 - 2.0 * t;
+        break;
+    default:
+        b[0] = -6.0 + 12.0 * t;           b[1] = 6.0 - 12.0 * t;
+        b[2] = -4.0 + 6.0 * t;            b[3] = 6.0 * t - 2.0;
+        break;
+    }
+}
+
+} // namespace
+
+PatchEval::PatchEval(double const* nodes16)
+{
+    std::copy(nodes16, nodes16 + 16, n);
+}
+
+double
+PatchEval::eval(double x, double y, int kx, int ky) const
+{
+    double bx[4], by[4];
+    hermite(x, kx, bx);
+    hermite(y, ky, by);
+    double r = 0.0;
+    for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+            double const* nd = n + 4 * (2 * b + a);
+            r += nd[0] * bx[a] * by[b] + nd[1] * bx[2 + a] * by[b]
+                + nd[2] * bx[a] * by[2 + b] + nd[3] * bx[2 + a] * by[2 + b];
+        }
+    return r;
+}
+
+/* ---------------------------------------------------------------------- */
+
+Surface::Ptr
+Surface::create(Bundle::ConstPtr bundle, StereoView::Ptr main_view, int scale,
+    FloatImage::ConstPtr init_depth)
+{
+    // lib/surface.cc:19-53
+    Ptr s(new Surface());
+    int const width = main_view->get_width(), height = main_view->get_height();
+    s->pixel_width = width;
+    s->pixel_height = height;
+    s->scale = scale;
+    s->patchsize = 1 << scale;
+    s->npx = (width - 2) / s->patchsize - 1;
+    s->npy = (height - 2) / s->patchsize - 1;
+    s->patch_valid.assign((size_t)s->npx * s->npy, 0);
+    s->node_valid.assign((size_t)(s->npx + 1) * (s->npy + 1), 0);
+    s->nodes.assign(s->node_valid.size() * 4, 0.0);
+    s->start_x = (width - s->npx * s->patchsize) / 2;
+    s->start_y = (height - s->npy * s->patchsize) / 2;
+    s->depth = FloatImage::create(width, height, 1);
+    if (init_depth == nullptr)
+        s->initialize_depth_from_bundle(bundle, main_view->get_camera(),
+            main_view->get_view_id());
+    else
+        for (int p = 0; p < s->depth->get_pixel_amount(); ++p)
+            if (init_depth->at(p) > 0.0)
+                s->depth->at(p) = init_depth->at(p);
+    s->fill_patches_from_depth();
+    return s;
+}
+
+void
+Surface::initialize_depth_from_bundle(Bundle::ConstPtr bundle,
+    CameraInfo const& cam, int view_id)
+{
+    // lib/surface.cc:90-130
+    int const width = pixel_width, height = pixel_height;
+    double const fwidth2 = (double)width / 2.0, fheight2 = (double)height / 2.0;
+    double const fnorm = (double)std::max(width, height);
+    for (auto const& feat : bundle->features)
+        for (int vid : feat.view_ids)
+            if (vid == view_id) {
+                float proj[3];
+                for (int r = 0; r < 3; ++r)
+                    proj[r] = cam.rot[3 * r] * feat.pos[0]
+                        + cam.rot[3 * r + 1] * feat.pos[1]
+                        + cam.rot[3 * r + 2] * feat.pos[2] + cam.trans[r];
+                float const d = proj[2];
+                proj[0] = proj[0] * cam.flen / proj[2];
+                proj[1] = proj[1] * cam.flen / proj[2];
+                float const ix = (float)(proj[0] * fnorm + fwidth2);
+                float const iy = (float)(proj[1] * fnorm + fheight2);
+                int const x = (int)std::floor(ix), y = (int)std::floor(iy);
+                if (x >= 0 && x < width && y >= 0 && y < height)
+                    depth->at(x, y, 0) = d;
+                break;
+            }
+}
+
+bool
+Surface::node_exists(int idx, int idy) const
+{
+    if (idx < 0 || idy < 0 || idx > npx || idy > npy)
+        return false;
+    return node_valid[(size_t)idy * (npx + 1) + idx] != 0;
+}
+
+bool
+Surface::patch_exists(int idx, int idy) const
+{
+    if (idx < 0 || idy < 0 || idx >= npx || idy >= npy)
+        return false;
+    return patch_valid[(size_t)idy * npx + idx] != 0;
+}
+
+int
+Surface::count_valid_patches(void) const
+{
+    int n = 0;
+    for (uint8_t v : patch_valid)
+        n += v ? 1 : 0;
+    return n;
+}
+
+void
+Surface::fill_node_ids_for_patch(std::size_t patch_id,
+    std::size_t* node_ids) const
+{
+    std::size_t const idx = patch_id % npx, idy = patch_id / npx;
+    std::size_t const stride = npx + 1;
+    node_ids[0] = idy * stride + idx;
+    node_ids[1] = node_ids[0] + 1;
+    node_ids[2] = node_ids[0] + stride;
+    node_ids[3] = node_ids[2] + 1;
+}
+
+void
+Surface::fill_patch_nodes(std::size_t patch_id, double* nodes16) const
+{
+    std::size_t ids[4];
+    fill_node_ids_for_patch(patch_id, ids);
+    for (int k = 0; k < 4; ++k)
+        std::copy(nodes.begin() + 4 * ids[k], nodes.begin() + 4 * ids[k] + 4,
+            nodes16 + 4 * k);
+}
+
+void
+Surface::patch_origin(std::size_t patch_id, int* px, int* py) const
+{
+    *px = start_x + (int)(patch_id % npx) * patchsize;
+    *py = start_y + (int)(patch_id / npx) * patchsize;
+}
+
+int
+Surface::fill_holes(void)
+{
+    // lib/surface.cc:630-651
+    int filled = 0;
+    for (int x = 0; x < npx; ++x)
+        for (int y = 0; y < npy; ++y) {
+            if (patch_exists(x, y))
+                continue;
+            if (node_exists(x, y) && node_exists(x + 1, y)
+                && node_exists(x, y + 1) && node_exists(x + 1, y + 1)) {
+                patch_valid[(size_t)y * npx + x] = 1;
+                filled += 1;
+            }
+        }
+    return filled;
+}
+
+void
+Surface::remove_nodes_without_patch(void)
+{
+    // lib/surface.cc:762-869: a node lives while one incident patch lives
+    int const stride = npx + 1;
+    for (std::size_t i = 0; i < node_valid.size(); ++i) {
+        if (!node_valid[i])
+            continue;
+        int const idx = (int)(i % stride), idy = (int)(i / stride);
+        if (!patch_exists(idx - 1, idy - 1) && !patch_exists(idx, idy - 1)
+            && !patch_exists(idx - 1, idy) && !patch_exists(idx, idy))
+            node_valid[i] = 0;
+    }
+}
+
+void
+Surface::remove_isolated_patches(void)
+{
+    // lib/surface.cc:887-927
+    for (int x = 0; x < npx; ++x)
+        for (int y = 0; y < npy; ++y) {
+            if (!patch_exists(x, y))
+                continue;
+            int neighbours = 0;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    if ((dx || dy) && patch_exists(x + dx, y + dy))
+                        neighbours += 1;
+            if (neighbours < 3)
+                patch_valid[(size_t)y * npx + x] = 0;
+        }
+    remove_nodes_without_patch();
+}
+
+void
+Surface::initialize_node_from_depth(int idx, int idy)
+{
+    // lib/surface.cc:667-760
+    int const stride = npx + 1;
+    std::size_t const id = (size_t)idy * stride + idx;
+    if (node_valid[id])
+        return;
+    int const x = idx * patchsize + start_x, y = idy * patchsize + start_y;
+    int const window = patchsize / 2;
+    std::vector<double> all;
+    double lowest[4] = { 0, 0, 0, 0 };
+    int quadrants = 4;
+    for (int q = 0; q < 4; ++q) {
+        int const i0 = (q & 1) ? 0 : -window, j0 = (q & 2) ? 0 : -window;
+        bool any = false;
+        for (int i = i0; i < i0 + window; ++i)
+            for (int j = j0; j < j0 + window; ++j) {
+                int const xx = x + i, yy = y + j;
+                if (xx < 0 || xx >= depth->width() || yy < 0
+                    || yy >= depth->height() || !(depth->at(xx, yy, 0) > 0.0))
+                    continue;
+                double const d = depth->at(xx, yy, 0);
+                lowest[q] = any ? std::min(lowest[q], d) : d;
+                any = true;
+                all.push_back(d);
+            }
+        if (!any)
+            quadrants -= 1;
+    }
+    if (quadrants == 0 || all.size() < 2)
+        return;
+    std::nth_element(all.begin(), all.begin() + all.size() / 2, all.end());
+    double* node = &nodes[4 * id];
+    node[0] = all[all.size() / 2];
+    node[1] = node[2] = node[3] = 0.0;
+    double const* a = lowest;
+    if (quadrants == 4) {
+        node[1] = ((a[1] + a[3]) - (a[0] + a[2])) / 2.0;
+        node[2] = ((a[2] + a[3]) - (a[0] + a[1])) / 2.0;
+        node[3] = ((a[3] - a[2]) - (a[1] - a[0]));
+    } else {
+        if ((a[1] == 0 || a[0] == 0) && a[3] != 0 && a[2] != 0)
+            node[1] = a[3] - a[2];
+        else if ((a[2] == 0 || a[3] == 0) && a[1] != 0 && a[0] != 0)
+            node[1] = a[1] - a[0];
+        if ((a[0] == 0 || a[2] == 0) && a[3] != 0 && a[1] != 0)
+            node[2] = a[3] - a[1];
+        else if ((a[1] == 0 || a[2] == 0) && a[0] != 0 && a[2] != 0)
+            node[2] = a[2] - a[0];
+    }
+    node_valid[id] = 1;
+}
+
+void
+Surface::fill_patches_from_depth(void)
+{
+    // lib/surface.cc:140-152
+    for (int i = 0; i < npx + 1; ++i)
+        for (int j = 0; j < npy + 1; ++j)
+            initialize_node_from_depth(i, j);
+    fill_holes();
+    remove_nodes_without_patch();
+}
+
+FloatImage::Ptr
+Surface::get_depth_map(void) const
+{
+    // lib/surface.cc:155-168 + lib/surface_patch.cc:15-28
+    FloatImage::Ptr dmap = FloatImage::create(pixel_width, pixel_height, 1);
+    for (std::size_t p = 0; p < patch_valid.size(); ++p) {
+        if (!patch_valid[p])
+            continue;
+        double n16[16];
+        fill_patch_nodes(p, n16);
+        PatchEval pe(n16);
+        int px, py;
+        patch_origin(p, &px, &py);
+        for (int j = 0; j < patchsize; ++j)
+            for (int i = 0; i < patchsize; ++i)
+                dmap->at(px + i, py + j, 0) = (float)pe.f((i + 0.5) / patchsize,
+                    (j + 0.5) / patchsize);
+    }
+    return dmap;
+}
+
+FloatImage::Ptr
+Surface::get_normal_map(float inv_flen) const
+{
+    // lib/surface.cc:170-183 + lib/surface_patch.cc:30-55
+    FloatImage::Ptr normals = FloatImage::create(pixel_width, pixel_height, 3);
+    for (std::size_t p = 0; p < patch_valid.size(); ++p) {
+        if (!patch_valid[p])
+            continue;
+        double n16[16];
+        fill_patch_nodes(p, n16);
+        PatchEval pe(n16);
+        int px, py;
+        patch_origin(p, &px, &py);
+        for (int j = 0; j < patchsize; ++j)
+            for (int i = 0; i < patchsize; ++i) {
+                double const u = (i + 0.5) / patchsize, v = (j + 0.5) / patchsize;
+                double const w = pe.f(u, v), wx = pe.dx(u, v) / patchsize,
+                    wy = pe.dy(u, v) / patchsize;
+                double const x = px + i + 0.5 - (double)pixel_width / 2.0;
+                double const y = py + j + 0.5 - (double)pixel_height / 2.0;
+                double nz = (x * wx + y * wy + w) * (double)inv_flen;
+                double const len = std::sqrt(wx * wx + wy * wy + nz * nz);
+                normals->at(px + i, py + j, 0) = (float)(wx / len);
+                normals->at(px + i, py + j, 1) = (float)(-wy / len);
+                normals->at(px + i, py + j, 2) = (float)(nz / len);
+            }
+    }
+    return normals;
+}
+
+void
+Surface::update_nodes(std::vector<double> const& delta)
+{
+    // lib/surface.cc:957-981
+    for (std::size_t i = 0; i < node_valid.size(); ++i) {
+        if (!node_valid[i])
+            continue;
+        for (int k = 0; k < 4; ++k)
+            nodes[4 * i + k] += delta[4 * i + k];
+    }
+}
+
+void
+Surface::subdivide_patches(void)
+{
+    // lib/surface.cc:983-1107
+    int const old_npx = npx, old_npy = npy, old_stride = npx + 1;
+    scale -= 1;
+    patchsize = 1 << scale;
+    int new_npx = (pixel_width - 2) / patchsize;
+    int new_npy = (pixel_height - 2) / patchsize;
+    int off_x = 0, off_y = 0;
+    if (new_npx - old_npx * 2 >= 2) {
+        new_npx = old_npx * 2 + 2;
+        start_x = (pixel_width - new_npx * patchsize) / 2;
+        off_x = 1;
+    } else
+        new_npx = old_npx * 2;
+    if (new_npy - old_npy * 2 >= 2) {
+        new_npy = old_npy * 2 + 2;
+        start_y = (pixel_height - new_npy * patchsize) / 2;
+        off_y = 1;
+    } else
+        new_npy = old_npy * 2;
+
+    int const new_stride = new_npx + 1;
+    std::vector<double> new_nodes((size_t)new_stride * (new_npy + 1) * 4, 0.0);
+    std::vector<uint8_t> new_valid((size_t)new_stride * (new_npy + 1), 0);
+
+    // five new nodes per patch: edge midpoints and the centre
+    struct Split { double u, v; int ox, oy; };
+    static Split const splits[5] = { { 0.5, 0.0, 1, 0 }, { 0.0, 0.5, 0, 1 },
+        { 0.5, 0.5, 1, 1 }, { 1.0, 0.5, 2, 1 }, { 0.5, 1.0, 1, 2 } };
+    for (std::size_t p = 0; p < patch_valid.size(); ++p) {
+        if (!patch_valid[p])
+            continue;
+        int const nx = 2 * (int)(p % old_npx) + off_x;
+        int const ny = 2 * (int)(p / old_npx) + off_y;
+        double n16[16];
+        fill_patch_nodes(p, n16);
+        PatchEval pe(n16);
+        for (Split const& s : splits) {
+            std::size_t const id = (size_t)(ny + s.oy) * new_stride + nx + s.ox;
+            new_nodes[4 * id + 0] = pe.f(s.u, s.v);
+            new_nodes[4 * id + 1] = pe.dx(s.u, s.v) / 2;
+            new_nodes[4 * id + 2] = pe.dy(s.u, s.v) / 2;
+            new_nodes[4 * id + 3] = pe.dxy(s.u, s.v) / 4;
+            new_valid[id] = 1;
+        }
+    }
+    // old nodes keep their values, derivatives rescaled to the new patch size
+    for (std::size_t i = 0; i < node_valid.size(); ++i) {
+        if (!node_valid[i])
+            continue;
+        std::size_t const id = (size_t)(2 * (i / old_stride) + off_y) * new_stride
+            + 2 * (i % old_stride) + off_x;
+        new_nodes[4 * id + 0] = nodes[4 * i + 0];
+        new_nodes[4 * id + 1] = nodes[4 * i + 1] / 2;
+        new_nodes[4 * id + 2] = nodes[4 * i + 2] / 2;
+        new_nodes[4 * id + 3] = nodes[4 * i + 3] / 4;
+        new_valid[id] = 1;
+    }
+    npx = new_npx;
+    npy = new_npy;
+    nodes.swap(new_nodes);
+    node_valid.swap(new_valid);
+    patch_valid.assign((size_t)npx * npy, 0);
+    fill_holes();
+    remove_nodes_without_patch();
+}
+
+int
+Surface::expand(void)
+{
+    // lib/surface.cc:482-628: two rounds of extrapolating new nodes from
+    // complete triples of neighbours; a later candidate replaces an earlier
+    // one only when it is more than 1/0.9 deeper (check_swap_nodes :472-480)
+    int const stride = npx + 1;
+    std::size_t const count = node_valid.size();
+    std::vector<double> proposal(count, 0.0);
+    std::vector<uint8_t> proposed(count, 0);
+    static int const off[8][2] = { { -1, -1 }, { 0, -1 }, { 1, -1 }, { -1, 0 },
+        { 1, 0 }, { -1, 1 }, { 0, 1 }, { 1, 1 } };
+    // triples and the (neighbour, axis, sign) terms averaged for each
+    struct Term { int nb; int axis; double sign; };
+    struct Rule { int need[3]; int nterms; Term terms[3]; };
+    static Rule const rules[8] = {
+        { { 0, 1, 3 }, 2, { { 3, 1, +1 }, { 1, 2, +1 }, { 0, 0, 0 } } },
+        { { 1, 2, 4 }, 2, { { 4, 1, -1 }, { 1, 2, +1 }, { 0, 0, 0 } } },
+        { { 3, 5, 6 }, 2, { { 3, 1, +1 }, { 6, 2, -1 }, { 0, 0, 0 } } },
+        { { 4, 6, 7 }, 2, { { 4, 1, -1 }, { 6, 2, -1 }, { 0, 0, 0 } } },
+        { { 0, 1, 2 }, 3, { { 0, 2, +1 }, { 1, 2, +1 }, { 2, 2, +1 } } },
+        { { 0, 3, 5 }, 3, { { 0, 1, +1 }, { 3, 1, +1 }, { 5, 1, +1 } } },
+        { { 5, 6, 7 }, 3, { { 5, 2, -1 }, { 6, 2, -1 }, { 7, 2, -1 } } },
+        { { 2, 4, 7 }, 3, { { 2, 1, -1 }, { 4, 1, -1 }, { 7, 1, -1 } } } };
+    for (int round = 0; round < 2; ++round) {
+        for (std::size_t id = 0; id < count; ++id) {
+            if (node_valid[id] && !proposed[id])
+                continue;
+            int const idx = (int)(id % stride), idy = (int)(id / stride);
+            double const* nb[8];
+            for (int k = 0; k < 8; ++k)
+                nb[k] = node_exists(idx + off[k][0], idy + off[k][1])
+                    ? &nodes[4 * ((size_t)(idy + off[k][1]) * stride + idx
+                        + off[k][0])] : nullptr;
+            for (Rule const& r : rules) {
+                if (!nb[r.need[0]] || !nb[r.need[1]] || !nb[r.need[2]])
+                    continue;
+                double sum = 0.0;
+                for (int t = 0; t < r.nterms; ++t) {
+                    Term const& tm = r.terms[t];
+                    double const term = tm.sign > 0
+                        ? nb[tm.nb][0] + nb[tm.nb][tm.axis] / 2.0
+                        : nb[tm.nb][0] - nb[tm.nb][tm.axis] / 2.0;
+                    sum = t == 0 ? term : sum + term;
+                }
+                double const cand = sum / (double)r.nterms;
+                if (!proposed[id] || cand * 0.9 > proposal[id]) {
+                    proposal[id] = cand;
+                    proposed[id] = 1;
+                }
+            }
+        }
+        for (std::size_t id = 0; id < count; ++id)
+            if (proposed[id]) {
+                nodes[4 * id] = proposal[id];
+                nodes[4 * id + 1] = nodes[4 * id + 2] = nodes[4 * id + 3] = 0.0;
+                node_valid[id] = 1;
+            }
+    }
+    int const filled = fill_holes();
+    remove_nodes_without_patch();
+    return filled;
+}
+
+} // namespace smvs_amd

@@ -1,0 +1,138 @@
+"""ctypes handle on the C++ host mirror (csrc/host/libsmvs_host.so):
+smvs_amd::DepthOptimizer::optimize and the SGM initialisation, driven with
+the inputs of smvs_amd.synth.pipeline_inputs()."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+
+HOST_LIB = os.path.join(_capi.HERE, "csrc", "host", "libsmvs_host.so")
+_lib = None
+
+_fp = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+
+
+class HostView(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("channels", C.c_int),
+                ("bytes", _u8p), ("flen", C.c_float), ("rot", C.c_float * 9),
+                ("trans", C.c_float * 3), ("view_id", C.c_int)]
+
+
+class HostBundle(C.Structure):
+    _fields_ = [("num_features", C.c_int), ("positions", _fp),
+                ("ref_offsets", _i32p), ("ref_views", _i32p)]
+
+
+class HostOptions(C.Structure):
+    _fields_ = [("regularization", C.c_double),
+                ("light_surf_regularization", C.c_double),
+                ("num_iterations", C.c_int), ("min_scale", C.c_int),
+                ("use_shading", C.c_int), ("use_sgm", C.c_int),
+                ("full_optimization", C.c_int), ("device", C.c_int)]
+
+
+class HostLog(C.Structure):
+    _fields_ = [("count", C.c_int), ("scale", C.c_int * 256),
+                ("iter", C.c_int * 256), ("newton_steps", C.c_int * 256),
+                ("valid_patches", C.c_int * 256), ("cg_iterations", C.c_int * 256),
+                ("has_lighting", C.c_int), ("lighting", C.c_double * 16)]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        _capi.load()  # libsmvs_hip.so first
+        if not os.path.exists(HOST_LIB):
+            raise _capi.SmvsError(-2, "host library %s is missing" % HOST_LIB)
+        _lib = C.CDLL(HOST_LIB)
+        _lib.smvs_host_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _view(img, cam, view_id, keep):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    keep.append(img)
+    v = HostView()
+    v.height, v.width, v.channels = img.shape
+    v.bytes = img.ctypes.data_as(_u8p)
+    v.flen = cam.flen
+    for i, x in enumerate(np.asarray(cam.R, dtype=np.float32).reshape(9)):
+        v.rot[i] = float(x)
+    for i, x in enumerate(np.asarray(cam.t, dtype=np.float32).reshape(3)):
+        v.trans[i] = float(x)
+    v.view_id = view_id
+    return v
+
+
+def _marshal(inputs, keep):
+    cams, images = inputs["cams"], inputs["images"]
+    main = _view(images[0], cams[0], inputs["view_ids"][0], keep)
+    n_subs = len(cams) - 1
+    subs = (HostView * n_subs)()
+    for j in range(n_subs):
+        subs[j] = _view(images[j + 1], cams[j + 1], inputs["view_ids"][j + 1], keep)
+    feats = np.ascontiguousarray(inputs["features"], dtype=np.float32).reshape(-1, 3)
+    nf = feats.shape[0]
+    offsets = (np.arange(nf + 1) * len(cams)).astype(np.int32)
+    refs = np.tile(np.asarray(inputs["view_ids"], dtype=np.int32), nf)
+    keep += [feats, offsets, refs]
+    b = HostBundle(nf, feats.ctypes.data_as(_fp), offsets.ctypes.data_as(_i32p),
+                   refs.ctypes.data_as(_i32p))
+    return main, subs, n_subs, b
+
+
+def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
+             min_scale=2, use_shading=False, sgm_depth=None,
+             full_optimization=False, device=0):
+    lib = load()
+    keep = []
+    main, subs, n_subs, b = _marshal(inputs, keep)
+    o = HostOptions(regularization, light_reg, num_iterations, min_scale,
+                    1 if use_shading else 0, 1 if sgm_depth is not None else 0,
+                    1 if full_optimization else 0, device)
+    h, w = main.height, main.width
+    depth = np.zeros((h, w), dtype=np.float32)
+    normals = np.zeros((h, w, 3), dtype=np.float32)
+    log = HostLog()
+    sd = rt = None
+    sw = sh = 0
+    if sgm_depth is not None:
+        sd = np.ascontiguousarray(sgm_depth, dtype=np.float32)
+        sh, sw = sd.shape
+        rt = np.zeros_like(sd)
+    rc = lib.smvs_host_optimize(C.byref(main), subs, n_subs, C.byref(b),
+        sd.ctypes.data_as(_fp) if sd is not None else None, sw, sh,
+        rt.ctypes.data_as(_fp) if rt is not None else None, C.byref(o),
+        depth.ctypes.data_as(_fp), normals.ctypes.data_as(_fp), C.byref(log))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    steps = [dict(scale=log.scale[i], iter=log.iter[i],
+                  newton_steps=log.newton_steps[i],
+                  valid_patches=log.valid_patches[i],
+                  cg_iterations=log.cg_iterations[i]) for i in range(log.count)]
+    return dict(depth=depth, normals=normals, log=steps, sgm_roundtrip=rt,
+                lighting=np.array(log.lighting[:]) if log.has_lighting else None)
+
+
+def sgm_depth(inputs, sgm_scale=1, min_depth=0.0, max_depth=0.0, device=0):
+    lib = load()
+    keep = []
+    main, subs, n_subs, b = _marshal(inputs, keep)
+    w, h = main.width, main.height
+    for _ in range(sgm_scale):
+        w, h = (w + 1) // 2, (h + 1) // 2
+    out = np.zeros((h, w), dtype=np.float32)
+    ow = C.c_int(0); oh = C.c_int(0)
+    rc = lib.smvs_host_sgm_depth(C.byref(main), subs, n_subs, C.byref(b),
+        sgm_scale, C.c_float(min_depth), C.c_float(max_depth), device,
+        out.ctypes.data_as(_fp), C.byref(ow), C.byref(oh))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    assert (ow.value, oh.value) == (w, h)
+    return out

@@ -345,3 +345,78 @@ def make_problem(width, height, n_subs, scale, shading=False, noise=0.002,
     surf = surface_from_depth(scene, main, subs, scale, noise=noise)
     return dict(surf=surf, views=views, lighting=lighting, images=imgs,
                 scene=scene, main=main, sub_cams=subs)
+
+
+# ------------------------------------------------- whole-pipeline scene inputs
+class PlaneScene:
+    """Slanted textured plane z = z0 + ax x + ay y (world = reference camera
+    frame); same interface as SphereScene."""
+
+    def __init__(self, z0=5.0, ax=0.12, ay=0.08, seed=1234, px_size=0.008):
+        self.z0, self.ax, self.ay = z0, ax, ay
+        rng = np.random.default_rng(seed)
+        n = 24
+        lam = px_size * np.exp(rng.uniform(np.log(8.0), np.log(160.0), size=n))
+        dirs = rng.standard_normal((n, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        self.freq = dirs * (2 * np.pi / lam)[:, None]
+        self.phase = rng.uniform(0, 2 * np.pi, size=n)
+        self.amp = rng.uniform(0.4, 1.0, size=n)
+
+    def intersect(self, origin, dirs):
+        # z = z0 + ax x + ay y  with  X = o + s d
+        nrm = np.array([-self.ax, -self.ay, 1.0])
+        s = (self.z0 - origin @ nrm) / (dirs @ nrm)
+        return origin + s[..., None] * dirs, np.ones(dirs.shape[:-1], bool)
+
+    def albedo(self, X):
+        v = np.zeros(X.shape[:-1])
+        for k in range(len(self.amp)):
+            v += self.amp[k] * np.sin(X @ self.freq[k] + self.phase[k])
+        v = v / np.sqrt(np.sum(self.amp ** 2))
+        return np.clip(0.5 + 0.22 * v, 0.02, 0.98)
+
+    def normal(self, X, hit):
+        n = np.array([self.ax, self.ay, -1.0])
+        n = n / np.linalg.norm(n)
+        return np.broadcast_to(n, X.shape).copy()
+
+
+def render_rgb(scene, cam, lighting=None):
+    """u8 RGB image (H, W, 3): the grey rendering with a fixed tint so the
+    three channels differ (ncc_for_patch reads channels 0..2)."""
+    g = render(scene, cam, lighting).astype(np.float32)
+    rgb = np.stack([g * 0.95, g, g * 0.9], axis=-1)
+    return np.clip(np.floor(rgb + 0.5), 0, 255).astype(np.uint8)
+
+
+def pipeline_inputs(kind, width, height, n_subs, flen=1.0, n_features=2000,
+                    seed=1234, lighting=None):
+    """Images + cameras + sparse features for a whole DepthOptimizer::optimize
+    run (BASELINE.json configs[0] for kind='plane')."""
+    rng = np.random.default_rng(seed)
+    if kind == "plane":
+        scene = PlaneScene(seed=seed, px_size=5.0 / (flen * max(width, height)))
+        main = Camera(np.eye(3), np.zeros(3), flen, width, height)
+        subs = []
+        for k in range(n_subs):
+            sign = 1.0 if k % 2 == 0 else -1.0
+            ang = 0.02 * sign * (1 + k // 2)
+            R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0],
+                          [-np.sin(ang), 0, np.cos(ang)]])
+            subs.append(Camera(R, np.array([0.3 * sign * (1 + k // 2), 0.05 * k, 0.0]),
+                               flen, width, height))
+    else:
+        main, subs = ring_cameras(width, height, n_subs, flen=flen)
+        scene = SphereScene(seed=seed, px_size=3.0 / (flen * max(width, height)))
+    cams = [main] + subs
+    images = [render_rgb(scene, c, lighting) for c in cams]
+    # sparse SfM features: random main-view pixels lifted to the surface
+    xs = rng.uniform(0.05 * width, 0.95 * width, n_features)
+    ys = rng.uniform(0.05 * height, 0.95 * height, n_features)
+    X, _ = scene.intersect(main.center, pixel_rays(main, xs, ys))
+    ys_g, xs_g = np.mgrid[0:height, 0:width].astype(np.float64)
+    truth = depth_at(scene, main, xs_g + 0.5, ys_g + 0.5).astype(np.float32)
+    return dict(scene=scene, cams=cams, images=images,
+                features=X.astype(np.float32), truth=truth,
+                view_ids=list(range(len(cams))))

@@ -236,3 +236,48 @@ def test_bilateral_upsample_matches_oracle(hip, oracle):
     want = oracle.bilateral_upsample(dm, ci)
     assert np.array_equal(got == 0, want == 0)
     assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+
+
+# ------------------------------------------------- whole optimizer (host C++)
+def _same_control_flow(a, b):
+    key = lambda e: (e["scale"], e["iter"], e["newton_steps"], e["valid_patches"])
+    return [key(e) for e in a] == [key(e) for e in b]
+
+
+def test_host_optimize_matches_oracle_config1(hip, oracle):
+    """configs[0]-like planar scene, --no-sgm, through smvs_amd::DepthOptimizer
+    (C++ host + HIP kernels) against the oracle's optimize(): identical scale /
+    iteration / patch-count trace, depth relative L2 <= 1e-4."""
+    from smvs_amd import synth, host
+    inputs = synth.pipeline_inputs("plane", 320, 240, 2)
+    got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2)
+    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
+    assert np.max(np.abs(got["normals"] - want["normals"])) < 1e-3
+
+
+def test_host_optimize_with_sgm_and_shading_matches_oracle(hip, oracle):
+    """configs[2]/[3]-like: SGM initialisation (device SGM, host L/R check and
+    merge) feeding the optimizer with the shading term on."""
+    from smvs_amd import synth, host
+    rng = np.random.default_rng(3000)
+    lighting = np.zeros(16); lighting[0] = 0.9
+    lighting[1:4] = rng.uniform(-0.2, 0.2, 3)
+    inputs = synth.pipeline_inputs("sphere", 384, 256, 3, flen=1.2,
+                                   lighting=lighting)
+    sgm = host.sgm_depth(inputs, sgm_scale=1)
+    assert (sgm > 0).mean() > 0.3
+    got = host.optimize(inputs, regularization=0.01, num_iterations=3, min_scale=2,
+                        use_shading=True, sgm_depth=sgm)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=3,
+                           min_scale=2, use_shading=True,
+                           sgm_depth=got["sgm_roundtrip"])
+    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert got["lighting"] is not None and want["lighting"] is not None
+    assert _rel(got["lighting"], want["lighting"]) < 1e-6
+    both = (got["depth"] > 0) & (want["depth"] > 0)
+    assert both.mean() > 0.3
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
