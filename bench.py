@@ -129,13 +129,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        p = torch.tensor([patch_steps, cg_its], dtype=torch.float64, device="cuda")
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        patch_steps, cg_its = int(p[0].item()), int(p[1].item())
+    # whole-job aggregate: units summed over ranks, time = max over ranks
+    from smvs_amd import shard
+    dev = torch.device("cuda", local_rank) if dist is not None else None
+    patch_steps, elapsed = shard.aggregate_throughput(patch_steps, elapsed, dist, dev)
+    cg_its, _ = shard.aggregate_throughput(cg_its, 0.0, dist, dev)
 
     # ---- roofline of the dominant kernel: same steps, HIP-event timed ----
     roof = None

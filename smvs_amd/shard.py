@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of reference views.
+
+Reference views are independent units (reference: app/smvsrecon.cc:658-733),
+so the path shards with NO data-path collective: one process per GPU, each
+rank optimises its own views.  Collectives appear only
+  * in the measurement (barrier, max-over-ranks time, summed work units), and
+  * in the opt-in "shared lighting" mode, where the 16x16 + 16 lighting normal
+    equations (light_optimizer.cc:32-49) of the views processed in lock step
+    are summed over ranks before the host pseudo inverse (2,176 bytes: pure
+    latency, ring-vs-tree and xGMI link bandwidth are irrelevant).
+torch.distributed is plumbing here: "nccl" is RCCL on ROCm, "gloo" on CPU.
+"""
+import numpy as np
+
+
+def assign_views(num_views, world_size, rank):
+    """Round-robin view -> rank map: rank r gets views r, r + W, r + 2W, ...
+    Neighbouring view ids usually share neighbour images, round-robin keeps
+    the per-rank work balanced when views differ in cost."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    return list(range(rank, num_views, world_size))
+
+
+def lockstep_batches(num_views, world_size):
+    """Batches of view ids processed in lock step (one per rank) so that
+    collective calls of the shared-lighting mode match across ranks; the last
+    batch may leave ranks idle (None)."""
+    batches = []
+    for start in range(0, num_views, world_size):
+        batches.append([start + r if start + r < num_views else None
+                        for r in range(world_size)])
+    return batches
+
+
+def allreduce_lighting(A, b, dist=None, device=None):
+    """Sum the lighting normal equations over ranks.  A (16,16), b (16) numpy;
+    returns the summed (A, b).  With dist None (single process) it is the
+    identity.  Ranks without a view in the batch pass zeros."""
+    buf = np.concatenate([np.asarray(A, dtype=np.float64).reshape(256),
+                          np.asarray(b, dtype=np.float64).reshape(16)])
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+        t = torch.from_numpy(buf.copy())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        buf = t.cpu().numpy()
+    return buf[:256].reshape(16, 16), buf[256:]
+
+
+def aggregate_throughput(units, seconds, dist=None, device=None):
+    """Whole-job numbers of one timed region: work units summed over ranks,
+    time = max over ranks.  Returns (total_units, max_seconds)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(units), float(seconds)
+    import torch
+    t = torch.tensor([float(seconds)], dtype=torch.float64)
+    u = torch.tensor([float(units)], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device); u = u.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(u.item()), float(t.item())
