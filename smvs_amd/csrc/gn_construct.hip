@@ -238,11 +238,12 @@ col_functions(int col, int *ex, int *ey)
 // ---------------------------------------------------------------------------
 // Phase 1: one lane = one sampled pixel -> (M6[21], v6[6])
 // ---------------------------------------------------------------------------
-template <int MAXS>
+// `nb` points at this lane's column of the per-neighbour scratch in LDS:
+// value k of neighbour slot c lives at nb[(c * 5 + k) * 64].
 __device__ __forceinline__ void
 pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
-    double const theta[16], int px, int py, int sx, int sy, uint32_t vis,
-    double M6[21], double v6[6])
+    double *nb, double const theta[16], int px, int py, int sx, int sy,
+    uint32_t vis, double M6[21], double v6[6])
 {
 #pragma unroll
     for (int i = 0; i < 21; ++i)
@@ -289,14 +290,11 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
     double const gm0 = gm.x, gm1 = gm.y;
 
     // ---- neighbours (gauss_newton_step.cc:175-208) ----
-    double s0[MAXS], s1[MAXS], P0[MAXS], P1[MAXS], Q[MAXS];
     int num_subs = 0;
-#pragma unroll
-    for (int j = 0; j < MAXS; ++j) {
-        s0[j] = s1[j] = P0[j] = P1[j] = Q[j] = 0.0;
-        if (j >= A.n_subs || !((vis >> j) & 1u))
+#pragma unroll 1
+    for (int j = 0; j < A.n_subs; ++j) {
+        if (!((vis >> j) & 1u))
             continue;
-        num_subs += 1;
         const double *M = A.cams->M[j];
         const double *t = A.cams->t[j];
         SubPlanes const sp = A.subs[j];
@@ -338,8 +336,8 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         double const hxy = tap_mix(h00.y, h10.y, h01.y, h11.y, tp);
         double const hyy = tap_mix(h00.z, h10.z, h01.z, h11.z, tp);
 
-        s0[j] = jac0 * g0 + jac1 * g1;
-        s1[j] = jac2 * g0 + jac3 * g1;
+        double const s0j = jac0 * g0 + jac1 * g1;
+        double const s1j = jac2 * g0 + jac3 * g1;
 
         double const du_w = (p * d - r * a) * inv_d2;
         double const dv_w = (q * d - r * b) * inv_d2;
@@ -368,9 +366,13 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         }
         double const cu = du_cp * inv_d2;
         double const cv = dv_cp * inv_d2;
-        P0[j] = du_A[0] * g0 + dv_A[0] * g1 + JH0 * du_w + JH1 * dv_w;
-        P1[j] = du_A[1] * g0 + dv_A[1] * g1 + JH2 * du_w + JH3 * dv_w;
-        Q[j] = cu * g0 + cv * g1;
+        double *slot = nb + (num_subs * 5) * 64;
+        slot[0 * 64] = s0j;
+        slot[1 * 64] = s1j;
+        slot[2 * 64] = du_A[0] * g0 + dv_A[0] * g1 + JH0 * du_w + JH1 * dv_w;
+        slot[3 * 64] = du_A[1] * g0 + dv_A[1] * g1 + JH2 * du_w + JH3 * dv_w;
+        slot[4 * 64] = cu * g0 + cv * g1;
+        num_subs += 1;
     }
 
     // ---- IRLS-weighted photometric terms (gauss_newton_step.cc:268-321):
@@ -378,34 +380,34 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
     // on the (w, w_x) / (w, w_y) rows of the basis table. ----
     double m_ww = 0.0, m_wx = 0.0, m_xx = 0.0, m_wy = 0.0, m_yy = 0.0;
     double v_w = 0.0, v_x = 0.0, v_y = 0.0;
-#pragma unroll
-    for (int j = 0; j < MAXS; ++j) {
-        if (j >= A.n_subs || !((vis >> j) & 1u))
-            continue;
+#pragma unroll 1
+    for (int j = 0; j < num_subs; ++j) {
+        const double *sj = nb + (j * 5) * 64;
+        double const s0j = sj[0], s1j = sj[64], P0j = sj[128], P1j = sj[192],
+            Qj = sj[256];
         {
-            double const diff0 = s0[j] - gm0, diff1 = s1[j] - gm1;
+            double const diff0 = s0j - gm0, diff1 = s1j - gm1;
             double const w0 = fast_rcp(fabs(diff0) + R_FACTOR);
             double const w1 = fast_rcp(fabs(diff1) + R_FACTOR);
-            double const a0 = w0 * P0[j], b0 = w0 * Q[j];
-            double const a1 = w1 * P1[j], b1 = w1 * Q[j];
-            m_ww += a0 * P0[j] + a1 * P1[j];
-            m_wx += a0 * Q[j];
-            m_xx += b0 * Q[j];
-            m_wy += a1 * Q[j];
-            m_yy += b1 * Q[j];
+            double const a0 = w0 * P0j, b0 = w0 * Qj;
+            double const a1 = w1 * P1j, b1 = w1 * Qj;
+            m_ww += a0 * P0j + a1 * P1j;
+            m_wx += a0 * Qj;
+            m_xx += b0 * Qj;
+            m_wy += a1 * Qj;
+            m_yy += b1 * Qj;
             v_w += a0 * diff0 + a1 * diff1;
             v_x += b0 * diff0;
             v_y += b1 * diff1;
         }
-#pragma unroll
-        for (int j2 = j + 1; j2 < MAXS; ++j2) {
-            if (j2 >= A.n_subs || !((vis >> j2) & 1u))
-                continue;
-            double const sd0 = s0[j] - s0[j2], sd1 = s1[j] - s1[j2];
+#pragma unroll 1
+        for (int j2 = j + 1; j2 < num_subs; ++j2) {
+            const double *sk = nb + (j2 * 5) * 64;
+            double const sd0 = s0j - sk[0], sd1 = s1j - sk[64];
             double const w0 = fast_rcp(fabs(sd0) + R_FACTOR);
             double const w1 = fast_rcp(fabs(sd1) + R_FACTOR);
-            double const dP0 = P0[j] - P0[j2], dP1 = P1[j] - P1[j2];
-            double const dQ = Q[j] - Q[j2];
+            double const dP0 = P0j - sk[128], dP1 = P1j - sk[192];
+            double const dQ = Qj - sk[256];
             double const a0 = w0 * dP0, b0 = w0 * dQ;
             double const a1 = w1 * dP1, b1 = w1 * dQ;
             m_ww += a0 * dP0 + a1 * dP1;
@@ -569,14 +571,17 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
 //   PPW patches per wave (4 when a patch has <= 16 sampled pixels, else 1),
 //   SLOTS = 64 / PPW pixel slots per patch and chunk.
 // ---------------------------------------------------------------------------
-template <int PPW, int MAXS>
-__global__ void __launch_bounds__(64)
+template <int PPW>
+__global__ void __launch_bounds__(64, 2)
 gn_patch_kernel(PatchKernelArgs A)
 {
     constexpr int SLOTS = 64 / PPW;
     extern __shared__ double lds[];
-    double *Msh = lds;             // [27][64]
-    double *tabs = lds + 27 * 64;  // [spr][12] rows of the sampled coords
+    // [27][64] pixel systems, aliased with the [5 * n_subs][64] neighbour
+    // scratch of phase 1 (dead once M6 is formed)
+    double *Msh = lds;
+    int const scratch_rows = max(27, 5 * A.n_subs);
+    double *tabs = lds + scratch_rows * 64;  // [spr][12] sampled coordinates
 
     int const lane = threadIdx.x;
     unsigned const wv = xcd_band_block(blockIdx.x, gridDim.x);
@@ -625,13 +630,9 @@ gn_patch_kernel(PatchKernelArgs A)
 
     double4_t acc[PPW];
     double gacc[PPW];
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        acc[q] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-        gacc[q] = 0.0;
-    }
-
-    int const chunks = (A.P + SLOTS - 1) / SLOTS;
+    // PPW == 4 means P <= 16 = SLOTS: a single chunk, so the accumulators are
+    // only live in phase 2
+    int const chunks = PPW == 4 ? 1 : (A.P + SLOTS - 1) / SLOTS;
     for (int c = 0; c < chunks; ++c) {
         __syncthreads();
         // ---- phase 1 ----
@@ -640,7 +641,7 @@ gn_patch_kernel(PatchKernelArgs A)
             int const si = c * SLOTS + sidx;
             if (live && si < A.P) {
                 int const sy = si / A.spr, sx = si - sy * A.spr;
-                pixel_system<MAXS>(A, tabs, theta, pox + sx * A.sampling,
+                pixel_system(A, tabs, Msh + lane, theta, pox + sx * A.sampling,
                     poy + sy * A.sampling, sx, sy, vis, M6, v6);
             } else {
 #pragma unroll
@@ -650,6 +651,9 @@ gn_patch_kernel(PatchKernelArgs A)
                 for (int i = 0; i < 6; ++i)
                     v6[i] = 0.0;
             }
+            // every lane is done reading its neighbour scratch before the
+            // aliased rows are overwritten
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < 21; ++i)
                 Msh[i * 64 + lane] = M6[i];
@@ -658,36 +662,48 @@ gn_patch_kernel(PatchKernelArgs A)
                 Msh[(21 + i) * 64 + lane] = v6[i];
         }
         __syncthreads();
+        if (c == 0) {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+                acc[q] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+                gacc[q] = 0.0;
+            }
+        }
         // ---- phase 2: H += sum_pix D6^T (M6 D6) on the matrix cores ----
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            int const pl = 4 * t + kg;            // pixel slot in the wave
-            int const q = PPW == 1 ? 0 : (t >> 2);
-            int si = c * SLOTS + (pl & (SLOTS - 1));
-            si = min(si, A.P - 1);
-            int const sy = si / A.spr, sx = si - sy * A.spr;
-            const double *X = tabs + sx * 12 + ex * 3;
-            const double *Y = tabs + sy * 12 + ey * 3;
-            double const x0 = X[0], x1 = X[1], x2 = X[2];
-            double const y0 = Y[0], y1 = Y[1], y2 = Y[2];
-            double D[6];
-            D[0] = x0 * y0; D[1] = x1 * y0; D[2] = x0 * y1;
-            D[3] = x1 * y1; D[4] = x2 * y0; D[5] = x0 * y2;
-            double Mx[21];
-#pragma unroll
-            for (int i = 0; i < 21; ++i)
-                Mx[i] = Msh[i * 64 + pl];
+        for (int qq = 0; qq < 4; ++qq) {
+            int const q = PPW == 1 ? 0 : qq;
+            double4_t accq = acc[q];
             double gsum = gacc[q];
+#pragma unroll 1
+            for (int tt = 0; tt < 4; ++tt) {
+                int const pl = 4 * (4 * qq + tt) + kg;  // pixel slot in the wave
+                int si = c * SLOTS + (pl & (SLOTS - 1));
+                si = min(si, A.P - 1);
+                int const sy = si / A.spr, sx = si - sy * A.spr;
+                const double *X = tabs + sx * 12 + ex * 3;
+                const double *Y = tabs + sy * 12 + ey * 3;
+                double const x0 = X[0], x1 = X[1], x2 = X[2];
+                double const y0 = Y[0], y1 = Y[1], y2 = Y[2];
+                double D[6];
+                D[0] = x0 * y0; D[1] = x1 * y0; D[2] = x0 * y1;
+                D[3] = x1 * y1; D[4] = x2 * y0; D[5] = x0 * y2;
+                double Mx[21];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double T = 0.0;
+                for (int i = 0; i < 21; ++i)
+                    Mx[i] = Msh[i * 64 + pl];
 #pragma unroll
-                for (int b = 0; b < 6; ++b)
-                    T = __builtin_fma(Mx[sym6(a, b)], D[b], T);
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[a], T, acc[q],
-                    0, 0, 0);
-                gsum = __builtin_fma(Msh[(21 + a) * 64 + pl], D[a], gsum);
+                for (int a = 0; a < 6; ++a) {
+                    double T = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 6; ++b)
+                        T = __builtin_fma(Mx[sym6(a, b)], D[b], T);
+                    accq = __builtin_amdgcn_mfma_f64_16x16x4f64(D[a], T, accq,
+                        0, 0, 0);
+                    gsum = __builtin_fma(Msh[(21 + a) * 64 + pl], D[a], gsum);
+                }
             }
+            acc[q] = accq;
             gacc[q] = gsum;
         }
     }
@@ -952,27 +968,19 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
-    size_t const lds = (size_t)(27 * 64 + A.spr * 12) * sizeof(double);
+    int const scratch_rows = 5 * ctx->n_subs > 27 ? 5 * ctx->n_subs : 27;
+    size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12) * sizeof(double);
     bool const four = A.P <= 16;
     int const ppw = four ? 4 : 1;
     unsigned const blocks = (unsigned)((ctx->num_patches + ppw - 1) / ppw);
     {
         ScopedKernelTimer timer(ctx, SMVS_K_PATCH);
-        if (ctx->n_subs <= 8) {
-            if (four)
-                hipLaunchKernelGGL((gn_patch_kernel<4, 8>), dim3(blocks),
-                    dim3(64), lds, ctx->stream, A);
-            else
-                hipLaunchKernelGGL((gn_patch_kernel<1, 8>), dim3(blocks),
-                    dim3(64), lds, ctx->stream, A);
-        } else {
-            if (four)
-                hipLaunchKernelGGL((gn_patch_kernel<4, 16>), dim3(blocks),
-                    dim3(64), lds, ctx->stream, A);
-            else
-                hipLaunchKernelGGL((gn_patch_kernel<1, 16>), dim3(blocks),
-                    dim3(64), lds, ctx->stream, A);
-        }
+        if (four)
+            hipLaunchKernelGGL((gn_patch_kernel<4>), dim3(blocks), dim3(64), lds,
+                ctx->stream, A);
+        else
+            hipLaunchKernelGGL((gn_patch_kernel<1>), dim3(blocks), dim3(64), lds,
+                ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
