@@ -25,6 +25,8 @@ namespace smvs_hip {
 constexpr int CG_THREADS = 256;
 constexpr int CG_MAX_BLOCKS = 1024;
 
+typedef double double4_v __attribute__((ext_vector_type(4)));
+
 struct CgState {
     double rr;       // z.r (r_dot_r of the reference)
     double q0;
@@ -224,12 +226,16 @@ cg_spmv_kernel(CgArgs A, int nb)
         A.state[A.k & 1] = prev;
     }
 
-    const double *d_old = A.dbuf[(A.k - 1) & 1];
-    double *d_new = A.dbuf[A.k & 1];
+    const double *__restrict__ d_old = A.dbuf[(A.k - 1) & 1];
+    double *__restrict__ d_new = A.dbuf[A.k & 1];
+    const double *__restrict__ H = A.H9;
+    const double *__restrict__ zv = A.z;
+    double *__restrict__ Ad = A.Ad;
     bool const first = A.k == 1;
     int const items = A.num_nodes * 4;
     size_t const N = (size_t)A.num_nodes;
     double v[1] = { 0.0 };
+#pragma unroll 2
     for (int gid = blockIdx.x * CG_THREADS + threadIdx.x; gid < items;
          gid += gridDim.x * CG_THREADS) {
         int const n = gid >> 2, row = gid & 3;
@@ -243,23 +249,35 @@ cg_spmv_kernel(CgArgs A, int nb)
             int const m = n + dy * A.stride + dx;
             if (mx < 0 || mx >= A.stride || m < 0 || m >= A.num_nodes)
                 continue;
-            const double *blk = A.H9 + ((size_t)s * N + n) * 16 + row * 4;
             double dm[4];
             if (first) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    dm[c] = d_new[(size_t)m * 4 + c];
+                double4_v const t = *reinterpret_cast<const double4_v *>(
+                    d_new + (size_t)m * 4);
+                dm[0] = t.x; dm[1] = t.y; dm[2] = t.z; dm[3] = t.w;
             } else {
 #pragma clang fp contract(off)
-                const double *zm = A.z + (size_t)m * 4;
-                const double *om = d_old + (size_t)m * 4;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    dm[c] = zm[c] + beta * om[c];
+                double4_v const zm = *reinterpret_cast<const double4_v *>(
+                    zv + (size_t)m * 4);
+                double4_v const om = *reinterpret_cast<const double4_v *>(
+                    d_old + (size_t)m * 4);
+                dm[0] = zm.x + beta * om.x;
+                dm[1] = zm.y + beta * om.y;
+                dm[2] = zm.z + beta * om.z;
+                dm[3] = zm.w + beta * om.w;
             }
             if (s == 4)
                 d_own = dm[row];
-            double const h0 = blk[0], h1 = blk[1], h2 = blk[2], h3 = blk[3];
+            // symmetric storage: slots 4..8 are stored at the node itself,
+            // slots 0..3 are the transposed blocks stored at the neighbour
+            double h0, h1, h2, h3;
+            if (s >= 4) {
+                double4_v const hrow = *reinterpret_cast<const double4_v *>(
+                    H + ((size_t)(s - 4) * N + n) * 16 + row * 4);
+                h0 = hrow.x; h1 = hrow.y; h2 = hrow.z; h3 = hrow.w;
+            } else {
+                const double *blk = H + ((size_t)(4 - s) * N + m) * 16 + row;
+                h0 = blk[0]; h1 = blk[4]; h2 = blk[8]; h3 = blk[12];
+            }
             {
 #pragma clang fp contract(off)
                 acc += h0 * dm[0];
@@ -268,7 +286,7 @@ cg_spmv_kernel(CgArgs A, int nb)
                 acc += h3 * dm[3];
             }
         }
-        A.Ad[gid] = acc;
+        Ad[gid] = acc;
         if (!first)
             d_new[gid] = d_own;
         v[0] += d_own * acc;

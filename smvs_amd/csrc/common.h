@@ -120,7 +120,7 @@ struct smvs_ctx {
     // Gauss-Newton system
     double *Hp = nullptr;           // [P][256] per-patch systems
     double *gp = nullptr;           // [P][16]
-    double *H9 = nullptr;           // [9][N][16] slot-major block stencil
+    double *H9 = nullptr;           // [5][N][16] upper half of the block stencil
     double *Pinv = nullptr;         // [N][16]
     double *g = nullptr;            // [N][4]
     double *lighting = nullptr;     // [16]

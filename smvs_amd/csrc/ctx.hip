@@ -354,7 +354,7 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
             || (rc = device_alloc(&ctx->node_valid, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->active, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->active_next, cap)) != SMVS_OK
-            || (rc = device_alloc(&ctx->H9, cap * 9 * 16)) != SMVS_OK
+            || (rc = device_alloc(&ctx->H9, cap * 5 * 16)) != SMVS_OK
             || (rc = device_alloc(&ctx->Pinv, cap * 16)) != SMVS_OK
             || (rc = device_alloc(&ctx->g, cap * 4)) != SMVS_OK
             || (rc = device_alloc(&ctx->x, cap * 4)) != SMVS_OK

@@ -54,7 +54,7 @@ struct PatchKernelArgs {
     int use_lighting;
 };
 
-// 1 / x for x >= 1e-4 to ~1 ulp: hardware estimate + two Newton steps.
+// 1 / x to ~1 ulp: hardware estimate (2^-26 or better) + two Newton steps.
 __device__ __forceinline__ double
 fast_rcp(double x)
 {
@@ -62,6 +62,26 @@ fast_rcp(double x)
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
+}
+
+// IRLS weight 1 / x: one Newton step (relative error <= 2^-46), the weights
+// only scale residual rows.
+__device__ __forceinline__ double
+weight_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
+// a / d, correctly rounded for normal-range operands: quotient from the
+// reciprocal plus one residual correction (the core of the IEEE sequence
+// without the scaling steps).
+__device__ __forceinline__ double
+div_corrected(double a, double d, double inv_d)
+{
+    double const q = a * inv_d;
+    double const r = __builtin_fma(-q, d, a);
+    return __builtin_fma(r, inv_d, q);
 }
 
 // mve::Image<float>::linear_at in the reference's float operation order
@@ -298,11 +318,11 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         const double *M = A.cams->M[j];
         const double *t = A.cams->t[j];
         SubPlanes const sp = A.subs[j];
-        double p, q, r, a, b, d, proj0, proj1;
+        double p, q, r, a, b, d, proj0, proj1, inv_d;
         {
-            // correspondence.cc:36-51 in the reference's operation order
-            // (true divisions, no contraction): the projection feeds the
-            // float tap coordinates.
+            // correspondence.cc:36-51 in the reference's operation order (no
+            // contraction, correctly rounded quotients): the projection feeds
+            // the float tap coordinates.
 #pragma clang fp contract(off)
             double const u = (double)px + 0.5, v = (double)py + 0.5;
             p = M[0] * u + M[1] * v + M[2];
@@ -311,13 +331,13 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
             a = w * p + t[0];
             b = w * q + t[1];
             d = w * r + t[2];
-            proj0 = a / d;
-            proj1 = b / d;
+            inv_d = fast_rcp(d);
+            proj0 = div_corrected(a, d, inv_d);
+            proj1 = div_corrected(b, d, inv_d);
             proj0 -= 0.5;
             proj1 -= 0.5;
         }
         // correspondence.cc:88-100 with reciprocals
-        double const inv_d = fast_rcp(d);
         double const inv_d2 = inv_d * inv_d;
         double const rx = wx * r + w * M[6], ry = wy * r + w * M[7];
         double const jac0 = (wx * p + w * M[0]) * inv_d - a * rx * inv_d2;
@@ -387,8 +407,8 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
             Qj = sj[256];
         {
             double const diff0 = s0j - gm0, diff1 = s1j - gm1;
-            double const w0 = fast_rcp(fabs(diff0) + R_FACTOR);
-            double const w1 = fast_rcp(fabs(diff1) + R_FACTOR);
+            double const w0 = weight_rcp(fabs(diff0) + R_FACTOR);
+            double const w1 = weight_rcp(fabs(diff1) + R_FACTOR);
             double const a0 = w0 * P0j, b0 = w0 * Qj;
             double const a1 = w1 * P1j, b1 = w1 * Qj;
             m_ww += a0 * P0j + a1 * P1j;
@@ -404,8 +424,8 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         for (int j2 = j + 1; j2 < num_subs; ++j2) {
             const double *sk = nb + (j2 * 5) * 64;
             double const sd0 = s0j - sk[0], sd1 = s1j - sk[64];
-            double const w0 = fast_rcp(fabs(sd0) + R_FACTOR);
-            double const w1 = fast_rcp(fabs(sd1) + R_FACTOR);
+            double const w0 = weight_rcp(fabs(sd0) + R_FACTOR);
+            double const w1 = weight_rcp(fabs(sd1) + R_FACTOR);
             double const dP0 = P0j - sk[128], dP1 = P1j - sk[192];
             double const dQ = Qj - sk[256];
             double const a0 = w0 * dP0, b0 = w0 * dQ;
@@ -738,7 +758,7 @@ struct AssembleArgs {
     const double *gp;
     const uint8_t *patch_valid;
     const uint8_t *active;
-    double *H9;     // [9][N][16]
+    double *H9;     // [5][N][16]: slots 4..8 of the block stencil
     double *Pinv;   // [N][16]
     double *g;      // [N][4]
     int npx, npy, stride, num_nodes;
@@ -851,9 +871,12 @@ gn_assemble_kernel(AssembleArgs A)
 
     if (in_range) {
         size_t const N = (size_t)A.num_nodes;
+        // H is symmetric (block (n, m) is the transpose of block (m, n), bit
+        // for bit): only the diagonal and the four "upper" neighbour slots
+        // are stored, H5[s - 4][n][16] for s = 4..8
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            double *dst = A.H9 + ((size_t)s * N + n) * 16 + r * 4;
+        for (int s = 4; s < 9; ++s) {
+            double *dst = A.H9 + ((size_t)(s - 4) * N + n) * 16 + r * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 dst[c] = out[s][c];
@@ -1057,14 +1080,29 @@ smvs_gn_download(smvs_ctx *ctx, double *H9, double *g, double *P)
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const N = (size_t)ctx->num_nodes;
     if (H9 != nullptr) {
-        std::vector<double> tmp(N * 9 * 16);
+        std::vector<double> tmp(N * 5 * 16);
         SMVS_HIP_CHECK(hipMemcpyAsync(tmp.data(), ctx->H9,
             tmp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (size_t s = 0; s < 9; ++s)
-            for (size_t n = 0; n < N; ++n)
-                memcpy(H9 + (n * 9 + s) * 16, tmp.data() + (s * N + n) * 16,
-                    16 * sizeof(double));
+        memset(H9, 0, N * 9 * 16 * sizeof(double));
+        long const stride = ctx->node_stride;
+        for (size_t s = 4; s < 9; ++s)
+            for (size_t n = 0; n < N; ++n) {
+                const double *blk = tmp.data() + ((s - 4) * N + n) * 16;
+                memcpy(H9 + (n * 9 + s) * 16, blk, 16 * sizeof(double));
+                if (s == 4)
+                    continue;
+                // mirrored block of the neighbour: slot 8 - s at node m
+                long const dx = (long)(s % 3) - 1, dy = (long)(s / 3) - 1;
+                long const mx = (long)(n % stride) + dx;
+                long const m = (long)n + dy * stride + dx;
+                if (mx < 0 || mx >= stride || m < 0 || m >= (long)N)
+                    continue;
+                double *dst = H9 + ((size_t)m * 9 + (8 - s)) * 16;
+                for (int r = 0; r < 4; ++r)
+                    for (int c = 0; c < 4; ++c)
+                        dst[c * 4 + r] = blk[r * 4 + c];
+            }
     }
     if (g != nullptr)
         SMVS_HIP_CHECK(hipMemcpyAsync(g, ctx->g, N * 4 * sizeof(double),
@@ -1087,10 +1125,11 @@ smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const N = (size_t)ctx->num_nodes;
-    std::vector<double> tmp(N * 9 * 16);
-    for (size_t s = 0; s < 9; ++s)
+    // the system must be symmetric: the upper slots are taken
+    std::vector<double> tmp(N * 5 * 16);
+    for (size_t s = 4; s < 9; ++s)
         for (size_t n = 0; n < N; ++n)
-            memcpy(tmp.data() + (s * N + n) * 16, H9 + (n * 9 + s) * 16,
+            memcpy(tmp.data() + ((s - 4) * N + n) * 16, H9 + (n * 9 + s) * 16,
                 16 * sizeof(double));
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->H9, tmp.data(),
         tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
