@@ -22,8 +22,8 @@
 
 namespace smvs_hip {
 
-constexpr int CG_THREADS = 256;
-constexpr int CG_MAX_BLOCKS = 1024;
+constexpr int CG_THREADS = 512;
+constexpr int CG_MAX_BLOCKS = 512;
 
 typedef double double4_v __attribute__((ext_vector_type(4)));
 
