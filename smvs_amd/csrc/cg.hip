@@ -235,11 +235,31 @@ cg_spmv_kernel(CgArgs A, int nb)
     int const items = A.num_nodes * 4;
     size_t const N = (size_t)A.num_nodes;
     double v[1] = { 0.0 };
-#pragma unroll 2
-    for (int gid = blockIdx.x * CG_THREADS + threadIdx.x; gid < items;
-         gid += gridDim.x * CG_THREADS) {
-        int const n = gid >> 2, row = gid & 3;
-        int const ix = n % A.stride;
+    // 2-D tiles of 16 x (CG_THREADS / 64) nodes: with symmetric storage the
+    // lower stencil slots re-read blocks stored at neighbouring nodes, which
+    // stay in L1 / L2 when the neighbour belongs to the same tile.  Tiles
+    // are handed out in row-major bands per XCD (blockIdx % 8) so vertical
+    // neighbours across a tile edge mostly share an XCD's L2.
+    constexpr int TX = 16, TY = CG_THREADS / 64;
+    int const rows_total = A.num_nodes / A.stride;
+    int const tiles_x = (A.stride + TX - 1) / TX;
+    int const tiles_y = (rows_total + TY - 1) / TY;
+    int const num_tiles = tiles_x * tiles_y;
+    int const xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    int const per_xcd_blocks = (gridDim.x + 7 - xcd) >> 3;
+    int const band_begin = (int)((long long)num_tiles * xcd / 8);
+    int const band_end = (int)((long long)num_tiles * (xcd + 1) / 8);
+    int const lnode = threadIdx.x >> 2, row = threadIdx.x & 3;
+    int const lx = lnode & (TX - 1), ly = lnode / TX;
+    (void)items;
+    for (int tile = band_begin + slot_in_xcd; tile < band_end;
+         tile += per_xcd_blocks) {
+        int const tx = tile % tiles_x, ty = tile / tiles_x;
+        int const ix = tx * TX + lx, iy = ty * TY + ly;
+        if (ix >= A.stride || iy >= rows_total)
+            continue;
+        int const n = iy * A.stride + ix;
+        int const gid = n * 4 + row;
         double acc = 0.0;
         double d_own = 0.0;
 #pragma unroll
