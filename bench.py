@@ -142,34 +142,47 @@ def main():
         ctx.set_nodes(surf["nodes"])
         ctx.profile(True)
         ctx.profile_reset()
-        run_steps(ctx, prob, args.steps)
+        prof_patch_steps, prof_cg_its = run_steps(ctx, prob, args.steps)
         prof = ctx.profile_get()
         ctx.profile(False)
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         n_nodes = ctx.num_nodes
-        # algorithmic bytes per launch (DESIGN.md "Kernels"):
-        per_node = {"cg_spmv": 9 * 128 + 32 + 32, "cg_update": 5 * 32 + 3 * 32 + 128,
-                    "cg_dir": 3 * 32}
         kernels = {k: dict(ms=round(v[0], 3), launches=int(v[1]),
                            avg_us=round(1e3 * v[0] / max(v[1], 1), 2))
                    for k, v in prof.items()}
+        # Algorithmic bytes / flops per launch.  The CG
+        # kernels are also launched as no-ops after convergence (the host
+        # learns the iteration count late): their average duration is taken
+        # over the launches that did work (= CG iterations of the profiled
+        # steps), with the no-op time left in the numerator.
+        per_node = {"cg_spmv": 5 * 128 + 32 + 32,          # H upper half, d, Ad
+                    "cg_update": 5 * 32 + 128 + 3 * 32}    # x d r Ad b, P, x r z
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_r1.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get(name)
         if name in per_node:
             bytes_per_launch = per_node[name] * n_nodes
-            avg_s = ms * 1e-3 / cnt
+            work_launches = max(prof_cg_its, 1)
+            avg_s = ms * 1e-3 / work_launches
             achieved = bytes_per_launch / avg_s / 1e9
             roof = dict(kernel=name, bound="hbm", achieved=round(achieved, 1),
                         peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
-                        traffic=None, bytes_per_launch=bytes_per_launch,
-                        avg_us=round(avg_s * 1e6, 2), kernels=kernels)
+                        traffic=traffic, bytes_per_launch=bytes_per_launch,
+                        avg_us=round(avg_s * 1e6, 2), launches_with_work=work_launches,
+                        kernels=kernels)
         else:
-            # construct kernels: FP64; algorithmic flops per active patch
-            # (~0.50 MFLOP at S = 8, P = 16) x patches per launch
-            flops = 0.50e6 * (patch_steps / max(args.steps, 1)) / max(world, 1)
+            # gn_patch_kernel: FP64.  0.17 MFLOP per active patch is what the
+            # factored formulation executes at S = 8, P = 16;
+            # SURVEY 8(d)'s 0.50 MFLOP prices the reference's unfactored rows.
+            flops = 0.17e6 * prof_patch_steps / max(cnt, 1)
             avg_s = ms * 1e-3 / cnt
             achieved = flops / avg_s / 1e12
             roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 3),
                         peak=78.6, unit="TFLOP/s", frac=round(achieved / 78.6, 4),
-                        traffic=None, avg_us=round(avg_s * 1e6, 2), kernels=kernels)
+                        traffic=traffic, flops_per_launch=flops,
+                        avg_us=round(avg_s * 1e6, 2), kernels=kernels)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(prob)
 

@@ -245,10 +245,11 @@ cg_spmv_kernel(CgArgs A, int nb)
     int const tiles_x = (A.stride + TX - 1) / TX;
     int const tiles_y = (rows_total + TY - 1) / TY;
     int const num_tiles = tiles_x * tiles_y;
-    int const xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
-    int const per_xcd_blocks = (gridDim.x + 7 - xcd) >> 3;
-    int const band_begin = (int)((long long)num_tiles * xcd / 8);
-    int const band_end = (int)((long long)num_tiles * (xcd + 1) / 8);
+    int const groups = min(8, (int)gridDim.x);
+    int const xcd = blockIdx.x % groups, slot_in_xcd = blockIdx.x / groups;
+    int const per_xcd_blocks = ((int)gridDim.x + groups - 1 - xcd) / groups;
+    int const band_begin = (int)((long long)num_tiles * xcd / groups);
+    int const band_end = (int)((long long)num_tiles * (xcd + 1) / groups);
     int const lnode = threadIdx.x >> 2, row = threadIdx.x & 3;
     int const lx = lnode & (TX - 1), ly = lnode / TX;
     (void)items;
@@ -411,7 +412,11 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
 
     // A_k for k = 1 .. max_iterations (A_max only finishes iteration max-1),
     // B_k for k = 1 .. max_iterations - 1.
-    int const chunk = 8;
+    // The host only learns the iteration count after the fact; kernels that
+    // run after convergence are no-ops.  The first chunk is sized by the
+    // previous solve of this context (iteration counts change slowly from one
+    // Newton step to the next), later chunks are short.
+    int chunk = ctx->last_cg_iterations > 0 ? ctx->last_cg_iterations + 1 : 8;
     int k = 1;
     bool done = false;
     while (!done) {
@@ -433,11 +438,13 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
             sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         done = ctx->status_host[I_DONE] != 0 || k > max_iterations;
+        chunk = 4;
     }
     if (ctx->status_host[I_DONE] == 0) {
         set_error("cg_solve_launch: solver did not report completion");
         return SMVS_ERR_STATE;
     }
+    ctx->last_cg_iterations = ctx->status_host[I_ITER];
     if (num_iterations != nullptr)
         *num_iterations = ctx->status_host[I_ITER];
     if (info != nullptr)

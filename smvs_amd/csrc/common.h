@@ -131,6 +131,7 @@ struct smvs_ctx {
     double *partials = nullptr;     // [4][1024] per-block reduction partials
     int max_blocks = 0;
     void *cg_state = nullptr;       // CgState[2] (cg.hip)
+    int last_cg_iterations = 0;     // sizes the first chunk of the next solve
     double *scalars = nullptr;      // [S_NUM]
     int *status = nullptr;          // [I_NUM]
     int *status_host = nullptr;     // pinned

@@ -102,8 +102,9 @@ reactivate_kernel(ReactivateArgs A)
                 double const q = M[3] * u + M[4] * v + M[5];
                 double const r = M[6] * u + M[7] * v + M[8];
                 double const d0 = w0 * r + t[2], d1 = w1 * r + t[2];
-                double const ex = (w0 * p + t[0]) / d0 - (w1 * p + t[0]) / d1;
-                double const ey = (w0 * q + t[1]) / d0 - (w1 * q + t[1]) / d1;
+                double const i0 = 1.0 / d0, i1 = 1.0 / d1;
+                double const ex = (w0 * p + t[0]) * i0 - (w1 * p + t[0]) * i1;
+                double const ey = (w0 * q + t[1]) * i0 - (w1 * q + t[1]) * i1;
                 double const diff = sqrt(ex * ex + ey * ey);
                 sum += diff;
                 cnt += 1.0;

@@ -81,10 +81,12 @@ def test_assembled_system_matches_oracle(hip, oracle, shading, light_reg):
     ctx.close()
 
 
-def test_spmv_and_cg_match_oracle(hip, oracle):
+@pytest.mark.parametrize("size,scale", [((256, 192), 2), ((128, 96), 4), ((96, 64), 5)])
+def test_spmv_and_cg_match_oracle(hip, oracle, size, scale):
     """ConjugateGradient::solve on identical systems: same iteration count,
-    same return info, x within 1e-9 (conjugate_gradient.h:72-202)."""
-    prob, ctx, orc = _setup(hip, oracle, 256, 192, 4, 2)
+    same return info, x within 1e-9 (conjugate_gradient.h:72-202); from a
+    single-workgroup grid (6 nodes) to several thousand nodes."""
+    prob, ctx, orc = _setup(hip, oracle, size[0], size[1], 4 if scale < 5 else 2, scale)
     active = prob["surf"]["node_valid"]
     ref = orc.gn_construct(active, 0.01)
     # feed the ORACLE's system to the GPU solver so only the solver differs
@@ -288,3 +290,36 @@ def test_host_optimize_with_sgm_and_shading_matches_oracle(hip, oracle):
     print("sgm+shading depth rel L2 %.3e" % _rel(got["depth"], want["depth"]))
     assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
     assert _rel(got["depth"], want["depth"]) <= 1e-4
+
+
+def test_empty_active_set_and_invalid_surface(hip, oracle):
+    """No active node: nothing is evaluated, H, g and x are exactly zero and
+    the loop does not start (depth_optimizer.cc:219-220)."""
+    prob, ctx, orc = _setup(hip, oracle, 192, 128, 2, 2)
+    ctx.set_active(np.zeros(ctx.num_nodes, np.uint8))
+    assert ctx.gn_construct(0.01) == 0
+    H9, g, P = ctx.gn_download()
+    assert not H9.any() and not g.any() and not P.any()
+    stats = ctx.run_loop(0.01, reset_active=False)
+    assert stats["newton_steps"] == 0 and stats["active_patch_steps"] == 0
+    # a surface without any valid patch
+    surf = dict(prob["surf"])
+    surf["patch_valid"] = np.zeros_like(surf["patch_valid"])
+    surf["node_valid"] = np.zeros_like(surf["node_valid"])
+    ctx.set_surface(surf)
+    assert ctx.gn_construct(0.01) == 0
+    assert not ctx.depth_map().any()
+    ctx.close()
+
+
+def test_call_order_errors(hip):
+    """Call-order violations surface as status codes, not crashes."""
+    from smvs_amd._capi import SmvsError
+    ctx = hip.ViewContext(64, 48, 2)
+    with pytest.raises(SmvsError):
+        ctx.gn_construct(0.01)            # no cameras / surface
+    with pytest.raises(SmvsError):
+        ctx.cg_solve()                    # no system
+    with pytest.raises(SmvsError):
+        hip.ViewContext(64, 48, 17)       # more than SMVS_MAX_SUBS
+    ctx.close()
