@@ -143,6 +143,81 @@ cost_kernel(const uint8_t *__restrict__ warped,
     cost[gid] = c;
 }
 
+// Tiled version of cost_kernel: a block stages a (16+8) x (8+6) pixel window of
+// 64 planes in LDS (each warped byte is needed by 63 census windows), one
+// wavefront walks pixels with its lanes along the plane axis, so LDS reads,
+// global loads and the u8 cost stores are all 64 contiguous bytes.
+constexpr int CT_W = 16, CT_H = 8, CT_D = 64;
+
+__global__ void __launch_bounds__(256)
+cost_tiled_kernel(const uint8_t *__restrict__ warped,
+    const unsigned long long *__restrict__ main_census, int w, int h, int D,
+    uint8_t *__restrict__ cost)
+{
+    __shared__ uint8_t tile[(CT_H + 6) * (CT_W + 8) * CT_D];
+    int const tiles_x = (w + CT_W - 1) / CT_W;
+    int const x0 = (blockIdx.x % tiles_x) * CT_W;
+    int const y0 = (blockIdx.x / tiles_x) * CT_H;
+    int const dbase = blockIdx.y * CT_D;
+    int const tid = threadIdx.x;
+
+    // stage: 4 planes (one u32) per thread and position
+    bool const aligned = (D & 3) == 0;
+    for (int idx = tid; idx < (CT_H + 6) * (CT_W + 8) * (CT_D / 4); idx += 256) {
+        int const pos = idx / (CT_D / 4), q = idx - pos * (CT_D / 4);
+        int const ty = pos / (CT_W + 8), tx = pos - ty * (CT_W + 8);
+        int const gx = x0 - 4 + tx, gy = y0 - 3 + ty;
+        int const d4 = dbase + 4 * q;
+        uint32_t v = 0;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h && d4 < D) {
+            size_t const o = ((size_t)gy * w + gx) * D + d4;
+            if (aligned)
+                v = *reinterpret_cast<const uint32_t *>(warped + o);
+            else
+                for (int k = 0; k < 4 && d4 + k < D; ++k)
+                    v |= (uint32_t)warped[o + k] << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(tile + (size_t)pos * CT_D + 4 * q) = v;
+    }
+    __syncthreads();
+
+    int const lane = tid & 63, wave = tid >> 6;
+    int const d = dbase + lane;
+    for (int py = wave; py < CT_H; py += 4) {
+        int const y = y0 + py;
+        if (y >= h)
+            break;
+        for (int px = 0; px < CT_W; ++px) {
+            int const x = x0 + px;
+            if (x >= w)
+                break;
+            const uint8_t *centre = tile + ((py + 3) * (CT_W + 8) + px + 4) * CT_D + lane;
+            uint32_t const thr = *centre;
+            uint32_t c = 255;
+            if (thr != 0) {
+                uint32_t hi = 0, lo = 0;
+                if (x >= 4 && x < w - 5 && y >= 3 && y < h - 4) {
+                    // sgm_stereo.cc:139-145: i outer, j inner, MSB first
+#pragma unroll
+                    for (int k = 0; k < 63; ++k) {
+                        int const i = k / 7, j = k - 7 * i;
+                        uint32_t const v = tile[((py + j) * (CT_W + 8) + px + i) * CT_D + lane];
+                        uint32_t const lt = thr < v ? 1u : 0u;
+                        if (k < 31)
+                            hi = (hi << 1) | lt;
+                        else
+                            lo = (lo << 1) | lt;
+                    }
+                }
+                unsigned long long const mc = main_census[(size_t)y * w + x];
+                c = __popc(hi ^ (uint32_t)(mc >> 32)) + __popc(lo ^ (uint32_t)mc);
+            }
+            if (d < D)
+                cost[((size_t)y * w + x) * D + d] = (uint8_t)c;
+        }
+    }
+}
+
 // ------------------------------------------------------------- aggregation
 struct PathArgs {
     const uint8_t *cost;
@@ -151,15 +226,43 @@ struct PathArgs {
     int dx, dy;        // direction of travel
     uint32_t p1, p2;
     int first;         // 1: S is written, not accumulated
+    int last;          // 1: last path, fuse the winner-takes-all
 };
 
+// Wave-wide unsigned minimum with DPP row operations (VALU latency instead of
+// the LDS crossbar of ds_bpermute): prefix-min inside each row of 16 lanes,
+// row_bcast:15 / row_bcast:31 to combine the rows, total in lane 63.
 __device__ __forceinline__ uint32_t
 wave_min_u32(uint32_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v = min(v, (uint32_t)__shfl_xor((int)v, off));
-    return v;
+    uint32_t const ident = 0xFFFFFFFFu;
+#define SMVS_DPP(x, ctrl, rmask)                                             \
+    (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)(x), ctrl, rmask, \
+        0xf, false)
+    v = min(v, SMVS_DPP(v, 0x111, 0xf));   // row_shr:1
+    v = min(v, SMVS_DPP(v, 0x112, 0xf));   // row_shr:2
+    v = min(v, SMVS_DPP(v, 0x114, 0xf));   // row_shr:4
+    v = min(v, SMVS_DPP(v, 0x118, 0xf));   // row_shr:8
+    v = min(v, SMVS_DPP(v, 0x142, 0xa));   // row_bcast:15 -> rows 1, 3
+    v = min(v, SMVS_DPP(v, 0x143, 0xc));   // row_bcast:31 -> rows 2, 3
+#undef SMVS_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// value of the previous / next lane (wave_shr:1 / wave_shl:1); lanes without
+// a source get `fill`
+__device__ __forceinline__ uint32_t
+lane_prev(uint32_t v, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf,
+        0xf, false);
+}
+
+__device__ __forceinline__ uint32_t
+lane_next(uint32_t v, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf,
+        0xf, false);
 }
 
 // One wavefront per line.  Lines: for a horizontal path the rows, for a
@@ -260,15 +363,321 @@ sgm_path_kernel(PathArgs A)
     }
 }
 
-// The reference seeds the whole entry column of the diagonal passes
-// (sgm_stereo.cc:523-534), also where a diagonal does not start: those pixels
-// lie on lines that start on the entry row.  For such a pixel the seed only
-// adds C to S and overwrites the path volume with C *before* the sweep; the
-// sweep then overwrites the path value again (x > 0 branch never runs for the
-// entry column, so the path value stays C there).  Net effect on the entry
-// column: L = C (a line start) and S += C.  Lines that start on the entry
-// column are handled in sgm_path_kernel; nothing else is needed because every
-// entry-column pixel IS the start of its own diagonal.
+// Line geometry shared by both path kernels.  Seeding follows the reference
+// exactly (sgm_stereo.cc:457-464, 511-534, 589-612): the first pixel of a
+// line copies C and adds it to S; for a diagonal path the corner pixel that
+// lies on both the entry row and the entry column is added twice (every
+// entry-column pixel is the start of its own diagonal, so the reference's
+// column seeding needs nothing else).
+__device__ __forceinline__ bool
+path_line(PathArgs const &A, int line, int *x, int *y, int *len, int *extra)
+{
+    int const w = A.w, h = A.h;
+    *extra = 0;
+    if (A.dy == 0) {
+        if (line >= h)
+            return false;
+        *y = line;
+        *x = A.dx > 0 ? 0 : w - 1;
+        *len = w;
+    } else if (A.dx == 0) {
+        if (line >= w)
+            return false;
+        *x = line;
+        *y = A.dy > 0 ? 0 : h - 1;
+        *len = h;
+    } else {
+        if (line >= w + h - 1)
+            return false;
+        int const y_entry = A.dy > 0 ? 0 : h - 1;
+        int const x_entry = A.dx > 0 ? 0 : w - 1;
+        if (line < w) {
+            *x = line;
+            *y = y_entry;
+            if (*x == x_entry)
+                *extra = 1;
+        } else {
+            int const k = line - w + 1;
+            *x = x_entry;
+            *y = A.dy > 0 ? k : h - 1 - k;
+        }
+        int const nx = A.dx > 0 ? w - *x : *x + 1;
+        int const ny = A.dy > 0 ? h - *y : *y + 1;
+        *len = min(nx, ny);
+    }
+    return true;
+}
+
+// Even plane counts: lane l owns planes (2l, 2l+1) packed in one u16 of C and
+// one u32 of S.  The loads of the next PF pixels are in flight while the
+// dependent recurrence of the current pixel runs (addresses do not depend on
+// the recurrence and every S entry is visited once per path).  With
+// A.last the path that runs last also performs the winner-takes-all of
+// sgm_stereo.cc:274-306 on the finished S values.
+template <int K>
+__global__ void __launch_bounds__(64)
+sgm_path_packed_kernel(PathArgs A, const uint8_t *__restrict__ main_img,
+    const float *__restrict__ depths, float *__restrict__ depth_out,
+    int32_t *__restrict__ argmin_out)
+{
+    int const lane = threadIdx.x;
+    int x0, y0, len, extra_seed;
+    if (!path_line(A, blockIdx.x, &x0, &y0, &len, &extra_seed))
+        return;
+    int const w = A.w, D = A.D;
+    int const pairs = D >> 1;
+    bool const ok = lane < pairs;
+    int const li = ok ? lane : 0;
+    const uint16_t *__restrict__ C16 = reinterpret_cast<const uint16_t *>(A.cost);
+    uint32_t *__restrict__ S32 = reinterpret_cast<uint32_t *>(A.sgm);
+    uint32_t const BIG = 0xFFFFu;
+    uint32_t prev0 = BIG, prev1 = BIG;
+
+    // Chunks of K pixels: the S loads of the chunk and the C loads of the
+    // next chunk are in flight while the dependent recurrence of the chunk
+    // runs from registers; the S stores follow as one burst.
+    uint32_t c_cur[K], c_next[K], s_old[K], addv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        c_cur[k] = 0;
+        if (k < len)
+            c_cur[k] = C16[(((size_t)(y0 + k * A.dy) * w + (x0 + k * A.dx)) * D >> 1) + li];
+    }
+    for (int base = 0; base < len; base += K) {
+        int const n = min(K, len - base);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            s_old[k] = 0;
+            if (!A.first && k < n) {
+                int const s = base + k;
+                s_old[k] = S32[(((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            c_next[k] = 0;
+            int const s = base + K + k;
+            if (s < len)
+                c_next[k] = C16[(((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k < n) {
+            int const s = base + k;
+            uint32_t const c0 = c_cur[k] & 0xFFu, c1 = c_cur[k] >> 8;
+            uint32_t l0, l1;
+            if (s == 0) {
+                l0 = c0;
+                l1 = c1;
+            } else {
+                uint32_t const mn = wave_min_u32(min(prev0, prev1));
+                // lanes outside the plane range hold BIG, which already acts
+                // as "no neighbour"; BIG + p1 must not wrap into range
+                uint32_t const left = lane_prev(prev1, BIG);
+                uint32_t const right = lane_next(prev0, BIG);
+                uint32_t const far = (mn + A.p2) & 0xFFFFu;
+                uint32_t u0 = prev0;
+                u0 = min(u0, left == BIG ? BIG : ((left + A.p1) & 0xFFFFu));
+                u0 = min(u0, (prev1 + A.p1) & 0xFFFFu);
+                u0 = min(u0, far);
+                uint32_t u1 = prev1;
+                u1 = min(u1, (prev0 + A.p1) & 0xFFFFu);
+                u1 = min(u1, right == BIG ? BIG : ((right + A.p1) & 0xFFFFu));
+                u1 = min(u1, far);
+                l0 = (c0 + u0 - mn) & 0xFFFFu;
+                l1 = (c1 + u1 - mn) & 0xFFFFu;
+            }
+            uint32_t add0 = l0, add1 = l1;
+            if (s == 0 && extra_seed) {
+                add0 = (2 * c0) & 0xFFFFu;
+                add1 = (2 * c1) & 0xFFFFu;
+            }
+            addv[k] = add0 | (add1 << 16);
+            prev0 = ok ? l0 : BIG;
+            prev1 = ok ? l1 : BIG;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k < n) {
+            int const s = base + k;
+            int const x = x0 + s * A.dx, y = y0 + s * A.dy;
+            uint32_t const n0 = ((s_old[k] & 0xFFFFu) + (addv[k] & 0xFFFFu)) & 0xFFFFu;
+            uint32_t const n1 = ((s_old[k] >> 16) + (addv[k] >> 16)) & 0xFFFFu;
+            if (ok)
+                S32[(((size_t)y * w + x) * D >> 1) + li] = n0 | (n1 << 16);
+            if (A.last) {
+                // first minimum wins: order by (value, plane)
+                uint32_t key = ok ? min(n0 * 256u + (uint32_t)(2 * lane),
+                    n1 * 256u + (uint32_t)(2 * lane + 1)) : 0xFFFFFFFFu;
+                key = wave_min_u32(key);
+                if (lane == 0) {
+                    int const min_index = (int)(key & 0xFFu);
+                    size_t const p = (size_t)y * w + x;
+                    if (argmin_out != nullptr)
+                        argmin_out[p] = min_index;
+                    if (depth_out != nullptr)
+                        depth_out[p] = (min_index < 2 || main_img[p] < 25)
+                            ? 0.0f : depths[min_index];
+                }
+            }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            c_cur[k] = c_next[k];
+    }
+}
+
+// All eight path directions in ONE launch.  The recurrences of different
+// directions are independent; only their sums meet in S.  Since the sums are
+// wrapping integer adds, S is accumulated with device-scope atomic adds on
+// the packed u32 (two u16 planes that cannot carry into each other: eight
+// paths of at most 255 + P2 plus the seeds stay below 65536), so the result
+// is bit-exact for any interleaving.  ~9000 wavefronts instead of <= 1500 per
+// launch, and the wall time is the longest line instead of the sum over
+// directions.  S must be zeroed first.
+template <int K>
+__global__ void __launch_bounds__(64)
+sgm_all_paths_kernel(PathArgs A)
+{
+    // block -> (direction, line); the long horizontal lines come first
+    int const w = A.w, h = A.h, D = A.D;
+    int const ndiag = w + h - 1;
+    int b = blockIdx.x;
+    int dir;
+    if (b < 2 * h) {
+        dir = b / h;              // 0: ->, 1: <-
+        b -= dir * h;
+    } else {
+        b -= 2 * h;
+        // remaining six: (0,1) (1,1) (-1,1) (0,-1) (1,-1) (-1,-1)
+        int const counts[6] = { w, ndiag, ndiag, w, ndiag, ndiag };
+        dir = 2;
+        for (int k = 0; k < 6; ++k) {
+            if (b < counts[k])
+                break;
+            b -= counts[k];
+            dir += 1;
+        }
+        if (dir > 7)
+            return;
+    }
+    int const dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 }, { -1, 1 },
+        { 0, -1 }, { 1, -1 }, { -1, -1 } };
+    A.dx = dirs[dir][0];
+    A.dy = dirs[dir][1];
+
+    int const lane = threadIdx.x;
+    int x0, y0, len, extra_seed;
+    if (!path_line(A, b, &x0, &y0, &len, &extra_seed))
+        return;
+    int const pairs = D >> 1;
+    bool const ok = lane < pairs;
+    int const li = ok ? lane : 0;
+    const uint16_t *__restrict__ C16 = reinterpret_cast<const uint16_t *>(A.cost);
+    uint32_t *__restrict__ S32 = reinterpret_cast<uint32_t *>(A.sgm);
+    uint32_t const BIG = 0xFFFFu;
+    uint32_t prev0 = BIG, prev1 = BIG;
+
+    uint32_t c_cur[K], c_next[K], addv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        c_cur[k] = 0;
+        if (k < len)
+            c_cur[k] = C16[(((size_t)(y0 + k * A.dy) * w + (x0 + k * A.dx)) * D >> 1) + li];
+    }
+    for (int base = 0; base < len; base += K) {
+        int const n = min(K, len - base);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            c_next[k] = 0;
+            int const s = base + K + k;
+            if (s < len)
+                c_next[k] = C16[(((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            addv[k] = 0;
+            if (k < n) {
+                int const s = base + k;
+                uint32_t const c0 = c_cur[k] & 0xFFu, c1 = c_cur[k] >> 8;
+                uint32_t l0, l1;
+                if (s == 0) {
+                    l0 = c0;
+                    l1 = c1;
+                } else {
+                    uint32_t const mn = wave_min_u32(min(prev0, prev1));
+                    uint32_t const left = lane_prev(prev1, BIG);
+                    uint32_t const right = lane_next(prev0, BIG);
+                    uint32_t const far = (mn + A.p2) & 0xFFFFu;
+                    uint32_t u0 = prev0;
+                    u0 = min(u0, left == BIG ? BIG : ((left + A.p1) & 0xFFFFu));
+                    u0 = min(u0, (prev1 + A.p1) & 0xFFFFu);
+                    u0 = min(u0, far);
+                    uint32_t u1 = prev1;
+                    u1 = min(u1, (prev0 + A.p1) & 0xFFFFu);
+                    u1 = min(u1, right == BIG ? BIG : ((right + A.p1) & 0xFFFFu));
+                    u1 = min(u1, far);
+                    l0 = (c0 + u0 - mn) & 0xFFFFu;
+                    l1 = (c1 + u1 - mn) & 0xFFFFu;
+                }
+                uint32_t add0 = l0, add1 = l1;
+                if (s == 0 && extra_seed) {
+                    add0 = (2 * c0) & 0xFFFFu;
+                    add1 = (2 * c1) & 0xFFFFu;
+                }
+                addv[k] = add0 | (add1 << 16);
+                prev0 = ok ? l0 : BIG;
+                prev1 = ok ? l1 : BIG;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k < n && ok) {
+                int const s = base + k;
+                size_t const o = (((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li;
+                (void)__hip_atomic_fetch_add(&S32[o], addv[k], __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            c_cur[k] = c_next[k];
+    }
+}
+
+// WTA with 16 lanes per pixel (sgm_stereo.cc:274-306): lane sub reads planes
+// sub, sub + 16, ...; the first minimum wins through the (value, plane) key.
+__global__ void __launch_bounds__(256)
+wta_rows_kernel(const uint16_t *__restrict__ sgm,
+    const uint8_t *__restrict__ main_img, const float *__restrict__ depths,
+    size_t npix, int D, float *__restrict__ depth, int32_t *__restrict__ argmin)
+{
+    size_t const p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int const sub = threadIdx.x & 15;
+    uint32_t key = 0xFFFFFFFFu;
+    if (p < npix)
+        for (int d = sub; d < D; d += 16)
+            key = min(key, (uint32_t)sgm[p * D + d] * 256u + (uint32_t)d);
+    uint32_t const ident = 0xFFFFFFFFu;
+#define SMVS_DPP(x, ctrl)                                                     \
+    (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)(x), ctrl, 0xf,   \
+        0xf, false)
+    key = min(key, SMVS_DPP(key, 0x111));
+    key = min(key, SMVS_DPP(key, 0x112));
+    key = min(key, SMVS_DPP(key, 0x114));
+    key = min(key, SMVS_DPP(key, 0x118));
+#undef SMVS_DPP
+    if (sub == 15 && p < npix) {
+        int const min_index = (int)(key & 0xFFu);
+        if (argmin != nullptr)
+            argmin[p] = min_index;
+        if (depth != nullptr)
+            depth[p] = (min_index < 2 || main_img[p] < 25) ? 0.0f
+                : depths[min_index];
+    }
+}
 
 // WTA (sgm_stereo.cc:274-306): first minimum wins; invalid if index < 2 or
 // main intensity < 25.
@@ -433,36 +842,68 @@ smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
     W.warped = d_warped.as<uint8_t>();
     unsigned const vblocks = (unsigned)((vol + 255) / 256);
     hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
-    hipLaunchKernelGGL(cost_kernel, dim3(vblocks), dim3(256), 0, stream,
-        d_warped.as<uint8_t>(), d_census.as<unsigned long long>(), w, h,
-        num_steps, d_cost.as<uint8_t>());
+    {
+        int const tiles = ((w + CT_W - 1) / CT_W) * ((h + CT_H - 1) / CT_H);
+        hipLaunchKernelGGL(cost_tiled_kernel,
+            dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
+            d_warped.as<uint8_t>(), d_census.as<unsigned long long>(), w, h,
+            num_steps, d_cost.as<uint8_t>());
+    }
     SMVS_HIP_CHECK(hipGetLastError());
 
     // the eight paths in the reference's order: ->, <-, then the three
     // top-to-bottom paths, then the three bottom-to-top paths
     static const int dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 },
         { -1, 1 }, { 0, -1 }, { 1, -1 }, { -1, -1 } };
-    for (int k = 0; k < 8; ++k) {
+    bool const packed = (num_steps % 2) == 0;
+    if (packed) {
+        SMVS_HIP_CHECK(hipMemsetAsync(d_sgm.p, 0, sizeof(uint16_t) * vol, stream));
         PathArgs P;
         P.cost = d_cost.as<uint8_t>();
         P.sgm = d_sgm.as<uint16_t>();
         P.w = w;
         P.h = h;
         P.D = num_steps;
-        P.dx = dirs[k][0];
-        P.dy = dirs[k][1];
+        P.dx = P.dy = 0;
         P.p1 = penalty1;
         P.p2 = penalty2;
-        P.first = k == 0 ? 1 : 0;
-        int lines = P.dy == 0 ? h : (P.dx == 0 ? w : w + h - 1);
-        hipLaunchKernelGGL(sgm_path_kernel, dim3(lines), dim3(64), 0, stream, P);
+        P.first = 0;
+        P.last = 0;
+        int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
+        hipLaunchKernelGGL((sgm_all_paths_kernel<16>), dim3(lines), dim3(64), 0,
+            stream, P);
+        SMVS_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(wta_rows_kernel,
+            dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
+            d_sgm.as<uint16_t>(), d_main.as<uint8_t>(), d_depths.as<float>(),
+            npix, num_steps, d_depth.as<float>(), d_argmin.as<int32_t>());
+        SMVS_HIP_CHECK(hipGetLastError());
+    } else {
+        // odd plane counts: one launch per direction, scalar accesses
+        for (int k = 0; k < 8; ++k) {
+            PathArgs P;
+            P.cost = d_cost.as<uint8_t>();
+            P.sgm = d_sgm.as<uint16_t>();
+            P.w = w;
+            P.h = h;
+            P.D = num_steps;
+            P.dx = dirs[k][0];
+            P.dy = dirs[k][1];
+            P.p1 = penalty1;
+            P.p2 = penalty2;
+            P.first = k == 0 ? 1 : 0;
+            P.last = 0;
+            int lines = P.dy == 0 ? h : (P.dx == 0 ? w : w + h - 1);
+            hipLaunchKernelGGL(sgm_path_kernel, dim3(lines), dim3(64), 0, stream,
+                P);
+        }
+        SMVS_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(wta_rows_kernel,
+            dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
+            d_sgm.as<uint16_t>(), d_main.as<uint8_t>(), d_depths.as<float>(),
+            npix, num_steps, d_depth.as<float>(), d_argmin.as<int32_t>());
+        SMVS_HIP_CHECK(hipGetLastError());
     }
-    SMVS_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(wta_kernel, dim3((unsigned)((npix + 255) / 256)),
-        dim3(256), 0, stream, d_sgm.as<uint16_t>(), d_main.as<uint8_t>(),
-        d_depths.as<float>(), npix, num_steps, d_depth.as<float>(),
-        d_argmin.as<int32_t>());
-    SMVS_HIP_CHECK(hipGetLastError());
     SMVS_HIP_CHECK(hipDeviceSynchronize());
 
     if (depth != nullptr)
