@@ -27,6 +27,18 @@ constexpr int CG_MAX_BLOCKS = 512;
 
 typedef double double4_v __attribute__((ext_vector_type(4)));
 
+// broadcast lane (CTRL & 3) of every quad to the quad (DPP quad_perm)
+template <int CTRL>
+__device__ __forceinline__ double
+quad_bcast(double v)
+{
+    long long const bits = __double_as_longlong(v);
+    int lo = (int)(bits & 0xFFFFFFFFll), hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 struct CgState {
     double rr;       // z.r (r_dot_r of the reference)
     double q0;
@@ -42,6 +54,7 @@ struct CgArgs {
     const double *H9;
     const double *Pinv;
     const double *g;
+    const uint8_t *active;   // rows / columns of inactive nodes are zero
     double *x, *r, *z, *Ad, *b;
     double *dbuf[2];
     double *partials;      // [4][CG_MAX_BLOCKS]
@@ -231,6 +244,7 @@ cg_spmv_kernel(CgArgs A, int nb)
     const double *__restrict__ H = A.H9;
     const double *__restrict__ zv = A.z;
     double *__restrict__ Ad = A.Ad;
+    const uint8_t *__restrict__ act = A.active;
     bool const first = A.k == 1;
     int const items = A.num_nodes * 4;
     size_t const N = (size_t)A.num_nodes;
@@ -261,6 +275,15 @@ cg_spmv_kernel(CgArgs A, int nb)
             continue;
         int const n = iy * A.stride + ix;
         int const gid = n * 4 + row;
+        // Inactive nodes have no row and no column in the reference's matrix
+        // (gauss_newton_step.cc:91-105): their b, r, z, d and x stay zero, so
+        // nothing has to be read for them.
+        if (act != nullptr && !act[n]) {
+            Ad[gid] = 0.0;
+            if (!first)
+                d_new[gid] = 0.0;
+            continue;
+        }
         double acc = 0.0;
         double d_own = 0.0;
 #pragma unroll
@@ -270,24 +293,25 @@ cg_spmv_kernel(CgArgs A, int nb)
             int const m = n + dy * A.stride + dx;
             if (mx < 0 || mx >= A.stride || m < 0 || m >= A.num_nodes)
                 continue;
-            double dm[4];
-            if (first) {
-                double4_v const t = *reinterpret_cast<const double4_v *>(
-                    d_new + (size_t)m * 4);
-                dm[0] = t.x; dm[1] = t.y; dm[2] = t.z; dm[3] = t.w;
-            } else {
+            if (act != nullptr && !act[m])
+                continue;
+            // d_k of the neighbour: every row-lane forms its own component
+            // and the quad shares the four values by DPP broadcast (one
+            // 8-byte load per lane instead of two 32-byte loads)
+            double own;
+            if (first)
+                own = d_new[(size_t)m * 4 + row];
+            else {
 #pragma clang fp contract(off)
-                double4_v const zm = *reinterpret_cast<const double4_v *>(
-                    zv + (size_t)m * 4);
-                double4_v const om = *reinterpret_cast<const double4_v *>(
-                    d_old + (size_t)m * 4);
-                dm[0] = zm.x + beta * om.x;
-                dm[1] = zm.y + beta * om.y;
-                dm[2] = zm.z + beta * om.z;
-                dm[3] = zm.w + beta * om.w;
+                own = zv[(size_t)m * 4 + row] + beta * d_old[(size_t)m * 4 + row];
             }
+            double dm[4];
+            dm[0] = quad_bcast<0x00>(own);
+            dm[1] = quad_bcast<0x55>(own);
+            dm[2] = quad_bcast<0xAA>(own);
+            dm[3] = quad_bcast<0xFF>(own);
             if (s == 4)
-                d_own = dm[row];
+                d_own = own;
             // symmetric storage: slots 4..8 are stored at the node itself,
             // slots 0..3 are the transposed blocks stored at the neighbour
             double h0, h1, h2, h3;
@@ -335,8 +359,9 @@ cg_update_kernel(CgArgs A, int nb)
     for (int round = 0; round < rounds; ++round) {
         int const gid = (round * gridDim.x + blockIdx.x) * CG_THREADS
             + threadIdx.x;
-        bool const in_range = gid < items;
         int const n = gid >> 2, row = gid & 3;
+        bool const in_range = gid < items
+            && (A.active == nullptr || A.active[n] != 0);
         double xi = 0.0, ri = 0.0;
         if (in_range) {
 #pragma clang fp contract(off)
@@ -380,6 +405,7 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.H9 = ctx->H9;
     A.Pinv = ctx->Pinv;
     A.g = ctx->g;
+    A.active = ctx->cg_use_active ? ctx->active : nullptr;
     A.x = ctx->x;
     A.r = ctx->r;
     A.z = ctx->z;

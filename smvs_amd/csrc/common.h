@@ -132,6 +132,7 @@ struct smvs_ctx {
     int max_blocks = 0;
     void *cg_state = nullptr;       // CgState[2] (cg.hip)
     int last_cg_iterations = 0;     // sizes the first chunk of the next solve
+    bool cg_use_active = false;     // system built by gn_construct: skip inactive nodes
     double *scalars = nullptr;      // [S_NUM]
     int *status = nullptr;          // [I_NUM]
     int *status_host = nullptr;     // pinned

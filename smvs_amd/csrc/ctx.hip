@@ -409,6 +409,7 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->has_surface = true;
     ctx->has_system = false;
+    ctx->cg_use_active = false;
     return SMVS_OK;
 }
 
@@ -421,6 +422,8 @@ smvs_ctx_set_active(smvs_ctx *ctx, const uint8_t *active)
         return SMVS_ERR_STATE;
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    // a system built for another active set no longer matches the flags
+    ctx->cg_use_active = false;
     if (active == nullptr) {
         hipLaunchKernelGGL(init_active_kernel,
             dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,

@@ -1027,6 +1027,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     }
     SMVS_HIP_CHECK(hipGetLastError());
     ctx->has_system = true;
+    ctx->cg_use_active = true;
     return SMVS_OK;
 }
 
@@ -1139,6 +1140,7 @@ smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
         hipMemcpyHostToDevice, ctx->stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->has_system = true;
+    ctx->cg_use_active = false;
     return SMVS_OK;
 }
 
