@@ -83,6 +83,24 @@ int smvs_ctx_upload_main(smvs_ctx *ctx, const float *grad2,
 int smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
     const float *grad2, const float *hess3);
 
+/* Scale space on the device: what StereoView's constructor
+ * and StereoView::set_scale compute on the host (stereo_view.cc:16-46, 97-188).
+ * smvs_ctx_upload_image stores the u8 image of the main view (view = -1) or of
+ * neighbour `view` (interleaved channels, 1 or 3).  smvs_ctx_set_scale then
+ * produces, for every view with an image, the gradient / Hessian planes of
+ * that scale (byte -> float, Gaussian blur with sigma = 0.12 * 2^scale + 0.2,
+ * luminance, 3x3 quadratic fit) directly in the context: nothing crosses PCIe
+ * per scale.  smvs_ctx_download_planes hands planes back to host-side
+ * topology code; hess3 may be NULL (the main view keeps no Hessian). */
+int smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
+    int channels, const uint8_t *bytes);
+int smvs_ctx_set_scale(smvs_ctx *ctx, int scale);
+int smvs_ctx_download_planes(smvs_ctx *ctx, int view, float *grad2,
+    float *hess3);
+/* shading image + gradients alone (scale independent, stereo_view.cc:64-84) */
+int smvs_ctx_upload_shading(smvs_ctx *ctx, const float *shading1,
+    const float *shading_grad2);
+
 /* Surface state (surface.h:106-120) as flat arrays.
  *   nodes[(npx+1)*(npy+1)][4] = f, dx, dy, dxy (patch units);
  *   node_valid / patch_valid: non-null node / patch;

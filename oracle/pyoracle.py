@@ -559,3 +559,14 @@ def gradients_and_hessian(img):
     lib().orc_gradients_and_hessian(_p(img, c_float_p), w, h, _p(g, c_float_p),
                                     _p(hs, c_float_p))
     return g, hs
+
+
+def scale_planes(img_u8, scale):
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    h, w, c = img.shape
+    g = np.zeros((h, w, 2), np.float32); hs = np.zeros((h, w, 3), np.float32)
+    lib().orc_scale_planes(_p(img, c_u8_p), w, h, c, C.c_int(scale),
+                           _p(g, c_float_p), _p(hs, c_float_p))
+    return g, hs

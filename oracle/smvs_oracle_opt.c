@@ -1332,3 +1332,22 @@ orc_rescale_half_size_u8(const uint8_t *in, int w, int h, uint8_t *out)
         }
     }
 }
+
+/* StereoView::StereoView + set_scale (stereo_view.cc:16-46) for one u8 image:
+ * the gradient (2 ch) and Hessian (3 ch) planes of `scale`. */
+void
+orc_scale_planes(const uint8_t *bytes, int w, int h, int c, int scale,
+    float *grad2, float *hess3)
+{
+    orc_view_input in;
+    memset(&in, 0, sizeof(in));
+    in.width = w; in.height = h; in.channels = c; in.bytes = bytes;
+    in.flen = 1.0f;
+    OView v;
+    oview_init(&v, &in, 0);
+    oview_set_scale(&v, scale);
+    memcpy(grad2, v.grad, sizeof(float) * 2 * (size_t)w * h);
+    if (hess3 != NULL)
+        memcpy(hess3, v.hess, sizeof(float) * 3 * (size_t)w * h);
+    oview_free(&v);
+}

@@ -66,6 +66,9 @@ void orc_gradients_and_hessian(const float *input, int w, int h,
 void orc_fill_reprojection(const float *Ks_inv, const float *Rs,
     const float *ts, const float *Kd, const float *Rd, const float *td,
     float *M, float *t);
+/* StereoView constructor + set_scale for one u8 image (stereo_view.cc:16-46) */
+void orc_scale_planes(const uint8_t *bytes, int w, int h, int c, int scale,
+    float *grad2, float *hess3);
 /* mve::image::rescale_half_size<uint8_t> [MVE-unverified] */
 void orc_rescale_half_size_u8(const uint8_t *in, int w, int h, uint8_t *out);
 

@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmvs_hip.so")
-SOURCES = ["ctx.hip", "gn_construct.hip", "cg.hip", "update.hip", "sgm.hip"]
+SOURCES = ["ctx.hip", "gn_construct.hip", "cg.hip", "update.hip", "sgm.hip",
+           "scale.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 

@@ -141,6 +141,13 @@ struct smvs_ctx {
     float *stage = nullptr;         // upload staging (3-channel planes)
     size_t stage_cap = 0;
 
+    // scale space on the device (scale.hip): float images of the views
+    struct ViewImage { int w = 0, h = 0, c = 0; float *data = nullptr; };
+    ViewImage images[SMVS_MAX_SUBS + 1];   // [0] main, [1 + j] neighbour j
+    float *blur_tmp[2] = { nullptr, nullptr };
+    size_t blur_cap = 0;
+    float *main_hess_scratch = nullptr;    // set_scale writes no main Hessian
+
     smvs_hip::Profile prof;
 };
 

@@ -172,6 +172,13 @@ smvs_ctx_destroy(smvs_ctx *ctx)
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
+    for (int i = 0; i <= SMVS_MAX_SUBS; ++i)
+        if (ctx->images[i].data)
+            (void)hipFree(ctx->images[i].data);
+    if (ctx->blur_tmp[0])
+        (void)hipFree(ctx->blur_tmp[0]);
+    if (ctx->blur_tmp[1])
+        (void)hipFree(ctx->blur_tmp[1]);
     for (int i = 0; i < SMVS_MAX_SUBS; ++i) {
         if (ctx->subs[i].grad)
             (void)hipFree(ctx->subs[i].grad);

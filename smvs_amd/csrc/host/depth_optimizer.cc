@@ -182,21 +182,42 @@ DepthOptimizer::create_initial_surface(void)
 void
 DepthOptimizer::set_scale_everywhere(int scale)
 {
-    main_view->set_scale(scale);
-    for (auto const& v : sub_views)
-        v->set_scale(scale);
-    FloatImage::ConstPtr sh = opts.use_shading ? main_view->get_shading_image()
-        : nullptr;
-    FloatImage::ConstPtr shg = opts.use_shading
-        ? main_view->get_shading_gradients() : nullptr;
-    check(smvs_ctx_upload_main(ctx, main_view->get_image_gradients()->begin(),
-        sh ? sh->begin() : nullptr, shg ? shg->begin() : nullptr),
-        "smvs_ctx_upload_main");
-    for (std::size_t j = 0; j < sub_views.size(); ++j)
-        check(smvs_ctx_upload_sub(ctx, (int)j, sub_views[j]->get_width(),
-            sub_views[j]->get_height(),
-            sub_views[j]->get_image_gradients()->begin(),
-            sub_views[j]->get_image_hessian()->begin()), "smvs_ctx_upload_sub");
+    // StereoView::set_scale for the main view and every neighbour
+    // (lib/depth_optimizer.cc:63-66, 99-103) on the device; the planes come
+    // back once per scale for the host-side topology code.
+    if (!images_uploaded) {
+        ByteImage::ConstPtr mb = main_view->get_raw_bytes();
+        check(smvs_ctx_upload_image(ctx, -1, mb->width(), mb->height(),
+            mb->channels(), mb->begin()), "smvs_ctx_upload_image");
+        for (std::size_t j = 0; j < sub_views.size(); ++j) {
+            ByteImage::ConstPtr sb = sub_views[j]->get_raw_bytes();
+            check(smvs_ctx_upload_image(ctx, (int)j, sb->width(), sb->height(),
+                sb->channels(), sb->begin()), "smvs_ctx_upload_image");
+        }
+        if (opts.use_shading)
+            check(smvs_ctx_upload_shading(ctx,
+                main_view->get_shading_image()->begin(),
+                main_view->get_shading_gradients()->begin()),
+                "smvs_ctx_upload_shading");
+        images_uploaded = true;
+    }
+    check(smvs_ctx_set_scale(ctx, scale), "smvs_ctx_set_scale");
+    {
+        FloatImage::Ptr g = FloatImage::create(main_view->get_width(),
+            main_view->get_height(), 2);
+        check(smvs_ctx_download_planes(ctx, -1, g->begin(), nullptr),
+            "smvs_ctx_download_planes");
+        main_view->set_scale_planes(g, nullptr);
+    }
+    for (std::size_t j = 0; j < sub_views.size(); ++j) {
+        FloatImage::Ptr g = FloatImage::create(sub_views[j]->get_width(),
+            sub_views[j]->get_height(), 2);
+        FloatImage::Ptr hs = FloatImage::create(sub_views[j]->get_width(),
+            sub_views[j]->get_height(), 3);
+        check(smvs_ctx_download_planes(ctx, (int)j, g->begin(), hs->begin()),
+            "smvs_ctx_download_planes");
+        sub_views[j]->set_scale_planes(g, hs);
+    }
 }
 
 void

@@ -81,6 +81,7 @@ private:
     Surface::Ptr surface;
     std::vector<uint32_t> subsurfaces;   // bit j: neighbour j sees the patch
     bool lit = false;
+    bool images_uploaded = false;
     double lighting[16];
     smvs_ctx* ctx = nullptr;
     std::vector<IterationLog> log;

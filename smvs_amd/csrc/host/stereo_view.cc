@@ -192,6 +192,13 @@ StereoView::set_scale(int scale, bool)
 }
 
 void
+StereoView::set_scale_planes(FloatImage::Ptr gradients, FloatImage::Ptr hessian)
+{
+    this->image_grad = gradients;
+    this->image_hessian = hessian;
+}
+
+void
 StereoView::initialize_linear(bool gamma_correction)
 {
     // lib/stereo_view.cc:64-84

@@ -23,6 +23,9 @@ public:
         bool gamma_correction = false);
 
     void set_scale(int scale, bool debug = false);
+    // planes of a scale computed elsewhere (smvs_ctx_set_scale on the device)
+    void set_scale_planes(FloatImage::Ptr gradients, FloatImage::Ptr hessian);
+    ByteImage::ConstPtr get_raw_bytes(void) const { return bytes; }
 
     int get_width(void) const { return image->width(); }
     int get_height(void) const { return image->height(); }

@@ -1,0 +1,334 @@
+// Scale space on the device: byte -> float, separable Gaussian blur,
+// luminance and the 3x3 quadratic-fit gradient / Hessian.
+//
+// Replaces the host work of StereoView::StereoView (reference:
+// lib/stereo_view.cc:16-22) and StereoView::set_scale /
+// compute_gradients_and_hessian (:24-46, :97-188) for every view of a context.
+// All float arithmetic keeps the reference's operation order with FMA
+// contraction off, so the planes are bit-identical to the host computation
+// (the Gaussian weights are evaluated on the host with the same expf).
+// MVE's blur_gaussian / desaturate semantics are recalled [MVE-unverified].
+#include "common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace smvs_hip {
+
+__global__ void __launch_bounds__(256)
+byte_to_float_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+    size_t n)
+{
+#pragma clang fp contract(off)
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = (float)in[i] / 255.0f;
+}
+
+// one separable pass; axis 0: along x, axis 1: along y.  Accum<float>:
+// v += value * weight; w += weight; result v / w, borders clamped.
+__global__ void __launch_bounds__(256)
+blur_pass_kernel(const float *__restrict__ in, float *__restrict__ out, int w,
+    int h, int c, int ks, const float *__restrict__ kernel, int axis)
+{
+#pragma clang fp contract(off)
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t const n = (size_t)w * h * c;
+    if (i >= n)
+        return;
+    int const cc = (int)(i % c);
+    size_t const p = i / c;
+    int const x = (int)(p % w), y = (int)(p / w);
+    float av = 0.0f, aw = 0.0f;
+    for (int k = -ks; k <= ks; ++k) {
+        float const kw = kernel[k < 0 ? -k : k];
+        float v;
+        if (axis == 0) {
+            int const xx = min(max(x + k, 0), w - 1);
+            v = in[((size_t)y * w + xx) * c + cc];
+        } else {
+            int const yy = min(max(y + k, 0), h - 1);
+            v = in[((size_t)yy * w + x) * c + cc];
+        }
+        av += v * kw;
+        aw += kw;
+    }
+    out[i] = av / aw;
+}
+
+// luminance (0.21, 0.72, 0.07) + quadratic fit on the 3x3 window, double
+// accumulation in the reference's order (stereo_view.cc:167-187)
+struct FitMatrix { double m[6][9]; };
+
+__global__ void __launch_bounds__(256)
+gradients_kernel(const float *__restrict__ img, int w, int h, int c,
+    FitMatrix fit, float2 *__restrict__ grad, float4 *__restrict__ hess)
+{
+#pragma clang fp contract(off)
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= w)
+        return;
+    size_t const p = (size_t)y * w + x;
+    float2 g = make_float2(0.f, 0.f);
+    float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        double v[9];
+        int k = 0;
+        for (int a = -1; a < 2; ++a)
+            for (int b = -1; b < 2; ++b) {
+                const float *px = img + ((size_t)(y + b) * w + (x + a)) * c;
+                float lum;
+                if (c >= 3)
+                    lum = px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f;
+                else
+                    lum = px[0];
+                v[k++] = lum;
+            }
+        double r[6];
+        for (int q = 0; q < 6; ++q) {
+            double s = 0.0;
+            for (int i = 0; i < 9; ++i)
+                s += fit.m[q][i] * v[i];
+            r[q] = s;
+        }
+        g = make_float2((float)r[3], (float)r[4]);
+        hs = make_float4((float)(2.0 * r[0]), (float)r[2], (float)(2.0 * r[1]),
+            0.f);
+    }
+    grad[p] = g;
+    if (hess != nullptr)
+        hess[p] = hs;
+}
+
+__global__ void __launch_bounds__(256)
+compact_hessian_kernel(const float4 *__restrict__ src, float *__restrict__ dst,
+    size_t count)
+{
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    float4 const v = src[i];
+    dst[3 * i] = v.x;
+    dst[3 * i + 1] = v.y;
+    dst[3 * i + 2] = v.z;
+}
+
+static FitMatrix
+quadratic_fit_matrix(void)
+{
+    // least-squares fit of c_xx a^2 + c_yy b^2 + c_xy ab + c_x a + c_y b + c_0
+    // to the window (a outer, b inner): rows xx, yy, xy, x, y, 1
+    FitMatrix f;
+    int col = 0;
+    for (int a = -1; a <= 1; ++a)
+        for (int b = -1; b <= 1; ++b, ++col) {
+            f.m[0][col] = a == 0 ? -1.0 / 3.0 : 1.0 / 6.0;
+            f.m[1][col] = b == 0 ? -1.0 / 3.0 : 1.0 / 6.0;
+            f.m[2][col] = (double)(a * b) / 4.0;
+            f.m[3][col] = (double)a / 6.0;
+            f.m[4][col] = (double)b / 6.0;
+            f.m[5][col] = (a == 0 && b == 0) ? 5.0 / 9.0
+                : ((a == 0 || b == 0) ? 2.0 / 9.0 : -1.0 / 9.0);
+        }
+    return f;
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
+    int channels, const uint8_t *bytes)
+{
+    SMVS_REQUIRE(ctx && bytes, "null argument");
+    SMVS_REQUIRE(view >= -1 && view < ctx->n_subs, "view index out of range");
+    SMVS_REQUIRE(width > 2 && height > 2 && (channels == 1 || channels == 3),
+        "bad image");
+    if (view == -1)
+        SMVS_REQUIRE(width == ctx->width && height == ctx->height,
+            "main image size differs from the context");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    smvs_ctx::ViewImage &vi = ctx->images[view + 1];
+    size_t const n = (size_t)width * height * channels;
+    int rc;
+    if (vi.w != width || vi.h != height || vi.c != channels || !vi.data) {
+        if ((rc = device_alloc(&vi.data, n)) != SMVS_OK)
+            return rc;
+        vi.w = width;
+        vi.h = height;
+        vi.c = channels;
+    }
+    uint8_t *staging = nullptr;
+    if ((rc = device_alloc(&staging, n)) != SMVS_OK)
+        return rc;
+    hipError_t e = hipMemcpyAsync(staging, bytes, n, hipMemcpyHostToDevice,
+        ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+            dim3(256), 0, ctx->stream, staging, vi.data, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(staging);
+    if (e != hipSuccess) {
+        set_error("smvs_ctx_upload_image: %s", hipGetErrorString(e));
+        return SMVS_ERR_HIP;
+    }
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    SMVS_REQUIRE(scale >= 0 && scale <= 10, "scale out of range");
+    for (int v = 0; v <= ctx->n_subs; ++v)
+        if (ctx->images[v].data == nullptr) {
+            set_error("smvs_ctx_set_scale: view %d has no image", v - 1);
+            return SMVS_ERR_STATE;
+        }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    // stereo_view.cc:29-31; the weights use the host's expf like the reference
+    double const sigma_d = 0.12 * std::pow(2.0, scale) + 0.2;
+    float const sigma = (float)sigma_d;
+    int const ks = (int)std::ceil(sigma * 2.884f);
+    std::vector<float> kernel(ks + 1);
+    for (int i = 0; i <= ks; ++i)
+        kernel[i] = std::exp(-((float)i * (float)i) / (2.0f * sigma * sigma));
+    float *kernel_dev = nullptr;
+    int rc = device_alloc(&kernel_dev, kernel.size());
+    if (rc != SMVS_OK)
+        return rc;
+    hipError_t e = hipMemcpyAsync(kernel_dev, kernel.data(),
+        kernel.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    FitMatrix const fit = quadratic_fit_matrix();
+    bool const blur = !(std::fabs(sigma) < 0.1f);
+
+    for (int v = 0; v <= ctx->n_subs && e == hipSuccess; ++v) {
+        smvs_ctx::ViewImage const &vi = ctx->images[v];
+        size_t const n = (size_t)vi.w * vi.h * vi.c;
+        if (n > ctx->blur_cap) {
+            if ((rc = device_alloc(&ctx->blur_tmp[0], n)) != SMVS_OK
+                || (rc = device_alloc(&ctx->blur_tmp[1], n)) != SMVS_OK) {
+                (void)hipFree(kernel_dev);
+                return rc;
+            }
+            ctx->blur_cap = n;
+        }
+        const float *src = vi.data;
+        if (blur) {
+            unsigned const blocks = (unsigned)((n + 255) / 256);
+            ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+            hipLaunchKernelGGL(blur_pass_kernel, dim3(blocks), dim3(256), 0,
+                ctx->stream, vi.data, ctx->blur_tmp[0], vi.w, vi.h, vi.c, ks,
+                kernel_dev, 0);
+            hipLaunchKernelGGL(blur_pass_kernel, dim3(blocks), dim3(256), 0,
+                ctx->stream, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w, vi.h,
+                vi.c, ks, kernel_dev, 1);
+            src = ctx->blur_tmp[1];
+        }
+        float2 *grad;
+        float4 *hess;
+        if (v == 0) {
+            grad = ctx->main_grad;
+            hess = nullptr;
+        } else {
+            SubPlanes &sp = ctx->subs[v - 1];
+            size_t const npix = (size_t)vi.w * vi.h;
+            if (sp.width != vi.w || sp.height != vi.h || sp.grad == nullptr) {
+                if ((rc = device_alloc(&sp.grad, npix)) != SMVS_OK
+                    || (rc = device_alloc(&sp.hess, npix)) != SMVS_OK) {
+                    (void)hipFree(kernel_dev);
+                    return rc;
+                }
+                sp.width = vi.w;
+                sp.height = vi.h;
+            }
+            grad = sp.grad;
+            hess = sp.hess;
+        }
+        {
+            ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+            hipLaunchKernelGGL(gradients_kernel, dim3((vi.w + 255) / 256, vi.h),
+                dim3(256), 0, ctx->stream, src, vi.w, vi.h, vi.c, fit, grad, hess);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ctx->subs_dev, ctx->subs,
+            sizeof(SubPlanes) * SMVS_MAX_SUBS, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(kernel_dev);
+    if (e != hipSuccess) {
+        set_error("smvs_ctx_set_scale: %s", hipGetErrorString(e));
+        return SMVS_ERR_HIP;
+    }
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_download_planes(smvs_ctx *ctx, int view, float *grad2, float *hess3)
+{
+    SMVS_REQUIRE(ctx && grad2, "null argument");
+    SMVS_REQUIRE(view >= -1 && view < ctx->n_subs, "view index out of range");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (view == -1) {
+        SMVS_REQUIRE(hess3 == nullptr, "the main view keeps no Hessian plane");
+        SMVS_HIP_CHECK(hipMemcpyAsync(grad2, ctx->main_grad,
+            (size_t)ctx->width * ctx->height * sizeof(float2),
+            hipMemcpyDeviceToHost, ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return SMVS_OK;
+    }
+    SubPlanes const &sp = ctx->subs[view];
+    if (sp.grad == nullptr) {
+        set_error("smvs_ctx_download_planes: view %d has no planes", view);
+        return SMVS_ERR_STATE;
+    }
+    size_t const npix = (size_t)sp.width * sp.height;
+    SMVS_HIP_CHECK(hipMemcpyAsync(grad2, sp.grad, npix * sizeof(float2),
+        hipMemcpyDeviceToHost, ctx->stream));
+    if (hess3 != nullptr) {
+        if (ctx->stage_cap < npix * 3) {
+            int rc = device_alloc(&ctx->stage, npix * 3);
+            if (rc != SMVS_OK)
+                return rc;
+            ctx->stage_cap = npix * 3;
+        }
+        hipLaunchKernelGGL(compact_hessian_kernel,
+            dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream,
+            sp.hess, ctx->stage, npix);
+        SMVS_HIP_CHECK(hipGetLastError());
+        SMVS_HIP_CHECK(hipMemcpyAsync(hess3, ctx->stage,
+            npix * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_upload_shading(smvs_ctx *ctx, const float *shading1,
+    const float *shading_grad2)
+{
+    SMVS_REQUIRE(ctx && shading1 && shading_grad2, "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const npix = (size_t)ctx->width * ctx->height;
+    int rc;
+    if (ctx->main_shading == nullptr) {
+        if ((rc = device_alloc(&ctx->main_shading, npix)) != SMVS_OK)
+            return rc;
+        if ((rc = device_alloc(&ctx->main_shading_grad, npix)) != SMVS_OK)
+            return rc;
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->main_shading, shading1,
+        npix * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->main_shading_grad, shading_grad2,
+        npix * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->has_shading = true;
+    return SMVS_OK;
+}

@@ -75,6 +75,29 @@ class ViewContext:
             check(self.lib.smvs_ctx_upload_sub(self.handle, j, g.shape[1],
                   g.shape[0], _p(g, _fp), _p(h, _fp)))
 
+    def upload_image(self, view, img_u8):
+        """view = -1: main view, otherwise neighbour index."""
+        img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        h, w, c = img.shape
+        check(self.lib.smvs_ctx_upload_image(self.handle, view, w, h, c,
+                                             _p(img, _u8p)))
+        if not hasattr(self, "_image_shapes"):
+            self._image_shapes = {}
+        self._image_shapes[view] = (h, w)
+
+    def set_scale(self, scale):
+        check(self.lib.smvs_ctx_set_scale(self.handle, scale))
+
+    def download_planes(self, view):
+        h, w = self._image_shapes[view]
+        grad = np.zeros((h, w, 2), np.float32)
+        hess = np.zeros((h, w, 3), np.float32) if view >= 0 else None
+        check(self.lib.smvs_ctx_download_planes(self.handle, view, _p(grad, _fp),
+                                                _p(hess, _fp)))
+        return grad, hess
+
     def set_surface(self, surf):
         nodes = _f64(surf["nodes"]).reshape(-1, 4)
         nv = np.ascontiguousarray(surf["node_valid"], dtype=np.uint8)

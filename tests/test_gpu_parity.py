@@ -356,3 +356,24 @@ def test_device_bicubic_matches_reference_known_answers(hip):
         checked += 1
     assert checked == 4
     ctx.close()
+
+
+@pytest.mark.parametrize("scale", [2, 4, 6])
+def test_device_scale_space_is_bit_exact(hip, oracle, scale):
+    """Byte -> float, Gaussian blur, luminance and the 3x3 quadratic-fit
+    gradient / Hessian on the device (stereo_view.cc:16-46, 97-188) are
+    bit-identical to the host restatement, RGB and grey, ragged sizes."""
+    rng = np.random.default_rng(scale)
+    main = rng.integers(0, 256, size=(61, 83, 3)).astype(np.uint8)
+    sub0 = rng.integers(0, 256, size=(61, 83, 3)).astype(np.uint8)
+    sub1 = rng.integers(0, 256, size=(47, 70)).astype(np.uint8)   # grey, other size
+    ctx = hip.ViewContext(83, 61, 2)
+    ctx.upload_image(-1, main); ctx.upload_image(0, sub0); ctx.upload_image(1, sub1)
+    ctx.set_scale(scale)
+    for view, img in ((-1, main), (0, sub0), (1, sub1)):
+        g_ref, h_ref = oracle.scale_planes(img, scale)
+        g, h = ctx.download_planes(view)
+        assert np.array_equal(g, g_ref), (view, np.abs(g - g_ref).max())
+        if view >= 0:
+            assert np.array_equal(h, h_ref), (view, np.abs(h - h_ref).max())
+    ctx.close()
