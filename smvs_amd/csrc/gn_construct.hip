@@ -310,7 +310,64 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
     double const gm0 = gm.x, gm1 = gm.y;
 
     // ---- neighbours (gauss_newton_step.cc:175-208) ----
-    int num_subs = 0;
+    // Neighbour loop, software pipelined: the taps of neighbour j are issued,
+    // then the IRLS terms of the PREVIOUS neighbour (reference term and its
+    // pairs with all earlier neighbours, read from LDS) run while the loads
+    // are in flight, then neighbour j's row coefficients are formed.
+    double m_ww = 0.0, m_wx = 0.0, m_xx = 0.0, m_wy = 0.0, m_yy = 0.0;
+    double v_w = 0.0, v_x = 0.0, v_y = 0.0;
+    int num_subs = 0;            // neighbours folded into the sums so far
+    bool have_prev = false;
+    double s0p = 0.0, s1p = 0.0, P0p = 0.0, P1p = 0.0, Qp = 0.0;
+
+    // reference term of the pending neighbour and its pairs with slots
+    // 0 .. num_subs-1, then the pending values go to slot num_subs
+    auto fold_pending = [&](bool keep) {
+        {
+            double const diff0 = s0p - gm0, diff1 = s1p - gm1;
+            double const w0 = weight_rcp(fabs(diff0) + R_FACTOR);
+            double const w1 = weight_rcp(fabs(diff1) + R_FACTOR);
+            double const a0 = w0 * P0p, b0 = w0 * Qp;
+            double const a1 = w1 * P1p, b1 = w1 * Qp;
+            m_ww += a0 * P0p + a1 * P1p;
+            m_wx += a0 * Qp;
+            m_xx += b0 * Qp;
+            m_wy += a1 * Qp;
+            m_yy += b1 * Qp;
+            v_w += a0 * diff0 + a1 * diff1;
+            v_x += b0 * diff0;
+            v_y += b1 * diff1;
+        }
+#pragma unroll 1
+        for (int j2 = 0; j2 < num_subs; ++j2) {
+            const double *sk = nb + (j2 * 5) * 64;
+            double const sd0 = sk[0] - s0p, sd1 = sk[64] - s1p;
+            double const w0 = weight_rcp(fabs(sd0) + R_FACTOR);
+            double const w1 = weight_rcp(fabs(sd1) + R_FACTOR);
+            double const dP0 = sk[128] - P0p, dP1 = sk[192] - P1p;
+            double const dQ = sk[256] - Qp;
+            double const a0 = w0 * dP0, b0 = w0 * dQ;
+            double const a1 = w1 * dP1, b1 = w1 * dQ;
+            m_ww += a0 * dP0 + a1 * dP1;
+            m_wx += a0 * dQ;
+            m_xx += b0 * dQ;
+            m_wy += a1 * dQ;
+            m_yy += b1 * dQ;
+            v_w += a0 * sd0 + a1 * sd1;
+            v_x += b0 * sd0;
+            v_y += b1 * sd1;
+        }
+        if (keep) {
+            double *slot = nb + (num_subs * 5) * 64;
+            slot[0 * 64] = s0p;
+            slot[1 * 64] = s1p;
+            slot[2 * 64] = P0p;
+            slot[3 * 64] = P1p;
+            slot[4 * 64] = Qp;
+        }
+        num_subs += 1;
+    };
+
 #pragma unroll 1
     for (int j = 0; j < A.n_subs; ++j) {
         if (!((vis >> j) & 1u))
@@ -337,6 +394,23 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
             proj0 -= 0.5;
             proj1 -= 0.5;
         }
+        Taps const tp = make_taps((float)proj0, (float)proj1, sp.width,
+            sp.height);
+        float2 const g00 = sp.grad[tp.o00], g10 = sp.grad[tp.o10],
+            g01 = sp.grad[tp.o01], g11 = sp.grad[tp.o11];
+        float4 const h00 = sp.hess[tp.o00], h10 = sp.hess[tp.o10],
+            h01 = sp.hess[tp.o01], h11 = sp.hess[tp.o11];
+
+        // ---- the previous neighbour's IRLS terms hide the tap latency ----
+        if (have_prev)
+            fold_pending(true);
+
+        double const g0 = tap_mix(g00.x, g10.x, g01.x, g11.x, tp);
+        double const g1 = tap_mix(g00.y, g10.y, g01.y, g11.y, tp);
+        double const hxx = tap_mix(h00.x, h10.x, h01.x, h11.x, tp);
+        double const hxy = tap_mix(h00.y, h10.y, h01.y, h11.y, tp);
+        double const hyy = tap_mix(h00.z, h10.z, h01.z, h11.z, tp);
+
         // correspondence.cc:88-100 with reciprocals
         double const inv_d2 = inv_d * inv_d;
         double const rx = wx * r + w * M[6], ry = wy * r + w * M[7];
@@ -344,20 +418,6 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         double const jac2 = (wy * p + w * M[1]) * inv_d - a * ry * inv_d2;
         double const jac1 = (wx * q + w * M[3]) * inv_d - b * rx * inv_d2;
         double const jac3 = (wy * q + w * M[4]) * inv_d - b * ry * inv_d2;
-        Taps const tp = make_taps((float)proj0, (float)proj1, sp.width,
-            sp.height);
-        float2 const g00 = sp.grad[tp.o00], g10 = sp.grad[tp.o10],
-            g01 = sp.grad[tp.o01], g11 = sp.grad[tp.o11];
-        float4 const h00 = sp.hess[tp.o00], h10 = sp.hess[tp.o10],
-            h01 = sp.hess[tp.o01], h11 = sp.hess[tp.o11];
-        double const g0 = tap_mix(g00.x, g10.x, g01.x, g11.x, tp);
-        double const g1 = tap_mix(g00.y, g10.y, g01.y, g11.y, tp);
-        double const hxx = tap_mix(h00.x, h10.x, h01.x, h11.x, tp);
-        double const hxy = tap_mix(h00.y, h10.y, h01.y, h11.y, tp);
-        double const hyy = tap_mix(h00.z, h10.z, h01.z, h11.z, tp);
-
-        double const s0j = jac0 * g0 + jac1 * g1;
-        double const s1j = jac2 * g0 + jac3 * g1;
 
         double const du_w = (p * d - r * a) * inv_d2;
         double const dv_w = (q * d - r * b) * inv_d2;
@@ -386,60 +446,16 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         }
         double const cu = du_cp * inv_d2;
         double const cv = dv_cp * inv_d2;
-        double *slot = nb + (num_subs * 5) * 64;
-        slot[0 * 64] = s0j;
-        slot[1 * 64] = s1j;
-        slot[2 * 64] = du_A[0] * g0 + dv_A[0] * g1 + JH0 * du_w + JH1 * dv_w;
-        slot[3 * 64] = du_A[1] * g0 + dv_A[1] * g1 + JH2 * du_w + JH3 * dv_w;
-        slot[4 * 64] = cu * g0 + cv * g1;
-        num_subs += 1;
+        s0p = jac0 * g0 + jac1 * g1;
+        s1p = jac2 * g0 + jac3 * g1;
+        P0p = du_A[0] * g0 + dv_A[0] * g1 + JH0 * du_w + JH1 * dv_w;
+        P1p = du_A[1] * g0 + dv_A[1] * g1 + JH2 * du_w + JH3 * dv_w;
+        Qp = cu * g0 + cv * g1;
+        have_prev = true;
     }
+    if (have_prev)
+        fold_pending(false);   // the last neighbour needs no LDS slot
 
-    // ---- IRLS-weighted photometric terms (gauss_newton_step.cc:268-321):
-    // ref-neighbour residuals and all neighbour-neighbour pairs, expressed
-    // on the (w, w_x) / (w, w_y) rows of the basis table. ----
-    double m_ww = 0.0, m_wx = 0.0, m_xx = 0.0, m_wy = 0.0, m_yy = 0.0;
-    double v_w = 0.0, v_x = 0.0, v_y = 0.0;
-#pragma unroll 1
-    for (int j = 0; j < num_subs; ++j) {
-        const double *sj = nb + (j * 5) * 64;
-        double const s0j = sj[0], s1j = sj[64], P0j = sj[128], P1j = sj[192],
-            Qj = sj[256];
-        {
-            double const diff0 = s0j - gm0, diff1 = s1j - gm1;
-            double const w0 = weight_rcp(fabs(diff0) + R_FACTOR);
-            double const w1 = weight_rcp(fabs(diff1) + R_FACTOR);
-            double const a0 = w0 * P0j, b0 = w0 * Qj;
-            double const a1 = w1 * P1j, b1 = w1 * Qj;
-            m_ww += a0 * P0j + a1 * P1j;
-            m_wx += a0 * Qj;
-            m_xx += b0 * Qj;
-            m_wy += a1 * Qj;
-            m_yy += b1 * Qj;
-            v_w += a0 * diff0 + a1 * diff1;
-            v_x += b0 * diff0;
-            v_y += b1 * diff1;
-        }
-#pragma unroll 1
-        for (int j2 = j + 1; j2 < num_subs; ++j2) {
-            const double *sk = nb + (j2 * 5) * 64;
-            double const sd0 = s0j - sk[0], sd1 = s1j - sk[64];
-            double const w0 = weight_rcp(fabs(sd0) + R_FACTOR);
-            double const w1 = weight_rcp(fabs(sd1) + R_FACTOR);
-            double const dP0 = P0j - sk[128], dP1 = P1j - sk[192];
-            double const dQ = Qj - sk[256];
-            double const a0 = w0 * dP0, b0 = w0 * dQ;
-            double const a1 = w1 * dP1, b1 = w1 * dQ;
-            m_ww += a0 * dP0 + a1 * dP1;
-            m_wx += a0 * dQ;
-            m_xx += b0 * dQ;
-            m_wy += a1 * dQ;
-            m_yy += b1 * dQ;
-            v_w += a0 * sd0 + a1 * sd1;
-            v_x += b0 * sd0;
-            v_y += b1 * sd1;
-        }
-    }
     M6[sym6(0, 0)] = m_ww;
     M6[sym6(0, 1)] = m_wx;
     M6[sym6(1, 1)] = m_xx;
@@ -600,7 +616,7 @@ gn_patch_kernel(PatchKernelArgs A)
     // [27][64] pixel systems, aliased with the [5 * n_subs][64] neighbour
     // scratch of phase 1 (dead once M6 is formed)
     double *Msh = lds;
-    int const scratch_rows = max(27, 5 * A.n_subs);
+    int const scratch_rows = max(27, 5 * (A.n_subs - 1));
     double *tabs = lds + scratch_rows * 64;  // [spr][12] sampled coordinates
 
     int const lane = threadIdx.x;
@@ -991,7 +1007,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
-    int const scratch_rows = 5 * ctx->n_subs > 27 ? 5 * ctx->n_subs : 27;
+    int const scratch_rows = 5 * (ctx->n_subs - 1) > 27 ? 5 * (ctx->n_subs - 1) : 27;
     size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12) * sizeof(double);
     bool const four = A.P <= 16;
     int const ppw = four ? 4 : 1;
