@@ -19,6 +19,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace smvs_hip {
 
@@ -55,31 +56,45 @@ struct CgArgs {
     const double *Pinv;
     const double *g;
     const uint8_t *active;   // rows / columns of inactive nodes are zero
+    uint16_t *mask;          // bit s: stencil slot s of the node is in the matrix
     double *x, *r, *z, *Ad, *b;
     double *dbuf[2];
     double *partials;      // [4][CG_MAX_BLOCKS]
     CgState *state;        // [2]
     int *status;
-    int num_nodes, stride;
+    int num_nodes, stride, rows_total;
     int k;                 // iteration index of this launch
     int max_iterations;
     double q_tolerance;
     double fixed_tolerance;  // < 0: 0.01 * ||g||
 };
 
-// Sum NV arrays of `nb` per-block partials in a fixed order; every thread of
-// every block gets the same values.
+// Sum NV arrays of `nb` (<= CG_THREADS) per-block partials in a fixed order;
+// every thread of every block gets the same values.  The loads are split
+// from the reduction so that a kernel can request them together with its
+// other operands and pay one memory round trip instead of two.
 template <int NV>
 __device__ __forceinline__ void
-reduce_partials(const double *partials, int nb, double (&out)[NV])
+load_partials(const double *partials, int nb, double (&mine)[NV])
+{
+#pragma unroll
+    // branch-free and unmasked (reduce_loaded masks): the loads stay
+    // countable for s_waitcnt and nothing waits for them here
+    for (int k = 0; k < NV; ++k)
+        mine[k] = partials[(size_t)k * CG_MAX_BLOCKS
+            + min((int)threadIdx.x, nb - 1)];
+}
+
+template <int NV>
+__device__ __forceinline__ void
+reduce_loaded(double (&mine)[NV], int nb, double (&out)[NV])
 {
     __shared__ double red[NV][CG_THREADS / 64];
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         double s = 0.0;
-        for (int i = threadIdx.x; i < nb; i += CG_THREADS)
-            s += partials[(size_t)k * CG_MAX_BLOCKS + i];
+        s += (int)threadIdx.x < nb ? mine[k] : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             s += __shfl_xor(s, off);
@@ -96,6 +111,15 @@ reduce_partials(const double *partials, int nb, double (&out)[NV])
         out[k] = s;
     }
     __syncthreads();
+}
+
+template <int NV>
+__device__ __forceinline__ void
+reduce_partials(const double *partials, int nb, double (&out)[NV])
+{
+    double mine[NV];
+    load_partials<NV>(partials, nb, mine);
+    reduce_loaded<NV>(mine, nb, out);
 }
 
 // Block-level sum of per-thread values -> partials[k][blockIdx.x]
@@ -157,6 +181,27 @@ cg_init_kernel(CgArgs A)
         A.dbuf[1][gid] = zi;
         v[0] += zi * bi;
         v[1] += gi * gi;
+        if (row == 0) {
+            // Inactive nodes have no row and no column in the reference's
+            // matrix (gauss_newton_step.cc:91-105): their b, r, z, d and x
+            // stay zero, and nothing is read for them.
+            unsigned mask = 0u;
+            if (A.active == nullptr || A.active[n] != 0) {
+                int const ix = n % A.stride;
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    int const dx = s % 3 - 1, dy = s / 3 - 1;
+                    int const mx = ix + dx;
+                    int const m = n + dy * A.stride + dx;
+                    if (mx < 0 || mx >= A.stride || m < 0 || m >= A.num_nodes)
+                        continue;
+                    if (A.active != nullptr && !A.active[m])
+                        continue;
+                    mask |= 1u << s;
+                }
+            }
+            A.mask[n] = (uint16_t)mask;
+        }
     }
     store_partials<2>(v, A.partials);
 }
@@ -186,24 +231,168 @@ cg_init_finalize_kernel(CgArgs A, int nb)
 }
 
 // A_k: finish iteration k-1, form d_k, Ad_k = A d_k, partial d.Ad.
-// One thread per (node, row); a wave reads 16 consecutive nodes' rows of one
-// slot as one contiguous 2 KiB segment.  The product follows the reference's
+// One thread per (node, row) of a 16 x 8 node tile; a wave reads 16
+// consecutive nodes' rows of one slot as one contiguous 2 KiB segment.  The
+// direction d_k = z_k + beta d_{k-1} of the tile and its one-node halo is
+// formed once and shared through LDS.  The product follows the reference's
 // accumulation order (ascending block column, then column inside the block,
 // separate mul/add) and is bit-identical to BlockSparseMatrix::multiply.
-__global__ void __launch_bounds__(CG_THREADS)
+//
+// A launch is a chain of dependent memory round trips (a few microseconds
+// each at this size), not a bandwidth problem, so the kernel needs three:
+// {solver state, partial sums, stencil masks of both tiles}, then the first
+// tile's matrix rows and direction operands (requested before the reduction
+// of the partial sums), then the second tile's.  All loads are unconditional
+// (absent operands are redirected to a valid, already cached address): the
+// tile body is straight-line code whose loads are in flight together.
+constexpr int SPMV_TX = 16, SPMV_TY = CG_THREADS / 4 / SPMV_TX;
+constexpr int SPMV_HALO = 2 * (SPMV_TX + 2) + 2 * SPMV_TY;
+
+__global__ void __launch_bounds__(CG_THREADS, 4)
 cg_spmv_kernel(CgArgs A, int nb)
 {
+    constexpr int TX = SPMV_TX, TY = SPMV_TY, LW = TX + 2;
+    __shared__ double dtile[(TY + 2) * LW][4];
+    const double *__restrict__ d_old = A.dbuf[(A.k - 1) & 1];
+    double *__restrict__ d_new = A.dbuf[A.k & 1];
+    const double *__restrict__ H = A.H9;
+    double *__restrict__ Ad = A.Ad;
+    bool const first = A.k == 1;
+    unsigned const Nu = (unsigned)A.num_nodes;
+    // Tiles are handed out in row-major bands per XCD (blockIdx % 8) so that
+    // the transposed blocks stored at vertical neighbours across a tile edge
+    // mostly come from the same XCD's L2.
+    // (8 bands, or one for grids of fewer than 8 blocks; shifts and 32-bit
+    // divisions only: this prologue is on every launch's critical path)
+    unsigned const rows_total = A.rows_total;
+    unsigned const tiles_x = ((unsigned)A.stride + TX - 1) / TX;
+    unsigned const tiles_y = (rows_total + TY - 1) / TY;
+    unsigned const num_tiles = tiles_x * tiles_y;
+    unsigned const gshift = gridDim.x >= 8u ? 3u : 0u;
+    unsigned const groups = 1u << gshift;
+    unsigned const xcd = blockIdx.x & (groups - 1u);
+    unsigned const slot_in_xcd = blockIdx.x >> gshift;
+    int const per_xcd_blocks
+        = (int)((gridDim.x + groups - 1u - xcd) >> gshift);
+    int const band_begin = (int)((num_tiles * xcd) >> gshift);
+    int const band_end = (int)((num_tiles * (xcd + 1u)) >> gshift);
+    int const tid = threadIdx.x;
+    int const lnode = tid >> 2, row = tid & 3;
+    int const lx = lnode & (TX - 1), ly = lnode / TX;
+    int const lcore = (ly + 1) * LW + lx + 1;
+    // halo position served by this thread (threads 0 .. 4 * SPMV_HALO - 1)
+    bool const has_halo = lnode < SPMV_HALO;
+    int hx, hy;
+    if (lnode < LW) {
+        hx = lnode; hy = 0;
+    } else if (lnode < 2 * LW) {
+        hx = lnode - LW; hy = TY + 1;
+    } else if (lnode < 2 * LW + TY) {
+        hx = 0; hy = lnode - 2 * LW + 1;
+    } else {
+        hx = TX + 1; hy = lnode - 2 * LW - TY + 1;
+    }
+    int const lhalo = has_halo ? hy * LW + hx : 0;
+
+    // Node of this thread in a tile (0 and in_grid = false outside the grid)
+    auto tile_node = [&](int tile, bool &in_grid) -> int {
+        unsigned const ty = (unsigned)tile / tiles_x;
+        unsigned const tx = (unsigned)tile - ty * tiles_x;
+        int const ix = (int)tx * TX + lx, iy = (int)ty * TY + ly;
+        in_grid = tile < band_end && ix < A.stride && iy < (int)rows_total;
+        return in_grid ? iy * A.stride + ix : 0;
+    };
+    // halo node of this thread in a tile (-1: none)
+    auto halo_node = [&](int tile) -> int {
+        unsigned const ty = (unsigned)tile / tiles_x;
+        unsigned const tx = (unsigned)tile - ty * tiles_x;
+        int const ix = (int)tx * TX + hx - 1, iy = (int)ty * TY + hy - 1;
+        bool const ok = has_halo && tile < band_end && ix >= 0
+            && ix < A.stride && iy >= 0 && iy < (int)rows_total;
+        return ok ? iy * A.stride + ix : -1;
+    };
+
+    // first round trip: stencil masks of this block's first two tiles, the
+    // partial sums and the solver state, all requested before any is used
+    int tile = band_begin + slot_in_xcd;
+    bool grid_cur, grid_next;
+    int n_cur = tile_node(tile, grid_cur);
+    int n_next = tile_node(tile + per_xcd_blocks, grid_next);
+    unsigned const raw_cur = A.mask[n_cur], raw_next = A.mask[n_next];
+    double mine[3];   // (unused garbage in the first iteration)
+    load_partials<3>(A.partials + CG_MAX_BLOCKS, nb, mine);
+    // A launch after convergence is a no-op.  It takes no early exit here (a
+    // branch would serialise the state load ahead of everything else): its
+    // operand requests are all redirected to one cached line instead.
     CgState const prev = A.state[(A.k - 1) & 1];
-    if (prev.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0)
+    bool const idle = prev.done != 0;
+    // stencil mask: 0 outside the grid, 0x8000 in the grid but inactive
+    unsigned mask_cur = grid_cur && !idle ? (0x8000u | raw_cur) : 0u;
+    unsigned mask_next = grid_next && !idle ? (0x8000u | raw_next) : 0u;
+    n_cur = idle ? 0 : n_cur;
+
+    // in the first iteration d_1 = z was written by the init kernel
+    const double *__restrict__ dir_a = first ? d_new : A.z;
+    const double *__restrict__ dir_b = first ? d_new : d_old;
+
+    // Operands of one work item; none depends on beta, so the first tile's
+    // are requested before the reduction.
+    struct Operands {
+        double h[9][4];
+        double za, zb, ha, hb;   // direction operands: own node, halo node
+    };
+    auto load_operands = [&](int tile_, int n, unsigned mask, Operands &o) {
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            bool const present = (mask >> s) & 1u;
+            int const dx = s % 3 - 1, dy = s / 3 - 1;
+            int const m = n + dy * A.stride + dx;
+            // symmetric storage: slots 4..8 are stored at the node itself,
+            // slots 0..3 are the transposed blocks stored at the neighbour
+            // (32-bit element offsets from the uniform base: H has fewer
+            // than 2^32 elements)
+            if (s >= 4) {
+                unsigned const off = ((unsigned)(present ? s - 4 : 0) * Nu
+                    + (unsigned)n) * 16u + (unsigned)row * 4u;
+                double4_v const hrow
+                    = *reinterpret_cast<const double4_v *>(H + off);
+                o.h[s][0] = hrow.x; o.h[s][1] = hrow.y;
+                o.h[s][2] = hrow.z; o.h[s][3] = hrow.w;
+            } else {
+                unsigned const off = present
+                    ? ((unsigned)(4 - s) * Nu + (unsigned)m) * 16u + (unsigned)row
+                    : (unsigned)n * 16u + (unsigned)row;
+                const double *blk = H + off;
+                o.h[s][0] = blk[0]; o.h[s][1] = blk[4];
+                o.h[s][2] = blk[8]; o.h[s][3] = blk[12];
+            }
+        }
+        unsigned const own_off = (unsigned)n * 4u + (unsigned)row;
+        o.za = dir_a[own_off];
+        o.zb = dir_b[own_off];
+        int const hn = idle ? -1 : halo_node(tile_);
+        unsigned const halo_off = (unsigned)(hn < 0 ? n : hn) * 4u
+            + (unsigned)row;
+        o.ha = dir_a[halo_off];
+        o.hb = dir_b[halo_off];
+        if (hn < 0) {
+            o.ha = 0.0;
+            o.hb = 0.0;
+        }
+    };
+    Operands op;
+    load_operands(tile, n_cur, mask_cur, op);
+
+    if (idle) {
+        if (blockIdx.x == 0 && tid == 0)
             A.state[A.k & 1] = prev;
         return;
     }
     double beta = 0.0;
-    if (A.k > 1) {
+    if (!first) {
         // termination tests of iteration k-1 (conjugate_gradient.h:136-198)
         double v[3];
-        reduce_partials<3>(A.partials + CG_MAX_BLOCKS, nb, v);
+        reduce_loaded<3>(mine, nb, v);
         double const new_rr = v[0];
         double const Q1 = -1.0 * v[1];
         int const it = prev.iter;  // == k - 1
@@ -219,7 +408,7 @@ cg_spmv_kernel(CgArgs A, int nb)
             }
         }
         beta = v[2] / prev.rr;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blockIdx.x == 0 && tid == 0) {
             CgState s = prev;
             s.rr = v[2];
             s.q0 = Q1;
@@ -235,164 +424,159 @@ cg_spmv_kernel(CgArgs A, int nb)
         }
         if (done)
             return;
-    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    } else if (blockIdx.x == 0 && tid == 0) {
         A.state[A.k & 1] = prev;
     }
 
-    const double *__restrict__ d_old = A.dbuf[(A.k - 1) & 1];
-    double *__restrict__ d_new = A.dbuf[A.k & 1];
-    const double *__restrict__ H = A.H9;
-    const double *__restrict__ zv = A.z;
-    double *__restrict__ Ad = A.Ad;
-    const uint8_t *__restrict__ act = A.active;
-    bool const first = A.k == 1;
-    int const items = A.num_nodes * 4;
-    size_t const N = (size_t)A.num_nodes;
     double v[1] = { 0.0 };
-    // 2-D tiles of 16 x (CG_THREADS / 64) nodes: with symmetric storage the
-    // lower stencil slots re-read blocks stored at neighbouring nodes, which
-    // stay in L1 / L2 when the neighbour belongs to the same tile.  Tiles
-    // are handed out in row-major bands per XCD (blockIdx % 8) so vertical
-    // neighbours across a tile edge mostly share an XCD's L2.
-    constexpr int TX = 16, TY = CG_THREADS / 64;
-    int const rows_total = A.num_nodes / A.stride;
-    int const tiles_x = (A.stride + TX - 1) / TX;
-    int const tiles_y = (rows_total + TY - 1) / TY;
-    int const num_tiles = tiles_x * tiles_y;
-    int const groups = min(8, (int)gridDim.x);
-    int const xcd = blockIdx.x % groups, slot_in_xcd = blockIdx.x / groups;
-    int const per_xcd_blocks = ((int)gridDim.x + groups - 1 - xcd) / groups;
-    int const band_begin = (int)((long long)num_tiles * xcd / groups);
-    int const band_end = (int)((long long)num_tiles * (xcd + 1) / groups);
-    int const lnode = threadIdx.x >> 2, row = threadIdx.x & 3;
-    int const lx = lnode & (TX - 1), ly = lnode / TX;
-    (void)items;
-    for (int tile = band_begin + slot_in_xcd; tile < band_end;
-         tile += per_xcd_blocks) {
-        int const tx = tile % tiles_x, ty = tile / tiles_x;
-        int const ix = tx * TX + lx, iy = ty * TY + ly;
-        if (ix >= A.stride || iy >= rows_total)
-            continue;
-        int const n = iy * A.stride + ix;
-        int const gid = n * 4 + row;
-        // Inactive nodes have no row and no column in the reference's matrix
-        // (gauss_newton_step.cc:91-105): their b, r, z, d and x stay zero, so
-        // nothing has to be read for them.
-        if (act != nullptr && !act[n]) {
-            Ad[gid] = 0.0;
-            if (!first)
-                d_new[gid] = 0.0;
-            continue;
+    bool first_tile = true;
+    for (; tile < band_end; tile += per_xcd_blocks) {
+        if (!first_tile) {
+            n_cur = n_next;
+            mask_cur = mask_next;
+            load_operands(tile, n_cur, mask_cur, op);
+            bool grid;
+            n_next = tile_node(tile + per_xcd_blocks, grid);
+            unsigned const raw = A.mask[n_next];
+            mask_next = grid ? (0x8000u | raw) : 0u;
+            __syncthreads();   // the previous tile's readers are done
         }
+        first_tile = false;
+        int const n = n_cur;
+        int const gid = n * 4 + row;
+        double own, halo;
+        {
+#pragma clang fp contract(off)
+            own = first ? op.za : op.za + beta * op.zb;
+            halo = first ? op.ha : op.ha + beta * op.hb;
+        }
+        dtile[lcore][row] = own;
+        if (has_halo)
+            dtile[lhalo][row] = halo;
+        __syncthreads();
         double acc = 0.0;
-        double d_own = 0.0;
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
+            bool const present = (mask_cur >> s) & 1u;
             int const dx = s % 3 - 1, dy = s / 3 - 1;
-            int const mx = ix + dx;
-            int const m = n + dy * A.stride + dx;
-            if (mx < 0 || mx >= A.stride || m < 0 || m >= A.num_nodes)
-                continue;
-            if (act != nullptr && !act[m])
-                continue;
-            // d_k of the neighbour: every row-lane forms its own component
-            // and the quad shares the four values by DPP broadcast (one
-            // 8-byte load per lane instead of two 32-byte loads)
-            double own;
-            if (first)
-                own = d_new[(size_t)m * 4 + row];
-            else {
-#pragma clang fp contract(off)
-                own = zv[(size_t)m * 4 + row] + beta * d_old[(size_t)m * 4 + row];
-            }
-            double dm[4];
-            dm[0] = quad_bcast<0x00>(own);
-            dm[1] = quad_bcast<0x55>(own);
-            dm[2] = quad_bcast<0xAA>(own);
-            dm[3] = quad_bcast<0xFF>(own);
-            if (s == 4)
-                d_own = own;
-            // symmetric storage: slots 4..8 are stored at the node itself,
-            // slots 0..3 are the transposed blocks stored at the neighbour
-            double h0, h1, h2, h3;
-            if (s >= 4) {
-                double4_v const hrow = *reinterpret_cast<const double4_v *>(
-                    H + ((size_t)(s - 4) * N + n) * 16 + row * 4);
-                h0 = hrow.x; h1 = hrow.y; h2 = hrow.z; h3 = hrow.w;
-            } else {
-                const double *blk = H + ((size_t)(4 - s) * N + m) * 16 + row;
-                h0 = blk[0]; h1 = blk[4]; h2 = blk[8]; h3 = blk[12];
-            }
+            double4_v const dm = *reinterpret_cast<const double4_v *>(
+                &dtile[lcore + dy * LW + dx][0]);
+            double t = acc;
             {
 #pragma clang fp contract(off)
-                acc += h0 * dm[0];
-                acc += h1 * dm[1];
-                acc += h2 * dm[2];
-                acc += h3 * dm[3];
+                t += op.h[s][0] * dm.x;
+                t += op.h[s][1] * dm.y;
+                t += op.h[s][2] * dm.z;
+                t += op.h[s][3] * dm.w;
             }
+            acc = present ? t : acc;
         }
-        Ad[gid] = acc;
-        if (!first)
-            d_new[gid] = d_own;
-        v[0] += d_own * acc;
+        if (mask_cur != 0u) {
+            // inactive nodes: no row in the matrix, d stays zero
+            double const d_own = (mask_cur & 0x10u) ? own : 0.0;
+            Ad[gid] = acc;
+            if (!first)
+                d_new[gid] = d_own;
+            v[0] += d_own * acc;
+        }
     }
     store_partials<1>(v, A.partials);
 }
 
 // B_k: x += alpha d; r -= alpha Ad; z = P r; partials of r.r, x.(b + r), z.r
+// All operands of the (at most two) rounds are requested together with the
+// d.Ad partials: one memory round trip per launch.
 __global__ void __launch_bounds__(CG_THREADS)
 cg_update_kernel(CgArgs A, int nb)
 {
-    CgState const st = A.state[A.k & 1];
-    if (st.done)
-        return;
-    double dad[1];
-    reduce_partials<1>(A.partials, nb, dad);
-    double const alpha = st.rr / dad[0];
     const double *d = A.dbuf[A.k & 1];
     int const items = A.num_nodes * 4;
-    // every thread runs the same number of rounds so the shuffles stay
+    // every thread runs the same number of rounds so the DPP exchanges stay
     // convergent
     int const rounds = (items + gridDim.x * CG_THREADS - 1)
         / (gridDim.x * CG_THREADS);
-    double v[3] = { 0.0, 0.0, 0.0 };
-    for (int round = 0; round < rounds; ++round) {
+    struct Item {
+        bool in_range;
+        unsigned mask;
+        double x, d, r, Ad, b;
+        double4_v P;
+    };
+    // A launch after convergence takes no early exit (the branch would put
+    // the state load ahead of everything else): its requests all go to the
+    // first line of each array instead.
+    CgState const st = A.state[A.k & 1];
+    bool const idle = st.done != 0;
+    auto load_item = [&](int round, Item &it) {
         int const gid = (round * gridDim.x + blockIdx.x) * CG_THREADS
             + threadIdx.x;
-        int const n = gid >> 2, row = gid & 3;
-        bool const in_range = gid < items
-            && (A.active == nullptr || A.active[n] != 0);
+        bool const inside = gid < items && !idle;
+        unsigned const at = inside ? (unsigned)gid : (unsigned)(gid & 3);
+        unsigned const n = at >> 2, row = at & 3u;
+        it.in_range = inside;
+        it.mask = A.mask[n];
+        it.x = A.x[at];
+        it.d = d[at];
+        it.r = A.r[at];
+        it.Ad = A.Ad[at];
+        it.b = A.b[at];
+        it.P = *reinterpret_cast<const double4_v *>(A.Pinv + n * 16u + row * 4u);
+    };
+    // (rounds beyond the grid are redirected like idle ones: no branches
+    // between the requests)
+    constexpr int PRE = 2;
+    double mine[1], dad[1];
+    load_partials<1>(A.partials, nb, mine);
+    Item pre[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i)
+        load_item(i, pre[i]);
+    if (idle)
+        return;
+    reduce_loaded<1>(mine, nb, dad);
+    double const alpha = st.rr / dad[0];
+    double v[3] = { 0.0, 0.0, 0.0 };
+    auto process = [&](int round, Item const &item) {
+        int const gid = (round * gridDim.x + blockIdx.x) * CG_THREADS
+            + threadIdx.x;
+        bool const in_range = item.in_range && (item.mask & 0x1FFu) != 0u;
         double xi = 0.0, ri = 0.0;
         if (in_range) {
 #pragma clang fp contract(off)
-            xi = A.x[gid] + alpha * d[gid];
-            ri = A.r[gid] - alpha * A.Ad[gid];
+            xi = item.x + alpha * item.d;
+            ri = item.r - alpha * item.Ad;
         }
         // z = P r needs the node's whole residual: the four row-lanes of a
         // node are neighbours in the wave.
-        int const base_lane = (threadIdx.x & 63) & ~3;
         double rn[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            rn[c] = __shfl(ri, base_lane + c);
+        rn[0] = quad_bcast<0x00>(ri);
+        rn[1] = quad_bcast<0x55>(ri);
+        rn[2] = quad_bcast<0xAA>(ri);
+        rn[3] = quad_bcast<0xFF>(ri);
         if (in_range) {
             A.x[gid] = xi;
             A.r[gid] = ri;
-            const double *P = A.Pinv + (size_t)n * 16 + row * 4;
             double zi;
             {
 #pragma clang fp contract(off)
                 zi = 0.0;
-                zi += P[0] * rn[0];
-                zi += P[1] * rn[1];
-                zi += P[2] * rn[2];
-                zi += P[3] * rn[3];
+                zi += item.P.x * rn[0];
+                zi += item.P.y * rn[1];
+                zi += item.P.z * rn[2];
+                zi += item.P.w * rn[3];
             }
             A.z[gid] = zi;
             v[0] += ri * ri;
-            v[1] += xi * (A.b[gid] + ri);
+            v[1] += xi * (item.b + ri);
             v[2] += zi * ri;
         }
+    };
+#pragma unroll
+    for (int i = 0; i < PRE; ++i)
+        process(i, pre[i]);
+    for (int round = PRE; round < rounds; ++round) {
+        Item item;
+        load_item(round, item);
+        process(round, item);
     }
     store_partials<3>(v, A.partials + CG_MAX_BLOCKS);
 }
@@ -406,6 +590,7 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.Pinv = ctx->Pinv;
     A.g = ctx->g;
     A.active = ctx->cg_use_active ? ctx->active : nullptr;
+    A.mask = ctx->cg_mask;
     A.x = ctx->x;
     A.r = ctx->r;
     A.z = ctx->z;
@@ -418,6 +603,7 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.status = ctx->status;
     A.num_nodes = ctx->num_nodes;
     A.stride = ctx->node_stride;
+    A.rows_total = ctx->num_nodes / ctx->node_stride;
     A.k = 0;
     A.max_iterations = max_iterations;
     A.q_tolerance = q_tolerance;
@@ -450,8 +636,8 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
             A.k = k;
             {
                 ScopedKernelTimer timer(ctx, SMVS_K_CG_SPMV);
-                hipLaunchKernelGGL(cg_spmv_kernel, dim3(nb), dim3(CG_THREADS),
-                    0, ctx->stream, A, nb);
+                hipLaunchKernelGGL(cg_spmv_kernel, dim3(nb),
+                    dim3(CG_THREADS), 0, ctx->stream, A, nb);
             }
             if (k < max_iterations) {
                 ScopedKernelTimer timer(ctx, SMVS_K_CG_UPDATE);

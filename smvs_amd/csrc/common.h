@@ -114,6 +114,7 @@ struct smvs_ctx {
     uint8_t *patch_valid = nullptr;
     uint32_t *patch_vis = nullptr;
     uint8_t *active = nullptr, *active_next = nullptr;
+    uint16_t *cg_mask = nullptr;    // per node: stencil slots present in the CG matrix
     double *hermite_tab = nullptr;  // [ps][12] 1-D Hermite basis table
     int hermite_tab_ps = 0;
 

@@ -164,7 +164,7 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = { ctx->main_grad, ctx->main_shading, ctx->main_shading_grad,
         ctx->cams, ctx->subs_dev, ctx->nodes, ctx->node_valid, ctx->patch_valid,
-        ctx->patch_vis, ctx->active, ctx->active_next, ctx->hermite_tab,
+        ctx->patch_vis, ctx->active, ctx->active_next, ctx->cg_mask, ctx->hermite_tab,
         ctx->Hp, ctx->gp, ctx->H9, ctx->Pinv, ctx->g, ctx->lighting, ctx->x,
         ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->d2, ctx->b, ctx->partials,
         ctx->cg_state, ctx->scalars,
@@ -361,6 +361,7 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
             || (rc = device_alloc(&ctx->node_valid, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->active, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->active_next, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->cg_mask, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->H9, cap * 5 * 16)) != SMVS_OK
             || (rc = device_alloc(&ctx->Pinv, cap * 16)) != SMVS_OK
             || (rc = device_alloc(&ctx->g, cap * 4)) != SMVS_OK
