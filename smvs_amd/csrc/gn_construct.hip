@@ -24,6 +24,16 @@
 
 namespace smvs_hip {
 
+// Per-patch normal equations as stored between the two kernels: the 10 node
+// blocks (bi <= bj) of the upper block triangle, [block][4][4] doubles.
+constexpr int PATCH_H_STRIDE = 160;
+__host__ __device__ __forceinline__ constexpr int
+upper_block(int bi, int bj)
+{
+    return bi * 4 - bi * (bi - 1) / 2 + (bj - bi);
+}
+
+
 #define R_FACTOR 1e-4  // gauss_newton_step.cc:17
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -753,10 +763,15 @@ gn_patch_kernel(PatchKernelArgs A)
         gv += __shfl_xor(gv, 32);
         if (patch >= A.num_patches)
             continue;
-        double *Hout = A.Hp + (size_t)patch * 256;
+        // Packed store: only the 10 node blocks (bi <= bj) of the upper block
+        // triangle, 16 doubles each (the assembly mirrors the rest); the 16
+        // lanes of a block write one 128-byte line.
+        double *Hout = A.Hp + (size_t)patch * PATCH_H_STRIDE;
+        int const bj = col >> 2, jc = col & 3;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-            Hout[(kg + 4 * rr) * 16 + col] = acc[q][rr];
+            if (rr <= bj)
+                Hout[upper_block(rr, bj) * 16 + kg * 4 + jc] = acc[q][rr];
         if (lane < 16)
             A.gp[(size_t)patch * 16 + lane] = gv;
     }
@@ -863,7 +878,7 @@ gn_assemble_kernel(AssembleArgs A)
             int const p = pyq * A.npx + pxq;
             if (!A.patch_valid[p])
                 continue;
-            const double *Hl = A.Hp + (size_t)p * 256;
+            const double *Hl = A.Hp + (size_t)p * PATCH_H_STRIDE;
             int const n00 = pyq * A.stride + pxq;
 #pragma unroll
             for (int lm = 0; lm < 4; ++lm) {
@@ -873,11 +888,16 @@ gn_assemble_kernel(AssembleArgs A)
                 int const dx = (lm & 1) - (1 - (q & 1));
                 int const dy = (lm >> 1) - (1 - (q >> 1));
                 int const slot = (dy + 1) * 3 + (dx + 1);
-                int const i = 4 * ln + r;
+                // only the stored stencil slots (neighbour >= node, i.e.
+                // lm >= ln) are assembled; the diagonal block is mirrored
+                // from its upper triangle
+                if (lm < ln)
+                    continue;
+                const double *blk = Hl + upper_block(ln, lm) * 16;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    int const j = 4 * lm + c;
-                    double const v = i <= j ? Hl[i * 16 + j] : Hl[j * 16 + i];
+                    double const v = (lm > ln || r <= c) ? blk[r * 4 + c]
+                        : blk[c * 4 + r];
                     out[slot][c] += v;
                 }
             }
@@ -1170,12 +1190,34 @@ smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp)
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const P = (size_t)ctx->num_patches;
-    if (Hp != nullptr)
-        SMVS_HIP_CHECK(hipMemcpyAsync(Hp, ctx->Hp, P * 256 * sizeof(double),
-            hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> packed;
+    if (Hp != nullptr) {
+        packed.resize(P * PATCH_H_STRIDE);
+        SMVS_HIP_CHECK(hipMemcpyAsync(packed.data(), ctx->Hp,
+            packed.size() * sizeof(double), hipMemcpyDeviceToHost,
+            ctx->stream));
+    }
     if (gp != nullptr)
         SMVS_HIP_CHECK(hipMemcpyAsync(gp, ctx->gp, P * 16 * sizeof(double),
             hipMemcpyDeviceToHost, ctx->stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (Hp != nullptr) {
+        // unpack the upper block triangle; blocks below it are the mirror
+        for (size_t p = 0; p < P; ++p) {
+            const double *src = packed.data() + p * PATCH_H_STRIDE;
+            double *dst = Hp + p * 256;
+            for (int bi = 0; bi < 4; ++bi)
+                for (int bj = bi; bj < 4; ++bj) {
+                    const double *blk = src + upper_block(bi, bj) * 16;
+                    for (int r = 0; r < 4; ++r)
+                        for (int c = 0; c < 4; ++c) {
+                            dst[(4 * bi + r) * 16 + 4 * bj + c] = blk[r * 4 + c];
+                            if (bj > bi)
+                                dst[(4 * bj + c) * 16 + 4 * bi + r]
+                                    = blk[r * 4 + c];
+                        }
+                }
+        }
+    }
     return SMVS_OK;
 }
