@@ -97,7 +97,7 @@ div_corrected(double a, double d, double inv_d)
 // mve::Image<float>::linear_at in the reference's float operation order
 // (no FMA contraction) on the packed device planes. [MVE-unverified]
 struct Taps {
-    int o00, o10, o01, o11;
+    unsigned o00, o10, o01, o11;
     float w00, w10, w01, w11;
 };
 
@@ -116,10 +116,10 @@ make_taps(float x, float y, int w, int h)
     float const w0 = 1.0f - w1;
     float const w3 = y - (float)fy;
     float const w2 = 1.0f - w3;
-    t.o00 = fy * w + fx;
-    t.o10 = fy * w + fx1;
-    t.o01 = fy1 * w + fx;
-    t.o11 = fy1 * w + fx1;
+    t.o00 = (unsigned)(fy * w + fx);
+    t.o10 = (unsigned)(fy * w + fx1);
+    t.o01 = (unsigned)(fy1 * w + fx);
+    t.o11 = (unsigned)(fy1 * w + fx1);
     t.w00 = w0 * w2;
     t.w10 = w1 * w2;
     t.w01 = w0 * w3;
@@ -406,10 +406,18 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         }
         Taps const tp = make_taps((float)proj0, (float)proj1, sp.width,
             sp.height);
-        float2 const g00 = sp.grad[tp.o00], g10 = sp.grad[tp.o10],
-            g01 = sp.grad[tp.o01], g11 = sp.grad[tp.o11];
-        float4 const h00 = sp.hess[tp.o00], h10 = sp.hess[tp.o10],
-            h01 = sp.hess[tp.o01], h11 = sp.hess[tp.o11];
+        // (pointers read from memory are generic to the compiler; the
+        // planes live in global memory: global_load instead of flat_load)
+        typedef float fvec2 __attribute__((ext_vector_type(2)));
+        typedef float fvec4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) fvec2 *gf2_ptr;
+        typedef const __attribute__((address_space(1))) fvec4 *gf4_ptr;
+        gf2_ptr const grad = (gf2_ptr)sp.grad;
+        gf4_ptr const hess = (gf4_ptr)sp.hess;
+        fvec2 const g00 = grad[tp.o00], g10 = grad[tp.o10],
+            g01 = grad[tp.o01], g11 = grad[tp.o11];
+        fvec4 const h00 = hess[tp.o00], h10 = hess[tp.o10],
+            h01 = hess[tp.o01], h11 = hess[tp.o11];
 
         // ---- the previous neighbour's IRLS terms hide the tap latency ----
         if (have_prev)
@@ -716,6 +724,16 @@ gn_patch_kernel(PatchKernelArgs A)
             }
         }
         // ---- phase 2: H += sum_pix D6^T (M6 D6) on the matrix cores ----
+        // With PPW == 4 and 4 x 4 samples per patch, pixel slot
+        // pl = 16 qq + 4 tt + kg is sample (sx, sy) = (kg, tt) of patch qq:
+        // the x-functions of a lane are loop invariant, the y-functions
+        // depend on tt only.
+        bool const grid4 = PPW == 4 && A.spr == 4;
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        if (grid4) {
+            const double *X = tabs + kg * 12 + ex * 3;
+            x0 = X[0]; x1 = X[1]; x2 = X[2];
+        }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             int const q = PPW == 1 ? 0 : qq;
@@ -724,13 +742,19 @@ gn_patch_kernel(PatchKernelArgs A)
 #pragma unroll 1
             for (int tt = 0; tt < 4; ++tt) {
                 int const pl = 4 * (4 * qq + tt) + kg;  // pixel slot in the wave
-                int si = c * SLOTS + (pl & (SLOTS - 1));
-                si = min(si, A.P - 1);
-                int const sy = si / A.spr, sx = si - sy * A.spr;
-                const double *X = tabs + sx * 12 + ex * 3;
-                const double *Y = tabs + sy * 12 + ey * 3;
-                double const x0 = X[0], x1 = X[1], x2 = X[2];
-                double const y0 = Y[0], y1 = Y[1], y2 = Y[2];
+                double y0, y1, y2;
+                if (grid4) {
+                    const double *Y = tabs + tt * 12 + ey * 3;
+                    y0 = Y[0]; y1 = Y[1]; y2 = Y[2];
+                } else {
+                    int si = c * SLOTS + (pl & (SLOTS - 1));
+                    si = min(si, A.P - 1);
+                    int const sy = si / A.spr, sx = si - sy * A.spr;
+                    const double *X = tabs + sx * 12 + ex * 3;
+                    const double *Y = tabs + sy * 12 + ey * 3;
+                    x0 = X[0]; x1 = X[1]; x2 = X[2];
+                    y0 = Y[0]; y1 = Y[1]; y2 = Y[2];
+                }
                 double D[6];
                 D[0] = x0 * y0; D[1] = x1 * y0; D[2] = x0 * y1;
                 D[3] = x1 * y1; D[4] = x2 * y0; D[5] = x0 * y2;

@@ -76,22 +76,25 @@ reactivate_kernel(ReactivateArgs A)
         int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
         if ((A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
             | A.active[ids[3]]) != 0) {
-            double th0[16], th1[16];
+            // w1 - w0 is the patch evaluated on the node deltas (the patch
+            // is linear in its nodes)
+            double th0[16], thd[16];
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    double const v = A.nodes[4 * (size_t)ids[n] + k];
-                    th0[4 * n + k] = v;
-                    th1[4 * n + k] = v + A.x[4 * (size_t)ids[n] + k];
+                    th0[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
+                    thd[4 * n + k] = A.x[4 * (size_t)ids[n] + k];
                 }
             int const ci = pid % A.ps, cj = pid / A.ps;
-            double w0, w1, dum0, dum1;
+            double w0, dw, dum0, dum1;
             eval_patch(A.hermite_tab, ci, cj, th0, &w0, &dum0, &dum1);
-            eval_patch(A.hermite_tab, ci, cj, th1, &w1, &dum0, &dum1);
+            eval_patch(A.hermite_tab, ci, cj, thd, &dw, &dum0, &dum1);
+            double const w1 = w0 + dw;
             double const u = (double)(A.start_x + ix * A.ps + ci);
             double const v = (double)(A.start_y + iy * A.ps + cj);
             uint32_t const vis = A.patch_vis[patch];
+            double const th2 = A.threshold * A.threshold;
             bool moved = false;
             for (int j = 0; j < A.n_subs; ++j) {
                 if (!((vis >> j) & 1u))
@@ -101,14 +104,23 @@ reactivate_kernel(ReactivateArgs A)
                 double const p = M[0] * u + M[1] * v + M[2];
                 double const q = M[3] * u + M[4] * v + M[5];
                 double const r = M[6] * u + M[7] * v + M[8];
-                double const d0 = w0 * r + t[2], d1 = w1 * r + t[2];
-                double const i0 = 1.0 / d0, i1 = 1.0 / d1;
-                double const ex = (w0 * p + t[0]) * i0 - (w1 * p + t[0]) * i1;
-                double const ey = (w0 * q + t[1]) * i0 - (w1 * q + t[1]) * i1;
-                double const diff = sqrt(ex * ex + ey * ey);
-                sum += diff;
+                // (w0 p + t0)/(w0 r + t2) - (w1 p + t0)/(w1 r + t2)
+                //   = (w0 - w1)(p t2 - r t0) / ((w0 r + t2)(w1 r + t2)):
+                // no cancellation, one reciprocal (v_rcp_f64 + two Newton
+                // steps); the result only feeds the 0.15 px test and the
+                // mean shift (depth_optimizer.cc:669-672, 277-303)
+                double const den = (w0 * r + t[2]) * (w1 * r + t[2]);
+                double inv = __builtin_amdgcn_rcp(den);
+                inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+                inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+                double const scale = -dw * inv;
+                double const ex = scale * (p * t[2] - r * t[0]);
+                double const ey = scale * (q * t[2] - r * t[1]);
+                double const d2 = ex * ex + ey * ey;
+                if (A.full_optimization)
+                    sum += sqrt(d2);
                 cnt += 1.0;
-                moved |= diff > A.threshold;
+                moved |= d2 > th2;
             }
             if (moved && !A.full_optimization) {
                 A.active_next[ids[0]] = 1;
