@@ -18,6 +18,7 @@
 // blocks read bank (k-1)&1.  The host only polls a "done" word per chunk.
 #include "common.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -62,12 +63,34 @@ struct CgArgs {
     double *partials;      // [4][CG_MAX_BLOCKS]
     CgState *state;        // [2]
     int *status;
+    int *progress;         // pinned host memory, see cg_solve_launch
+    int solve_tag;         // solve id << 16
     int num_nodes, stride, rows_total;
     int k;                 // iteration index of this launch
     int max_iterations;
     double q_tolerance;
     double fixed_tolerance;  // < 0: 0.01 * ||g||
 };
+
+// Progress words in pinned host memory (the host paces its launches on them
+// instead of synchronising): [0] = tag | k once A_k has settled the solver
+// state, [1] = tag | 1 once the solve is finished, [2] = info, [3] = the
+// iteration count.  The tag (solve id << 16) keeps late writes of an earlier
+// solve's trailing no-op launches from being mistaken for this solve's.
+__device__ __forceinline__ void
+publish_progress(CgArgs const &A, int done, int info, int iter)
+{
+    if (done) {
+        __hip_atomic_store(A.progress + 2, info, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.progress + 3, iter, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.progress + 1, A.solve_tag | 1, __ATOMIC_RELEASE,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(A.progress + 0, A.solve_tag | A.k, __ATOMIC_RELEASE,
+        __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Sum NV arrays of `nb` (<= CG_THREADS) per-block partials in a fixed order;
 // every thread of every block gets the same values.  The loads are split
@@ -203,31 +226,9 @@ cg_init_kernel(CgArgs A)
             A.mask[n] = (uint16_t)mask;
         }
     }
-    store_partials<2>(v, A.partials);
-}
-
-__global__ void __launch_bounds__(CG_THREADS)
-cg_init_finalize_kernel(CgArgs A, int nb)
-{
-    double v[2];
-    reduce_partials<2>(A.partials, nb, v);
-    if (threadIdx.x != 0)
-        return;
-    CgState s;
-    s.rr = v[0];
-    s.q0 = -0.0;  // -1.0 * x.(b + r) with x = 0
-    s.gnorm = sqrt(v[1]);
-    s.tol = A.fixed_tolerance < 0.0 ? s.gnorm * 0.01 : A.fixed_tolerance;
-    s.iter = 1;
-    // loop condition `num_iterations < max_iterations` fails at once
-    s.done = A.max_iterations <= 1 ? 1 : 0;
-    s.info = SMVS_CG_MAX_ITERATIONS;
-    s.pad = 0;
-    A.state[1] = s;
-    A.state[0] = s;
-    A.status[I_DONE] = s.done;
-    A.status[I_INFO] = s.info;
-    A.status[I_ITER] = 1;
+    // rows 4, 5 of the partial buffer: A_1 reduces them while its fast
+    // blocks already write row 0
+    store_partials<2>(v, A.partials + 4 * CG_MAX_BLOCKS);
 }
 
 // A_k: finish iteration k-1, form d_k, Ad_k = A d_k, partial d.Ad.
@@ -319,13 +320,15 @@ cg_spmv_kernel(CgArgs A, int nb)
     int n_cur = tile_node(tile, grid_cur);
     int n_next = tile_node(tile + per_xcd_blocks, grid_next);
     unsigned const raw_cur = A.mask[n_cur], raw_next = A.mask[n_next];
-    double mine[3];   // (unused garbage in the first iteration)
-    load_partials<3>(A.partials + CG_MAX_BLOCKS, nb, mine);
+    // (A_1 reduces the two sums of the init kernel: z.r and g.g)
+    double mine[3];
+    load_partials<3>(A.partials + (first ? 4 : 1) * CG_MAX_BLOCKS, nb, mine);
     // A launch after convergence is a no-op.  It takes no early exit here (a
     // branch would serialise the state load ahead of everything else): its
     // operand requests are all redirected to one cached line instead.
-    CgState const prev = A.state[(A.k - 1) & 1];
-    bool const idle = prev.done != 0;
+    // (A_1 has no predecessor state: it builds the initial one below.)
+    CgState prev = A.state[(A.k - 1) & 1];
+    bool const idle = !first && prev.done != 0;
     // stencil mask: 0 outside the grid, 0x8000 in the grid but inactive
     unsigned mask_cur = grid_cur && !idle ? (0x8000u | raw_cur) : 0u;
     unsigned mask_next = grid_next && !idle ? (0x8000u | raw_next) : 0u;
@@ -384,8 +387,10 @@ cg_spmv_kernel(CgArgs A, int nb)
     load_operands(tile, n_cur, mask_cur, op);
 
     if (idle) {
-        if (blockIdx.x == 0 && tid == 0)
+        if (blockIdx.x == 0 && tid == 0) {
             A.state[A.k & 1] = prev;
+            publish_progress(A, 0, 0, 0);
+        }
         return;
     }
     double beta = 0.0;
@@ -421,11 +426,36 @@ cg_spmv_kernel(CgArgs A, int nb)
                 A.status[I_INFO] = info;
                 A.status[I_ITER] = iter_out;
             }
+            publish_progress(A, done, info, iter_out);
         }
         if (done)
             return;
-    } else if (blockIdx.x == 0 && tid == 0) {
-        A.state[A.k & 1] = prev;
+    } else {
+        // initial state: x = 0, r = b = -g, z = P r, d = z
+        // (conjugate_gradient.h:86-118)
+        double v[2];
+        double init[2] = { mine[0], mine[1] };
+        reduce_loaded<2>(init, nb, v);
+        prev.rr = v[0];
+        prev.q0 = -0.0;  // -1.0 * x.(b + r) with x = 0
+        prev.gnorm = sqrt(v[1]);
+        prev.tol = A.fixed_tolerance < 0.0 ? prev.gnorm * 0.01
+            : A.fixed_tolerance;
+        prev.iter = 1;
+        // loop condition `num_iterations < max_iterations` fails at once
+        prev.done = A.max_iterations <= 1 ? 1 : 0;
+        prev.info = SMVS_CG_MAX_ITERATIONS;
+        prev.pad = 0;
+        if (blockIdx.x == 0 && tid == 0) {
+            A.state[1] = prev;
+            A.state[0] = prev;
+            A.status[I_DONE] = prev.done;
+            A.status[I_INFO] = prev.info;
+            A.status[I_ITER] = 1;
+            publish_progress(A, prev.done, prev.info, 1);
+        }
+        if (prev.done)
+            return;
     }
 
     double v[1] = { 0.0 };
@@ -601,6 +631,11 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.partials = ctx->partials;
     A.state = reinterpret_cast<CgState *>(ctx->cg_state);
     A.status = ctx->status;
+    A.progress = ctx->cg_progress;
+    ctx->cg_solve_id = (ctx->cg_solve_id + 1) & 0x7FFF;
+    if (ctx->cg_solve_id == 0)
+        ctx->cg_solve_id = 1;
+    A.solve_tag = ctx->cg_solve_id << 16;
     A.num_nodes = ctx->num_nodes;
     A.stride = ctx->node_stride;
     A.rows_total = ctx->num_nodes / ctx->node_stride;
@@ -617,22 +652,28 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         ScopedKernelTimer timer(ctx, SMVS_K_CG_INIT);
         hipLaunchKernelGGL(cg_init_kernel, dim3(nb), dim3(CG_THREADS), 0,
             ctx->stream, A);
-        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(CG_THREADS),
-            0, ctx->stream, A, nb);
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
     // A_k for k = 1 .. max_iterations (A_max only finishes iteration max-1),
     // B_k for k = 1 .. max_iterations - 1.
-    // The host only learns the iteration count after the fact; kernels that
-    // run after convergence are no-ops.  The first chunk is sized by the
-    // previous solve of this context (iteration counts change slowly from one
-    // Newton step to the next), later chunks are short.
-    int chunk = ctx->last_cg_iterations > 0 ? ctx->last_cg_iterations + 1 : 8;
+    // The host does not synchronise: the kernels publish their progress in
+    // pinned host memory and the host stays AHEAD launches in front of the
+    // last iteration it has seen settle.  Launches that run after convergence
+    // are no-ops, at most AHEAD of them per solve.
+    constexpr int AHEAD = 3;
+    volatile int *progress = ctx->cg_progress;
     int k = 1;
-    bool done = false;
-    while (!done) {
-        for (int c = 0; c < chunk && k <= max_iterations; ++c, ++k) {
+    auto const t_start = std::chrono::steady_clock::now();
+    long spins = 0;
+    for (;;) {
+        int const done_word = __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE);
+        if (done_word == (A.solve_tag | 1))
+            break;
+        int const seen_word = __atomic_load_n(&progress[0], __ATOMIC_ACQUIRE);
+        int const seen = (seen_word & ~0xFFFF) == A.solve_tag
+            ? (seen_word & 0xFFFF) : 0;
+        if (k <= max_iterations && k <= seen + AHEAD) {
             A.k = k;
             {
                 ScopedKernelTimer timer(ctx, SMVS_K_CG_SPMV);
@@ -644,23 +685,43 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                 hipLaunchKernelGGL(cg_update_kernel, dim3(nb),
                     dim3(CG_THREADS), 0, ctx->stream, A, nb);
             }
+            ++k;
+            continue;
         }
-        SMVS_HIP_CHECK(hipGetLastError());
-        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
-            sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
-        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        done = ctx->status_host[I_DONE] != 0 || k > max_iterations;
-        chunk = 4;
+        if (k > max_iterations && seen >= max_iterations) {
+            // A_max settles the state as done (the done word is published
+            // before the progress word); reaching this means it did not
+            if (__atomic_load_n(&progress[1], __ATOMIC_ACQUIRE)
+                == (A.solve_tag | 1))
+                break;
+            set_error("cg_solve_launch: solver did not report completion");
+            return SMVS_ERR_STATE;
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            SMVS_HIP_CHECK(hipGetLastError());
+            if (hipStreamQuery(ctx->stream) == hipSuccess
+                && __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE)
+                    != (A.solve_tag | 1)
+                && k > max_iterations) {
+                set_error("cg_solve_launch: solver did not report completion");
+                return SMVS_ERR_STATE;
+            }
+            auto const dt = std::chrono::steady_clock::now() - t_start;
+            if (dt > std::chrono::seconds(60)) {
+                set_error("cg_solve_launch: timed out waiting for the device");
+                return SMVS_ERR_STATE;
+            }
+        }
     }
-    if (ctx->status_host[I_DONE] == 0) {
-        set_error("cg_solve_launch: solver did not report completion");
-        return SMVS_ERR_STATE;
-    }
-    ctx->last_cg_iterations = ctx->status_host[I_ITER];
+    SMVS_HIP_CHECK(hipGetLastError());
+    int const iters = progress[3];
+    int const solve_info = progress[2];
+    ctx->last_cg_iterations = iters;
     if (num_iterations != nullptr)
-        *num_iterations = ctx->status_host[I_ITER];
+        *num_iterations = iters;
     if (info != nullptr)
-        *info = ctx->status_host[I_INFO];
+        *info = solve_info;
     return SMVS_OK;
 }
 
@@ -677,6 +738,8 @@ smvs_cg_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         set_error("smvs_cg_solve: no system constructed");
         return SMVS_ERR_STATE;
     }
+    SMVS_REQUIRE(max_iterations >= 0 && max_iterations <= 0xFFFF,
+        "max_iterations out of range");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     return cg_solve_launch(ctx, max_iterations, error_tolerance, q_tolerance,
         num_iterations, info);

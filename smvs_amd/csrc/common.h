@@ -137,6 +137,8 @@ struct smvs_ctx {
     double *scalars = nullptr;      // [S_NUM]
     int *status = nullptr;          // [I_NUM]
     int *status_host = nullptr;     // pinned
+    int *cg_progress = nullptr;     // pinned, written by the CG kernels (cg.hip)
+    int cg_solve_id = 0;
     double *scalars_host = nullptr; // pinned
     double *lightAb = nullptr;      // [272] lighting normal equations
     float *stage = nullptr;         // upload staging (3-channel planes)

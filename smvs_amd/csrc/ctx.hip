@@ -142,7 +142,8 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         smvs_ctx_destroy(ctx);
         return rc;
     }
-    if (hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM) != hipSuccess
+    if (hipHostMalloc((void **)&ctx->cg_progress, sizeof(int) * 8) != hipSuccess
+        || hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM) != hipSuccess
         || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM) != hipSuccess) {
         set_error("hipHostMalloc failed");
         smvs_ctx_destroy(ctx);
@@ -150,6 +151,8 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     }
     (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
     (void)hipMemsetAsync(ctx->status, 0, sizeof(int) * I_NUM, ctx->stream);
+    for (int i = 0; i < 8; ++i)
+        ctx->cg_progress[i] = 0;
     *out = ctx;
     return SMVS_OK;
 }
@@ -187,6 +190,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
     }
     if (ctx->status_host)
         (void)hipHostFree(ctx->status_host);
+    if (ctx->cg_progress)
+        (void)hipHostFree(ctx->cg_progress);
     if (ctx->scalars_host)
         (void)hipHostFree(ctx->scalars_host);
     for (auto &p : ctx->prof.pending) {

@@ -62,6 +62,7 @@ struct PatchKernelArgs {
     double inv_f, f2inv;         // 1 / flen, 1 / flen^2 (double)
     double reg, light_reg;
     int use_lighting;
+    int *status;
 };
 
 // 1 / x to ~1 ulp: hardware estimate (2^-26 or better) + two Newton steps.
@@ -673,6 +674,9 @@ gn_patch_kernel(PatchKernelArgs A)
             poy = A.start_y + iy * A.ps;
         }
     }
+    // the assembly kernel, which runs next, counts the live patches
+    if (blockIdx.x == 0 && lane == 0)
+        A.status[I_ACTIVE_PATCHES] = 0;
     // wave-uniform early exit: nothing to do for any of the PPW patches
     if (__ballot(live) == 0ull)
         return;
@@ -817,6 +821,7 @@ struct AssembleArgs {
     double *Pinv;   // [N][16]
     double *g;      // [N][4]
     int npx, npy, stride, num_nodes;
+    int *status;
 };
 
 // lib/ldl_decomposition.h:43-92 for a 4x4 block, same operation order.
@@ -929,6 +934,22 @@ gn_assemble_kernel(AssembleArgs A)
         }
     }
 
+    // number of patches the construction touched (a patch with at least one
+    // active node, gauss_newton_step.cc:146-149): counted at the patch's
+    // top-left node
+    {
+        bool live = false;
+        if (in_range && r == 0 && ix < A.npx && iy < A.npy) {
+            int const p = iy * A.npx + ix;
+            live = A.patch_valid[p]
+                && (A.active[n] | A.active[n + 1] | A.active[n + A.stride]
+                    | A.active[n + A.stride + 1]) != 0;
+        }
+        int const cnt = __syncthreads_count(live);
+        if (threadIdx.x == 0 && cnt != 0)
+            atomicAdd(&A.status[I_ACTIVE_PATCHES], cnt);
+    }
+
     if (in_range) {
         size_t const N = (size_t)A.num_nodes;
         // H is symmetric (block (n, m) is the transpose of block (m, n), bit
@@ -968,23 +989,6 @@ gn_assemble_kernel(AssembleArgs A)
         for (int i = 0; i < 16; ++i)
             dst[i] = nancheck ? blk[i] : inv[i];
     }
-}
-
-__global__ void
-count_active_patches_kernel(const uint8_t *__restrict__ patch_valid,
-    const uint8_t *__restrict__ active, int npx, int stride, int num_patches,
-    int *__restrict__ status)
-{
-    int const p = blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = false;
-    if (p < num_patches && patch_valid[p]) {
-        int const n00 = (p / npx) * stride + (p % npx);
-        live = (active[n00] | active[n00 + 1] | active[n00 + stride]
-            | active[n00 + stride + 1]) != 0;
-    }
-    int const cnt = __syncthreads_count(live);
-    if (threadIdx.x == 0 && cnt != 0)
-        atomicAdd(&status[I_ACTIVE_PATCHES], cnt);
 }
 
 static int
@@ -1039,17 +1043,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     A.reg = reg;
     A.light_reg = light_reg;
     A.use_lighting = use_lighting ? 1 : 0;
-
-    SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_ACTIVE_PATCHES, 0,
-        sizeof(int), ctx->stream));
-    {
-        ScopedKernelTimer timer(ctx, SMVS_K_MISC);
-        hipLaunchKernelGGL(count_active_patches_kernel,
-            dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0,
-            ctx->stream, ctx->patch_valid, ctx->active, ctx->npx,
-            ctx->node_stride, ctx->num_patches, ctx->status);
-    }
-    SMVS_HIP_CHECK(hipGetLastError());
+    A.status = ctx->status;
 
     int const scratch_rows = 5 * (ctx->n_subs - 1) > 27 ? 5 * (ctx->n_subs - 1) : 27;
     size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12) * sizeof(double);
@@ -1072,6 +1066,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     B.gp = ctx->gp;
     B.patch_valid = ctx->patch_valid;
     B.active = ctx->active;
+    B.status = ctx->status;
     B.H9 = ctx->H9;
     B.Pinv = ctx->Pinv;
     B.g = ctx->g;

@@ -499,7 +499,6 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
                 prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
             return rc;
         stats->linear_iterations += iters;
-        stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
         if ((rc = reactivate_launch(ctx, prm->active_threshold,
                 prm->full_optimization)) != SMVS_OK)
             return rc;
@@ -508,6 +507,7 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->scalars_host, ctx->scalars,
             sizeof(double) * S_NUM, hipMemcpyDeviceToHost, ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
         if (ctx->status_host[I_NAN]) {
             stats->nan_break = 1;
             break;
