@@ -661,7 +661,7 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     // pinned host memory and the host stays AHEAD launches in front of the
     // last iteration it has seen settle.  Launches that run after convergence
     // are no-ops, at most AHEAD of them per solve.
-    constexpr int AHEAD = 3;
+    constexpr int AHEAD = 2;
     volatile int *progress = ctx->cg_progress;
     int k = 1;
     auto const t_start = std::chrono::steady_clock::now();
