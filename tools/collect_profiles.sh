@@ -12,3 +12,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- $CMD > "$OUT/write.log" 2>&1
 ls -R "$OUT" | head -30
+python $ROOT/tools/summarise_profiles.py "$OUT" "$OUT/summary" "${1:-r1}"
