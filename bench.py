@@ -173,10 +173,13 @@ def main():
                         avg_us=round(avg_s * 1e6, 2), launches_with_work=work_launches,
                         kernels=kernels)
         else:
-            # gn_patch_kernel: FP64.  0.17 MFLOP per active patch is what the
-            # factored formulation executes at S = 8, P = 16;
+            # gn_patch_kernel: FP64 arithmetic (VALU + v_mfma_f64).  0.132 MFLOP
+            # per active patch is what the factored formulation executes at
+            # S = 8 neighbours, P = 16 samples, counted from the SQ instruction
+            # counters (profiles/r1_patch_kernel_counters.txt);
             # SURVEY 8(d)'s 0.50 MFLOP prices the reference's unfactored rows.
-            flops = 0.17e6 * prof_patch_steps / max(cnt, 1)
+            # Peak: 78.6 TFLOP/s, MI355X's FP64 rate (vector and matrix alike).
+            flops = 0.132e6 * prof_patch_steps / max(cnt, 1)
             avg_s = ms * 1e-3 / cnt
             achieved = flops / avg_s / 1e12
             roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 3),
