@@ -155,8 +155,8 @@ def main():
         # learns the iteration count late): their average duration is taken
         # over the launches that did work (= CG iterations of the profiled
         # steps), with the no-op time left in the numerator.
-        per_node = {"cg_spmv": 5 * 128 + 32 + 32,          # H upper half, d, Ad
-                    "cg_update": 5 * 32 + 128 + 3 * 32}    # x d r Ad b, P, x r z
+        per_node = {"cg_spmv": 5 * 128 + 2 * 32 + 2 * 32,      # H upper half; z, d_old; Ad, d_new
+                    "cg_update": 5 * 32 + 128 + 3 * 32 + 2}    # x d r Ad b; P; x r z; mask
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_r1.json")
         if os.path.exists(tfile):
