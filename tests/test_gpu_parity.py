@@ -377,3 +377,110 @@ def test_device_scale_space_is_bit_exact(hip, oracle, scale):
         if view >= 0:
             assert np.array_equal(h, h_ref), (view, np.abs(h - h_ref).max())
     ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json's full sizes (configs[1] / configs[2])
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_size_problem(hip, oracle):
+    """The bench workload: 1920x1080, 8 neighbours, scale 2."""
+    import bench
+    prob = bench.make_problem(0, False)
+    surf = prob["surf"]
+    ctx = hip.ViewContext(surf["width"], surf["height"], bench.NSUBS)
+    ctx.set_views(prob["views"])
+    ctx.set_surface(surf)
+    orc = oracle.OracleProblem(surf, prob["views"])
+    yield prob, ctx, orc, bench.REG
+    ctx.close()
+
+
+def test_full_size_newton_step_matches_oracle(hip, oracle, full_size_problem):
+    """One Newton step of the bench workload (1920x1080, 8 neighbours,
+    130k nodes): sampled per-patch systems against the oracle's patch
+    routine, then the oracle's PCG and active-set update on the GPU-built
+    system against the GPU's."""
+    prob, ctx, orc, reg = full_size_problem
+    surf = prob["surf"]
+    ctx.set_nodes(surf["nodes"]); ctx.set_active(None)
+    n_active_patches = ctx.gn_construct(reg)
+    assert n_active_patches == int(surf["patch_valid"].sum())
+    Hp, gp = ctx.gn_patch_systems()
+    valid = np.flatnonzero(surf["patch_valid"])
+    pick = np.random.default_rng(5).choice(valid, size=64, replace=False)
+    for p in pick:
+        g_ref, H_ref = orc.gn_patch(int(p), reg)
+        # FP64, factored summation order over 72 residual rows: 1e-9 relative
+        assert _rel(np.triu(Hp[p]), np.triu(H_ref)) < 1e-9
+        assert _rel(gp[p], g_ref) < 1e-9
+    del Hp, gp
+    H9, g, P = ctx.gn_download()
+    # size-independent structure: H is symmetric block for block
+    N = H9.shape[0]; stride = surf["npx"] + 1
+    n = np.arange(N - stride - 1)
+    for s, off in [(5, 1), (7, stride), (8, stride + 1)]:
+        a = H9[n, s].reshape(-1, 4, 4)
+        b = H9[n + off, 8 - s].reshape(-1, 4, 4).transpose(0, 2, 1)
+        assert np.array_equal(a, b)
+    # the solve, on the same (GPU-built) system
+    it, info = ctx.cg_solve(200, -1.0, 1e-3)
+    x = ctx.cg_x()
+    present = (np.abs(H9).sum(axis=2) > 0).astype(np.uint8)
+    xr, itr, infor = orc.cg_solve(H9, present, P, -g, 200, 0.01 * np.linalg.norm(g), 1e-3)
+    assert (it, info) == (itr, infor)
+    assert _rel(x, xr) < 1e-9
+    # residual actually went down: |Hx + g| < |g| (energy property of PCG)
+    r = orc.spmv(H9, present, x) + g
+    assert np.linalg.norm(r) < 0.5 * np.linalg.norm(g)
+    # node update + re-activation
+    active = surf["node_valid"].copy()
+    n_gpu, _, nan = ctx.update_and_reactivate(0.15, False)
+    new_active, n_ref, _ = orc.update_and_reactivate(xr, active)
+    a_gpu, cnt = ctx.get_active()
+    assert nan == 0 and n_gpu == n_ref == cnt
+    assert np.array_equal(a_gpu, new_active)
+    assert np.max(np.abs(ctx.get_nodes() - orc.nodes)) < 1e-12
+
+
+def test_full_size_loop_converges_to_the_scene(hip, full_size_problem):
+    """Whole Newton batch at full size: the depth error against the
+    analytic sphere shrinks (the initial nodes carry seeded noise) and the
+    run is deterministic."""
+    from smvs_amd import synth
+    prob, ctx, orc, reg = full_size_problem
+    surf = prob["surf"]
+    xs, ys = np.meshgrid(np.arange(surf["width"], dtype=float),
+                         np.arange(surf["height"], dtype=float))
+    gt = synth.depth_at(prob["scene"], prob["main"], xs, ys)
+
+    def run():
+        ctx.set_nodes(surf["nodes"])
+        stats = ctx.run_loop(reg)
+        return stats, ctx.depth_map()
+
+    ctx.set_nodes(surf["nodes"]); ctx.set_active(None)
+    d0 = ctx.depth_map()
+    mask = d0 > 0
+    assert mask.sum() > 0.2 * mask.size
+    s1, d1 = run()
+    s2, d2 = run()
+    assert s1 == s2 and np.array_equal(d1, d2)
+    e0 = np.sqrt(np.mean((d0[mask] - gt[mask]) ** 2))
+    e1 = np.sqrt(np.mean((d1[mask] - gt[mask]) ** 2))
+    assert s1["newton_steps"] >= 2 and s1["nan_break"] == 0
+    assert e1 < 0.7 * e0, (e0, e1)
+
+
+def test_full_size_sgm_bit_exact(hip, oracle):
+    """configs[2]: 960x540 (sgm_scale 1 of 1920x1080), 128 planes, 8 paths."""
+    main, nbr, M, t = _sgm_pair(960, 540, seed=11)
+    out = hip.sgm_run(main, nbr, M, t, 1.0, 12.0, 128, 6, 96, want_volumes=True)
+    depths = oracle.sgm_depths(1.0, 12.0, 128)
+    cost = oracle.sgm_cost_volume(main, nbr, M, t, depths)
+    assert np.array_equal(out["cost"], cost)
+    sgm = oracle.sgm_aggregate(cost, 6, 96)
+    assert np.array_equal(out["sgm"], sgm)
+    depth, argmin = oracle.sgm_depth_from_volume(sgm, main, depths)
+    assert np.array_equal(out["argmin"], argmin)
+    assert np.array_equal(out["depth"], depth)
