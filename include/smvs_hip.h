@@ -229,6 +229,30 @@ int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     int kernel_size, float *out);
 
 /* ------------------------------------------------------------------ */
+/* topology tests between Newton batches              */
+/* ------------------------------------------------------------------ */
+
+/* The per-(patch, neighbour) part of DepthOptimizer::create_subview_surfaces,
+ * depth_optimizer.cc:433-590, for the surface of smvs_ctx_set_surface and the
+ * images of smvs_ctx_upload_image: z-buffer of the surface depth map (and of
+ * sgm_depth[W*H], may be NULL; the reference splats it when use_sgm is set,
+ * :463-466) in every neighbour, then border / occlusion test (:505-530),
+ * warp anisotropy <= 8 (:532-575) and, if use_ncc (the reference's !use_sgm,
+ * :577-580), ncc_for_patch >= 0 (:792-912).
+ * patch_vis_out[num_patches]: bit j = patch visible in neighbour j; 0 for
+ * invalid patches.  The mask also becomes the context's patch visibility.
+ * Deleting the patches without any neighbour (:592-603) stays with the
+ * caller, which owns the topology. */
+int smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
+    uint32_t *patch_vis_out);
+
+/* DepthOptimizer::mse_for_patch, depth_optimizer.cc:747-790, for every valid
+ * patch with the visibility set by smvs_ctx_set_surface: mean gradient
+ * mismatch against the visible neighbours (1.0 without any); -1 for invalid
+ * patches.  cut_boundaries (:360-431) thresholds it at 0.05. */
+int smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out);
+
+/* ------------------------------------------------------------------ */
 /* measurement                                                        */
 /* ------------------------------------------------------------------ */
 

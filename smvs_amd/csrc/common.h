@@ -2,6 +2,7 @@
 // gfx950 only: no portability shims.
 #pragma once
 
+#include "host/topo_math.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -150,6 +151,17 @@ struct smvs_ctx {
     float *blur_tmp[2] = { nullptr, nullptr };
     size_t blur_cap = 0;
     float *main_hess_scratch = nullptr;    // set_scale writes no main Hessian
+
+    // topology tests between Newton batches (topology.hip)
+    float *topo_zbuf[SMVS_MAX_SUBS] = { nullptr };
+    size_t topo_zbuf_cap[SMVS_MAX_SUBS] = { 0 };
+    float *topo_sgm = nullptr;
+    size_t topo_sgm_cap = 0;
+    smvs_topo::NccSample *topo_ncc = nullptr;
+    int topo_ncc_off[33] = { 0 };
+    int topo_ncc_ps = 0;
+    double *topo_mse = nullptr;
+    size_t topo_mse_cap = 0;
 
     smvs_hip::Profile prof;
 };

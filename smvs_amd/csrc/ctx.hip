@@ -178,6 +178,15 @@ smvs_ctx_destroy(smvs_ctx *ctx)
     for (int i = 0; i <= SMVS_MAX_SUBS; ++i)
         if (ctx->images[i].data)
             (void)hipFree(ctx->images[i].data);
+    for (int i = 0; i < SMVS_MAX_SUBS; ++i)
+        if (ctx->topo_zbuf[i])
+            (void)hipFree(ctx->topo_zbuf[i]);
+    if (ctx->topo_sgm)
+        (void)hipFree(ctx->topo_sgm);
+    if (ctx->topo_ncc)
+        (void)hipFree(ctx->topo_ncc);
+    if (ctx->topo_mse)
+        (void)hipFree(ctx->topo_mse);
     if (ctx->blur_tmp[0])
         (void)hipFree(ctx->blur_tmp[0]);
     if (ctx->blur_tmp[1])

@@ -1,5 +1,11 @@
 // Host mirror of lib/depth_optimizer.cc driving the HIP hot path.
 #include "depth_optimizer.h"
+#include "topo_math.h"
+#include <string>
+#include <map>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -8,36 +14,48 @@
 
 #include "../../../include/smvs_hip.h"
 
+// Wall-clock breakdown of optimize() on stderr when SMVS_HOST_TIMING is set
+// (where the time between Newton batches goes: SURVEY 8(f)-2).
+namespace {
+struct HostTimers {
+    bool on = std::getenv("SMVS_HOST_TIMING") != nullptr;
+    std::map<std::string, double> acc;
+    ~HostTimers() { report(); }
+    void report()
+    {
+        if (!on || acc.empty())
+            return;
+        double total = 0.0;
+        for (auto const& kv : acc)
+            total += kv.second;
+        for (auto const& kv : acc)
+            std::fprintf(stderr, "[smvs host] %-28s %9.2f ms (%4.1f%%)\n",
+                kv.first.c_str(), 1e3 * kv.second, 100.0 * kv.second / total);
+        acc.clear();
+    }
+};
+HostTimers g_timers;
+struct ScopedHostTimer {
+    char const* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit ScopedHostTimer(char const* n) : name(n),
+        t0(std::chrono::steady_clock::now()) {}
+    ~ScopedHostTimer()
+    {
+        if (g_timers.on)
+            g_timers.acc[name] += std::chrono::duration<double>(
+                std::chrono::steady_clock::now() - t0).count();
+    }
+};
+}
+
 namespace smvs_amd {
 
 namespace {
 
 // Projection of a main-view pixel with depth w into a neighbour
 // (lib/correspondence.cc:20-51, 88-100).
-struct Warp
-{
-    double p, q, r, a, b, d;
-    Warp(double const* M, double const* t, double u, double v, double w)
-    {
-        p = M[0] * u + M[1] * v + M[2];
-        q = M[3] * u + M[4] * v + M[5];
-        r = M[6] * u + M[7] * v + M[8];
-        a = w * p + t[0];
-        b = w * q + t[1];
-        d = w * r + t[2];
-    }
-    double x(void) const { return a / d; }
-    double y(void) const { return b / d; }
-    void jacobian(double const* M, double w, double wx, double wy,
-        double* jac) const
-    {
-        double const d2 = d * d;
-        jac[0] = (wx * p + w * M[0]) / d - a * (wx * r + w * M[6]) / d2;
-        jac[2] = (wy * p + w * M[1]) / d - a * (wy * r + w * M[7]) / d2;
-        jac[1] = (wx * q + w * M[3]) / d - b * (wx * r + w * M[6]) / d2;
-        jac[3] = (wy * q + w * M[4]) / d - b * (wy * r + w * M[7]) / d2;
-    }
-};
+typedef smvs_topo::Warp Warp;
 
 // Moore-Penrose solve of the symmetric PSD 16x16 lighting system through a
 // cyclic Jacobi eigen decomposition (math::matrix_pseudo_inverse in the
@@ -185,6 +203,7 @@ DepthOptimizer::set_scale_everywhere(int scale)
     // StereoView::set_scale for the main view and every neighbour
     // (lib/depth_optimizer.cc:63-66, 99-103) on the device; the planes come
     // back once per scale for the host-side topology code.
+    ScopedHostTimer timer("set_scale (device + download)");
     if (!images_uploaded) {
         ByteImage::ConstPtr mb = main_view->get_raw_bytes();
         check(smvs_ctx_upload_image(ctx, -1, mb->width(), mb->height(),
@@ -247,20 +266,37 @@ void
 DepthOptimizer::optimize(void)
 {
     // lib/depth_optimizer.cc:53-162
-    this->create_initial_surface();
+    {
+        ScopedHostTimer timer("create_initial_surface");
+        this->create_initial_surface();
+    }
     this->set_scale_everywhere(surface->get_scale());
     this->run_newton_iterations(opts.num_iterations);
 
     while (surface->get_scale() > opts.min_scale && surface->get_scale() > 0) {
-        surface->subdivide_patches();
+        {
+            ScopedHostTimer timer("subdivide_patches");
+            surface->subdivide_patches();
+        }
         this->set_scale_everywhere(surface->get_scale());
-        surface->fill_patches_from_depth();
-        if (opts.use_shading && surface->get_scale() < 4)
+        {
+            ScopedHostTimer timer("fill_patches_from_depth");
+            surface->fill_patches_from_depth();
+        }
+        if (opts.use_shading && surface->get_scale() < 4) {
+            ScopedHostTimer timer("fit_lighting");
             this->fit_lighting();
+        }
         this->run_newton_iterations(opts.num_iterations);
     }
-    main_view->write_depth_to_view(surface->get_depth_map(), opts.output_name);
-    main_view->write_image_to_view(this->get_normals(), opts.output_name + "N");
+    {
+        ScopedHostTimer timer("depth + normal maps");
+        main_view->write_depth_to_view(surface->get_depth_map(),
+            opts.output_name);
+        main_view->write_image_to_view(this->get_normals(),
+            opts.output_name + "N");
+    }
+    g_timers.report();
 }
 
 FloatImage::Ptr
@@ -283,14 +319,19 @@ DepthOptimizer::run_newton_iterations(int num_iters)
     for (int iter = 0; iter < num_iters; ++iter) {
         int const num_valid_patches = surface->count_valid_patches();
         if (iter == 0) {
-            this->create_subview_surfaces();
-            int deleted = std::numeric_limits<int>::max();
-            while (deleted > 10)
-                deleted = this->cut_boundaries();
+            {
+                ScopedHostTimer timer("create_subview_surfaces");
+                this->create_subview_surfaces();
+            }
+            ScopedHostTimer timer("cut_boundaries");
+            this->cut_boundaries_until_stable();
         }
 
         // the whole Newton loop (:204-304) on the device
-        upload_surface();
+        {
+            ScopedHostTimer timer("upload_surface");
+            upload_surface();
+        }
         smvs_gn_loop_params prm;
         prm.regularization = opts.regularization;
         prm.light_surf_regularization = opts.light_surf_regularization;
@@ -304,25 +345,37 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         std::copy(lighting, lighting + 16, prm.lighting);
         prm.reset_active = 1;
         smvs_gn_loop_stats stats;
-        check(smvs_gn_run_loop(ctx, &prm, &stats), "smvs_gn_run_loop");
-        check(smvs_get_nodes(ctx, surface->node_values().data()),
-            "smvs_get_nodes");
+        {
+            ScopedHostTimer timer("device Newton loop");
+            check(smvs_gn_run_loop(ctx, &prm, &stats), "smvs_gn_run_loop");
+            check(smvs_get_nodes(ctx, surface->node_values().data()),
+                "smvs_get_nodes");
+        }
         log.push_back({ surface->get_scale(), iter, stats.newton_steps,
             num_valid_patches, stats.linear_iterations });
 
         if (finished)
             break;
-        int deleted = std::numeric_limits<int>::max();
-        while (deleted > 10)
-            deleted = this->cut_boundaries();
-        if (!opts.use_sgm) {
-            surface->expand();
-            this->create_subview_surfaces();
-            deleted = std::numeric_limits<int>::max();
-            while (deleted > 10)
-                deleted = this->cut_boundaries();
+        {
+            ScopedHostTimer timer("cut_boundaries");
+            this->cut_boundaries_until_stable();
         }
-        surface->remove_isolated_patches();
+        if (!opts.use_sgm) {
+            {
+                ScopedHostTimer timer("expand");
+                surface->expand();
+            }
+            {
+                ScopedHostTimer timer("create_subview_surfaces");
+                this->create_subview_surfaces();
+            }
+            ScopedHostTimer timer("cut_boundaries");
+            this->cut_boundaries_until_stable();
+        }
+        {
+            ScopedHostTimer timer("remove_isolated_patches");
+            surface->remove_isolated_patches();
+        }
 
         int const num_valid_new = surface->count_valid_patches();
         double const change = 1.0
@@ -334,128 +387,31 @@ DepthOptimizer::run_newton_iterations(int num_iters)
     }
 }
 
-double
-DepthOptimizer::mse_for_patch(std::size_t patch_id)
+void
+DepthOptimizer::refresh_patch_mse(void)
 {
-    // lib/depth_optimizer.cc:747-790
-    int const ps = surface->get_patchsize();
-    double n16[16];
-    surface->fill_patch_nodes(patch_id, n16);
-    PatchEval pe(n16);
-    int px, py;
-    surface->patch_origin(patch_id, &px, &py);
-    FloatImage::ConstPtr main_grad = main_view->get_image_gradients();
-    double error = 0.0, counter = 0.0;
-    for (int j = 0; j < ps; ++j)
-        for (int i = 0; i < ps; ++i) {
-            double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
-            double const w = pe.f(u, v), wx = pe.dx(u, v) / ps,
-                wy = pe.dy(u, v) / ps;
-            double const gm0 = main_grad->at(px + i, py + j, 0);
-            double const gm1 = main_grad->at(px + i, py + j, 1);
-            for (std::size_t s = 0; s < sub_views.size(); ++s) {
-                if (!(subsurfaces[patch_id] & (1u << s)))
-                    continue;
-                FloatImage::ConstPtr sg = sub_views[s]->get_image_gradients();
-                Warp wp(&Mi[9 * s], &ti[3 * s], px + i + 0.5, py + j + 0.5, w);
-                double jac[4];
-                wp.jacobian(&Mi[9 * s], w, wx, wy, jac);
-                float const qx = (float)(wp.x() - 0.5), qy = (float)(wp.y() - 0.5);
-                double const g0 = sg->linear_at(qx, qy, 0);
-                double const g1 = sg->linear_at(qx, qy, 1);
-                double const d0 = gm0 - (jac[0] * g0 + jac[1] * g1);
-                double const d1 = gm1 - (jac[2] * g0 + jac[3] * g1);
-                error += std::sqrt(d0 * d0 + d1 * d1);
-                counter += 1.0;
-            }
-        }
-    return counter == 0.0 ? 1.0 : error / counter;
+    // mse_for_patch (lib/depth_optimizer.cc:747-790) for all patches at once
+    // on the device.  The values only depend on the nodes and on the
+    // visibility masks, which the passes of cut_boundaries do not change.
+    this->upload_surface();
+    patch_mse.resize(surface->get_num_patches());
+    check(smvs_topology_patch_mse(ctx, patch_mse.data()),
+        "smvs_topology_patch_mse");
 }
 
-double
-DepthOptimizer::ncc_for_patch(std::size_t patch_id, std::size_t sub_id)
+int
+DepthOptimizer::cut_boundaries_until_stable(void)
 {
-    // lib/depth_optimizer.cc:792-912
-    FloatImage::ConstPtr main_image = main_view->get_image();
-    FloatImage::ConstPtr sub_image = sub_views[sub_id]->get_image();
-    int const ps = surface->get_patchsize();
-    double n16[16];
-    surface->fill_patch_nodes(patch_id, n16);
-    PatchEval pe(n16);
-    int px, py;
-    surface->patch_origin(patch_id, &px, &py);
-    struct Sample { double x, y, depth; };
-    std::vector<Sample> samples;
-    samples.reserve((size_t)ps * ps + 8 * ps + 16);
-    for (int j = 0; j < ps; ++j)
-        for (int i = 0; i < ps; ++i)
-            samples.push_back({ (double)(px + i), (double)(py + j),
-                pe.f((i + 0.5) / ps, (j + 0.5) / ps) });
-    double const min_x = px, min_y = py, max_x = px + ps, max_y = py + ps;
-    if (min_x > 1 && max_x < main_image->width() - 2 && min_y > 1
-        && max_y < main_image->height() - 2) {
-        samples.push_back({ min_x - 1, min_y - 1, n16[0] });
-        samples.push_back({ max_x + 1, min_y - 1, n16[4] });
-        samples.push_back({ min_x - 1, max_y + 1, n16[8] });
-        samples.push_back({ max_x + 1, max_y + 1, n16[12] });
+    // the `while (deleted > 10)` loops of lib/depth_optimizer.cc:186-190,
+    // 323-337
+    this->refresh_patch_mse();
+    int total = 0;
+    int deleted = std::numeric_limits<int>::max();
+    while (deleted > 10) {
+        deleted = this->cut_boundaries();
+        total += deleted;
     }
-    // the list grows while it is walked (:823-857)
-    for (std::size_t i = 0; i < samples.size(); ++i) {
-        Sample const s = samples[i];
-        if (min_y > 2 && s.y == min_y) {
-            samples.push_back({ s.x, s.y - 2, s.depth });
-            samples.push_back({ s.x, s.y - 1, s.depth });
-        }
-        if (max_y < main_image->height() - 3 && s.y == max_y) {
-            samples.push_back({ s.x, s.y + 2, s.depth });
-            samples.push_back({ s.x, s.y + 1, s.depth });
-        }
-        if (min_x > 2 && s.x == min_x) {
-            samples.push_back({ s.x - 2, s.y, s.depth });
-            samples.push_back({ s.x - 1, s.y, s.depth });
-        }
-        if (max_x < main_image->width() - 3 && s.x == max_x) {
-            samples.push_back({ s.x + 2, s.y, s.depth });
-            samples.push_back({ s.x + 1, s.y, s.depth });
-        }
-    }
-    std::size_t const n = samples.size();
-    std::vector<double> v0(3 * n), v1(3 * n);
-    double mean0[3] = { 0, 0, 0 }, mean1[3] = { 0, 0, 0 }, cnt[3] = { 0, 0, 0 };
-    int const mc = main_image->channels(), sc = sub_image->channels();
-    for (std::size_t i = 0; i < n; ++i) {
-        Warp wp(&Mi[9 * sub_id], &ti[3 * sub_id], samples[i].x + 0.5,
-            samples[i].y + 0.5, samples[i].depth);
-        double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-        if (qx < 1 || qx > sub_image->width() - 2 || qy < 1
-            || qy > sub_image->height() - 2)
-            return -1;
-        for (int c = 0; c < 3; ++c) {
-            double const cm = main_image->at((int64_t)samples[i].x,
-                (int64_t)samples[i].y, std::min(c, mc - 1));
-            double const cs = sub_image->linear_at((float)qx, (float)qy,
-                std::min(c, sc - 1));
-            cnt[c] += 1.0;
-            mean0[c] += (cm - mean0[c]) / cnt[c];
-            mean1[c] += (cs - mean1[c]) / cnt[c];
-            v0[3 * i + c] = cm;
-            v1[3 * i + c] = cs;
-        }
-    }
-    double n0 = 0.0, n1 = 0.0, dot = 0.0;
-    for (std::size_t i = 0; i < n; ++i)
-        for (int c = 0; c < 3; ++c) {
-            double const a = v0[3 * i + c] - mean0[c];
-            double const b = v1[3 * i + c] - mean1[c];
-            n0 += a * a;
-            n1 += b * b;
-            dot += a * b;
-        }
-    n0 = std::sqrt(n0);
-    n1 = std::sqrt(n1);
-    if (n0 + n1 < 0.001 * n)
-        return 1;
-    return dot / (n0 * n1);
+    return total;
 }
 
 int
@@ -507,7 +463,7 @@ DepthOptimizer::cut_boundaries(void)
             continue;
         std::size_t ids[4];
         surface->fill_node_ids_for_patch(p, ids);
-        double const error = this->mse_for_patch(p);
+        double const error = patch_mse[p];
         for (int k = 0; k < 4; ++k) {
             int const nx = (int)(ids[k] % stride), ny = (int)(ids[k] / stride);
             int missing = 0;
@@ -529,104 +485,16 @@ DepthOptimizer::cut_boundaries(void)
 void
 DepthOptimizer::create_subview_surfaces(void)
 {
-    // lib/depth_optimizer.cc:433-604
+    // lib/depth_optimizer.cc:433-604.  The per-(patch, neighbour) tests --
+    // z-buffer visibility, warp anisotropy, NCC -- run on the device
+    // (smvs_topology_subviews); deleting the patches nobody sees stays here.
     std::size_t const num_patches = surface->get_num_patches();
     subsurfaces.assign(num_patches, 0);
-    std::size_t const S = sub_views.size();
+    this->upload_surface();
+    check(smvs_topology_subviews(ctx,
+        opts.use_sgm ? sgm_depth->begin() : nullptr, opts.use_sgm ? 0 : 1,
+        subsurfaces.data()), "smvs_topology_subviews");
 
-    // z-buffer of the current surface (and the SGM depth) in every neighbour
-    std::vector<FloatImage::Ptr> zbuf(S);
-    for (std::size_t s = 0; s < S; ++s) {
-        zbuf[s] = FloatImage::create(sub_views[s]->get_width() + 1,
-            sub_views[s]->get_height() + 1, 1);
-        zbuf[s]->fill(10000.0f);
-    }
-    FloatImage::Ptr depth = surface->get_depth_map();
-    auto splat = [&](int x, int y, double w) {
-        for (std::size_t s = 0; s < S; ++s) {
-            Warp wp(&Mi[9 * s], &ti[3 * s], x + 0.5, y + 0.5, w);
-            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-            double const cutoffset = 3.0;
-            if (qx < cutoffset || qx >= sub_views[s]->get_width() - cutoffset
-                || qy < cutoffset || qy >= sub_views[s]->get_height() - cutoffset)
-                continue;
-            int const cx = (int)qx, cy = (int)qy;
-            for (int dx = -1; dx < 2; ++dx)
-                for (int dy = -1; dy < 2; ++dy)
-                    if (wp.d < zbuf[s]->at(cx + dx, cy + dy, 0))
-                        zbuf[s]->at(cx + dx, cy + dy, 0) = (float)wp.d;
-        }
-    };
-    for (int x = 0; x < depth->width(); ++x)
-        for (int y = 0; y < depth->height(); ++y) {
-            if (depth->at(x, y, 0) != 0)
-                splat(x, y, depth->at(x, y, 0));
-            if (opts.use_sgm && sgm_depth->at(x, y, 0) != 0)
-                splat(x, y, sgm_depth->at(x, y, 0));
-        }
-
-    int const ps = surface->get_patchsize();
-    std::vector<double> w(ps * ps), wx(ps * ps), wy(ps * ps);
-    for (std::size_t p = 0; p < num_patches; ++p) {
-        if (!surface->patch_validity()[p])
-            continue;
-        double n16[16];
-        surface->fill_patch_nodes(p, n16);
-        PatchEval pe(n16);
-        int px, py;
-        surface->patch_origin(p, &px, &py);
-        for (int j = 0; j < ps; ++j)
-            for (int i = 0; i < ps; ++i) {
-                double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
-                w[j * ps + i] = pe.f(u, v);
-                wx[j * ps + i] = pe.dx(u, v) / ps;
-                wy[j * ps + i] = pe.dy(u, v) / ps;
-            }
-        for (std::size_t s = 0; s < S; ++s) {
-            double const sw = sub_views[s]->get_width();
-            double const sh = sub_views[s]->get_height();
-            double const cutoffset = 0.03 * std::max(sw, sh);
-            bool visible = true;
-            for (int k = 0; k < ps * ps && visible; ++k) {
-                Warp wp(&Mi[9 * s], &ti[3 * s], px + k % ps + 0.5,
-                    py + k / ps + 0.5, w[k]);
-                double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-                if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
-                    || qy >= sh - cutoffset) {
-                    visible = false;
-                    break;
-                }
-                int const cx = (int)qx, cy = (int)qy;
-                for (int dx = -1; dx < 2; ++dx)
-                    for (int dy = -1; dy < 2; ++dy)
-                        if (wp.d * 0.95 > zbuf[s]->at(cx + dx, cy + dy, 0))
-                            visible = false;
-            }
-            if (!visible)
-                continue;
-            // anisotropy of the warp: ratio of squared singular values
-            double worst = 0.0;
-            for (int k = 0; k < ps * ps; ++k) {
-                Warp wp(&Mi[9 * s], &ti[3 * s], px + k % ps + 0.5,
-                    py + k / ps + 0.5, w[k]);
-                double jac[4];
-                wp.jacobian(&Mi[9 * s], w[k], wx[k], wy[k], jac);
-                double const e = std::sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
-                    + (jac[1] + jac[2]) * (jac[1] + jac[2]));
-                double const g = std::sqrt((jac[0] + jac[3]) * (jac[0] + jac[3])
-                    + (jac[1] - jac[2]) * (jac[1] - jac[2]));
-                double const s0 = (e + g) / 2.0;
-                double const s1 = std::fabs(s0 - e);
-                double const hi = std::max(s0, s1), lo = std::min(s0, s1);
-                worst = std::max(worst, (hi * hi) / (lo * lo));
-            }
-            if (worst > 8.0)
-                continue;
-            if (!opts.use_sgm && this->ncc_for_patch(p, s) < 0)
-                continue;
-            subsurfaces[p] |= (1u << s);
-        }
-    }
     std::size_t removed = 0;
     for (std::size_t p = 0; p < num_patches; ++p)
         if (surface->patch_validity()[p] && subsurfaces[p] == 0) {

@@ -61,8 +61,8 @@ private:
     void create_subview_surfaces(void);
     void run_newton_iterations(int num_iters);
     int cut_boundaries(void);
-    double mse_for_patch(std::size_t patch_id);
-    double ncc_for_patch(std::size_t patch_id, std::size_t sub_id);
+    int cut_boundaries_until_stable(void);
+    void refresh_patch_mse(void);
     FloatImage::Ptr depthmap_bilateral_filter(FloatImage::ConstPtr dm,
         FloatImage::ConstPtr ci, float sigma = 5, int kernel_size = 5);
     void fit_lighting(void);
@@ -80,6 +80,7 @@ private:
     FloatImage::ConstPtr sgm_depth;
     Surface::Ptr surface;
     std::vector<uint32_t> subsurfaces;   // bit j: neighbour j sees the patch
+    std::vector<double> patch_mse;       // mse_for_patch of every patch (device)
     bool lit = false;
     bool images_uploaded = false;
     double lighting[16];

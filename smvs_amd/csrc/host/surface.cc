@@ -2,36 +2,13 @@
 // and lib/surface_patch.cc.  Topology operations run on the host between
 // Newton batches.
 #include "surface.h"
+#include "topo_math.h"
 
 #include <algorithm>
 #include <cmath>
 
 namespace smvs_amd {
 
-namespace {
-
-// 1-D cubic Hermite basis and derivatives: value@0, value@1, slope@0, slope@1
-inline void
-hermite(double t, int k, double* b)
-{
-    double const t2 = t * t, t3 = t2 * t;
-    switch (k) {
-    case 0:
-        b[0] = 1.0 - 3.0 * t2 + 2.0 * t3; b[1] = 3.0 * t2 - 2.0 * t3;
-        b[2] = t - 2.0 * t2 + t3;         b[3] = t3 - t2;
-        break;
-    case 1:
-        b[0] = -6.0 * t + 6.0 * t2;       b[1] = 6.0 * t - 6.0 * t2;
-        b[2] = 1.0 - 4.0 * t + 3.0 * t2;  b[3] = 3.0 * t2 - 2.0 * t;
-        break;
-    default:
-        b[0] = -6.0 + 12.0 * t;           b[1] = 6.0 - 12.0 * t;
-        b[2] = -4.0 + 6.0 * t;            b[3] = 6.0 * t - 2.0;
-        break;
-    }
-}
-
-} // namespace
 
 PatchEval::PatchEval(double const* nodes16)
 {
@@ -41,17 +18,8 @@ PatchEval::PatchEval(double const* nodes16)
 double
 PatchEval::eval(double x, double y, int kx, int ky) const
 {
-    double bx[4], by[4];
-    hermite(x, kx, bx);
-    hermite(y, ky, by);
-    double r = 0.0;
-    for (int b = 0; b < 2; ++b)
-        for (int a = 0; a < 2; ++a) {
-            double const* nd = n + 4 * (2 * b + a);
-            r += nd[0] * bx[a] * by[b] + nd[1] * bx[2 + a] * by[b]
-                + nd[2] * bx[a] * by[2 + b] + nd[3] * bx[2 + a] * by[2 + b];
-        }
-    return r;
+    // shared with the device topology kernels (topo_math.h)
+    return smvs_topo::patch_eval(n, x, y, kx, ky);
 }
 
 /* ---------------------------------------------------------------------- */

@@ -1,0 +1,458 @@
+// Per-patch topology tests of DepthOptimizer between Newton batches
+// (SURVEY.md row (f)-2), on the device:
+//
+//   * create_subview_surfaces (lib/depth_optimizer.cc:433-604): z-buffer of
+//     the current surface (and of the SGM depth) in every neighbour, then per
+//     (patch, neighbour) the image-border / occlusion test, the warp
+//     anisotropy test and ncc_for_patch (:792-912) -> visibility bit mask;
+//   * mse_for_patch (:747-790) for every valid patch, the quantity
+//     cut_boundaries (:360-431) thresholds.
+//
+// The host keeps the topology itself (which patches and nodes exist): these
+// kernels only produce the per-patch numbers the host decides on, and they do
+// so with the arithmetic of csrc/host/topo_math.h, the same source the C++
+// host mirror compiles, in the same order, one thread per (patch, neighbour)
+// resp. per patch.  The z-buffer minimum is order independent:
+// (float)min(d) == min((float)d) because rounding is monotone.
+#include "common.h"
+#include "host/topo_math.h"
+
+#include <vector>
+
+namespace smvs_hip {
+
+using smvs_topo::NccSample;
+using smvs_topo::Warp;
+
+struct TopoView {
+    int w, h, c;
+    const float *image;   // interleaved float image (bytes / 255)
+};
+
+struct TopoArgs {
+    const double *nodes;
+    const uint8_t *patch_valid;
+    const uint32_t *patch_vis;      // input of the mse kernel
+    uint32_t *vis_out;
+    double *mse_out;
+    const DeviceCameras *cams;
+    TopoView views[1 + SMVS_MAX_SUBS];   // [0] main, [1 + j] neighbour j
+    const float2 *main_grad;
+    const SubPlanes *subs;
+    float *zbuf[SMVS_MAX_SUBS];     // [(h + 1)][(w + 1)]
+    const float *sgm_depth;         // [H][W] or nullptr
+    const NccSample *ncc;           // 32 concatenated templates
+    int ncc_off[33];
+    int W, H, npx, npy, stride, ps, start_x, start_y, n_subs, num_patches;
+    int use_ncc;
+};
+
+__device__ __forceinline__ void
+load_patch_nodes(TopoArgs const &A, int p, double n16[16])
+{
+    int const ix = p % A.npx, iy = p / A.npx;
+    int const n00 = iy * A.stride + ix;
+    int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            n16[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
+}
+
+// min over floats of any sign with integer atomics
+__device__ __forceinline__ void
+atomic_min_float(float *addr, float v)
+{
+    if (v >= 0.0f)
+        atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else
+        atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+// ---- z-buffer splat (depth_optimizer.cc:441-470), one thread per pixel ----
+__global__ void __launch_bounds__(256)
+topo_splat_kernel(TopoArgs A)
+{
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= A.W || y >= A.H)
+        return;
+    float depths[2] = { 0.0f, 0.0f };
+    // Surface::get_depth_map (surface.cc:155-168): float of the patch value
+    int const gx = x - A.start_x, gy = y - A.start_y;
+    if (gx >= 0 && gy >= 0 && gx < A.npx * A.ps && gy < A.npy * A.ps) {
+        int const ix = gx / A.ps, iy = gy / A.ps;
+        int const p = iy * A.npx + ix;
+        if (A.patch_valid[p]) {
+            double n16[16];
+            load_patch_nodes(A, p, n16);
+            int const i = gx - ix * A.ps, j = gy - iy * A.ps;
+            depths[0] = (float)smvs_topo::patch_eval(n16, (i + 0.5) / A.ps,
+                (j + 0.5) / A.ps, 0, 0);
+        }
+    }
+    if (A.sgm_depth != nullptr)
+        depths[1] = A.sgm_depth[(size_t)y * A.W + x];
+    for (int k = 0; k < 2; ++k) {
+        if (depths[k] == 0.0f)   // (NaN splats like the reference: no effect)
+            continue;
+        double const w = depths[k];
+        for (int s = 0; s < A.n_subs; ++s) {
+            Warp wp(A.cams->M[s], A.cams->t[s], x + 0.5, y + 0.5, w);
+            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+            double const cutoffset = 3.0;
+            int const sw = A.views[1 + s].w, sh = A.views[1 + s].h;
+            if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
+                || qy >= sh - cutoffset)
+                continue;
+            int const cx = (int)qx, cy = (int)qy;
+            float const df = (float)wp.d;
+            if (!(df == df))
+                continue;
+            for (int dx = -1; dx < 2; ++dx)
+                for (int dy = -1; dy < 2; ++dy)
+                    atomic_min_float(A.zbuf[s] + (size_t)(cy + dy) * (sw + 1)
+                        + (cx + dx), df);
+        }
+    }
+}
+
+// ---- ncc_for_patch (depth_optimizer.cc:792-912) ----
+__device__ double
+ncc_for_patch(TopoArgs const &A, double const n16[16], int px, int py, int s)
+{
+#pragma clang fp contract(off)
+    TopoView const mv = A.views[0], sv = A.views[1 + s];
+    int const ps = A.ps;
+    int const flags = smvs_topo::ncc_flags(px, py, ps, mv.w, mv.h);
+    const NccSample *tpl = A.ncc + A.ncc_off[flags];
+    int const n = A.ncc_off[flags + 1] - A.ncc_off[flags];
+    const double *M = A.cams->M[s];
+    const double *t = A.cams->t[s];
+    double mean0[3] = { 0, 0, 0 }, mean1[3] = { 0, 0, 0 }, cnt[3] = { 0, 0, 0 };
+    double n0 = 0.0, n1 = 0.0, dot = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < n; ++i) {
+            NccSample const smp = tpl[i];
+            double depth;
+            if (smp.src >= 0)
+                depth = smvs_topo::patch_eval(n16, (smp.src % ps + 0.5) / ps,
+                    (smp.src / ps + 0.5) / ps, 0, 0);
+            else
+                depth = n16[4 * (-1 - smp.src)];
+            double const sx = (double)(px + smp.dx), sy = (double)(py + smp.dy);
+            Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
+            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+            if (pass == 0 && (qx < 1 || qx > sv.w - 2 || qy < 1
+                || qy > sv.h - 2))
+                return -1;
+            for (int c = 0; c < 3; ++c) {
+                int const cmi = c < mv.c - 1 ? c : mv.c - 1;
+                int const csi = c < sv.c - 1 ? c : sv.c - 1;
+                double const cm = mv.image[((size_t)(py + smp.dy) * mv.w
+                    + (px + smp.dx)) * mv.c + cmi];
+                double const cs = smvs_topo::linear_at(sv.image, sv.w, sv.h,
+                    sv.c, (float)qx, (float)qy, csi);
+                if (pass == 0) {
+                    cnt[c] += 1.0;
+                    mean0[c] += (cm - mean0[c]) / cnt[c];
+                    mean1[c] += (cs - mean1[c]) / cnt[c];
+                } else {
+                    double const a = cm - mean0[c];
+                    double const b = cs - mean1[c];
+                    n0 += a * a;
+                    n1 += b * b;
+                    dot += a * b;
+                }
+            }
+        }
+    }
+    n0 = sqrt(n0);
+    n1 = sqrt(n1);
+    if (n0 + n1 < 0.001 * n)
+        return 1;
+    return dot / (n0 * n1);
+}
+
+// ---- visibility of every patch in every neighbour (:472-590) ----
+__global__ void __launch_bounds__(256)
+topo_visibility_kernel(TopoArgs A)
+{
+#pragma clang fp contract(off)
+    long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int const p = (int)(gid / A.n_subs);
+    int const s = (int)(gid - (long long)p * A.n_subs);
+    if (p >= A.num_patches || !A.patch_valid[p])
+        return;
+    double n16[16];
+    load_patch_nodes(A, p, n16);
+    int const ps = A.ps;
+    int const px = A.start_x + (p % A.npx) * ps;
+    int const py = A.start_y + (p / A.npx) * ps;
+    const double *M = A.cams->M[s];
+    const double *t = A.cams->t[s];
+    double const sw = A.views[1 + s].w, sh = A.views[1 + s].h;
+    int const zw = A.views[1 + s].w + 1;
+    double const cutoffset = 0.03 * (sw < sh ? sh : sw);
+    const float *zbuf = A.zbuf[s];
+
+    bool visible = true;
+    for (int k = 0; k < ps * ps && visible; ++k) {
+        int const i = k % ps, j = k / ps;
+        double const w = smvs_topo::patch_eval(n16, (i + 0.5) / ps,
+            (j + 0.5) / ps, 0, 0);
+        Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
+        double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+        if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
+            || qy >= sh - cutoffset) {
+            visible = false;
+            break;
+        }
+        int const cx = (int)qx, cy = (int)qy;
+        for (int dx = -1; dx < 2; ++dx)
+            for (int dy = -1; dy < 2; ++dy)
+                if (wp.d * 0.95 > zbuf[(size_t)(cy + dy) * zw + (cx + dx)])
+                    visible = false;
+    }
+    if (!visible)
+        return;
+    // anisotropy of the warp: ratio of squared singular values
+    double worst = 0.0;
+    for (int k = 0; k < ps * ps; ++k) {
+        int const i = k % ps, j = k / ps;
+        double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
+        double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
+        double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
+        double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) / ps;
+        Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
+        double jac[4];
+        wp.jacobian(M, w, wx, wy, jac);
+        double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
+            + (jac[1] + jac[2]) * (jac[1] + jac[2]));
+        double const g = sqrt((jac[0] + jac[3]) * (jac[0] + jac[3])
+            + (jac[1] - jac[2]) * (jac[1] - jac[2]));
+        double const s0 = (e + g) / 2.0;
+        double const s1 = fabs(s0 - e);
+        double const hi = s0 < s1 ? s1 : s0, lo = s1 < s0 ? s1 : s0;
+        double const ratio = (hi * hi) / (lo * lo);
+        worst = worst < ratio ? ratio : worst;   // std::max(worst, ratio)
+    }
+    if (worst > 8.0)
+        return;
+    if (A.use_ncc && ncc_for_patch(A, n16, px, py, s) < 0)
+        return;
+    atomicOr(&A.vis_out[p], 1u << s);
+}
+
+// ---- mse_for_patch (:747-790), one thread per patch ----
+__global__ void __launch_bounds__(128)
+topo_mse_kernel(TopoArgs A)
+{
+#pragma clang fp contract(off)
+    int const p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.num_patches)
+        return;
+    if (!A.patch_valid[p]) {
+        A.mse_out[p] = -1.0;
+        return;
+    }
+    double n16[16];
+    load_patch_nodes(A, p, n16);
+    int const ps = A.ps;
+    int const px = A.start_x + (p % A.npx) * ps;
+    int const py = A.start_y + (p / A.npx) * ps;
+    uint32_t const vis = A.patch_vis[p];
+    double error = 0.0, counter = 0.0;
+    for (int j = 0; j < ps; ++j)
+        for (int i = 0; i < ps; ++i) {
+            double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
+            double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
+            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
+            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) / ps;
+            float2 const gm = A.main_grad[(size_t)(py + j) * A.W + (px + i)];
+            double const gm0 = gm.x, gm1 = gm.y;
+            for (int s = 0; s < A.n_subs; ++s) {
+                if (!(vis & (1u << s)))
+                    continue;
+                SubPlanes const sp = A.subs[s];
+                const double *M = A.cams->M[s];
+                Warp wp(M, A.cams->t[s], px + i + 0.5, py + j + 0.5, w);
+                double jac[4];
+                wp.jacobian(M, w, wx, wy, jac);
+                float const qx = (float)(wp.x() - 0.5),
+                    qy = (float)(wp.y() - 0.5);
+                const float *grad = reinterpret_cast<const float *>(sp.grad);
+                double const g0 = smvs_topo::linear_at(grad, sp.width,
+                    sp.height, 2, qx, qy, 0);
+                double const g1 = smvs_topo::linear_at(grad, sp.width,
+                    sp.height, 2, qx, qy, 1);
+                double const d0 = gm0 - (jac[0] * g0 + jac[1] * g1);
+                double const d1 = gm1 - (jac[2] * g0 + jac[3] * g1);
+                error += sqrt(d0 * d0 + d1 * d1);
+                counter += 1.0;
+            }
+        }
+    A.mse_out[p] = counter == 0.0 ? 1.0 : error / counter;
+}
+
+static int
+fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
+{
+    if (!ctx->has_surface || !ctx->has_cameras) {
+        set_error("%s: cameras and surface must be set first", who);
+        return SMVS_ERR_STATE;
+    }
+    for (int v = 0; v <= ctx->n_subs; ++v)
+        if (ctx->images[v].data == nullptr) {
+            set_error("%s: view %d has no image (smvs_ctx_upload_image)", who,
+                v - 1);
+            return SMVS_ERR_STATE;
+        }
+    A->nodes = ctx->nodes;
+    A->patch_valid = ctx->patch_valid;
+    A->patch_vis = ctx->patch_vis;
+    A->vis_out = ctx->patch_vis;
+    A->mse_out = ctx->topo_mse;
+    A->cams = ctx->cams;
+    for (int v = 0; v <= ctx->n_subs; ++v) {
+        A->views[v].w = ctx->images[v].w;
+        A->views[v].h = ctx->images[v].h;
+        A->views[v].c = ctx->images[v].c;
+        A->views[v].image = ctx->images[v].data;
+    }
+    A->main_grad = ctx->main_grad;
+    A->subs = ctx->subs_dev;
+    for (int s = 0; s < SMVS_MAX_SUBS; ++s)
+        A->zbuf[s] = ctx->topo_zbuf[s];
+    A->sgm_depth = nullptr;
+    A->ncc = ctx->topo_ncc;
+    for (int i = 0; i < 33; ++i)
+        A->ncc_off[i] = ctx->topo_ncc_off[i];
+    A->W = ctx->width;
+    A->H = ctx->height;
+    A->npx = ctx->npx;
+    A->npy = ctx->npy;
+    A->stride = ctx->node_stride;
+    A->ps = ctx->patchsize;
+    A->start_x = ctx->start_x;
+    A->start_y = ctx->start_y;
+    A->n_subs = ctx->n_subs;
+    A->num_patches = ctx->num_patches;
+    A->use_ncc = 0;
+    return SMVS_OK;
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
+    uint32_t *patch_vis_out)
+{
+    SMVS_REQUIRE(ctx && patch_vis_out, "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->images[0].data != nullptr
+        && (ctx->images[0].w != ctx->width || ctx->images[0].h != ctx->height)) {
+        set_error("smvs_topology_subviews: main image size differs from the context");
+        return SMVS_ERR_INVALID;
+    }
+    int rc;
+    // the 32 sample templates of ncc_for_patch for this patch size
+    if (ctx->topo_ncc_ps != ctx->patchsize && ctx->has_surface) {
+        std::vector<smvs_topo::NccSample> all;
+        for (int f = 0; f < 32; ++f) {
+            ctx->topo_ncc_off[f] = (int)all.size();
+            std::vector<smvs_topo::NccSample> const one
+                = smvs_topo::build_ncc_template(ctx->patchsize, f);
+            all.insert(all.end(), one.begin(), one.end());
+        }
+        ctx->topo_ncc_off[32] = (int)all.size();
+        if ((rc = device_alloc(&ctx->topo_ncc, all.size())) != SMVS_OK)
+            return rc;
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->topo_ncc, all.data(),
+            all.size() * sizeof(smvs_topo::NccSample), hipMemcpyHostToDevice,
+            ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->topo_ncc_ps = ctx->patchsize;
+    }
+    for (int s = 0; s < ctx->n_subs; ++s) {
+        size_t const n = (size_t)(ctx->images[1 + s].w + 1)
+            * (ctx->images[1 + s].h + 1);
+        if (n > ctx->topo_zbuf_cap[s]) {
+            if ((rc = device_alloc(&ctx->topo_zbuf[s], n)) != SMVS_OK)
+                return rc;
+            ctx->topo_zbuf_cap[s] = n;
+        }
+    }
+    size_t const npix = (size_t)ctx->width * ctx->height;
+    if (sgm_depth != nullptr && ctx->topo_sgm_cap < npix) {
+        if ((rc = device_alloc(&ctx->topo_sgm, npix)) != SMVS_OK)
+            return rc;
+        ctx->topo_sgm_cap = npix;
+    }
+    TopoArgs A;
+    if ((rc = fill_args(ctx, &A, "smvs_topology_subviews")) != SMVS_OK)
+        return rc;
+    A.use_ncc = use_ncc ? 1 : 0;
+    if (sgm_depth != nullptr) {
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->topo_sgm, sgm_depth,
+            npix * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        A.sgm_depth = ctx->topo_sgm;
+    }
+    for (int s = 0; s < ctx->n_subs; ++s) {
+        size_t const n = (size_t)(ctx->images[1 + s].w + 1)
+            * (ctx->images[1 + s].h + 1);
+        // 10000.0f
+        SMVS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ctx->topo_zbuf[s],
+            0x461C4000, n, ctx->stream));
+    }
+    SMVS_HIP_CHECK(hipMemsetAsync(ctx->patch_vis, 0,
+        sizeof(uint32_t) * ctx->num_patches, ctx->stream));
+    hipLaunchKernelGGL(topo_splat_kernel, dim3((ctx->width + 255) / 256,
+        ctx->height), dim3(256), 0, ctx->stream, A);
+    long long const items = (long long)ctx->num_patches * ctx->n_subs;
+    hipLaunchKernelGGL(topo_visibility_kernel,
+        dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    SMVS_HIP_CHECK(hipGetLastError());
+    SMVS_HIP_CHECK(hipMemcpyAsync(patch_vis_out, ctx->patch_vis,
+        sizeof(uint32_t) * ctx->num_patches, hipMemcpyDeviceToHost,
+        ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
+{
+    SMVS_REQUIRE(ctx && mse_out, "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->main_grad == nullptr) {
+        set_error("smvs_topology_patch_mse: no gradient planes");
+        return SMVS_ERR_STATE;
+    }
+    for (int j = 0; j < ctx->n_subs; ++j)
+        if (ctx->subs[j].grad == nullptr) {
+            set_error("smvs_topology_patch_mse: sub view %d has no planes", j);
+            return SMVS_ERR_STATE;
+        }
+    int rc;
+    if ((size_t)ctx->num_patches > ctx->topo_mse_cap) {
+        if ((rc = device_alloc(&ctx->topo_mse, (size_t)ctx->num_patches))
+            != SMVS_OK)
+            return rc;
+        ctx->topo_mse_cap = (size_t)ctx->num_patches;
+    }
+    TopoArgs A;
+    if ((rc = fill_args(ctx, &A, "smvs_topology_patch_mse")) != SMVS_OK)
+        return rc;
+    hipLaunchKernelGGL(topo_mse_kernel,
+        dim3((unsigned)((ctx->num_patches + 127) / 128)), dim3(128), 0,
+        ctx->stream, A);
+    SMVS_HIP_CHECK(hipGetLastError());
+    SMVS_HIP_CHECK(hipMemcpyAsync(mse_out, ctx->topo_mse,
+        sizeof(double) * ctx->num_patches, hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}

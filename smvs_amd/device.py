@@ -218,6 +218,22 @@ class ViewContext:
         check(self.lib.smvs_light_accumulate(self.handle, _p(A, _dp), _p(b, _dp)))
         return A, b
 
+    # ------------------------------------------------------------ topology
+    def topology_subviews(self, sgm_depth=None, use_ncc=True):
+        """create_subview_surfaces' per-(patch, neighbour) tests -> bit masks."""
+        sd = _f32(sgm_depth) if sgm_depth is not None else None
+        if sd is not None:
+            assert sd.shape == (self.height, self.width)
+        vis = np.zeros(self.num_patches, dtype=np.uint32)
+        check(self.lib.smvs_topology_subviews(self.handle, _p(sd, _fp),
+              1 if use_ncc else 0, _p(vis, _u32p)))
+        return vis
+
+    def topology_patch_mse(self):
+        mse = np.zeros(self.num_patches)
+        check(self.lib.smvs_topology_patch_mse(self.handle, _p(mse, _dp)))
+        return mse
+
     def synchronize(self):
         check(self.lib.smvs_ctx_synchronize(self.handle))
 
