@@ -201,9 +201,8 @@ void
 DepthOptimizer::set_scale_everywhere(int scale)
 {
     // StereoView::set_scale for the main view and every neighbour
-    // (lib/depth_optimizer.cc:63-66, 99-103) on the device; the planes come
-    // back once per scale for the host-side topology code.
-    ScopedHostTimer timer("set_scale (device + download)");
+    // (lib/depth_optimizer.cc:63-66, 99-103) on the device.
+    ScopedHostTimer timer("set_scale (device)");
     if (!images_uploaded) {
         ByteImage::ConstPtr mb = main_view->get_raw_bytes();
         check(smvs_ctx_upload_image(ctx, -1, mb->width(), mb->height(),
@@ -221,6 +220,14 @@ DepthOptimizer::set_scale_everywhere(int scale)
         images_uploaded = true;
     }
     check(smvs_ctx_set_scale(ctx, scale), "smvs_ctx_set_scale");
+    // The planes stay on the device: every consumer (Newton loop, patch MSE,
+    // NCC) runs there.  StereoView::get_image_gradients() of the views keeps
+    // what the caller last set; download_scale_planes() fetches them.
+}
+
+void
+DepthOptimizer::download_scale_planes(void)
+{
     {
         FloatImage::Ptr g = FloatImage::create(main_view->get_width(),
             main_view->get_height(), 2);

@@ -55,6 +55,11 @@ public:
     bool has_lighting(void) const { return lit; }
     double const* get_lighting(void) const { return lighting; }
 
+    // The scale-space planes live on the device; this copies the current
+    // scale's gradient / Hessian planes into the StereoViews (not in the
+    // reference, where StereoView::set_scale fills them on the host).
+    void download_scale_planes(void);
+
 private:
     void prepare_correspondences(void);
     void create_initial_surface(void);

@@ -10,9 +10,8 @@
 //
 // The host keeps the topology itself (which patches and nodes exist): these
 // kernels only produce the per-patch numbers the host decides on, and they do
-// so with the arithmetic of csrc/host/topo_math.h, the same source the C++
-// host mirror compiles, in the same order, one thread per (patch, neighbour)
-// resp. per patch.  The z-buffer minimum is order independent:
+// so with the arithmetic of csrc/host/topo_math.h (the source the C++ host
+// mirror compiles too).  The z-buffer minimum is order independent:
 // (float)min(d) == min((float)d) because rounding is monotone.
 #include "common.h"
 #include "host/topo_math.h"
@@ -118,154 +117,208 @@ topo_splat_kernel(TopoArgs A)
     }
 }
 
-// ---- ncc_for_patch (depth_optimizer.cc:792-912) ----
-__device__ double
-ncc_for_patch(TopoArgs const &A, double const n16[16], int px, int py, int s)
+// A group of G = min(64, ps^2) consecutive lanes works on one (patch,
+// neighbour) resp. one patch: the pixels / samples are dealt round-robin to
+// the lanes and the group combines its partial results with xor-shuffles in a
+// fixed order (deterministic).  The reference's loops are sequential; every
+// quantity here is a conjunction, a maximum or a sum, so only the summation
+// order differs (by rounding, far below the 0.05 / 8.0 / 0.0 thresholds the
+// results are compared with).
+__device__ __forceinline__ int
+group_size(int ps)
 {
-#pragma clang fp contract(off)
-    TopoView const mv = A.views[0], sv = A.views[1 + s];
-    int const ps = A.ps;
-    int const flags = smvs_topo::ncc_flags(px, py, ps, mv.w, mv.h);
-    const NccSample *tpl = A.ncc + A.ncc_off[flags];
-    int const n = A.ncc_off[flags + 1] - A.ncc_off[flags];
-    const double *M = A.cams->M[s];
-    const double *t = A.cams->t[s];
-    double mean0[3] = { 0, 0, 0 }, mean1[3] = { 0, 0, 0 }, cnt[3] = { 0, 0, 0 };
-    double n0 = 0.0, n1 = 0.0, dot = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int i = 0; i < n; ++i) {
-            NccSample const smp = tpl[i];
-            double depth;
-            if (smp.src >= 0)
-                depth = smvs_topo::patch_eval(n16, (smp.src % ps + 0.5) / ps,
-                    (smp.src / ps + 0.5) / ps, 0, 0);
-            else
-                depth = n16[4 * (-1 - smp.src)];
-            double const sx = (double)(px + smp.dx), sy = (double)(py + smp.dy);
-            Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
-            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-            if (pass == 0 && (qx < 1 || qx > sv.w - 2 || qy < 1
-                || qy > sv.h - 2))
-                return -1;
-            for (int c = 0; c < 3; ++c) {
-                int const cmi = c < mv.c - 1 ? c : mv.c - 1;
-                int const csi = c < sv.c - 1 ? c : sv.c - 1;
-                double const cm = mv.image[((size_t)(py + smp.dy) * mv.w
-                    + (px + smp.dx)) * mv.c + cmi];
-                double const cs = smvs_topo::linear_at(sv.image, sv.w, sv.h,
-                    sv.c, (float)qx, (float)qy, csi);
-                if (pass == 0) {
-                    cnt[c] += 1.0;
-                    mean0[c] += (cm - mean0[c]) / cnt[c];
-                    mean1[c] += (cs - mean1[c]) / cnt[c];
-                } else {
-                    double const a = cm - mean0[c];
-                    double const b = cs - mean1[c];
-                    n0 += a * a;
-                    n1 += b * b;
-                    dot += a * b;
-                }
-            }
-        }
-    }
-    n0 = sqrt(n0);
-    n1 = sqrt(n1);
-    if (n0 + n1 < 0.001 * n)
-        return 1;
-    return dot / (n0 * n1);
+    int const pp = ps * ps;
+    return pp >= 64 ? 64 : pp;   // ps is a power of two: 1, 4, 16, 64
 }
 
-// ---- visibility of every patch in every neighbour (:472-590) ----
+template <typename T>
+__device__ __forceinline__ T
+group_sum(T v, int G)
+{
+    for (int off = G >> 1; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ double
+group_max(double v, int G)
+{
+    for (int off = G >> 1; off > 0; off >>= 1) {
+        double const o = __shfl_xor(v, off);
+        v = v < o ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool
+group_all(bool ok, int G, int lane)
+{
+    unsigned long long const b = __ballot(ok);
+    unsigned long long const gmask = G >= 64 ? ~0ull
+        : (((1ull << G) - 1ull) << ((lane / G) * G));
+    return (b & gmask) == gmask;
+}
+
+// ---- visibility of every patch in every neighbour (:472-590), incl.
+// ncc_for_patch (:792-912) ----
 __global__ void __launch_bounds__(256)
 topo_visibility_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
-    long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int const ps = A.ps;
+    int const G = group_size(ps);
+    int const lane = threadIdx.x & 63;
+    int const gl = threadIdx.x % G;           // lane inside the group
+    long long const gid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
     int const p = (int)(gid / A.n_subs);
     int const s = (int)(gid - (long long)p * A.n_subs);
-    if (p >= A.num_patches || !A.patch_valid[p])
-        return;
+    bool alive = p < A.num_patches && A.patch_valid[p];
+    int const pc = alive ? p : 0;
     double n16[16];
-    load_patch_nodes(A, p, n16);
-    int const ps = A.ps;
-    int const px = A.start_x + (p % A.npx) * ps;
-    int const py = A.start_y + (p / A.npx) * ps;
+    load_patch_nodes(A, pc, n16);
+    int const px = A.start_x + (pc % A.npx) * ps;
+    int const py = A.start_y + (pc / A.npx) * ps;
     const double *M = A.cams->M[s];
     const double *t = A.cams->t[s];
-    double const sw = A.views[1 + s].w, sh = A.views[1 + s].h;
-    int const zw = A.views[1 + s].w + 1;
+    TopoView const mv = A.views[0], sv = A.views[1 + s];
+    double const sw = sv.w, sh = sv.h;
+    int const zw = sv.w + 1;
     double const cutoffset = 0.03 * (sw < sh ? sh : sw);
     const float *zbuf = A.zbuf[s];
 
+    // border / occlusion test and the warp anisotropy, one pass over the
+    // patch's pixels
     bool visible = true;
-    for (int k = 0; k < ps * ps && visible; ++k) {
-        int const i = k % ps, j = k / ps;
-        double const w = smvs_topo::patch_eval(n16, (i + 0.5) / ps,
-            (j + 0.5) / ps, 0, 0);
-        Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
-        double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-        if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
-            || qy >= sh - cutoffset) {
-            visible = false;
-            break;
-        }
-        int const cx = (int)qx, cy = (int)qy;
-        for (int dx = -1; dx < 2; ++dx)
-            for (int dy = -1; dy < 2; ++dy)
-                if (wp.d * 0.95 > zbuf[(size_t)(cy + dy) * zw + (cx + dx)])
-                    visible = false;
-    }
-    if (!visible)
-        return;
-    // anisotropy of the warp: ratio of squared singular values
     double worst = 0.0;
-    for (int k = 0; k < ps * ps; ++k) {
-        int const i = k % ps, j = k / ps;
-        double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
-        double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
-        double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
-        double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) / ps;
-        Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
-        double jac[4];
-        wp.jacobian(M, w, wx, wy, jac);
-        double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
-            + (jac[1] + jac[2]) * (jac[1] + jac[2]));
-        double const g = sqrt((jac[0] + jac[3]) * (jac[0] + jac[3])
-            + (jac[1] - jac[2]) * (jac[1] - jac[2]));
-        double const s0 = (e + g) / 2.0;
-        double const s1 = fabs(s0 - e);
-        double const hi = s0 < s1 ? s1 : s0, lo = s1 < s0 ? s1 : s0;
-        double const ratio = (hi * hi) / (lo * lo);
-        worst = worst < ratio ? ratio : worst;   // std::max(worst, ratio)
+    if (alive)
+        for (int k = gl; k < ps * ps; k += G) {
+            int const i = k % ps, j = k / ps;
+            double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
+            double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
+            Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
+            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+            if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
+                || qy >= sh - cutoffset) {
+                visible = false;
+                break;
+            }
+            int const cx = (int)qx, cy = (int)qy;
+            for (int dx = -1; dx < 2; ++dx)
+                for (int dy = -1; dy < 2; ++dy)
+                    if (wp.d * 0.95 > zbuf[(size_t)(cy + dy) * zw + (cx + dx)])
+                        visible = false;
+            // ratio of the squared singular values of the warp Jacobian
+            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
+            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) / ps;
+            double jac[4];
+            wp.jacobian(M, w, wx, wy, jac);
+            double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
+                + (jac[1] + jac[2]) * (jac[1] + jac[2]));
+            double const g = sqrt((jac[0] + jac[3]) * (jac[0] + jac[3])
+                + (jac[1] - jac[2]) * (jac[1] - jac[2]));
+            double const s0 = (e + g) / 2.0;
+            double const s1 = fabs(s0 - e);
+            double const hi = s0 < s1 ? s1 : s0, lo = s1 < s0 ? s1 : s0;
+            double const ratio = (hi * hi) / (lo * lo);
+            // std::max(worst, ratio): a NaN ratio leaves worst unchanged
+            worst = worst < ratio ? ratio : worst;
+        }
+    visible = group_all(visible, G, lane);
+    worst = group_max(worst, G);
+    alive = alive && visible && !(worst > 8.0);
+
+    // ncc_for_patch
+    double ncc = 1.0;
+    if (A.use_ncc) {
+        int const flags = smvs_topo::ncc_flags(px, py, ps, mv.w, mv.h);
+        const NccSample *tpl = A.ncc + A.ncc_off[flags];
+        int const n = A.ncc_off[flags + 1] - A.ncc_off[flags];
+        bool inside = true;
+        double sum0[3] = { 0, 0, 0 }, sum1[3] = { 0, 0, 0 };
+        double mean0[3], mean1[3];
+        double n0 = 0.0, n1 = 0.0, dot = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (alive && inside)
+                for (int i = gl; i < n; i += G) {
+                    NccSample const smp = tpl[i];
+                    double depth;
+                    if (smp.src >= 0)
+                        depth = smvs_topo::patch_eval(n16,
+                            (smp.src % ps + 0.5) / ps,
+                            (smp.src / ps + 0.5) / ps, 0, 0);
+                    else
+                        depth = n16[4 * (-1 - smp.src)];
+                    double const sx = (double)(px + smp.dx);
+                    double const sy = (double)(py + smp.dy);
+                    Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
+                    double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+                    if (pass == 0 && (qx < 1 || qx > sv.w - 2 || qy < 1
+                        || qy > sv.h - 2)) {
+                        inside = false;
+                        break;
+                    }
+                    for (int c = 0; c < 3; ++c) {
+                        int const cmi = c < mv.c - 1 ? c : mv.c - 1;
+                        int const csi = c < sv.c - 1 ? c : sv.c - 1;
+                        double const cm = mv.image[((size_t)(py + smp.dy) * mv.w
+                            + (px + smp.dx)) * mv.c + cmi];
+                        double const cs = smvs_topo::linear_at(sv.image, sv.w,
+                            sv.h, sv.c, (float)qx, (float)qy, csi);
+                        if (pass == 0) {
+                            sum0[c] += cm;
+                            sum1[c] += cs;
+                        } else {
+                            double const a = cm - mean0[c];
+                            double const b = cs - mean1[c];
+                            n0 += a * a;
+                            n1 += b * b;
+                            dot += a * b;
+                        }
+                    }
+                }
+            if (pass == 0) {
+                inside = group_all(inside, G, lane);
+                for (int c = 0; c < 3; ++c) {
+                    mean0[c] = group_sum(sum0[c], G) / n;
+                    mean1[c] = group_sum(sum1[c], G) / n;
+                }
+            }
+        }
+        n0 = sqrt(group_sum(n0, G));
+        n1 = sqrt(group_sum(n1, G));
+        dot = group_sum(dot, G);
+        if (!inside)
+            ncc = -1.0;
+        else if (n0 + n1 < 0.001 * n)
+            ncc = 1.0;
+        else
+            ncc = dot / (n0 * n1);
     }
-    if (worst > 8.0)
-        return;
-    if (A.use_ncc && ncc_for_patch(A, n16, px, py, s) < 0)
-        return;
-    atomicOr(&A.vis_out[p], 1u << s);
+    if (alive && gl == 0 && !(ncc < 0))
+        atomicOr(&A.vis_out[p], 1u << s);
 }
 
-// ---- mse_for_patch (:747-790), one thread per patch ----
-__global__ void __launch_bounds__(128)
+// ---- mse_for_patch (:747-790), one lane group per patch ----
+__global__ void __launch_bounds__(256)
 topo_mse_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
-    int const p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.num_patches)
-        return;
-    if (!A.patch_valid[p]) {
-        A.mse_out[p] = -1.0;
-        return;
-    }
-    double n16[16];
-    load_patch_nodes(A, p, n16);
     int const ps = A.ps;
-    int const px = A.start_x + (p % A.npx) * ps;
-    int const py = A.start_y + (p / A.npx) * ps;
-    uint32_t const vis = A.patch_vis[p];
+    int const G = group_size(ps);
+    int const gl = threadIdx.x % G;
+    int const p = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) / G);
+    bool const in_range = p < A.num_patches;
+    bool const alive = in_range && A.patch_valid[p];
+    int const pc = alive ? p : 0;
+    double n16[16];
+    load_patch_nodes(A, pc, n16);
+    int const px = A.start_x + (pc % A.npx) * ps;
+    int const py = A.start_y + (pc / A.npx) * ps;
+    uint32_t const vis = alive ? A.patch_vis[pc] : 0u;
     double error = 0.0, counter = 0.0;
-    for (int j = 0; j < ps; ++j)
-        for (int i = 0; i < ps; ++i) {
+    if (alive)
+        for (int k = gl; k < ps * ps; k += G) {
+            int const i = k % ps, j = k / ps;
             double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
             double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
             double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
@@ -293,7 +346,11 @@ topo_mse_kernel(TopoArgs A)
                 counter += 1.0;
             }
         }
-    A.mse_out[p] = counter == 0.0 ? 1.0 : error / counter;
+    error = group_sum(error, G);
+    counter = group_sum(counter, G);
+    if (in_range && gl == 0)
+        A.mse_out[p] = !alive ? -1.0
+            : (counter == 0.0 ? 1.0 : error / counter);
 }
 
 static int
@@ -412,7 +469,9 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         sizeof(uint32_t) * ctx->num_patches, ctx->stream));
     hipLaunchKernelGGL(topo_splat_kernel, dim3((ctx->width + 255) / 256,
         ctx->height), dim3(256), 0, ctx->stream, A);
-    long long const items = (long long)ctx->num_patches * ctx->n_subs;
+    int const pp = ctx->patchsize * ctx->patchsize;
+    long long const group = pp >= 64 ? 64 : pp;
+    long long const items = (long long)ctx->num_patches * ctx->n_subs * group;
     hipLaunchKernelGGL(topo_visibility_kernel,
         dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
     SMVS_HIP_CHECK(hipGetLastError());
@@ -447,9 +506,11 @@ smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
     TopoArgs A;
     if ((rc = fill_args(ctx, &A, "smvs_topology_patch_mse")) != SMVS_OK)
         return rc;
+    int const pp = ctx->patchsize * ctx->patchsize;
+    long long const group = pp >= 64 ? 64 : pp;
+    long long const items = (long long)ctx->num_patches * group;
     hipLaunchKernelGGL(topo_mse_kernel,
-        dim3((unsigned)((ctx->num_patches + 127) / 128)), dim3(128), 0,
-        ctx->stream, A);
+        dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
     SMVS_HIP_CHECK(hipGetLastError());
     SMVS_HIP_CHECK(hipMemcpyAsync(mse_out, ctx->topo_mse,
         sizeof(double) * ctx->num_patches, hipMemcpyDeviceToHost, ctx->stream));
