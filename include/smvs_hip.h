@@ -252,6 +252,18 @@ int smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
  * patches.  cut_boundaries (:360-431) thresholds it at 0.05. */
 int smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out);
 
+/* The `while (deleted > 10) cut_boundaries()` loops of the optimiser
+ * (depth_optimizer.cc:186-190, 323-337; cut_boundaries :360-431) on the
+ * surface of smvs_ctx_set_surface (incl. its visibility masks): every pass
+ * deletes patches with a depth discontinuity (:371-399) and patches that have
+ * a node with more than one missing neighbour node and mse_for_patch > 0.05
+ * (:401-428), then nodes without a patch (Surface::remove_nodes_without_patch).
+ * inv_calibration9: CameraInfo::fill_inverse_calibration of the main view.
+ * patch_valid_out[num_patches], node_valid_out[num_nodes]: validity after the
+ * last pass (also the context's); *total_deleted (may be NULL). */
+int smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
+    uint8_t *patch_valid_out, uint8_t *node_valid_out, int *total_deleted);
+
 /* ------------------------------------------------------------------ */
 /* measurement                                                        */
 /* ------------------------------------------------------------------ */

@@ -65,6 +65,7 @@ enum {
     I_TICKET2,
     I_TICKET3,
     I_MAXITER,
+    I_TOPO_DELETED,  // patches deleted by one cut_boundaries pass
     I_NUM = 16
 };
 

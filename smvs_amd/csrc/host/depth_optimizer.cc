@@ -298,8 +298,7 @@ DepthOptimizer::optimize(void)
     }
     {
         ScopedHostTimer timer("depth + normal maps");
-        main_view->write_depth_to_view(surface->get_depth_map(),
-            opts.output_name);
+        main_view->write_depth_to_view(this->get_depth(), opts.output_name);
         main_view->write_image_to_view(this->get_normals(),
             opts.output_name + "N");
     }
@@ -309,13 +308,23 @@ DepthOptimizer::optimize(void)
 FloatImage::Ptr
 DepthOptimizer::get_depth(void)
 {
-    return surface->get_depth_map();
+    // Surface::get_depth_map (lib/surface.cc:155-168) on the device
+    this->upload_surface();
+    FloatImage::Ptr dm = FloatImage::create(main_view->get_width(),
+        main_view->get_height(), 1);
+    check(smvs_get_depth_map(ctx, dm->begin()), "smvs_get_depth_map");
+    return dm;
 }
 
 FloatImage::Ptr
 DepthOptimizer::get_normals(void)
 {
-    return surface->get_normal_map(main_view->get_inverse_flen());
+    // Surface::get_normal_map (lib/surface.cc:170-183) on the device
+    this->upload_surface();
+    FloatImage::Ptr nm = FloatImage::create(main_view->get_width(),
+        main_view->get_height(), 3);
+    check(smvs_get_normal_map(ctx, nm->begin()), "smvs_get_normal_map");
+    return nm;
 }
 
 void
@@ -394,99 +403,27 @@ DepthOptimizer::run_newton_iterations(int num_iters)
     }
 }
 
-void
-DepthOptimizer::refresh_patch_mse(void)
-{
-    // mse_for_patch (lib/depth_optimizer.cc:747-790) for all patches at once
-    // on the device.  The values only depend on the nodes and on the
-    // visibility masks, which the passes of cut_boundaries do not change.
-    this->upload_surface();
-    patch_mse.resize(surface->get_num_patches());
-    check(smvs_topology_patch_mse(ctx, patch_mse.data()),
-        "smvs_topology_patch_mse");
-}
-
 int
 DepthOptimizer::cut_boundaries_until_stable(void)
 {
-    // the `while (deleted > 10)` loops of lib/depth_optimizer.cc:186-190,
-    // 323-337
-    this->refresh_patch_mse();
-    int total = 0;
-    int deleted = std::numeric_limits<int>::max();
-    while (deleted > 10) {
-        deleted = this->cut_boundaries();
-        total += deleted;
-    }
-    return total;
-}
-
-int
-DepthOptimizer::cut_boundaries(void)
-{
-    // lib/depth_optimizer.cc:360-431
-    int deleted = 0;
-    int const ps = surface->get_patchsize();
+    // The `while (deleted > 10) cut_boundaries()` loops of
+    // lib/depth_optimizer.cc:186-190, 323-337 with cut_boundaries (:360-431)
+    // and mse_for_patch (:747-790) on the device; the host applies the
+    // resulting validity to its Surface.
+    this->upload_surface();
     float invproj[9];
     main_view->get_camera().fill_inverse_calibration(invproj,
         (float)main_view->get_width(), (float)main_view->get_height());
     std::size_t const num_patches = surface->get_num_patches();
-
-    // depth discontinuities
-    for (std::size_t p = 0; p < num_patches; ++p) {
-        if (!surface->patch_validity()[p])
-            continue;
-        double n16[16];
-        surface->fill_patch_nodes(p, n16);
-        double const f[4] = { n16[0], n16[4], n16[8], n16[12] };
-        int lo = 0, hi = 0;  // first minimum, last maximum (multimap order)
-        for (int i = 1; i < 4; ++i) {
-            if (f[i] < f[lo])
-                lo = i;
-            if (f[i] >= f[hi])
-                hi = i;
-        }
-        double dd_factor = 5.0;
-        if (lo + hi == 3)
-            dd_factor *= 1.41421356237309504880;
-        int px, py;
-        surface->patch_origin(p, &px, &py);
-        float const fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-        float v[3];
-        for (int r = 0; r < 3; ++r)
-            v[r] = invproj[3 * r] * fx + invproj[3 * r + 1] * fy
-                + invproj[3 * r + 2] * 1.0f;
-        float const vnorm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        double const threshold = dd_factor * f[lo] * invproj[0] * ps / vnorm;
-        if (f[hi] - f[lo] > threshold) {
+    std::vector<uint8_t> pv(num_patches), nv(surface->get_num_nodes());
+    int total = 0;
+    check(smvs_topology_cut_boundaries(ctx, invproj, pv.data(), nv.data(),
+        &total), "smvs_topology_cut_boundaries");
+    for (std::size_t p = 0; p < num_patches; ++p)
+        if (surface->patch_validity()[p] && !pv[p])
             surface->delete_patch(p);
-            deleted += 1;
-        }
-    }
-    // high-error patches on the border of the surface
-    int const stride = surface->get_node_stride();
-    for (std::size_t p = 0; p < num_patches; ++p) {
-        if (!surface->patch_validity()[p])
-            continue;
-        std::size_t ids[4];
-        surface->fill_node_ids_for_patch(p, ids);
-        double const error = patch_mse[p];
-        for (int k = 0; k < 4; ++k) {
-            int const nx = (int)(ids[k] % stride), ny = (int)(ids[k] / stride);
-            int missing = 0;
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx)
-                    if ((dx || dy) && !surface->node_exists(nx + dx, ny + dy))
-                        missing += 1;
-            if (missing > 1 && error > 0.05) {
-                surface->delete_patch(p);
-                deleted += 1;
-                break;
-            }
-        }
-    }
     surface->remove_nodes_without_patch();
-    return deleted;
+    return total;
 }
 
 void

@@ -65,9 +65,7 @@ private:
     void create_initial_surface(void);
     void create_subview_surfaces(void);
     void run_newton_iterations(int num_iters);
-    int cut_boundaries(void);
     int cut_boundaries_until_stable(void);
-    void refresh_patch_mse(void);
     FloatImage::Ptr depthmap_bilateral_filter(FloatImage::ConstPtr dm,
         FloatImage::ConstPtr ci, float sigma = 5, int kernel_size = 5);
     void fit_lighting(void);
@@ -85,7 +83,6 @@ private:
     FloatImage::ConstPtr sgm_depth;
     Surface::Ptr surface;
     std::vector<uint32_t> subsurfaces;   // bit j: neighbour j sees the patch
-    std::vector<double> patch_mse;       // mse_for_patch of every patch (device)
     bool lit = false;
     bool images_uploaded = false;
     double lighting[16];

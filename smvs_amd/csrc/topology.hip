@@ -44,6 +44,12 @@ struct TopoArgs {
     int ncc_off[33];
     int W, H, npx, npy, stride, ps, start_x, start_y, n_subs, num_patches;
     int use_ncc;
+    // cut_boundaries
+    uint8_t *patch_valid_rw;
+    uint8_t *node_valid_rw;
+    int *deleted;               // status word
+    float invproj[9];
+    int num_nodes;
 };
 
 __device__ __forceinline__ void
@@ -353,6 +359,89 @@ topo_mse_kernel(TopoArgs A)
             : (counter == 0.0 ? 1.0 : error / counter);
 }
 
+// ---- one pass of cut_boundaries (:360-431), patches ----
+__global__ void __launch_bounds__(256)
+topo_cut_patches_kernel(TopoArgs A)
+{
+#pragma clang fp contract(off)
+    int const p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool remove = false;
+    if (p < A.num_patches && A.patch_valid_rw[p]) {
+        int const ix = p % A.npx, iy = p / A.npx;
+        int const n00 = iy * A.stride + ix;
+        int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+        // depth discontinuity (:371-399)
+        double f[4];
+        for (int k = 0; k < 4; ++k)
+            f[k] = A.nodes[4 * (size_t)ids[k]];
+        int lo = 0, hi = 0;  // first minimum, last maximum (multimap order)
+        for (int i = 1; i < 4; ++i) {
+            if (f[i] < f[lo])
+                lo = i;
+            if (f[i] >= f[hi])
+                hi = i;
+        }
+        double dd_factor = 5.0;
+        if (lo + hi == 3)
+            dd_factor *= 1.41421356237309504880;
+        int const px = A.start_x + ix * A.ps, py = A.start_y + iy * A.ps;
+        float const fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+        float v[3];
+        for (int r = 0; r < 3; ++r)
+            v[r] = A.invproj[3 * r] * fx + A.invproj[3 * r + 1] * fy
+                + A.invproj[3 * r + 2] * 1.0f;
+        float const vnorm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        double const threshold = dd_factor * f[lo] * A.invproj[0] * A.ps / vnorm;
+        if (f[hi] - f[lo] > threshold)
+            remove = true;
+        // high-error patch on the border of the surface (:401-428); node
+        // validity is the state before this pass
+        if (!remove && A.mse_out[p] > 0.05) {
+            for (int k = 0; k < 4 && !remove; ++k) {
+                int const nx = ids[k] % A.stride, ny = ids[k] / A.stride;
+                int missing = 0;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (!dx && !dy)
+                            continue;
+                        int const mx = nx + dx, my = ny + dy;
+                        bool const exists = mx >= 0 && my >= 0 && mx <= A.npx
+                            && my <= A.npy
+                            && A.node_valid_rw[(size_t)my * A.stride + mx] != 0;
+                        missing += exists ? 0 : 1;
+                    }
+                if (missing > 1)
+                    remove = true;
+            }
+        }
+        if (remove)
+            A.patch_valid_rw[p] = 0;
+    }
+    int const cnt = __syncthreads_count(remove);
+    if (threadIdx.x == 0 && cnt != 0)
+        atomicAdd(A.deleted, cnt);
+}
+
+// ---- Surface::remove_nodes_without_patch (surface.cc:762-869) ----
+__global__ void __launch_bounds__(256)
+topo_cut_nodes_kernel(TopoArgs A)
+{
+    int const n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= A.num_nodes || !A.node_valid_rw[n])
+        return;
+    int const idx = n % A.stride, idy = n / A.stride;
+    bool any = false;
+    for (int dy = -1; dy <= 0; ++dy)
+        for (int dx = -1; dx <= 0; ++dx) {
+            int const qx = idx + dx, qy = idy + dy;
+            if (qx >= 0 && qy >= 0 && qx < A.npx && qy < A.npy
+                && A.patch_valid_rw[(size_t)qy * A.npx + qx])
+                any = true;
+        }
+    if (!any)
+        A.node_valid_rw[n] = 0;
+}
+
 static int
 fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
 {
@@ -397,6 +486,12 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     A->n_subs = ctx->n_subs;
     A->num_patches = ctx->num_patches;
     A->use_ncc = 0;
+    A->patch_valid_rw = ctx->patch_valid;
+    A->node_valid_rw = ctx->node_valid;
+    A->deleted = ctx->status + I_TOPO_DELETED;
+    A->num_nodes = ctx->num_nodes;
+    for (int i = 0; i < 9; ++i)
+        A->invproj[i] = 0.0f;
     return SMVS_OK;
 }
 
@@ -482,18 +577,16 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
     return SMVS_OK;
 }
 
-extern "C" int
-smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
+static int
+launch_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
 {
-    SMVS_REQUIRE(ctx && mse_out, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     if (ctx->main_grad == nullptr) {
-        set_error("smvs_topology_patch_mse: no gradient planes");
+        set_error("%s: no gradient planes", who);
         return SMVS_ERR_STATE;
     }
     for (int j = 0; j < ctx->n_subs; ++j)
         if (ctx->subs[j].grad == nullptr) {
-            set_error("smvs_topology_patch_mse: sub view %d has no planes", j);
+            set_error("%s: sub view %d has no planes", who, j);
             return SMVS_ERR_STATE;
         }
     int rc;
@@ -503,17 +596,70 @@ smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
             return rc;
         ctx->topo_mse_cap = (size_t)ctx->num_patches;
     }
-    TopoArgs A;
-    if ((rc = fill_args(ctx, &A, "smvs_topology_patch_mse")) != SMVS_OK)
+    if ((rc = fill_args(ctx, A, who)) != SMVS_OK)
         return rc;
     int const pp = ctx->patchsize * ctx->patchsize;
     long long const group = pp >= 64 ? 64 : pp;
     long long const items = (long long)ctx->num_patches * group;
     hipLaunchKernelGGL(topo_mse_kernel,
-        dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+        dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, *A);
     SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
+{
+    SMVS_REQUIRE(ctx && mse_out, "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    TopoArgs A;
+    int const rc = launch_patch_mse(ctx, &A, "smvs_topology_patch_mse");
+    if (rc != SMVS_OK)
+        return rc;
     SMVS_HIP_CHECK(hipMemcpyAsync(mse_out, ctx->topo_mse,
         sizeof(double) * ctx->num_patches, hipMemcpyDeviceToHost, ctx->stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
+    uint8_t *patch_valid_out, uint8_t *node_valid_out, int *total_deleted)
+{
+    SMVS_REQUIRE(ctx && inv_calibration9 && patch_valid_out && node_valid_out,
+        "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    TopoArgs A;
+    int const rc = launch_patch_mse(ctx, &A, "smvs_topology_cut_boundaries");
+    if (rc != SMVS_OK)
+        return rc;
+    for (int i = 0; i < 9; ++i)
+        A.invproj[i] = inv_calibration9[i];
+    int total = 0;
+    int deleted = 11;
+    while (deleted > 10) {   // depth_optimizer.cc:186-190, 323-337
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_TOPO_DELETED, 0,
+            sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(topo_cut_patches_kernel,
+            dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0,
+            ctx->stream, A);
+        hipLaunchKernelGGL(topo_cut_nodes_kernel,
+            dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
+            ctx->stream, A);
+        SMVS_HIP_CHECK(hipGetLastError());
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host + I_TOPO_DELETED,
+            ctx->status + I_TOPO_DELETED, sizeof(int), hipMemcpyDeviceToHost,
+            ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        deleted = ctx->status_host[I_TOPO_DELETED];
+        total += deleted;
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(patch_valid_out, ctx->patch_valid,
+        (size_t)ctx->num_patches, hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpyAsync(node_valid_out, ctx->node_valid,
+        (size_t)ctx->num_nodes, hipMemcpyDeviceToHost, ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (total_deleted != nullptr)
+        *total_deleted = total;
     return SMVS_OK;
 }
