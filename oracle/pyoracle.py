@@ -570,3 +570,65 @@ def scale_planes(img_u8, scale):
     lib().orc_scale_planes(_p(img, c_u8_p), w, h, c, C.c_int(scale),
                            _p(g, c_float_p), _p(hs, c_float_p))
     return g, hs
+
+
+# ---------------------------------------------------------------------------
+# topology tests between Newton batches (depth_optimizer.cc:360-604, 747-912)
+# ---------------------------------------------------------------------------
+class TopoView(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("c", C.c_int),
+                ("image", c_float_p), ("grad", c_float_p), ("flen", C.c_float)]
+
+
+class TopologyProblem:
+    """Surface + float images + gradient planes for the orc_topology_* entry
+    points.  images[0] / grads[0] belong to the main view."""
+
+    def __init__(self, surf, images, grads, M, t, flen):
+        self.nodes = f64(surf["nodes"]).reshape(-1, 4).copy()
+        self.node_valid = np.ascontiguousarray(surf["node_valid"], dtype=np.uint8).copy()
+        self.patch_valid = np.ascontiguousarray(surf["patch_valid"], dtype=np.uint8).copy()
+        self.patch_vis = np.ascontiguousarray(surf["patch_vis"], dtype=np.uint32).copy()
+        s = Surface()
+        s.width, s.height = surf["width"], surf["height"]
+        s.scale = surf["scale"]; s.patchsize = 1 << surf["scale"]
+        s.npx, s.npy = surf["npx"], surf["npy"]
+        s.start_x, s.start_y = surf["start_x"], surf["start_y"]
+        s.nodes = _p(self.nodes, c_double_p)
+        s.node_valid = _p(self.node_valid, c_u8_p)
+        s.patch_valid = _p(self.patch_valid, c_u8_p)
+        s.patch_vis = _p(self.patch_vis, c_u32_p)
+        self.surf = s
+        self.images = [f32(im if im.ndim == 3 else im[:, :, None]) for im in images]
+        self.grads = [f32(g) for g in grads]
+        self.M = f64(M).reshape(-1, 9); self.t = f64(t).reshape(-1, 3)
+        n = len(images) - 1
+        self.n_subs = n
+        self.main = TopoView()
+        self.subs = (TopoView * n)()
+        for k, tv in enumerate([self.main] + [self.subs[j] for j in range(n)]):
+            im = self.images[k]
+            tv.h, tv.w, tv.c = im.shape
+            tv.image = _p(im, c_float_p)
+            tv.grad = _p(self.grads[k], c_float_p)
+            tv.flen = flen
+
+    def subviews(self, sgm_depth=None):
+        sd = f32(sgm_depth) if sgm_depth is not None else None
+        lib().orc_topology_subviews(C.byref(self.surf), C.byref(self.main), self.subs,
+                                    self.n_subs, _p(self.M, c_double_p), _p(self.t, c_double_p),
+                                    _p(sd, c_float_p), 1 if sd is not None else 0)
+        return self.patch_vis.copy()
+
+    def patch_mse(self):
+        out = np.zeros(self.patch_valid.size)
+        lib().orc_topology_patch_mse(C.byref(self.surf), C.byref(self.main), self.subs,
+                                     self.n_subs, _p(self.M, c_double_p), _p(self.t, c_double_p),
+                                     _p(out, c_double_p))
+        return out
+
+    def cut_boundaries(self):
+        lib().orc_topology_cut_boundaries.restype = C.c_int
+        return lib().orc_topology_cut_boundaries(C.byref(self.surf), C.byref(self.main),
+                                                 self.subs, self.n_subs, _p(self.M, c_double_p),
+                                                 _p(self.t, c_double_p))

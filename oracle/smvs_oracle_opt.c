@@ -1098,6 +1098,82 @@ opt_cut_boundaries(OOpt *O)
     return deleted;
 }
 
+/* ---------------------------------------------------------------------- */
+/* Test access to the topology tests above on caller-provided state         */
+/* (the device versions, smvs_topology_*, are checked against these).       */
+/* ---------------------------------------------------------------------- */
+static void
+topo_setup(OOpt *O, OView *mainv, OView *subv, orc_opt_options *opts,
+    orc_surface *s, const orc_topo_view *main_view, const orc_topo_view *subs,
+    int n_subs, const double *Mi, const double *ti, const float *sgm_depth,
+    int use_sgm)
+{
+    memset(O, 0, sizeof(*O));
+    memset(opts, 0, sizeof(*opts));
+    opts->use_sgm = use_sgm;
+    O->opts = opts;
+    memset(mainv, 0, sizeof(*mainv));
+    mainv->w = main_view->w; mainv->h = main_view->h; mainv->c = main_view->c;
+    mainv->image = (float *)main_view->image;
+    mainv->grad = (float *)main_view->grad;
+    fill_calibration(main_view->flen, mainv->w, mainv->h, mainv->K, mainv->Kinv);
+    for (int j = 0; j < n_subs; ++j)
+    {
+        memset(&subv[j], 0, sizeof(OView));
+        subv[j].w = subs[j].w; subv[j].h = subs[j].h; subv[j].c = subs[j].c;
+        subv[j].image = (float *)subs[j].image;
+        subv[j].grad = (float *)subs[j].grad;
+    }
+    O->main = mainv;
+    O->subs = subv;
+    O->n_subs = n_subs;
+    O->Mi = (double *)Mi;
+    O->ti = (double *)ti;
+    O->surf.s = *s;
+    O->sgm_depth = sgm_depth;
+}
+
+void
+orc_topology_subviews(orc_surface *s, const orc_topo_view *main_view,
+    const orc_topo_view *subs, int n_subs, const double *Mi, const double *ti,
+    const float *sgm_depth, int use_sgm)
+{
+    OOpt O; OView mainv; OView subv[32]; orc_opt_options opts;
+    topo_setup(&O, &mainv, subv, &opts, s, main_view, subs, n_subs, Mi, ti,
+        sgm_depth, use_sgm);
+    opt_create_subview_surfaces(&O);
+}
+
+void
+orc_topology_patch_mse(orc_surface *s, const orc_topo_view *main_view,
+    const orc_topo_view *subs, int n_subs, const double *Mi, const double *ti,
+    double *mse_out)
+{
+    OOpt O; OView mainv; OView subv[32]; orc_opt_options opts;
+    topo_setup(&O, &mainv, subv, &opts, s, main_view, subs, n_subs, Mi, ti,
+        NULL, 0);
+    int const np = s->npx * s->npy;
+    for (int p = 0; p < np; ++p)
+        mse_out[p] = s->patch_valid[p] ? opt_mse_for_patch(&O, p) : -1.0;
+}
+
+int
+orc_topology_cut_boundaries(orc_surface *s, const orc_topo_view *main_view,
+    const orc_topo_view *subs, int n_subs, const double *Mi, const double *ti)
+{
+    OOpt O; OView mainv; OView subv[32]; orc_opt_options opts;
+    topo_setup(&O, &mainv, subv, &opts, s, main_view, subs, n_subs, Mi, ti,
+        NULL, 0);
+    /* the loops of depth_optimizer.cc:186-190, 323-337 */
+    int total = 0, deleted = 11;
+    while (deleted > 10)
+    {
+        deleted = opt_cut_boundaries(&O);
+        total += deleted;
+    }
+    return total;
+}
+
 static void
 log_push(orc_opt_log *log, int scale, int iter, int steps, int patches,
     int cg_iterations)

@@ -51,6 +51,30 @@ typedef struct {
     double lighting[16];
 } orc_opt_log;
 
+/* Test access to the topology tests between Newton batches on caller-provided
+ * state.  The orc_surface arrays (patch_vis, patch_valid, node_valid) are
+ * modified in place like the optimiser's own surface. */
+typedef struct {
+    int w, h, c;
+    const float *image;   /* byte_to_float_image, w*h*c (StereoView::get_image) */
+    const float *grad;    /* current scale, w*h*2 */
+    float flen;           /* CameraInfo::flen (main view only) */
+} orc_topo_view;
+
+/* create_subview_surfaces, depth_optimizer.cc:433-604 (sgm_depth: filtered,
+ * full resolution, or NULL) */
+void orc_topology_subviews(orc_surface *s, const orc_topo_view *main_view,
+    const orc_topo_view *subs, int n_subs, const double *Mi, const double *ti,
+    const float *sgm_depth, int use_sgm);
+/* mse_for_patch, :747-790, for every valid patch (-1 otherwise) */
+void orc_topology_patch_mse(orc_surface *s, const orc_topo_view *main_view,
+    const orc_topo_view *subs, int n_subs, const double *Mi, const double *ti,
+    double *mse_out);
+/* `while (deleted > 10) deleted = cut_boundaries();` (:186-190, :360-431);
+ * returns the total number of deleted patches */
+int orc_topology_cut_boundaries(orc_surface *s, const orc_topo_view *main_view,
+    const orc_topo_view *subs, int n_subs, const double *Mi, const double *ti);
+
 /* depth_optimizer.cc:53-162.  sgm_depth: what StereoView::get_sgm_depth()
  * returns (z-depth, sgm_width x sgm_height) or NULL.  depth_out W*H,
  * normals_out W*H*3 (either may be NULL). */

@@ -234,6 +234,16 @@ class ViewContext:
         check(self.lib.smvs_topology_patch_mse(self.handle, _p(mse, _dp)))
         return mse
 
+    def topology_cut_boundaries(self, inv_calibration):
+        """`while (deleted > 10) cut_boundaries()` -> (patch_valid, node_valid, deleted)."""
+        k = _f32(inv_calibration).reshape(9)
+        pv = np.zeros(self.num_patches, dtype=np.uint8)
+        nv = np.zeros(self.num_nodes, dtype=np.uint8)
+        n = C.c_int(0)
+        check(self.lib.smvs_topology_cut_boundaries(self.handle, _p(k, _fp),
+              _p(pv, _u8p), _p(nv, _u8p), C.byref(n)))
+        return pv, nv, n.value
+
     def synchronize(self):
         check(self.lib.smvs_ctx_synchronize(self.handle))
 

@@ -484,3 +484,88 @@ def test_full_size_sgm_bit_exact(hip, oracle):
     depth, argmin = oracle.sgm_depth_from_volume(sgm, main, depths)
     assert np.array_equal(out["argmin"], argmin)
     assert np.array_equal(out["depth"], depth)
+
+
+# ---------------------------------------------------------------------------
+# topology tests between Newton batches
+# ---------------------------------------------------------------------------
+def _topology_setup(hip, oracle, width, height, n_subs, scale, noise):
+    from smvs_amd import synth
+    prob = synth.make_problem(width, height, n_subs, scale, noise=noise)
+    surf = dict(prob["surf"])
+    # every patch of the grid takes part: silhouette-straddling and
+    # background patches exercise the occlusion / border / NCC branches
+    surf["patch_valid"] = np.ones_like(surf["patch_valid"])
+    surf["node_valid"] = np.ones_like(surf["node_valid"])
+    surf["patch_vis"] = np.zeros_like(surf["patch_vis"])
+    ctx = hip.ViewContext(width, height, n_subs)
+    ctx.set_views(prob["views"])                  # cameras (planes are replaced below)
+    for v, img in enumerate(prob["images"]):
+        ctx.upload_image(v - 1, img)
+    ctx.set_scale(scale)                          # device scale space
+    grads = [ctx.download_planes(v - 1)[0] for v in range(n_subs + 1)]
+    images = [img.astype(np.float32) / np.float32(255.0) for img in prob["images"]]
+    tp = oracle.TopologyProblem(surf, images, grads, prob["views"]["M"],
+                                prob["views"]["t"], prob["main"].flen)
+    return prob, surf, ctx, tp
+
+
+def _inverse_calibration(flen, w, h):
+    f = np.float32
+    ax = f(flen) * f(max(w, h))
+    return np.array([f(1) / ax, 0, -f(w) * f(0.5) / ax, 0, f(1) / ax,
+                     -f(h) * f(0.5) / ax, 0, 0, 1], dtype=np.float32)
+
+
+@pytest.mark.parametrize("size,n_subs,scale", [((320, 256), 4, 2), ((384, 256), 3, 3),
+                                               ((512, 384), 2, 4)])
+def test_topology_subviews_mse_and_cuts_match_oracle(hip, oracle, size, n_subs, scale):
+    """create_subview_surfaces, mse_for_patch and the cut_boundaries loop
+    (depth_optimizer.cc:360-604, 747-912) on the device against the oracle:
+    identical visibility masks and validity, MSE to 1e-10."""
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, size[0], size[1], n_subs, scale, 0.01)
+    ctx.set_surface(surf)
+    vis_gpu = ctx.topology_subviews(None, use_ncc=True)
+    vis_ref = tp.subviews()
+    assert np.array_equal(vis_gpu, vis_ref)
+    # the test is not vacuous: visible, partly visible and invisible patches
+    assert (vis_ref == 0).any() and (vis_ref == (1 << n_subs) - 1).any()
+    assert ((vis_ref != 0) & (vis_ref != (1 << n_subs) - 1)).any()
+
+    # continue from the oracle's surface (invisible patches deleted)
+    surf2 = dict(surf)
+    surf2["patch_valid"] = tp.patch_valid.copy()
+    surf2["node_valid"] = tp.node_valid.copy()
+    surf2["patch_vis"] = tp.patch_vis.copy()
+    ctx.set_surface(surf2)
+    mse_gpu = ctx.topology_patch_mse()
+    mse_ref = tp.patch_mse()
+    valid = surf2["patch_valid"] != 0
+    assert np.all(mse_gpu[~valid] == -1.0)
+    assert np.max(np.abs(mse_gpu[valid] - mse_ref[valid]) / np.maximum(mse_ref[valid], 1e-30)) < 1e-10
+
+    pv, nv, deleted = ctx.topology_cut_boundaries(
+        _inverse_calibration(prob["main"].flen, size[0], size[1]))
+    deleted_ref = tp.cut_boundaries()
+    assert deleted == deleted_ref
+    if scale <= 3:
+        assert deleted_ref > 0   # the passes actually delete something
+    assert np.array_equal(pv, tp.patch_valid)
+    assert np.array_equal(nv, tp.node_valid)
+    ctx.close()
+
+
+def test_topology_subviews_with_sgm_depth(hip, oracle):
+    """use_sgm variant: the SGM depth is splatted into the z-buffers too and
+    the NCC test is skipped (depth_optimizer.cc:463-466, 577-580)."""
+    from smvs_amd import synth
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, 320, 256, 3, 2, 0.0)
+    xs, ys = np.meshgrid(np.arange(320, dtype=float), np.arange(256, dtype=float))
+    sgm = synth.depth_at(prob["scene"], prob["main"], xs, ys).astype(np.float32)
+    sgm[::7, ::5] = 0.0            # holes, as SGM leaves them
+    sgm[100:140, 150:200] *= 0.8   # a wrong foreground blob occludes real surface
+    ctx.set_surface(surf)
+    vis_gpu = ctx.topology_subviews(sgm, use_ncc=False)
+    vis_ref = tp.subviews(sgm)
+    assert np.array_equal(vis_gpu, vis_ref)
+    ctx.close()
