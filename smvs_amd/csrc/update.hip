@@ -506,7 +506,14 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->scalars_host, ctx->scalars,
             sizeof(double) * S_NUM, hipMemcpyDeviceToHost, ctx->stream));
-        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // spin instead of a blocking wait: the next step's launches should
+        // follow the end of this one within microseconds
+        {
+            hipError_t q;
+            while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
+                __builtin_ia32_pause();
+            SMVS_HIP_CHECK(q);
+        }
         stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
         if (ctx->status_host[I_NAN]) {
             stats->nan_break = 1;
