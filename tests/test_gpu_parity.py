@@ -569,3 +569,36 @@ def test_topology_subviews_with_sgm_depth(hip, oracle):
     vis_ref = tp.subviews(sgm)
     assert np.array_equal(vis_gpu, vis_ref)
     ctx.close()
+
+
+def test_full_size_shading_step_matches_oracle(hip, oracle):
+    """configs[3]: the shading-aware step at 1920x1080 with 8 neighbours --
+    SH lighting fit (light_optimizer.cc:22-55) and the construct with the
+    shading residual (gauss_newton_step.cc:420-517), sampled patches."""
+    import bench
+    from smvs_amd import synth
+    prob = synth.make_problem(bench.W, bench.H, bench.NSUBS, bench.SCALE, shading=True,
+                              noise=bench.NOISE)
+    surf = prob["surf"]
+    ctx = hip.ViewContext(bench.W, bench.H, bench.NSUBS)
+    ctx.set_views(prob["views"])
+    ctx.set_surface(surf)
+    orc = oracle.OracleProblem(surf, prob["views"])
+    # lighting fit on the current surface
+    A_gpu, b_gpu = ctx.light_accumulate()
+    normals = orc.normal_map()
+    A_ref, b_ref = oracle.light_accumulate(normals, prob["views"]["shading"])
+    assert _rel(A_gpu, A_ref) < 1e-9 and _rel(b_gpu, b_ref) < 1e-9
+    lighting = oracle.light_solve(A_ref, b_ref)
+    # construct with the shading term, geometric regulariser off (Q8) and on
+    valid = np.flatnonzero(surf["patch_valid"])
+    pick = np.random.default_rng(9).choice(valid, size=48, replace=False)
+    for light_reg in (0.0, 0.5):
+        n = ctx.gn_construct(bench.REG, light_reg, lighting)
+        assert n == int(surf["patch_valid"].sum())
+        Hp, gp = ctx.gn_patch_systems()
+        for p in pick:
+            g_ref, H_ref = orc.gn_patch(int(p), bench.REG, light_reg, lighting)
+            assert _rel(np.triu(Hp[p]), np.triu(H_ref)) < 1e-9
+            assert _rel(gp[p], g_ref) < 1e-9
+    ctx.close()
