@@ -112,38 +112,8 @@ warp_kernel(WarpArgs A)
     A.warped[gid] = out;
 }
 
-// census of every warped plane + Hamming distance to the main census
-// (sgm_stereo.cc:224-243): cost 255 where nothing was warped.
-__global__ void __launch_bounds__(256)
-cost_kernel(const uint8_t *__restrict__ warped,
-    const unsigned long long *__restrict__ main_census, int w, int h, int D,
-    uint8_t *__restrict__ cost)
-{
-    size_t const gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t const total = (size_t)w * h * D;
-    if (gid >= total)
-        return;
-    int const d = (int)(gid % D);
-    size_t const p = gid / D;
-    int const x = (int)(p % w), y = (int)(p / w);
-    uint8_t const thr = warped[gid];
-    uint8_t c = 255;
-    if (thr != 0) {
-        unsigned long long census = 0;
-        if (x >= 4 && x < w - 5 && y >= 3 && y < h - 4) {
-            for (int i = x - 4; i < x + 5; ++i)
-                for (int j = y - 3; j < y + 4; ++j) {
-                    census <<= 1;
-                    if (thr < warped[((size_t)j * w + i) * D + d])
-                        census |= 1ull;
-                }
-        }
-        c = (uint8_t)__popcll(main_census[p] ^ census);
-    }
-    cost[gid] = c;
-}
-
-// Tiled version of cost_kernel: a block stages a (16+8) x (8+6) pixel window of
+// Cost volume (sgm_stereo.cc:192-244): census of the warped planes + Hamming
+// distance to the main census.  A block stages a (16+8) x (8+6) pixel window of
 // 64 planes in LDS (each warped byte is needed by 63 census windows), one
 // wavefront walks pixels with its lanes along the plane axis, so LDS reads,
 // global loads and the u8 cost stores are all 64 contiguous bytes.
@@ -408,127 +378,6 @@ path_line(PathArgs const &A, int line, int *x, int *y, int *len, int *extra)
     return true;
 }
 
-// Even plane counts: lane l owns planes (2l, 2l+1) packed in one u16 of C and
-// one u32 of S.  The loads of the next PF pixels are in flight while the
-// dependent recurrence of the current pixel runs (addresses do not depend on
-// the recurrence and every S entry is visited once per path).  With
-// A.last the path that runs last also performs the winner-takes-all of
-// sgm_stereo.cc:274-306 on the finished S values.
-template <int K>
-__global__ void __launch_bounds__(64)
-sgm_path_packed_kernel(PathArgs A, const uint8_t *__restrict__ main_img,
-    const float *__restrict__ depths, float *__restrict__ depth_out,
-    int32_t *__restrict__ argmin_out)
-{
-    int const lane = threadIdx.x;
-    int x0, y0, len, extra_seed;
-    if (!path_line(A, blockIdx.x, &x0, &y0, &len, &extra_seed))
-        return;
-    int const w = A.w, D = A.D;
-    int const pairs = D >> 1;
-    bool const ok = lane < pairs;
-    int const li = ok ? lane : 0;
-    const uint16_t *__restrict__ C16 = reinterpret_cast<const uint16_t *>(A.cost);
-    uint32_t *__restrict__ S32 = reinterpret_cast<uint32_t *>(A.sgm);
-    uint32_t const BIG = 0xFFFFu;
-    uint32_t prev0 = BIG, prev1 = BIG;
-
-    // Chunks of K pixels: the S loads of the chunk and the C loads of the
-    // next chunk are in flight while the dependent recurrence of the chunk
-    // runs from registers; the S stores follow as one burst.
-    uint32_t c_cur[K], c_next[K], s_old[K], addv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        c_cur[k] = 0;
-        if (k < len)
-            c_cur[k] = C16[(((size_t)(y0 + k * A.dy) * w + (x0 + k * A.dx)) * D >> 1) + li];
-    }
-    for (int base = 0; base < len; base += K) {
-        int const n = min(K, len - base);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            s_old[k] = 0;
-            if (!A.first && k < n) {
-                int const s = base + k;
-                s_old[k] = S32[(((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            c_next[k] = 0;
-            int const s = base + K + k;
-            if (s < len)
-                c_next[k] = C16[(((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k < n) {
-            int const s = base + k;
-            uint32_t const c0 = c_cur[k] & 0xFFu, c1 = c_cur[k] >> 8;
-            uint32_t l0, l1;
-            if (s == 0) {
-                l0 = c0;
-                l1 = c1;
-            } else {
-                uint32_t const mn = wave_min_u32(min(prev0, prev1));
-                // lanes outside the plane range hold BIG, which already acts
-                // as "no neighbour"; BIG + p1 must not wrap into range
-                uint32_t const left = lane_prev(prev1, BIG);
-                uint32_t const right = lane_next(prev0, BIG);
-                uint32_t const far = (mn + A.p2) & 0xFFFFu;
-                uint32_t u0 = prev0;
-                u0 = min(u0, left == BIG ? BIG : ((left + A.p1) & 0xFFFFu));
-                u0 = min(u0, (prev1 + A.p1) & 0xFFFFu);
-                u0 = min(u0, far);
-                uint32_t u1 = prev1;
-                u1 = min(u1, (prev0 + A.p1) & 0xFFFFu);
-                u1 = min(u1, right == BIG ? BIG : ((right + A.p1) & 0xFFFFu));
-                u1 = min(u1, far);
-                l0 = (c0 + u0 - mn) & 0xFFFFu;
-                l1 = (c1 + u1 - mn) & 0xFFFFu;
-            }
-            uint32_t add0 = l0, add1 = l1;
-            if (s == 0 && extra_seed) {
-                add0 = (2 * c0) & 0xFFFFu;
-                add1 = (2 * c1) & 0xFFFFu;
-            }
-            addv[k] = add0 | (add1 << 16);
-            prev0 = ok ? l0 : BIG;
-            prev1 = ok ? l1 : BIG;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k < n) {
-            int const s = base + k;
-            int const x = x0 + s * A.dx, y = y0 + s * A.dy;
-            uint32_t const n0 = ((s_old[k] & 0xFFFFu) + (addv[k] & 0xFFFFu)) & 0xFFFFu;
-            uint32_t const n1 = ((s_old[k] >> 16) + (addv[k] >> 16)) & 0xFFFFu;
-            if (ok)
-                S32[(((size_t)y * w + x) * D >> 1) + li] = n0 | (n1 << 16);
-            if (A.last) {
-                // first minimum wins: order by (value, plane)
-                uint32_t key = ok ? min(n0 * 256u + (uint32_t)(2 * lane),
-                    n1 * 256u + (uint32_t)(2 * lane + 1)) : 0xFFFFFFFFu;
-                key = wave_min_u32(key);
-                if (lane == 0) {
-                    int const min_index = (int)(key & 0xFFu);
-                    size_t const p = (size_t)y * w + x;
-                    if (argmin_out != nullptr)
-                        argmin_out[p] = min_index;
-                    if (depth_out != nullptr)
-                        depth_out[p] = (min_index < 2 || main_img[p] < 25)
-                            ? 0.0f : depths[min_index];
-                }
-            }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            c_cur[k] = c_next[k];
-    }
-}
-
 // All eight path directions in ONE launch.  The recurrences of different
 // directions are independent; only their sums meet in S.  Since the sums are
 // wrapping integer adds, S is accumulated with device-scope atomic adds on
@@ -677,31 +526,6 @@ wta_rows_kernel(const uint16_t *__restrict__ sgm,
             depth[p] = (min_index < 2 || main_img[p] < 25) ? 0.0f
                 : depths[min_index];
     }
-}
-
-// WTA (sgm_stereo.cc:274-306): first minimum wins; invalid if index < 2 or
-// main intensity < 25.
-__global__ void __launch_bounds__(256)
-wta_kernel(const uint16_t *__restrict__ sgm, const uint8_t *__restrict__ main_img,
-    const float *__restrict__ depths, size_t npix, int D,
-    float *__restrict__ depth, int32_t *__restrict__ argmin)
-{
-    size_t const p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix)
-        return;
-    uint32_t min_error = 0xFFFFu;
-    int min_index = 0;
-    for (int i = 0; i < D; ++i) {
-        uint32_t const v = sgm[p * D + i];
-        if (v < min_error) {
-            min_error = v;
-            min_index = i;
-        }
-    }
-    if (argmin != nullptr)
-        argmin[p] = min_index;
-    if (depth != nullptr)
-        depth[p] = (min_index < 2 || main_img[p] < 25) ? 0.0f : depths[min_index];
 }
 
 __global__ void __launch_bounds__(256)
