@@ -274,7 +274,6 @@ enum {
     SMVS_K_ASSEMBLE,      /* block gather + 4x4 LDL (K5)    */
     SMVS_K_CG_SPMV,       /* block-stencil SpMV + d.Ad (K6) */
     SMVS_K_CG_UPDATE,     /* x, r, z update + reductions (K7/K8) */
-    SMVS_K_CG_DIR,        /* d = z + beta d */
     SMVS_K_CG_INIT,
     SMVS_K_REACTIVATE,    /* K9 */
     SMVS_K_MISC,

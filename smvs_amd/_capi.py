@@ -43,7 +43,7 @@ class LoopStats(C.Structure):
                 ("nan_break", C.c_int)]
 
 
-K_NAMES = ["patch", "assemble", "cg_spmv", "cg_update", "cg_dir", "cg_init",
+K_NAMES = ["patch", "assemble", "cg_spmv", "cg_update", "cg_init",
            "reactivate", "misc"]
 
 

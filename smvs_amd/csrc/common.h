@@ -60,11 +60,6 @@ enum {
     I_NAN,           // delta[0] is NaN
     I_NUM_ACTIVE,    // active nodes after re-activation
     I_ACTIVE_PATCHES,
-    I_TICKET0,       // ticket counters for last-block reductions
-    I_TICKET1,
-    I_TICKET2,
-    I_TICKET3,
-    I_MAXITER,
     I_TOPO_DELETED,  // patches deleted by one cut_boundaries pass
     I_NUM = 16
 };
@@ -132,7 +127,6 @@ struct smvs_ctx {
     double *x = nullptr, *r = nullptr, *z = nullptr, *Ad = nullptr,
         *d = nullptr, *d2 = nullptr, *b = nullptr;
     double *partials = nullptr;     // [4][1024] per-block reduction partials
-    int max_blocks = 0;
     void *cg_state = nullptr;       // CgState[2] (cg.hip)
     int last_cg_iterations = 0;     // sizes the first chunk of the next solve
     bool cg_use_active = false;     // system built by gn_construct: skip inactive nodes

@@ -52,7 +52,7 @@ struct ReactivateArgs {
     double *partials;
     double *scalars;
     int *status;
-    int npx, stride, ps, start_x, start_y, n_subs, num_patches, max_blocks;
+    int npx, stride, ps, start_x, start_y, n_subs, num_patches;
     double threshold;
     int full_optimization;
 };
@@ -134,7 +134,6 @@ reactivate_kernel(ReactivateArgs A)
         return;
     // mean reprojection delta (depth_optimizer.cc:277-282)
     __shared__ double red[2][4];
-    __shared__ bool is_last;
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -158,7 +157,6 @@ reactivate_kernel(ReactivateArgs A)
         atomicAdd(&A.scalars[S_SUMDIFF], s);
         atomicAdd(&A.scalars[S_COUNT_DIFF], c);
     }
-    (void)is_last;
 }
 
 // delta[0] NaN guard (depth_optimizer.cc:267-268) and reset of the next set
@@ -235,7 +233,6 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization)
     A.start_y = ctx->start_y;
     A.n_subs = ctx->n_subs;
     A.num_patches = ctx->num_patches;
-    A.max_blocks = ctx->max_blocks;
     A.threshold = threshold;
     A.full_optimization = full_optimization;
     long long const items = (long long)ctx->num_patches * ctx->patchsize
