@@ -602,3 +602,47 @@ def test_full_size_shading_step_matches_oracle(hip, oracle):
             assert _rel(np.triu(Hp[p]), np.triu(H_ref)) < 1e-9
             assert _rel(gp[p], g_ref) < 1e-9
     ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# edge cases of the construct / loop
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("scale,size,n_subs", [(6, (512, 384), 3),    # 256 samples: 4 chunks per patch
+                                                (2, (160, 128), 1),    # single neighbour: no pair terms
+                                                (2, (160, 128), 16),   # SMVS_MAX_SUBS
+                                                (3, (333, 217), 5),    # ragged image size
+                                                (1, (96, 64), 2)])     # 2x2 patches: 4 samples per patch
+def test_patch_systems_edge_cases(hip, oracle, scale, size, n_subs):
+    prob, ctx, orc = _setup(hip, oracle, size[0], size[1], n_subs, scale)
+    reg = 0.01
+    n = ctx.gn_construct(reg)
+    assert n == int(prob["surf"]["patch_valid"].sum()) and n > 0
+    Hp, gp = ctx.gn_patch_systems()
+    valid = np.flatnonzero(prob["surf"]["patch_valid"])
+    pick = np.random.default_rng(3).choice(valid, size=min(30, valid.size), replace=False)
+    for p in pick:
+        g_ref, H_ref = orc.gn_patch(int(p), reg)
+        assert _rel(np.triu(Hp[p]), np.triu(H_ref)) < 1e-9
+        assert _rel(gp[p], g_ref) < 1e-9
+    ctx.close()
+
+
+def test_full_optimization_loop_matches_oracle(hip, oracle):
+    """full_optimization: every node stays active, the loop ends when the
+    mean reprojection shift drops under 0.01 px (depth_optimizer.cc:277-290)."""
+    prob, ctx, orc = _setup(hip, oracle, 256, 192, 4, 3, noise=0.01)
+    reg = 0.01
+    stats = ctx.run_loop(reg, full_optimization=True, max_newton_steps=8)
+    active = prob["surf"]["node_valid"].copy()
+    steps = 0
+    while steps < 8:
+        steps += 1
+        ref = orc.gn_construct(active, reg)
+        x, _, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
+                               0.01 * np.linalg.norm(ref["g"]), 1e-3)
+        _, _, mean = orc.update_and_reactivate(x, active, full_optimization=True)
+        if mean < 0.01:
+            break
+    assert stats["newton_steps"] == steps
+    assert _rel(ctx.depth_map(), orc.depth_map()) <= 1e-4
+    ctx.close()
