@@ -700,12 +700,21 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         __builtin_ia32_pause();
         if ((++spins & 0xFFFF) == 0) {
             SMVS_HIP_CHECK(hipGetLastError());
-            if (hipStreamQuery(ctx->stream) == hipSuccess
+            // a device fault surfaces here instead of an endless wait
+            hipError_t const q = hipStreamQuery(ctx->stream);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                SMVS_HIP_CHECK(q);
+            if (q == hipSuccess
                 && __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE)
                     != (A.solve_tag | 1)
-                && k > max_iterations) {
-                set_error("cg_solve_launch: solver did not report completion");
-                return SMVS_ERR_STATE;
+                && __atomic_load_n(&progress[0], __ATOMIC_ACQUIRE)
+                    == seen_word) {
+                // the stream is idle, nothing is in flight and the solver
+                // has not finished: the launches above were lost
+                if (k > max_iterations) {
+                    set_error("cg_solve_launch: solver did not report completion");
+                    return SMVS_ERR_STATE;
+                }
             }
             auto const dt = std::chrono::steady_clock::now() - t_start;
             if (dt > std::chrono::seconds(60)) {

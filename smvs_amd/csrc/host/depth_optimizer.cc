@@ -3,6 +3,7 @@
 #include "topo_math.h"
 #include <string>
 #include <map>
+#include <mutex>
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
@@ -20,9 +21,11 @@ namespace {
 struct HostTimers {
     bool on = std::getenv("SMVS_HOST_TIMING") != nullptr;
     std::map<std::string, double> acc;
+    std::mutex lock;   // optimizers of several views may run in threads
     ~HostTimers() { report(); }
     void report()
     {
+        std::lock_guard<std::mutex> guard(lock);
         if (!on || acc.empty())
             return;
         double total = 0.0;
@@ -42,9 +45,11 @@ struct ScopedHostTimer {
         t0(std::chrono::steady_clock::now()) {}
     ~ScopedHostTimer()
     {
-        if (g_timers.on)
+        if (g_timers.on) {
+            std::lock_guard<std::mutex> guard(g_timers.lock);
             g_timers.acc[name] += std::chrono::duration<double>(
                 std::chrono::steady_clock::now() - t0).count();
+        }
     }
 };
 }
