@@ -383,8 +383,16 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
     for (int j = 0; j < A.n_subs; ++j) {
         if (!((vis >> j) & 1u))
             continue;
-        const double *M = A.cams->M[j];
-        const double *t = A.cams->t[j];
+        // (copied up front: after the LDS stores below the compiler could
+        // no longer prove the cameras unmodified and would re-read them with
+        // vector loads)
+        double M[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            M[i] = A.cams->M[j][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            t[i] = A.cams->t[j][i];
         SubPlanes const sp = A.subs[j];
         double p, q, r, a, b, d, proj0, proj1, inv_d;
         {
@@ -424,12 +432,7 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         if (have_prev)
             fold_pending(true);
 
-        double const g0 = tap_mix(g00.x, g10.x, g01.x, g11.x, tp);
-        double const g1 = tap_mix(g00.y, g10.y, g01.y, g11.y, tp);
-        double const hxx = tap_mix(h00.x, h10.x, h01.x, h11.x, tp);
-        double const hxy = tap_mix(h00.y, h10.y, h01.y, h11.y, tp);
-        double const hyy = tap_mix(h00.z, h10.z, h01.z, h11.z, tp);
-
+        // ... and so does everything of this neighbour that needs no texel:
         // correspondence.cc:88-100 with reciprocals
         double const inv_d2 = inv_d * inv_d;
         double const rx = wx * r + w * M[6], ry = wy * r + w * M[7];
@@ -437,14 +440,8 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         double const jac2 = (wy * p + w * M[1]) * inv_d - a * ry * inv_d2;
         double const jac1 = (wx * q + w * M[3]) * inv_d - b * rx * inv_d2;
         double const jac3 = (wy * q + w * M[4]) * inv_d - b * ry * inv_d2;
-
         double const du_w = (p * d - r * a) * inv_d2;
         double const dv_w = (q * d - r * b) * inv_d2;
-        double const JH0 = jac0 * hxx + jac1 * hxy;
-        double const JH1 = jac0 * hxy + jac1 * hyy;
-        double const JH2 = jac2 * hxx + jac3 * hxy;
-        double const JH3 = jac2 * hxy + jac3 * hyy;
-
         // correspondence.cc:102-168
         double const d_prime_d4 = 2.0 * d * r * inv_d2 * inv_d2;
         double const du_cp = p * t[2] - r * t[0];
@@ -465,6 +462,27 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         }
         double const cu = du_cp * inv_d2;
         double const cv = dv_cp * inv_d2;
+
+        // The texels are first touched HERE: the empty asm takes them as
+        // operands, so the compiler cannot hoist their conversions (and the
+        // wait that goes with them) above the pair loop.
+        fvec2 c00 = g00, c10 = g10, c01 = g01, c11 = g11;
+        fvec4 k00 = h00, k10 = h10, k01 = h01, k11 = h11;
+        // (not volatile -- that would count as a memory access and demote
+        // the uniform camera loads to vector loads; the dependence on m_ww,
+        // which the pair loop produces, is what keeps it below that loop)
+        asm("" : "+v"(c00), "+v"(c10), "+v"(c01), "+v"(c11),
+            "+v"(k00), "+v"(k10), "+v"(k01), "+v"(k11) : "v"(m_ww));
+        double const g0 = tap_mix(c00.x, c10.x, c01.x, c11.x, tp);
+        double const g1 = tap_mix(c00.y, c10.y, c01.y, c11.y, tp);
+        double const hxx = tap_mix(k00.x, k10.x, k01.x, k11.x, tp);
+        double const hxy = tap_mix(k00.y, k10.y, k01.y, k11.y, tp);
+        double const hyy = tap_mix(k00.z, k10.z, k01.z, k11.z, tp);
+
+        double const JH0 = jac0 * hxx + jac1 * hxy;
+        double const JH1 = jac0 * hxy + jac1 * hyy;
+        double const JH2 = jac2 * hxx + jac3 * hxy;
+        double const JH3 = jac2 * hxy + jac3 * hyy;
         s0p = jac0 * g0 + jac1 * g1;
         s1p = jac2 * g0 + jac3 * g1;
         P0p = du_A[0] * g0 + dv_A[0] * g1 + JH0 * du_w + JH1 * dv_w;
