@@ -644,6 +644,12 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.q_tolerance = q_tolerance;
     A.fixed_tolerance = error_tolerance;
 
+    // the kernels index H with 32-bit element offsets
+    if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32) {
+        set_error("cg_solve_launch: %d nodes exceed the 32-bit offsets of the "
+            "SpMV kernel", ctx->num_nodes);
+        return SMVS_ERR_INVALID;
+    }
     size_t const items = (size_t)ctx->num_nodes * 4;
     int nb = (int)((items + CG_THREADS - 1) / CG_THREADS);
     if (nb > CG_MAX_BLOCKS)
