@@ -182,7 +182,7 @@ def main():
                         peak=78.6, unit="TFLOP/s", frac=round(achieved / 78.6, 4),
                         traffic=traffic, flops_per_launch=flops,
                         avg_us=round(avg_s * 1e6, 2), kernels=kernels)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # N = 1 only
             cpu = cpu_baseline(prob)
 
     if rank == 0:
