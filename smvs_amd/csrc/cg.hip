@@ -3,19 +3,23 @@
 // Replaces ConjugateGradient::solve (reference: lib/conjugate_gradient.h:72-202),
 // BlockSparseMatrix<4>::multiply (lib/block_sparse_matrix.h:276-298) and the
 // SSEVector kernels (lib/sse_vector.cc).  The node grid is regular, so the
-// block-CSC matrix of the reference becomes a 9-point stencil of 4x4 blocks,
-// stored slot-major H9[slot][node][16]: no index arrays, fully coalesced.
+// block-CSC matrix of the reference becomes a 9-point stencil of 4x4 blocks.
+// H is symmetric block for block, so only the diagonal and the four "upper"
+// neighbour slots are stored, slot-major H[5][node][16]: no index arrays,
+// fully coalesced; the lower slots are read as transposes from the neighbour.
 //
 // Two kernels per iteration, no atomics, no intra-kernel fences:
 //   A_k  finishes iteration k-1 (termination tests, beta), forms
-//        d_k = z + beta d_{k-1} on the fly, computes Ad_k and the d.Ad partials;
+//        d_k = z + beta d_{k-1}, computes Ad_k and the d.Ad partials;
 //   B_k  alpha = rr / d.Ad; x += alpha d; r -= alpha Ad; z = P r; partials of
 //        r.r, x.(b + r), z.r.
-// Every block re-reduces the (<= 1024) per-block partials of the previous
+// Every block re-reduces the (<= 512) per-block partials of the previous
 // kernel in the same fixed order, so all blocks derive bit-identical scalars
 // and the result is independent of scheduling.  The CG state (rr, Q0, iter,
 // done) is double-buffered: block 0 of A_k writes bank k&1 while the other
-// blocks read bank (k-1)&1.  The host only polls a "done" word per chunk.
+// blocks read bank (k-1)&1.  The host never synchronises inside a solve: it
+// paces its launches on progress words the kernels publish in pinned host
+// memory (cg_solve_launch).
 #include "common.h"
 
 #include <chrono>
