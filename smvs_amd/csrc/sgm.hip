@@ -14,10 +14,12 @@
 //
 // Aggregation: every path direction is an independent 1-D recurrence along a
 // row, a column or a diagonal line of the image, so one wavefront walks one
-// line (lane l owns planes 2l, 2l+1), with the loads of the next pixels
-// issued ahead of the dependent chain.  The eight directions run as eight
-// launches that read C once and read-modify-write S once each:
-// 5 bytes per (pixel, plane, path), the algorithmic traffic of SURVEY.md 8(d).
+// line (lane l owns planes 2l, 2l+1; neighbours and the minimum by DPP), with
+// the loads of the next pixels issued ahead of the dependent chain.  With 128
+// planes all eight directions run in ONE launch and add into S with atomics
+// on packed u16 pairs (integer adds commute: bit-exact); other plane counts
+// take one launch per direction.  Each path reads C once and
+// read-modify-writes S once.
 #include "common.h"
 
 #include <cmath>
