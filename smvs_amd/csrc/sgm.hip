@@ -15,10 +15,10 @@
 // Aggregation: every path direction is an independent 1-D recurrence along a
 // row, a column or a diagonal line of the image, so one wavefront walks one
 // line (lane l owns planes 2l, 2l+1; neighbours and the minimum by DPP), with
-// the loads of the next pixels issued ahead of the dependent chain.  With 128
-// planes all eight directions run in ONE launch and add into S with atomics
-// on packed u16 pairs (integer adds commute: bit-exact); other plane counts
-// take one launch per direction.  Each path reads C once and
+// the loads of the next pixels issued ahead of the dependent chain.  With an
+// even plane count all eight directions run in ONE launch and add into S with
+// atomics on packed u16 pairs (integer adds commute: bit-exact); odd plane
+// counts take one launch per direction.  Each path reads C once and
 // read-modify-writes S once.
 #include "common.h"
 
