@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (not part of the test suite): random image sizes,
+neighbour counts, scales, shading on / off, partially active sets; one Newton
+step on the GPU against the oracle."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import smvs_amd
+from smvs_amd import synth
+from oracle import pyoracle as oracle
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = dict(H=0, g=0, P=0, x=0)
+for case in range(n_cases):
+    scale = int(rng.integers(1, 6))
+    ps = 1 << scale
+    w = int(rng.integers(6 * ps + 8, 14 * ps + 40)); h = int(rng.integers(5 * ps + 8, 10 * ps + 40))
+    n_subs = int(rng.integers(1, 9))
+    shading = bool(rng.integers(0, 2))
+    light_reg = float(rng.choice([0.0, 0.5])) if shading else 0.0
+    prob = synth.make_problem(w, h, n_subs, scale, shading=shading, noise=0.01, seed=int(rng.integers(1, 10000)))
+    surf = prob["surf"]
+    if surf["patch_valid"].sum() < 4:
+        print("case %d skipped (no valid patches)" % case); continue
+    lighting = prob["lighting"] if shading else None
+    ctx = smvs_amd.ViewContext(w, h, n_subs)
+    ctx.set_views(prob["views"]); ctx.set_surface(surf)
+    orc = oracle.OracleProblem(surf, prob["views"])
+    active = surf["node_valid"].copy()
+    active[rng.random(active.size) < rng.choice([0.0, 0.3, 0.7])] = 0
+    ctx.set_active(active)
+    n_gpu = ctx.gn_construct(0.01, light_reg, lighting)
+    H9, g, P = ctx.gn_download()
+    ref = orc.gn_construct(active, 0.01, light_reg, lighting)
+    assert n_gpu == ref["active_patches"], (case, n_gpu, ref["active_patches"])
+    eH, eg, eP = rel(H9, ref["H9"]), rel(g, ref["g"]), rel(P, ref["P"])
+    it, info = ctx.cg_solve()
+    x = ctx.cg_x()
+    xr, itr, infor = orc.cg_solve(H9, ref["present"], P, -g, 200, 0.01 * np.linalg.norm(g), 1e-3)
+    ex = rel(x, xr) if np.linalg.norm(xr) > 0 else 0.0
+    ok_it = (it, info) == (itr, infor)
+    n_act, _, nan = ctx.update_and_reactivate(0.15, False)
+    new_active, n_ref, _ = orc.update_and_reactivate(xr, active)
+    a_gpu, _ = ctx.get_active()
+    same_active = np.array_equal(a_gpu, new_active)
+    print("case %2d: %4dx%-4d scale %d subs %d shading %d act %5d | H %.1e g %.1e P %.1e x %.1e it %s active %s"
+          % (case, w, h, scale, n_subs, shading, int(active.sum()), eH, eg, eP, ex, ok_it, same_active))
+    assert eH < 1e-8 and eg < 1e-8 and eP < 1e-5 and ex < 1e-8 and ok_it and same_active, case
+    for k, v in (("H", eH), ("g", eg), ("P", eP), ("x", ex)):
+        worst[k] = max(worst[k], v)
+    ctx.close()
+print("worst", worst)
