@@ -73,6 +73,10 @@ struct SubPlanes {
 struct DeviceCameras {
     double M[SMVS_MAX_SUBS][9];
     double t[SMVS_MAX_SUBS][3];
+    // p t2 - r t0 and q t2 - r t1 as affine functions of the pixel (u, v, 1),
+    // with (p, q, r) = M (u, v, 1): the numerators of the reprojection shift
+    // (update.hip, reactivate_kernel)
+    double shift[SMVS_MAX_SUBS][6];
 };
 
 struct Profile {

@@ -235,6 +235,12 @@ smvs_ctx_set_cameras(smvs_ctx *ctx, const double *Mi, const double *ti,
     for (int s = 0; s < ctx->n_subs; ++s) {
         memcpy(cams.M[s], Mi + 9 * s, sizeof(double) * 9);
         memcpy(cams.t[s], ti + 3 * s, sizeof(double) * 3);
+        const double *M = cams.M[s];
+        const double *t = cams.t[s];
+        for (int k = 0; k < 3; ++k) {
+            cams.shift[s][k] = M[k] * t[2] - M[6 + k] * t[0];
+            cams.shift[s][3 + k] = M[3 + k] * t[2] - M[6 + k] * t[1];
+        }
     }
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->cams, &cams, sizeof(cams),
         hipMemcpyHostToDevice, ctx->stream));

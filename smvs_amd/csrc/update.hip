@@ -101,26 +101,29 @@ reactivate_kernel(ReactivateArgs A)
                     continue;
                 const double *M = A.cams->M[j];
                 const double *t = A.cams->t[j];
-                double const p = M[0] * u + M[1] * v + M[2];
-                double const q = M[3] * u + M[4] * v + M[5];
-                double const r = M[6] * u + M[7] * v + M[8];
+                const double *sh = A.cams->shift[j];
                 // (w0 p + t0)/(w0 r + t2) - (w1 p + t0)/(w1 r + t2)
                 //   = (w0 - w1)(p t2 - r t0) / ((w0 r + t2)(w1 r + t2)):
-                // no cancellation, one reciprocal (v_rcp_f64 + two Newton
-                // steps); the result only feeds the 0.15 px test and the
-                // mean shift (depth_optimizer.cc:669-672, 277-303)
+                // no cancellation; the numerators are affine in the pixel
+                // (depth_optimizer.cc:669-672, 277-303)
+                double const r = M[6] * u + M[7] * v + M[8];
+                double const nx = sh[0] * u + sh[1] * v + sh[2];
+                double const ny = sh[3] * u + sh[4] * v + sh[5];
                 double const den = (w0 * r + t[2]) * (w1 * r + t[2]);
-                double inv = __builtin_amdgcn_rcp(den);
-                inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
-                inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
-                double const scale = -dw * inv;
-                double const ex = scale * (p * t[2] - r * t[0]);
-                double const ey = scale * (q * t[2] - r * t[1]);
-                double const d2 = ex * ex + ey * ey;
-                if (A.full_optimization)
-                    sum += sqrt(d2);
+                double const num2 = dw * dw * (nx * nx + ny * ny);
                 cnt += 1.0;
-                moved |= d2 > th2;
+                if (A.full_optimization) {
+                    // the mean shift needs the quotient itself
+                    double inv = __builtin_amdgcn_rcp(den);
+                    inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+                    inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+                    double const d2 = num2 * inv * inv;
+                    sum += sqrt(d2);
+                    moved |= d2 > th2;
+                } else {
+                    // shift^2 > threshold^2 without the division
+                    moved |= num2 > th2 * (den * den);
+                }
             }
             if (moved && !A.full_optimization) {
                 A.active_next[ids[0]] = 1;
