@@ -97,6 +97,7 @@ struct smvs_ctx {
     float flen = 0.f, inv_flen = 0.f;
     bool has_cameras = false, has_surface = false, has_system = false;
     bool has_shading = false;
+    bool update_prepared = false;   // active_next / counters cleared for the next update
 
     // image planes
     float2 *main_grad = nullptr;

@@ -404,6 +404,7 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
             return rc;
         ctx->cap_patches = cap;
     }
+    ctx->update_prepared = false;
     ctx->scale = scale;
     ctx->patchsize = ps;
     ctx->npx = npx;

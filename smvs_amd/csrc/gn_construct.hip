@@ -840,6 +840,8 @@ struct AssembleArgs {
     double *g;      // [N][4]
     int npx, npy, stride, num_nodes;
     int *status;
+    uint8_t *active_next;   // cleared here for the node update of this step
+    double *scalars;
 };
 
 // lib/ldl_decomposition.h:43-92 for a 4x4 block, same operation order.
@@ -950,6 +952,16 @@ gn_assemble_kernel(AssembleArgs A)
             }
             gout += A.gp[(size_t)p * 16 + 4 * ln + r];
         }
+    }
+
+    // what prepare_update_kernel does for a stand-alone update: clear the
+    // re-activation flags and the counters of this step's node update
+    if (in_range && r == 0)
+        A.active_next[n] = 0;
+    if (gid == 0) {
+        A.status[I_NUM_ACTIVE] = 0;
+        A.scalars[S_SUMDIFF] = 0.0;
+        A.scalars[S_COUNT_DIFF] = 0.0;
     }
 
     // number of patches the construction touched (a patch with at least one
@@ -1085,6 +1097,8 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     B.patch_valid = ctx->patch_valid;
     B.active = ctx->active;
     B.status = ctx->status;
+    B.active_next = ctx->active_next;
+    B.scalars = ctx->scalars;
     B.H9 = ctx->H9;
     B.Pinv = ctx->Pinv;
     B.g = ctx->g;
@@ -1101,6 +1115,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     SMVS_HIP_CHECK(hipGetLastError());
     ctx->has_system = true;
     ctx->cg_use_active = true;
+    ctx->update_prepared = true;
     return SMVS_OK;
 }
 
@@ -1212,6 +1227,7 @@ smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->Pinv, P, N * 16 * sizeof(double),
         hipMemcpyHostToDevice, ctx->stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->update_prepared = false;
     ctx->has_system = true;
     ctx->cg_use_active = false;
     return SMVS_OK;

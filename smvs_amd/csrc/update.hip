@@ -63,7 +63,8 @@ struct ReactivateArgs {
 __global__ void __launch_bounds__(256)
 reactivate_kernel(ReactivateArgs A)
 {
-    if (A.status[I_NAN])
+    // NaN guard of the reference on delta[0] (depth_optimizer.cc:267)
+    if (isnan(A.x[0]))
         return;
     int const pp = A.ps * A.ps;
     long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,14 +165,13 @@ reactivate_kernel(ReactivateArgs A)
 
 // delta[0] NaN guard (depth_optimizer.cc:267-268) and reset of the next set
 __global__ void
-prepare_update_kernel(const double *x, uint8_t *active_next, int num_nodes,
-    double *scalars, int *status)
+prepare_update_kernel(uint8_t *active_next, int num_nodes, double *scalars,
+    int *status)
 {
     int const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < num_nodes)
         active_next[i] = 0;
     if (i == 0) {
-        status[I_NAN] = isnan(x[0]) ? 1 : 0;
         status[I_NUM_ACTIVE] = 0;
         scalars[S_SUMDIFF] = 0.0;
         scalars[S_COUNT_DIFF] = 0.0;
@@ -185,8 +185,10 @@ apply_update_kernel(double *nodes, const double *x, const uint8_t *node_valid,
     uint8_t *active, const uint8_t *active_next, int num_nodes,
     int full_optimization, int *status)
 {
-    bool const skip = status[I_NAN] != 0;
+    bool const skip = isnan(x[0]);
     int const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        status[I_NAN] = skip ? 1 : 0;
     bool on = false;
     if (!skip && i < num_nodes) {
         if (node_valid[i]) {
@@ -210,12 +212,15 @@ int
 reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization)
 {
     int const N = ctx->num_nodes;
-    {
+    // (the assembly kernel of the same Newton step has already cleared the
+    // flags and counters when the system came from smvs_gn_construct)
+    if (!ctx->update_prepared) {
         ScopedKernelTimer timer(ctx, SMVS_K_MISC);
         hipLaunchKernelGGL(prepare_update_kernel, dim3((unsigned)((N + 255) / 256)),
-            dim3(256), 0, ctx->stream, ctx->x, ctx->active_next, N,
-            ctx->scalars, ctx->status);
+            dim3(256), 0, ctx->stream, ctx->active_next, N, ctx->scalars,
+            ctx->status);
     }
+    ctx->update_prepared = false;
     SMVS_HIP_CHECK(hipGetLastError());
     ReactivateArgs A;
     A.nodes = ctx->nodes;
