@@ -647,3 +647,18 @@ def test_full_optimization_loop_matches_oracle(hip, oracle):
     assert stats["newton_steps"] == steps
     assert _rel(ctx.depth_map(), orc.depth_map()) <= 1e-4
     ctx.close()
+
+
+def test_host_optimize_matches_oracle_960x540(hip, oracle):
+    """Whole optimize() (scales 5..2, device Newton loop, device topology
+    tests, host grid surgery) on a 960x540 sphere scene with 4 neighbours
+    against the oracle: identical batch log, same valid pixels, depth
+    relative L2 <= 1e-4 (north_star tolerance)."""
+    from smvs_amd import synth, host
+    inputs = synth.pipeline_inputs("sphere", 960, 540, 4, flen=1.2)
+    got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2)
+    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert len(got["log"]) >= 8
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
