@@ -8,6 +8,7 @@
 // LightOptimizer::fit_lighting_to_image (lib/light_optimizer.cc:32-49).
 #include "common.h"
 
+#include <chrono>
 #include <cmath>
 
 namespace smvs_hip {
@@ -515,8 +516,16 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         // follow the end of this one within microseconds
         {
             hipError_t q;
-            while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady)
+            auto const t_start = std::chrono::steady_clock::now();
+            long spins = 0;
+            while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) {
                 __builtin_ia32_pause();
+                if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now()
+                    - t_start > std::chrono::seconds(60)) {
+                    set_error("smvs_gn_run_loop: timed out waiting for the device");
+                    return SMVS_ERR_STATE;
+                }
+            }
             SMVS_HIP_CHECK(q);
         }
         stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
