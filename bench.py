@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--small", action="store_true", help="480x270 debug size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--views-in-flight", type=int, default=1,
+                    help="reference views processed concurrently per GPU (own context, "
+                         "stream and host thread each); the headline number uses 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,13 +120,38 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    run_steps(ctx, prob, args.warmup)
-    ctx.set_nodes(surf["nodes"])
+    # optional: more reference views in flight on this GPU (same inputs, own
+    # context / stream / host thread each); every view runs the K steps
+    extra = []
+    for _ in range(max(args.views_in_flight, 1) - 1):
+        c = smvs_amd.ViewContext(w, h, NSUBS, device=local_rank)
+        c.set_views(prob["views"]); c.set_surface(surf)
+        extra.append(c)
+
+    def run_all(steps):
+        import threading
+        res = [None] * (1 + len(extra))
+        def work(i, c):
+            res[i] = run_steps(c, prob, steps)
+        th = [threading.Thread(target=work, args=(i + 1, c)) for i, c in enumerate(extra)]
+        [t.start() for t in th]
+        work(0, ctx)
+        [t.join() for t in th]
+        return sum(r[0] for r in res), sum(r[1] for r in res)
+
+    run_all(args.warmup)
+    for c in [ctx] + extra:
+        c.set_nodes(surf["nodes"])
+        c.synchronize()
     barrier()
     t0 = time.perf_counter()
-    patch_steps, cg_its = run_steps(ctx, prob, args.steps)
+    patch_steps, cg_its = run_all(args.steps)
+    for c in extra:
+        c.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    for c in extra:
+        c.close()
 
     # whole-job aggregate: units summed over ranks, time = max over ranks
     from smvs_amd import shard
@@ -196,9 +224,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: %dx%d synthetic textured sphere, 1 ref + %d "
                                    "neighbours, -o2 (scale 2, %d patches), basic photometric "
-                                   "optimizer, one reference view per GPU"
-                                   % (w, h, NSUBS, int(surf["patch_valid"].sum())),
-                       "regularization": REG, "cg_iterations_per_step": cg_its / max(args.steps * world, 1)},
+                                   "optimizer, %s"
+                                   % (w, h, NSUBS, int(surf["patch_valid"].sum()),
+                                      "one reference view per GPU" if args.views_in_flight <= 1
+                                      else "%d reference views in flight per GPU" % args.views_in_flight),
+                       "regularization": REG,
+                       "cg_iterations_per_step": cg_its / max(args.steps * world * max(args.views_in_flight, 1), 1),
+                       "views_in_flight_per_gpu": max(args.views_in_flight, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
