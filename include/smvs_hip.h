@@ -223,6 +223,33 @@ int smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
     uint16_t penalty1, uint16_t penalty2, float *depth, int32_t *argmin,
     uint16_t *cost, uint16_t *sgm);
 
+/* The whole SGM initialisation of one reference view on the device:
+ * reconstruct_sgm_depth_for_view, app/smvsrecon.cc:346-384, i.e. for each of
+ * the first one or two neighbours SGMStereo::reconstruct (sgm_stereo.cc:46-96:
+ * run_sgm main -> neighbour, run_sgm neighbour -> main, left/right
+ * consistency check :64-91 with integer pixel coordinates, 3 % border and
+ * depth ratio 0.8) and the merge of the two checked maps (:366-377).  The
+ * four cost volumes, the depth maps and the check never leave the device;
+ * only the merged z-depth map (w*h floats) is copied back.
+ * Images: u8, one channel, already at SGM scale (SGMStereo's constructor,
+ * sgm_stereo.cc:27-39).  M_fwd / t_fwd: CameraInfo::fill_reprojection main ->
+ * neighbour at the two SGM image sizes (also the matrix of the check, :56-62);
+ * M_bwd / t_bwd: neighbour -> main.  range_main / range_neighbor: {min, max}
+ * depth of the two runs (SGMStereo::fill_depth_range_for_view, :669-720, or
+ * the caller's fixed range). */
+typedef struct {
+    const uint8_t *image;
+    int width, height;
+    float M_fwd[9], t_fwd[3];
+    float M_bwd[9], t_bwd[3];
+    float range_main[2];
+    float range_neighbor[2];
+} smvs_sgm_neighbor;
+
+int smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
+    const smvs_sgm_neighbor *neighbors, int n_neighbors, int num_steps,
+    uint16_t penalty1, uint16_t penalty2, float *depth);
+
 /* DepthOptimizer::depthmap_bilateral_filter, depth_optimizer.cc:957-1004 */
 int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     const float *ci, int w, int h, int channels, float sigma,
@@ -263,6 +290,31 @@ int smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out);
  * last pass (also the context's); *total_deleted (may be NULL). */
 int smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     uint8_t *patch_valid_out, uint8_t *node_valid_out, int *total_deleted);
+
+/* ------------------------------------------------------------------ */
+/* consumer of the depth / normal maps                */
+/* ------------------------------------------------------------------ */
+
+/* MeshGenerator::cut_depth_maps, mesh_generator.cc:24-158, with the normal
+ * preparation of generate_mesh (:189-208) and ViewProjection (:300-342): the
+ * cross-view consistency cut over all views at once.
+ *   depth   : width*height floats, MVE convention (ray length) as stored by
+ *             StereoView::write_depth_to_view (the "smvs-B<scale>" embedding);
+ *             overwritten with the cut map ("smvs-cut", :229)
+ *   normals : width*height*3 floats, camera space as DepthOptimizer writes
+ *             them ("smvs-B<scale>N"); overwritten with the world-space normals
+ *             (:199-207), which the point export reads afterwards
+ *   flen / rot / trans : mve::CameraInfo (world -> camera)
+ * With a single view only the normals are transformed (:211). */
+typedef struct {
+    int width, height;
+    float flen;
+    float rot[9], trans[3];
+    float *depth;
+    float *normals;
+} smvs_mesh_view;
+
+int smvs_cut_depth_maps(int device, smvs_mesh_view *views, int n_views);
 
 /* ------------------------------------------------------------------ */
 /* measurement                                                        */

@@ -545,6 +545,76 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
                 lighting=np.array(log.lighting[:]) if log.has_lighting else None)
 
 
+def _bundle(inputs, keep):
+    feats = f32(inputs["features"]).reshape(-1, 3)
+    nf = feats.shape[0]
+    nviews = len(inputs["cams"])
+    offsets = (np.arange(nf + 1) * nviews).astype(np.int32)
+    refs = np.tile(np.asarray(inputs["view_ids"], dtype=np.int32), nf)
+    keep += [feats, offsets, refs]
+    return Bundle(nf, _p(feats, c_float_p), _p(offsets, c_i32_p), _p(refs, c_i32_p))
+
+
+def sgm_depth_range(inputs, view_index=0):
+    """SGMStereo::fill_depth_range_for_view for one view of pipeline_inputs()."""
+    keep = []
+    v = _view_input(inputs["images"][view_index], inputs["cams"][view_index],
+                    inputs["view_ids"][view_index], keep)
+    b = _bundle(inputs, keep)
+    out = np.zeros(2, dtype=np.float32)
+    lib().orc_sgm_depth_range(C.byref(b), C.byref(v), _p(out, c_float_p))
+    return out
+
+
+def sgm_depth_for_view(inputs, sgm_scale=1, min_depth=0.0, max_depth=0.0,
+                       num_steps=128, penalty1=6, penalty2=96, roundtrip=False):
+    """reconstruct_sgm_depth_for_view (app/smvsrecon.cc:346-384) on the dict
+    of smvs_amd.synth.pipeline_inputs(): SGM against the first two neighbours,
+    L/R check, merge; roundtrip adds write_depth_to_view + get_sgm_depth."""
+    keep = []
+    cams, images = inputs["cams"], inputs["images"]
+    main = _view_input(images[0], cams[0], inputs["view_ids"][0], keep)
+    n = len(cams) - 1
+    subs = (ViewInput * n)()
+    for j in range(n):
+        subs[j] = _view_input(images[j + 1], cams[j + 1], inputs["view_ids"][j + 1], keep)
+    b = _bundle(inputs, keep)
+    w, h = main.width, main.height
+    for _ in range(sgm_scale):
+        w, h = (w + 1) // 2, (h + 1) // 2
+    out = np.zeros((h, w), dtype=np.float32)
+    ow = C.c_int(0); oh = C.c_int(0)
+    rc = lib().orc_sgm_depth_for_view(C.byref(main), subs, n, C.byref(b), sgm_scale,
+        C.c_float(min_depth), C.c_float(max_depth), num_steps, penalty1, penalty2,
+        1 if roundtrip else 0, _p(out, c_float_p), C.byref(ow), C.byref(oh))
+    if rc != 0:
+        raise RuntimeError("orc_sgm_depth_for_view failed: %d" % rc)
+    assert (ow.value, oh.value) == (w, h)
+    return out
+
+
+def cut_depth_maps(cams, depths, normals, view_ids=None):
+    """generate_mesh's normal preparation + MeshGenerator::cut_depth_maps
+    (mesh_generator.cc:189-208, 24-158).  depths[i]: (h, w) ray-length depth,
+    normals[i]: (h, w, 3) camera-space.  Returns (cut depths, world normals)."""
+    n = len(cams)
+    keep = []
+    views = (ViewInput * n)()
+    dummy = np.zeros((1, 1, 1), np.uint8)
+    for i in range(n):
+        views[i] = _view_input(dummy, cams[i], i if view_ids is None else view_ids[i], keep)
+    d = [f32(x).copy() for x in depths]
+    nm = [f32(x).copy() for x in normals]
+    w = (C.c_int * n)(*[x.shape[1] for x in d])
+    h = (C.c_int * n)(*[x.shape[0] for x in d])
+    dp = (c_float_p * n)(*[_p(x, c_float_p) for x in d])
+    npp = (c_float_p * n)(*[_p(x, c_float_p) for x in nm])
+    rc = lib().orc_cut_depth_maps(n, views, w, h, dp, npp)
+    if rc != 0:
+        raise RuntimeError("orc_cut_depth_maps failed: %d" % rc)
+    return d, nm
+
+
 def rescale_half_size_u8(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape

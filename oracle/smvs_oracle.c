@@ -679,6 +679,16 @@ orc_vec_dot(const double *a, const double *b, size_t n)
     return ret;
 }
 
+/* sse_vector.cc:139-213: multiply_add (sign > 0) / multiply_sub: a +- b * f,
+ * one multiplication and one addition per element in every branch. */
+void
+orc_vec_multiply_add(const double *a, const double *b, double factor,
+    int sign, double *out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        out[i] = sign > 0 ? a[i] + b[i] * factor : a[i] - b[i] * factor;
+}
+
 /* mve::Image<float>::linear_at [MVE-unverified: recalled semantics] */
 float
 orc_linear_at_f32(const float *img, int w, int h, int c, float x, float y,
@@ -770,6 +780,204 @@ patch_pixel_origin(const orc_surface *s, int patch_id, int *px, int *py)
 }
 
 #define ORC_MAX_SUBS 32
+
+/* Which restatement of gauss_newton_step.cc:252-383 orc_gn_patch runs:
+ *   0  the SSE4.1 branch (:252-333) with SSE2 intrinsics, two residual
+ *      components per register like the reference (default: the reference
+ *      build defines __SSE4_1__, lib/Makefile:4);
+ *   1  the same branch with the two lanes written out as scalars (must be
+ *      bit-identical to 0: every lane operation is the same IEEE operation);
+ *   2  the reference's scalar fallback (:335-383): same sums in a different
+ *      association, agrees with 0 to rounding (tests/test_oracle_core.py). */
+static int g_k2_mode = 0;
+void orc_set_k2_mode(int mode) { g_k2_mode = mode; }
+
+/* OpenMP threads of the per-patch loops (1 = the reference's behaviour per
+ * view: it parallelises over views, app/smvsrecon.cc:658-733, not inside). */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+static void
+k2_photometric(int num_subs, double (*j_grad_subs)[2],
+    double (*jac_entries)[16][2], const double *grad_main, double *gradient,
+    double *hessian_entries)
+{
+    if (g_k2_mode == 2)
+    {
+        /* :335-383 */
+        double weight[2], subweight[2], diff[2], subdiff[2], jace[2];
+        for (int j = 0; j < num_subs; ++j)
+        {
+            diff[0] = j_grad_subs[j][0] - grad_main[0];
+            diff[1] = j_grad_subs[j][1] - grad_main[1];
+            weight[0] = 1.0 / (R_FACTOR + fabs(diff[0]));
+            weight[1] = 1.0 / (R_FACTOR + fabs(diff[1]));
+            for (int col = 0; col < 16; ++col)
+            {
+                gradient[col] += (diff[0] * weight[0] * jac_entries[j][col][0]
+                    + diff[1] * weight[1] * jac_entries[j][col][1]);
+                for (int col2 = col; col2 < 16; ++col2)
+                    hessian_entries[col * 16 + col2] +=
+                        (jac_entries[j][col][0] * weight[0]
+                            * jac_entries[j][col2][0]
+                        + jac_entries[j][col][1] * weight[1]
+                            * jac_entries[j][col2][1]);
+            }
+            for (int j2 = j + 1; j2 < num_subs; ++j2)
+            {
+                subdiff[0] = j_grad_subs[j][0] - j_grad_subs[j2][0];
+                subdiff[1] = j_grad_subs[j][1] - j_grad_subs[j2][1];
+                subweight[0] = 1.0 / (R_FACTOR + fabs(subdiff[0]));
+                subweight[1] = 1.0 / (R_FACTOR + fabs(subdiff[1]));
+                for (int col = 0; col < 16; ++col)
+                {
+                    jace[0] = (jac_entries[j][col][0]
+                        - jac_entries[j2][col][0]) * subweight[0];
+                    jace[1] = (jac_entries[j][col][1]
+                        - jac_entries[j2][col][1]) * subweight[1];
+                    gradient[col] += (jace[0] * subdiff[0]
+                        + jace[1] * subdiff[1]);
+                    for (int col2 = col; col2 < 16; ++col2)
+                        hessian_entries[col * 16 + col2] +=
+                            (jace[0] * (jac_entries[j][col2][0]
+                                - jac_entries[j2][col2][0])
+                            + jace[1] * (jac_entries[j][col2][1]
+                                - jac_entries[j2][col2][1]));
+                }
+            }
+        }
+        return;
+    }
+#if defined(__SSE2__)
+    if (g_k2_mode == 0)
+    {
+        /* :252-333: the two residual components live in the two lanes of a
+         * register and are only summed at the end (:323-332) */
+        __m128d reg_grad[16];
+        __m128d reg_hessian[256];
+        __m128d const reg_grad_main = _mm_set_pd(grad_main[1], grad_main[0]);
+        __m128d const sign_mask = _mm_set1_pd(-0.);
+        __m128d const reg_rfactor = _mm_set1_pd(R_FACTOR);
+        for (int col = 0; col < 16; ++col)
+            reg_grad[col] = _mm_setzero_pd();
+        for (int col = 0; col < 16; ++col)
+            for (int col2 = col; col2 < 16; ++col2)
+                reg_hessian[col * 16 + col2] = _mm_setzero_pd();
+        for (int j = 0; j < num_subs; ++j)
+        {
+            __m128d const reg_jgrad_sub = _mm_loadu_pd(j_grad_subs[j]);
+            __m128d const reg_diff = _mm_sub_pd(reg_jgrad_sub, reg_grad_main);
+            __m128d const reg_weight = _mm_add_pd(
+                _mm_andnot_pd(sign_mask, reg_diff), reg_rfactor);
+            for (int col = 0; col < 16; ++col)
+            {
+                __m128d const jcol = _mm_loadu_pd(jac_entries[j][col]);
+                reg_grad[col] = _mm_add_pd(reg_grad[col],
+                    _mm_div_pd(_mm_mul_pd(reg_diff, jcol), reg_weight));
+                for (int col2 = col; col2 < 16; ++col2)
+                    reg_hessian[col * 16 + col2] = _mm_add_pd(
+                        reg_hessian[col * 16 + col2], _mm_mul_pd(jcol,
+                            _mm_div_pd(_mm_loadu_pd(jac_entries[j][col2]),
+                                reg_weight)));
+            }
+            for (int j2 = j + 1; j2 < num_subs; ++j2)
+            {
+                __m128d const reg_subdiff = _mm_sub_pd(reg_jgrad_sub,
+                    _mm_loadu_pd(j_grad_subs[j2]));
+                __m128d const reg_subweight = _mm_add_pd(
+                    _mm_andnot_pd(sign_mask, reg_subdiff), reg_rfactor);
+                for (int col = 0; col < 16; ++col)
+                {
+                    __m128d const reg_jace = _mm_div_pd(_mm_sub_pd(
+                        _mm_loadu_pd(jac_entries[j][col]),
+                        _mm_loadu_pd(jac_entries[j2][col])), reg_subweight);
+                    reg_grad[col] = _mm_add_pd(reg_grad[col],
+                        _mm_mul_pd(reg_jace, reg_subdiff));
+                    for (int col2 = col; col2 < 16; ++col2)
+                        reg_hessian[col * 16 + col2] = _mm_add_pd(
+                            reg_hessian[col * 16 + col2], _mm_mul_pd(reg_jace,
+                                _mm_sub_pd(_mm_loadu_pd(jac_entries[j][col2]),
+                                    _mm_loadu_pd(jac_entries[j2][col2]))));
+                }
+            }
+        }
+        for (int col = 0; col < 16; ++col)
+        {
+            double lanes[2];
+            _mm_storeu_pd(lanes, reg_grad[col]);
+            gradient[col] += lanes[0] + lanes[1];
+        }
+        for (int col = 0; col < 16; ++col)
+            for (int col2 = col; col2 < 16; ++col2)
+            {
+                double lanes[2];
+                _mm_storeu_pd(lanes, reg_hessian[col * 16 + col2]);
+                hessian_entries[col * 16 + col2] += lanes[0] + lanes[1];
+            }
+        return;
+    }
+#endif
+    {
+        double reg_grad[16][2];
+        double reg_hessian[256][2];
+        memset(reg_grad, 0, sizeof(reg_grad));
+        memset(reg_hessian, 0, sizeof(reg_hessian));
+        for (int j = 0; j < num_subs; ++j)
+        {
+            double reg_diff[2], reg_weight[2];
+            for (int k = 0; k < 2; ++k)
+            {
+                reg_diff[k] = j_grad_subs[j][k] - grad_main[k];
+                reg_weight[k] = fabs(reg_diff[k]) + R_FACTOR;
+            }
+            for (int col = 0; col < 16; ++col)
+                for (int k = 0; k < 2; ++k)
+                {
+                    double const jcol = jac_entries[j][col][k];
+                    reg_grad[col][k] = reg_grad[col][k]
+                        + (reg_diff[k] * jcol) / reg_weight[k];
+                    for (int col2 = col; col2 < 16; ++col2)
+                        reg_hessian[col * 16 + col2][k] =
+                            reg_hessian[col * 16 + col2][k]
+                            + jcol * (jac_entries[j][col2][k] / reg_weight[k]);
+                }
+            for (int j2 = j + 1; j2 < num_subs; ++j2)
+            {
+                double reg_subdiff[2], reg_subweight[2];
+                for (int k = 0; k < 2; ++k)
+                {
+                    reg_subdiff[k] = j_grad_subs[j][k] - j_grad_subs[j2][k];
+                    reg_subweight[k] = fabs(reg_subdiff[k]) + R_FACTOR;
+                }
+                for (int col = 0; col < 16; ++col)
+                    for (int k = 0; k < 2; ++k)
+                    {
+                        double const jace = (jac_entries[j][col][k]
+                            - jac_entries[j2][col][k]) / reg_subweight[k];
+                        reg_grad[col][k] = reg_grad[col][k]
+                            + jace * reg_subdiff[k];
+                        for (int col2 = col; col2 < 16; ++col2)
+                            reg_hessian[col * 16 + col2][k] =
+                                reg_hessian[col * 16 + col2][k]
+                                + jace * (jac_entries[j][col2][k]
+                                    - jac_entries[j2][col2][k]);
+                    }
+            }
+        }
+        for (int col = 0; col < 16; ++col)
+            gradient[col] += reg_grad[col][0] + reg_grad[col][1];
+        for (int col = 0; col < 16; ++col)
+            for (int col2 = col; col2 < 16; ++col2)
+                hessian_entries[col * 16 + col2] +=
+                    reg_hessian[col * 16 + col2][0]
+                    + reg_hessian[col * 16 + col2][1];
+    }
+}
 
 /* gauss_newton_step.cc:145-518 */
 void
@@ -893,62 +1101,10 @@ orc_gn_patch(const orc_views *views, const orc_surface *surf,
                 dd[2 * i + 1], normal_deriv);
         }
 
-        /* ---- fill_gradient_and_hessian_entries (:246-518), SSE branch:
-         * the two residual components live in two lanes that are only
-         * summed at the end (:323-332). ---- */
-        double reg_grad[16][2];
-        double reg_hessian[256][2];
-        memset(reg_grad, 0, sizeof(reg_grad));
-        memset(reg_hessian, 0, sizeof(reg_hessian));
-        for (int j = 0; j < num_subs; ++j)
-        {
-            double reg_diff[2], reg_weight[2];
-            for (int k = 0; k < 2; ++k)
-            {
-                reg_diff[k] = j_grad_subs[j][k] - grad_main[k];
-                reg_weight[k] = fabs(reg_diff[k]) + R_FACTOR;
-            }
-            for (int col = 0; col < 16; ++col)
-                for (int k = 0; k < 2; ++k)
-                {
-                    double const jcol = jac_entries[j][col][k];
-                    reg_grad[col][k] = reg_grad[col][k]
-                        + (reg_diff[k] * jcol) / reg_weight[k];
-                    for (int col2 = col; col2 < 16; ++col2)
-                        reg_hessian[col * 16 + col2][k] =
-                            reg_hessian[col * 16 + col2][k]
-                            + jcol * (jac_entries[j][col2][k] / reg_weight[k]);
-                }
-            for (int j2 = j + 1; j2 < num_subs; ++j2)
-            {
-                double reg_subdiff[2], reg_subweight[2];
-                for (int k = 0; k < 2; ++k)
-                {
-                    reg_subdiff[k] = j_grad_subs[j][k] - j_grad_subs[j2][k];
-                    reg_subweight[k] = fabs(reg_subdiff[k]) + R_FACTOR;
-                }
-                for (int col = 0; col < 16; ++col)
-                    for (int k = 0; k < 2; ++k)
-                    {
-                        double const jace = (jac_entries[j][col][k]
-                            - jac_entries[j2][col][k]) / reg_subweight[k];
-                        reg_grad[col][k] = reg_grad[col][k]
-                            + jace * reg_subdiff[k];
-                        for (int col2 = col; col2 < 16; ++col2)
-                            reg_hessian[col * 16 + col2][k] =
-                                reg_hessian[col * 16 + col2][k]
-                                + jace * (jac_entries[j][col2][k]
-                                    - jac_entries[j2][col2][k]);
-                    }
-            }
-        }
-        for (int col = 0; col < 16; ++col)
-            gradient[col] += reg_grad[col][0] + reg_grad[col][1];
-        for (int col = 0; col < 16; ++col)
-            for (int col2 = col; col2 < 16; ++col2)
-                hessian_entries[col * 16 + col2] +=
-                    reg_hessian[col * 16 + col2][0]
-                    + reg_hessian[col * 16 + col2][1];
+        /* ---- fill_gradient_and_hessian_entries (:246-518), photometric
+         * part (:252-383) ---- */
+        k2_photometric(num_subs, j_grad_subs, jac_entries, grad_main, gradient,
+            hessian_entries);
 
         if (opts->regularization <= 0.0)
             continue;
@@ -1114,62 +1270,94 @@ orc_gn_construct(const orc_views *views, const orc_surface *surf,
     memset(present9, 0, 9 * (size_t)num_nodes);
     memset(P, 0, sizeof(double) * 16 * (size_t)num_nodes);
 
+    /* The per-patch systems are independent: chunks of patches are evaluated
+     * by g_threads OpenMP threads, then scattered sequentially in ascending
+     * patch order -- the order the reference's patch loop feeds its std::map
+     * (:64-122), so the sums are the same with any thread count. */
+    enum { CHUNK = 4096 };
+    double *chunk_g = (double *)malloc(sizeof(double) * 16 * CHUNK);
+    double *chunk_h = (double *)malloc(sizeof(double) * 256 * CHUNK);
+    uint8_t *chunk_live = (uint8_t *)malloc(CHUNK);
     int evaluated = 0;
-    for (int patch_id = 0; patch_id < num_patches; ++patch_id)
+    for (int base = 0; base < num_patches; base += CHUNK)
     {
-        if (!surf->patch_valid[patch_id])
-            continue;
-        int node_ids[4];
-        patch_node_ids(surf, patch_id, node_ids);
-        if (active_nodes[node_ids[0]] == 0 && active_nodes[node_ids[1]] == 0
-            && active_nodes[node_ids[2]] == 0 && active_nodes[node_ids[3]] == 0)
-            continue;
-        evaluated += 1;
-
-        double sub_gradient[16];
-        double sub_hessian[256];
-        memset(sub_gradient, 0, sizeof(sub_gradient));
-        memset(sub_hessian, 0, sizeof(sub_hessian));
-        orc_gn_patch(views, surf, opts, lighting, patch_id, node_derivatives,
-            sub_gradient, sub_hessian);
-
-        for (int node = 0; node < 4; ++node) /* :89-96 */
+        int const count = num_patches - base < CHUNK ? num_patches - base : CHUNK;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+#endif
+        for (int k = 0; k < count; ++k)
         {
-            if (active_nodes[node_ids[node]] == 0)
+            int const patch_id = base + k;
+            chunk_live[k] = 0;
+            if (!surf->patch_valid[patch_id])
                 continue;
-            for (int value = 0; value < 4; ++value)
-                g[node_ids[node] * 4 + value] += sub_gradient[node * 4 + value];
+            int node_ids[4];
+            patch_node_ids(surf, patch_id, node_ids);
+            if (active_nodes[node_ids[0]] == 0 && active_nodes[node_ids[1]] == 0
+                && active_nodes[node_ids[2]] == 0
+                && active_nodes[node_ids[3]] == 0)
+                continue;
+            chunk_live[k] = 1;
+            double *sub_gradient = chunk_g + 16 * (size_t)k;
+            double *sub_hessian = chunk_h + 256 * (size_t)k;
+            memset(sub_gradient, 0, sizeof(double) * 16);
+            memset(sub_hessian, 0, sizeof(double) * 256);
+            orc_gn_patch(views, surf, opts, lighting, patch_id,
+                node_derivatives, sub_gradient, sub_hessian);
         }
-        for (int node1 = 0; node1 < 16; ++node1) /* :99-121 */
+        for (int k = 0; k < count; ++k)
         {
-            if (active_nodes[node_ids[node1 / 4]] == 0)
+            if (!chunk_live[k])
                 continue;
-            for (int node2 = node1; node2 < 16; ++node2)
+            int const patch_id = base + k;
+            int node_ids[4];
+            patch_node_ids(surf, patch_id, node_ids);
+            evaluated += 1;
+            const double *sub_gradient = chunk_g + 16 * (size_t)k;
+            const double *sub_hessian = chunk_h + 256 * (size_t)k;
+
+            for (int node = 0; node < 4; ++node) /* :89-96 */
             {
-                if (active_nodes[node_ids[node2 / 4]] == 0)
+                if (active_nodes[node_ids[node]] == 0)
                     continue;
-                int const n1 = node_ids[node1 / 4];
-                int const n2 = node_ids[node2 / 4];
-                int const ox = node1 % 4;
-                int const oy = node2 % 4;
-                /* block_id1 -> (row 4*n2, col 4*n1), values[ox + 4*oy] */
+                for (int value = 0; value < 4; ++value)
+                    g[node_ids[node] * 4 + value] +=
+                        sub_gradient[node * 4 + value];
+            }
+            for (int node1 = 0; node1 < 16; ++node1) /* :99-121 */
+            {
+                if (active_nodes[node_ids[node1 / 4]] == 0)
+                    continue;
+                for (int node2 = node1; node2 < 16; ++node2)
                 {
-                    int const s = stencil_slot(stride, n2, n1);
-                    present9[n2 * 9 + s] = 1;
-                    H9[((size_t)n2 * 9 + s) * 16 + ox + 4 * oy] +=
-                        sub_hessian[node1 * 16 + node2];
-                }
-                if (node1 != node2)
-                {
-                    /* block_id2 -> (row 4*n1, col 4*n2), values[ox*4 + oy] */
-                    int const s = stencil_slot(stride, n1, n2);
-                    present9[n1 * 9 + s] = 1;
-                    H9[((size_t)n1 * 9 + s) * 16 + ox * 4 + oy] +=
-                        sub_hessian[node1 * 16 + node2];
+                    if (active_nodes[node_ids[node2 / 4]] == 0)
+                        continue;
+                    int const n1 = node_ids[node1 / 4];
+                    int const n2 = node_ids[node2 / 4];
+                    int const ox = node1 % 4;
+                    int const oy = node2 % 4;
+                    /* block_id1 -> (row 4*n2, col 4*n1), values[ox + 4*oy] */
+                    {
+                        int const s = stencil_slot(stride, n2, n1);
+                        present9[n2 * 9 + s] = 1;
+                        H9[((size_t)n2 * 9 + s) * 16 + ox + 4 * oy] +=
+                            sub_hessian[node1 * 16 + node2];
+                    }
+                    if (node1 != node2)
+                    {
+                        /* block_id2 -> (row 4*n1, col 4*n2), values[ox*4 + oy] */
+                        int const s = stencil_slot(stride, n1, n2);
+                        present9[n1 * 9 + s] = 1;
+                        H9[((size_t)n1 * 9 + s) * 16 + ox * 4 + oy] +=
+                            sub_hessian[node1 * 16 + node2];
+                    }
                 }
             }
         }
     }
+    free(chunk_g);
+    free(chunk_h);
+    free(chunk_live);
 
     /* preconditioner: diagonal blocks, inverted (:131-142,
      * block_sparse_matrix.h:300-316: kept un-inverted on NaN) */

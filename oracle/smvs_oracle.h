@@ -102,6 +102,10 @@ void orc_ldl_inverse(double *A, int size);
 /* sse_vector.cc:19-41 (SSE4.1 branch) */
 double orc_vec_dot(const double *a, const double *b, size_t n);
 
+/* sse_vector.cc:139-213 multiply_add (sign > 0) / multiply_sub */
+void orc_vec_multiply_add(const double *a, const double *b, double factor,
+    int sign, double *out, size_t n);
+
 /* MVE Image<float>::linear_at, interleaved channels [MVE-unverified]. */
 float orc_linear_at_f32(const float *img, int w, int h, int c,
     float x, float y, int ch);
@@ -145,6 +149,15 @@ typedef struct {
     double regularization;
     double light_surf_regularization;
 } orc_gn_options;
+
+/* Restatement selector for gauss_newton_step.cc:252-383 (0: SSE4.1 branch
+ * with SSE2 intrinsics, default; 1: the same branch lane by lane in scalar
+ * code; 2: the reference's scalar fallback :335-383). */
+void orc_set_k2_mode(int mode);
+/* OpenMP threads used by the per-patch loops of orc_gn_construct (results do
+ * not depend on it). */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 
 /* gauss_newton_step.cc:145-518 for one patch: g16 += , H256 += (only
  * entries col2 >= col are touched). lighting16 may be NULL. */
@@ -216,6 +229,13 @@ void orc_sgm_aggregate(const uint16_t *cost, int w, int h, int num_steps,
 /* 1: evaluate the path recurrence literally as the reference's O(D^2) SSE
  * loop; 0 (default): the equivalent O(D) form. */
 void orc_sgm_set_literal(int on);
+/* One step of the path recurrence in the reference's two builds (Q18):
+ * scalar sgm_stereo.cc:310-346 (penalty2 adapted to |i1 - i2|) and SSE
+ * :361-406 (constant penalty2, evaluated literally). */
+void orc_sgm_path_step_scalar(const uint16_t *prev, const uint16_t *cost, int D,
+    int i1, int i2, uint16_t p1, uint16_t p2, uint16_t *out);
+void orc_sgm_path_step_sse(const uint16_t *prev, const uint16_t *cost, int D,
+    uint16_t p1, uint16_t p2, uint16_t *out);
 /* sgm_stereo.cc:274-306 */
 void orc_sgm_depth_from_volume(const uint16_t *sgm, const uint8_t *main_img,
     int w, int h, const float *depths, int num_steps, float *depth,

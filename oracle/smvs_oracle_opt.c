@@ -937,9 +937,17 @@ opt_create_subview_surfaces(OOpt *O)
     /* second pass (:502-585) */
     int const size = S->s.patchsize;
     int const n = size * size;
+    /* (patches are independent here: each writes its own patch_vis word) */
+#if defined(_OPENMP)
+#pragma omp parallel num_threads(orc_get_threads())
+#endif
+    {
     double *pix = (double *)malloc(sizeof(double) * 2 * n);
     double *dep = (double *)malloc(sizeof(double) * n);
     double *dd = (double *)malloc(sizeof(double) * 2 * n);
+#if defined(_OPENMP)
+#pragma omp for schedule(dynamic, 32)
+#endif
     for (int p = 0; p < np; ++p)
     {
         if (!S->s.patch_valid[p])
@@ -1005,6 +1013,7 @@ opt_create_subview_surfaces(OOpt *O)
         }
     }
     free(pix); free(dep); free(dd);
+    }
     int invalid = 0;
     for (int p = 0; p < np; ++p)
         if (S->s.patch_valid[p] && S->s.patch_vis[p] == 0)
@@ -1070,6 +1079,15 @@ opt_cut_boundaries(OOpt *O)
         }
     }
     int const stride = S->s.npx + 1;
+    /* mse_for_patch reads nothing this loop changes (node validity only
+     * changes in remove_nodes_without_patch below): evaluated up front, in
+     * parallel, for the patches the loop will visit */
+    double *errors = (double *)malloc(sizeof(double) * (size_t)np);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 32) num_threads(orc_get_threads())
+#endif
+    for (int p = 0; p < np; ++p)
+        errors[p] = S->s.patch_valid[p] ? opt_mse_for_patch(O, p) : 0.0;
     for (int p = 0; p < np; ++p)
     {
         if (!S->s.patch_valid[p])
@@ -1077,7 +1095,7 @@ opt_cut_boundaries(OOpt *O)
         int const idx = p % S->s.npx, idy = p / S->s.npx;
         int const ids[4] = { idy * stride + idx, idy * stride + idx + 1,
             (idy + 1) * stride + idx, (idy + 1) * stride + idx + 1 };
-        double const error = opt_mse_for_patch(O, p);
+        double const error = errors[p];
         for (int node = 0; node < 4; ++node)
         {
             int const nx = ids[node] % stride, ny = ids[node] / stride;
@@ -1094,6 +1112,7 @@ opt_cut_boundaries(OOpt *O)
             }
         }
     }
+    free(errors);
     surf_remove_nodes_without_patch(S);
     return deleted;
 }

@@ -96,6 +96,30 @@ void orc_scale_planes(const uint8_t *bytes, int w, int h, int c, int scale,
 /* mve::image::rescale_half_size<uint8_t> [MVE-unverified] */
 void orc_rescale_half_size_u8(const uint8_t *in, int w, int h, uint8_t *out);
 
+
+/* ---- callers either side of the optimiser (smvs_oracle_front.c) ---- */
+
+/* SGMStereo::fill_depth_range_for_view, sgm_stereo.cc:669-720 */
+void orc_sgm_depth_range(const orc_bundle *bundle, const orc_view_input *view,
+    float *range2);
+/* reconstruct_sgm_depth_for_view, app/smvsrecon.cc:346-384: two
+ * SGMStereo::reconstruct calls (sgm_stereo.cc:46-96: depth range from the
+ * bundle when max_depth == 0, run_sgm both ways, L/R check) and the merge.
+ * roundtrip != 0 additionally applies write_depth_to_view + get_sgm_depth
+ * (stereo_view.h:108-130), i.e. depth_out is what the optimiser reads.
+ * depth_out: ((w+1)>>scale ...) floats; out_w / out_h may be NULL. */
+int orc_sgm_depth_for_view(const orc_view_input *main_view,
+    const orc_view_input *neighbors, int n_neighbors, const orc_bundle *bundle,
+    int sgm_scale, float min_depth, float max_depth, int num_steps,
+    int penalty1, int penalty2, int roundtrip, float *depth_out, int *out_w,
+    int *out_h);
+/* generate_mesh's normal preparation (mesh_generator.cc:189-208) and
+ * MeshGenerator::cut_depth_maps (:24-158); depth[i] (ray length) and
+ * normals[i] (camera space) are overwritten with the cut maps / world-space
+ * normals. */
+int orc_cut_depth_maps(int n_views, const orc_view_input *cams, const int *w,
+    const int *h, float **depth, float **normals);
+
 #ifdef __cplusplus
 }
 #endif

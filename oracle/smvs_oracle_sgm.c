@@ -20,6 +20,10 @@ void
 orc_census_filter(const uint8_t *img, int w, int h, int c, uint64_t *out)
 {
     memset(out, 0, sizeof(uint64_t) * (size_t)w * h * c);
+    /* (pixels are independent; threads only when orc_set_threads asked) */
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(orc_get_threads())
+#endif
     for (int x = 4; x < w - 5; ++x)
         for (int y = 3; y < h - 4; ++y)
             for (int d = 0; d < c; ++d)
@@ -60,6 +64,9 @@ orc_sgm_warp(const uint8_t *neighbor, int nw, int nh, const float *M,
     uint8_t *warped)
 {
     memset(warped, 0, (size_t)w * h * num_steps);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(orc_get_threads())
+#endif
     for (int x = 0; x < w; ++x)
         for (int y = 0; y < h; ++y)
         {
@@ -182,6 +189,70 @@ fill_path_cost(const uint16_t *cost, uint16_t *sgm, uint16_t *path,
         v = (uint16_t)(v - min_prev);
         path[base + idx] = v;
         sgm[base + idx] = (uint16_t)(sgm[base + idx] + v);
+    }
+}
+
+/* One step of the path recurrence as the reference's two builds evaluate it
+ * (Q18), on caller-provided rows: prev[D] = path costs at the predecessor
+ * pixel, cost[D] = matching costs at the pixel, out[D] = new path costs.
+ *
+ * Scalar build, sgm_stereo.cc:310-346: penalty2 adapts to the intensity step
+ * between the two pixels, max(P1 * 3 / 2, P2 / (|i1 - i2| + 1)). */
+void
+orc_sgm_path_step_scalar(const uint16_t *prev, const uint16_t *cost, int D,
+    int i1, int i2, uint16_t p1, uint16_t p2_opt, uint16_t *out)
+{
+    uint16_t const diff = (uint16_t)(abs(i1 - i2) + 1);
+    uint16_t const penalty1 = p1;
+    int const a = penalty1 * 3 / 2, b = p2_opt / diff;
+    uint16_t const penalty2 = (uint16_t)(a > b ? a : b);
+    uint16_t min_prev_cost = 0xFFFF;
+    for (int i = 0; i < D; ++i)
+        if (prev[i] < min_prev_cost)
+            min_prev_cost = prev[i];
+    for (int i = 0; i < D; ++i)
+    {
+        uint16_t cost_update = prev[i];
+        for (int j = 0; j < D; ++j)
+        {
+            if (i == j)
+                continue;
+            uint16_t const cand = abs(j - i) == 1
+                ? (uint16_t)(prev[j] + penalty1) : (uint16_t)(prev[j] + penalty2);
+            if (cand < cost_update)
+                cost_update = cand;
+        }
+        out[i] = (uint16_t)(cost[i] + cost_update - min_prev_cost);
+    }
+}
+
+/* SSE build, sgm_stereo.cc:361-406, evaluated literally (D reductions over D
+ * planes), constant penalty2. */
+void
+orc_sgm_path_step_sse(const uint16_t *prev, const uint16_t *cost, int D,
+    uint16_t p1, uint16_t p2, uint16_t *out)
+{
+    uint16_t min_prev = 0xFFFF;
+    for (int k = 0; k < D; ++k)
+        if (prev[k] < min_prev)
+            min_prev = prev[k];
+    for (int idx = 0; idx < D; ++idx)
+    {
+        uint16_t m = 0xFFFF;
+        for (int k = 0; k < D; ++k)
+        {
+            uint16_t v;
+            if (k == idx)
+                v = prev[k];
+            else if (k == idx - 1 || k == idx + 1)
+                v = (uint16_t)(prev[k] + p1);
+            else
+                v = (uint16_t)(prev[k] + p2);
+            if (v < m)
+                m = v;
+        }
+        uint16_t r = (uint16_t)(cost[idx] + m);
+        out[idx] = (uint16_t)(r - min_prev);
     }
 }
 
@@ -360,6 +431,9 @@ orc_bilateral_upsample(const float *dm, int dm_w, int dm_h, const float *ci,
     memset(out, 0, sizeof(float) * (size_t)w * h);
     float const scale_x = (float)dm_w / (float)w;
     float const scale_y = (float)dm_h / (float)h;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(orc_get_threads())
+#endif
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x)
         {

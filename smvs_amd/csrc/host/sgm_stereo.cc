@@ -81,56 +81,80 @@ SGMStereo::fill_depth_range_for_view(Bundle::ConstPtr bundle,
     }
 }
 
+namespace {
+
+// One (main, neighbour) pair as the device entry wants it: SGM-scale images
+// (SGMStereo's constructor), both reprojections and both depth ranges
+// (lib/sgm_stereo.cc:46-62).
+struct PairInputs {
+    ByteImage::ConstPtr main_image, neighbor_image;
+    smvs_sgm_neighbor dev;
+};
+
+ByteImage::ConstPtr
+sgm_scale_image(StereoView::Ptr view, int scale)
+{
+    ByteImage::ConstPtr img = view->get_byte_image();
+    for (int i = 0; i < scale; ++i)
+        img = imgtools::rescale_half_size(img);
+    return img;
+}
+
+void
+prepare_pair(SGMStereo::Options const& o, StereoView::Ptr main_view,
+    StereoView::Ptr neighbor, Bundle::ConstPtr bundle,
+    ByteImage::ConstPtr main_image, PairInputs* out)
+{
+    out->main_image = main_image;
+    out->neighbor_image = sgm_scale_image(neighbor, o.scale);
+    smvs_sgm_neighbor& d = out->dev;
+    d.image = out->neighbor_image->begin();
+    d.width = out->neighbor_image->width();
+    d.height = out->neighbor_image->height();
+    float const mw = (float)main_image->width(), mh = (float)main_image->height();
+    float const nw = (float)d.width, nh = (float)d.height;
+    main_view->get_camera().fill_reprojection(neighbor->get_camera(), mw, mh,
+        nw, nh, d.M_fwd, d.t_fwd);
+    neighbor->get_camera().fill_reprojection(main_view->get_camera(), nw, nh,
+        mw, mh, d.M_bwd, d.t_bwd);
+    d.range_main[0] = d.range_neighbor[0] = o.min_depth;
+    d.range_main[1] = d.range_neighbor[1] = o.max_depth;
+    if (bundle != nullptr && o.max_depth == 0.0) {
+        SGMStereo::fill_depth_range_for_view(bundle, main_view, d.range_main);
+        SGMStereo::fill_depth_range_for_view(bundle, neighbor, d.range_neighbor);
+    }
+}
+
+FloatImage::Ptr
+run_pairs(SGMStereo::Options const& o, ByteImage::ConstPtr main_image,
+    std::vector<PairInputs> const& pairs)
+{
+    std::vector<smvs_sgm_neighbor> dev;
+    for (auto const& p : pairs)
+        dev.push_back(p.dev);
+    FloatImage::Ptr depth = FloatImage::create(main_image->width(),
+        main_image->height(), 1);
+    int const rc = smvs_sgm_depth_for_view(o.device, main_image->begin(),
+        main_image->width(), main_image->height(), dev.data(), (int)dev.size(),
+        o.num_steps, o.penalty1, o.penalty2, depth->begin());
+    if (rc != SMVS_OK)
+        throw std::runtime_error(std::string("smvs_sgm_depth_for_view: ")
+            + smvs_last_error());
+    return depth;
+}
+
+} // namespace
+
 FloatImage::Ptr
 SGMStereo::reconstruct(Options sgm_opts, StereoView::Ptr main_view,
     StereoView::Ptr neighbor, Bundle::ConstPtr bundle)
 {
-    // lib/sgm_stereo.cc:46-96
-    float depth_range[2] = { sgm_opts.min_depth, sgm_opts.max_depth };
-    if (bundle != nullptr && sgm_opts.max_depth == 0.0)
-        fill_depth_range_for_view(bundle, main_view, depth_range);
-    SGMStereo sgm1(sgm_opts, main_view, neighbor);
-    FloatImage::Ptr d_main = sgm1.run_sgm(depth_range[0], depth_range[1]);
-    if (bundle != nullptr && sgm_opts.max_depth == 0.0)
-        fill_depth_range_for_view(bundle, neighbor, depth_range);
-    SGMStereo sgm2(sgm_opts, neighbor, main_view);
-    FloatImage::Ptr d_neig = sgm2.run_sgm(depth_range[0], depth_range[1]);
-
-    float Mf[9], tf[3];
-    main_view->get_camera().fill_reprojection(neighbor->get_camera(),
-        (float)d_main->width(), (float)d_main->height(), (float)d_neig->width(),
-        (float)d_neig->height(), Mf, tf);
-    double M[9], t[3];
-    for (int i = 0; i < 9; ++i)
-        M[i] = Mf[i];
-    for (int i = 0; i < 3; ++i)
-        t[i] = tf[i];
-    // left / right consistency: integer pixel coordinates, truncating lookup
-    int const cut = (int)(0.03 * std::max(d_neig->width(), d_neig->height()));
-    for (int x = 0; x < d_main->width(); ++x)
-        for (int y = 0; y < d_main->height(); ++y) {
-            float& dm = d_main->at(x, y, 0);
-            if (dm == 0)
-                continue;
-            double const w = dm;
-            double const p = M[0] * x + M[1] * y + M[2];
-            double const q = M[3] * x + M[4] * y + M[5];
-            double const r = M[6] * x + M[7] * y + M[8];
-            double const d = w * r + t[2];
-            double const cx = (w * p + t[0]) / d, cy = (w * q + t[1]) / d;
-            if (cx < cut || cx >= d_neig->width() - cut || cy < cut
-                || cy >= d_neig->height() - cut) {
-                dm = 0;
-                continue;
-            }
-            float const cdepth = (float)d;
-            float const ndepth = d_neig->at((int)cx, (int)cy, 0);
-            float const ratio = std::min(cdepth, ndepth)
-                / std::max(cdepth, ndepth);
-            if (ndepth == 0 || ratio < 0.8)
-                dm = 0;
-        }
-    return d_main;
+    // lib/sgm_stereo.cc:46-96: both run_sgm calls and the left / right
+    // consistency check on the device
+    ByteImage::ConstPtr main_image = sgm_scale_image(main_view, sgm_opts.scale);
+    std::vector<PairInputs> pairs(1);
+    prepare_pair(sgm_opts, main_view, neighbor, bundle, main_image, &pairs[0]);
+    return run_pairs(sgm_opts, main_image, pairs);
 }
 
 FloatImage::Ptr
@@ -138,21 +162,15 @@ reconstruct_sgm_depth_for_view(SGMStereo::Options opts,
     StereoView::Ptr main_view, std::vector<StereoView::Ptr> const& neighbors,
     Bundle::ConstPtr bundle)
 {
-    FloatImage::Ptr d1 = SGMStereo::reconstruct(opts, main_view, neighbors[0],
-        bundle);
-    if (neighbors.size() > 1) {
-        FloatImage::Ptr d2 = SGMStereo::reconstruct(opts, main_view,
-            neighbors[1], bundle);
-        for (int p = 0; p < d1->get_pixel_amount(); ++p) {
-            if (d2->at(p) == 0.0f)
-                continue;
-            if (d1->at(p) == 0.0f) {
-                d1->at(p) = d2->at(p);
-                continue;
-            }
-            d1->at(p) = (d1->at(p) + d2->at(p)) * 0.5f;
-        }
-    }
+    // app/smvsrecon.cc:346-384: SGMStereo::reconstruct against the first two
+    // neighbours and the merge of the two checked maps, in one device call
+    if (neighbors.empty())
+        throw std::invalid_argument("reconstruct_sgm_depth_for_view: no neighbour");
+    ByteImage::ConstPtr main_image = sgm_scale_image(main_view, opts.scale);
+    std::vector<PairInputs> pairs(std::min<std::size_t>(neighbors.size(), 2));
+    for (std::size_t k = 0; k < pairs.size(); ++k)
+        prepare_pair(opts, main_view, neighbors[k], bundle, main_image, &pairs[k]);
+    FloatImage::Ptr d1 = run_pairs(opts, main_image, pairs);
     main_view->write_depth_to_view(d1, "smvs-sgm");
     return d1;
 }

@@ -1,6 +1,7 @@
 // Host mirror of smvs::SGMStereo (reference: lib/sgm_stereo.h:21-88).  The
-// cost volume, the 8-path aggregation and the WTA run on the device through
-// smvs_sgm_run; range estimation and the left/right check stay on the host.
+// cost volumes, the 8-path aggregation, the WTA, the left/right check and the
+// two-neighbour merge run on the device (smvs_sgm_depth_for_view); the host
+// keeps the depth range from the bundle and the image half-sizing.
 #pragma once
 
 #include "image.h"

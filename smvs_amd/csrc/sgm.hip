@@ -585,21 +585,237 @@ bilateral_kernel(BilateralArgs A)
     A.out[(size_t)y * A.w + x] = acc_w > 0 ? acc_v / acc_w : 0.0f;
 }
 
+// ------------------------------------------------------- L/R check + merge
+// SGMStereo::reconstruct, sgm_stereo.cc:64-91: the main view's depth is kept
+// where its correspondence in the neighbour (integer pixel coordinates, no
+// +0.5; Correspondence in double from the float M, t) lies inside the 3 %
+// border and the neighbour's own depth agrees within a factor 0.8; truncating
+// lookup.  Operation order of correspondence.cc:20-51, contraction off.
+struct LrArgs {
+    float *d_main;
+    const float *d_neig;
+    int w, h, nw, nh, cut;
+    double M[9], t[3];
+};
+
+__global__ void __launch_bounds__(256)
+sgm_lr_check_kernel(LrArgs A)
+{
+#pragma clang fp contract(off)
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= A.w)
+        return;
+    size_t const o = (size_t)y * A.w + x;
+    float const dm = A.d_main[o];
+    if (dm == 0.0f)
+        return;
+    double const u = (double)x, v = (double)y, wd = (double)dm;
+    double const p = A.M[0] * u + A.M[1] * v + A.M[2];
+    double const q = A.M[3] * u + A.M[4] * v + A.M[5];
+    double const r = A.M[6] * u + A.M[7] * v + A.M[8];
+    double const a = wd * p + A.t[0];
+    double const b = wd * q + A.t[1];
+    double const d = wd * r + A.t[2];
+    double const cx = a / d, cy = b / d;
+    if (cx < (double)A.cut || cx >= (double)(A.nw - A.cut)
+        || cy < (double)A.cut || cy >= (double)(A.nh - A.cut)) {
+        A.d_main[o] = 0.0f;
+        return;
+    }
+    float const cdepth = (float)d;
+    float const ndepth = A.d_neig[(size_t)(int)cy * A.nw + (size_t)(int)cx];
+    float const ratio = fminf(cdepth, ndepth) / fmaxf(cdepth, ndepth);
+    if (ndepth == 0.0f || (double)ratio < 0.8)
+        A.d_main[o] = 0.0f;
+}
+
+// app/smvsrecon.cc:366-377: average where both maps are valid
+__global__ void __launch_bounds__(256)
+sgm_merge_kernel(float *__restrict__ d1, const float *__restrict__ d2, size_t n)
+{
+#pragma clang fp contract(off)
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    float const b = d2[i];
+    if (b == 0.0f)
+        return;
+    float const a = d1[i];
+    d1[i] = a == 0.0f ? b : (a + b) * 0.5f;
+}
+
 struct DevBuf {
     void *p = nullptr;
+    size_t cap = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t bytes)
     {
+        if (p != nullptr && cap >= bytes)
+            return SMVS_OK;
+        if (p != nullptr) {
+            (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+        }
         hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
         if (e != hipSuccess) {
             set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
             p = nullptr;
             return SMVS_ERR_NOMEM;
         }
+        cap = bytes;
         return SMVS_OK;
     }
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
+
+// Work buffers of one run_sgm; reused by the runs of a view (the runs are
+// ordered on one stream).  Every run has its own depth table.
+struct SgmWorkspace {
+    static constexpr int MAX_RUNS = 4;
+    DevBuf depths, census, warped, cost, sgm, argmin;
+    int runs = 0;
+    int ensure(size_t npix, int num_steps)
+    {
+        size_t const vol = npix * (size_t)num_steps;
+        int rc;
+        if ((rc = depths.alloc(sizeof(float) * 128 * MAX_RUNS))
+            || (rc = census.alloc(sizeof(unsigned long long) * npix))
+            || (rc = warped.alloc(vol)) || (rc = cost.alloc(vol))
+            || (rc = sgm.alloc(sizeof(uint16_t) * vol))
+            || (rc = argmin.alloc(sizeof(int32_t) * npix)))
+            return rc;
+        return SMVS_OK;
+    }
+};
+
+static int
+check_sgm_options(int num_steps, float min_depth, float max_depth,
+    unsigned penalty1, unsigned penalty2)
+{
+    SMVS_REQUIRE(num_steps >= 2 && num_steps <= 128,
+        "num_steps must be in [2, 128]");
+    SMVS_REQUIRE(min_depth > 0.f && max_depth > min_depth, "bad depth range");
+    SMVS_REQUIRE(penalty2 >= penalty1, "penalty2 must not be below penalty1");
+    // The all-paths kernel adds the eight path costs into S with u32 atomics
+    // on packed u16 pairs: exact only while no 16-bit lane can carry into its
+    // neighbour, i.e. while S stays below 2^16.  Per path L <= 255 + P2 (Q20),
+    // border pixels add C up to 4 times more (Q19).  The reference wraps every
+    // u16 lane on its own (_mm_add_epi16), which this bound never reaches.
+    SMVS_REQUIRE(8u * (255u + penalty2) + 4u * 255u < 65536u,
+        "penalty2 too large for the u16 aggregation volume");
+    return SMVS_OK;
+}
+
+// SGMStereo::run_sgm (sgm_stereo.cc:98-124) on device images; the depth map
+// (and optionally argmin) stay on the device.  Asynchronous on `stream`.
+static int
+sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
+    int w, int h, const uint8_t *d_nbr, int nw, int nh, const float *M,
+    const float *t, float min_depth, float max_depth, int num_steps,
+    uint16_t penalty1, uint16_t penalty2, float *d_depth)
+{
+    int rc = check_sgm_options(num_steps, min_depth, max_depth, penalty1,
+        penalty2);
+    if (rc != SMVS_OK)
+        return rc;
+    SMVS_REQUIRE(B.runs < SgmWorkspace::MAX_RUNS, "too many runs on one workspace");
+    size_t const npix = (size_t)w * h;
+    size_t const vol = npix * num_steps;
+    if ((rc = B.ensure(npix, num_steps)) != SMVS_OK)
+        return rc;
+    // sgm_stereo.cc:195-203: inverse-depth planes by repeated float addition
+    float depths[128];
+    {
+#pragma clang fp contract(off)
+        float inv_depth = 1.0f / max_depth;
+        float const increment = (1.0f / min_depth - inv_depth) / (num_steps - 1);
+        for (int i = 0; i < num_steps; ++i) {
+            depths[i] = 1.0f / inv_depth;
+            inv_depth += increment;
+        }
+    }
+    float *d_depths = B.depths.as<float>() + 128 * B.runs;
+    B.runs += 1;
+    // (pageable source: the copy has returned from the host buffer when the
+    // call returns)
+    SMVS_HIP_CHECK(hipMemcpyAsync(d_depths, depths, sizeof(float) * num_steps,
+        hipMemcpyHostToDevice, stream));
+
+    hipLaunchKernelGGL(census_main_kernel, dim3((w + 255) / 256, h), dim3(256),
+        0, stream, d_main, w, h, B.census.as<unsigned long long>());
+    WarpArgs W;
+    W.neighbor = d_nbr;
+    W.nw = nw;
+    W.nh = nh;
+    memcpy(W.M, M, sizeof(float) * 9);
+    memcpy(W.t, t, sizeof(float) * 3);
+    W.depths = d_depths;
+    W.D = num_steps;
+    W.w = w;
+    W.h = h;
+    W.warped = B.warped.as<uint8_t>();
+    unsigned const vblocks = (unsigned)((vol + 255) / 256);
+    hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
+    {
+        int const tiles = ((w + CT_W - 1) / CT_W) * ((h + CT_H - 1) / CT_H);
+        hipLaunchKernelGGL(cost_tiled_kernel,
+            dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
+            B.warped.as<uint8_t>(), B.census.as<unsigned long long>(), w, h,
+            num_steps, B.cost.as<uint8_t>());
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+
+    // the eight paths in the reference's order: ->, <-, then the three
+    // top-to-bottom paths, then the three bottom-to-top paths
+    static const int dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 },
+        { -1, 1 }, { 0, -1 }, { 1, -1 }, { -1, -1 } };
+    PathArgs P;
+    P.cost = B.cost.as<uint8_t>();
+    P.sgm = B.sgm.as<uint16_t>();
+    P.w = w;
+    P.h = h;
+    P.D = num_steps;
+    P.p1 = penalty1;
+    P.p2 = penalty2;
+    P.last = 0;
+    if ((num_steps % 2) == 0) {
+        SMVS_HIP_CHECK(hipMemsetAsync(B.sgm.p, 0, sizeof(uint16_t) * vol, stream));
+        P.dx = P.dy = 0;
+        P.first = 0;
+        int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
+        hipLaunchKernelGGL((sgm_all_paths_kernel<16>), dim3(lines), dim3(64), 0,
+            stream, P);
+    } else {
+        // odd plane counts: one launch per direction, scalar accesses
+        for (int k = 0; k < 8; ++k) {
+            P.dx = dirs[k][0];
+            P.dy = dirs[k][1];
+            P.first = k == 0 ? 1 : 0;
+            int const lines = P.dy == 0 ? h : (P.dx == 0 ? w : w + h - 1);
+            hipLaunchKernelGGL(sgm_path_kernel, dim3(lines), dim3(64), 0, stream,
+                P);
+        }
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(wta_rows_kernel,
+        dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
+        B.sgm.as<uint16_t>(), d_main, d_depths, npix, num_steps, d_depth,
+        B.argmin.as<int32_t>());
+    SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
+static int
+select_device(int device)
+{
+    int count = 0;
+    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
+    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
+    SMVS_HIP_CHECK(hipSetDevice(device));
+    return SMVS_OK;
+}
 
 } // namespace smvs_hip
 
@@ -614,142 +830,117 @@ smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
 {
     SMVS_REQUIRE(main_img && neighbor_img && M && t, "null argument");
     SMVS_REQUIRE(w > 10 && h > 8 && nw > 1 && nh > 1, "image too small");
-    SMVS_REQUIRE(num_steps >= 2 && num_steps <= 128,
-        "num_steps must be in [2, 128]");
-    SMVS_REQUIRE(min_depth > 0.f && max_depth > min_depth, "bad depth range");
-    SMVS_REQUIRE(penalty2 >= penalty1, "penalty2 must not be below penalty1");
-    int count = 0;
-    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
-    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
-    SMVS_HIP_CHECK(hipSetDevice(device));
-
-    // sgm_stereo.cc:195-203: inverse-depth planes by repeated float addition
-    std::vector<float> depths(num_steps);
-    {
-        float inv_depth = 1.0f / max_depth;
-        float const increment = (1.0f / min_depth - inv_depth) / (num_steps - 1);
-        for (int i = 0; i < num_steps; ++i) {
-            depths[i] = 1.0f / inv_depth;
-            inv_depth += increment;
-        }
-    }
+    int rc = check_sgm_options(num_steps, min_depth, max_depth, penalty1,
+        penalty2);
+    if (rc != SMVS_OK || (rc = select_device(device)) != SMVS_OK)
+        return rc;
     size_t const npix = (size_t)w * h, nnpix = (size_t)nw * nh;
     size_t const vol = npix * num_steps;
-    DevBuf d_main, d_nbr, d_depths, d_census, d_warped, d_cost, d_sgm, d_depth,
-        d_argmin, d_cost16;
-    int rc;
+    SgmWorkspace B;
+    DevBuf d_main, d_nbr, d_depth, d_cost16;
     if ((rc = d_main.alloc(npix)) || (rc = d_nbr.alloc(nnpix))
-        || (rc = d_depths.alloc(sizeof(float) * num_steps))
-        || (rc = d_census.alloc(sizeof(unsigned long long) * npix))
-        || (rc = d_warped.alloc(vol)) || (rc = d_cost.alloc(vol))
-        || (rc = d_sgm.alloc(sizeof(uint16_t) * vol))
-        || (rc = d_depth.alloc(sizeof(float) * npix))
-        || (rc = d_argmin.alloc(sizeof(int32_t) * npix)))
+        || (rc = d_depth.alloc(sizeof(float) * npix)))
         return rc;
     hipStream_t stream = nullptr;  // default stream: one-shot entry point
     SMVS_HIP_CHECK(hipMemcpy(d_main.p, main_img, npix, hipMemcpyHostToDevice));
     SMVS_HIP_CHECK(hipMemcpy(d_nbr.p, neighbor_img, nnpix, hipMemcpyHostToDevice));
-    SMVS_HIP_CHECK(hipMemcpy(d_depths.p, depths.data(),
-        sizeof(float) * num_steps, hipMemcpyHostToDevice));
-
-    hipLaunchKernelGGL(census_main_kernel, dim3((w + 255) / 256, h), dim3(256),
-        0, stream, d_main.as<uint8_t>(), w, h,
-        d_census.as<unsigned long long>());
-    WarpArgs W;
-    W.neighbor = d_nbr.as<uint8_t>();
-    W.nw = nw;
-    W.nh = nh;
-    memcpy(W.M, M, sizeof(float) * 9);
-    memcpy(W.t, t, sizeof(float) * 3);
-    W.depths = d_depths.as<float>();
-    W.D = num_steps;
-    W.w = w;
-    W.h = h;
-    W.warped = d_warped.as<uint8_t>();
-    unsigned const vblocks = (unsigned)((vol + 255) / 256);
-    hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
-    {
-        int const tiles = ((w + CT_W - 1) / CT_W) * ((h + CT_H - 1) / CT_H);
-        hipLaunchKernelGGL(cost_tiled_kernel,
-            dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
-            d_warped.as<uint8_t>(), d_census.as<unsigned long long>(), w, h,
-            num_steps, d_cost.as<uint8_t>());
-    }
-    SMVS_HIP_CHECK(hipGetLastError());
-
-    // the eight paths in the reference's order: ->, <-, then the three
-    // top-to-bottom paths, then the three bottom-to-top paths
-    static const int dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 },
-        { -1, 1 }, { 0, -1 }, { 1, -1 }, { -1, -1 } };
-    bool const packed = (num_steps % 2) == 0;
-    if (packed) {
-        SMVS_HIP_CHECK(hipMemsetAsync(d_sgm.p, 0, sizeof(uint16_t) * vol, stream));
-        PathArgs P;
-        P.cost = d_cost.as<uint8_t>();
-        P.sgm = d_sgm.as<uint16_t>();
-        P.w = w;
-        P.h = h;
-        P.D = num_steps;
-        P.dx = P.dy = 0;
-        P.p1 = penalty1;
-        P.p2 = penalty2;
-        P.first = 0;
-        P.last = 0;
-        int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
-        hipLaunchKernelGGL((sgm_all_paths_kernel<16>), dim3(lines), dim3(64), 0,
-            stream, P);
-        SMVS_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(wta_rows_kernel,
-            dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
-            d_sgm.as<uint16_t>(), d_main.as<uint8_t>(), d_depths.as<float>(),
-            npix, num_steps, d_depth.as<float>(), d_argmin.as<int32_t>());
-        SMVS_HIP_CHECK(hipGetLastError());
-    } else {
-        // odd plane counts: one launch per direction, scalar accesses
-        for (int k = 0; k < 8; ++k) {
-            PathArgs P;
-            P.cost = d_cost.as<uint8_t>();
-            P.sgm = d_sgm.as<uint16_t>();
-            P.w = w;
-            P.h = h;
-            P.D = num_steps;
-            P.dx = dirs[k][0];
-            P.dy = dirs[k][1];
-            P.p1 = penalty1;
-            P.p2 = penalty2;
-            P.first = k == 0 ? 1 : 0;
-            P.last = 0;
-            int lines = P.dy == 0 ? h : (P.dx == 0 ? w : w + h - 1);
-            hipLaunchKernelGGL(sgm_path_kernel, dim3(lines), dim3(64), 0, stream,
-                P);
-        }
-        SMVS_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(wta_rows_kernel,
-            dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
-            d_sgm.as<uint16_t>(), d_main.as<uint8_t>(), d_depths.as<float>(),
-            npix, num_steps, d_depth.as<float>(), d_argmin.as<int32_t>());
-        SMVS_HIP_CHECK(hipGetLastError());
-    }
+    if ((rc = sgm_run_device(stream, B, d_main.as<uint8_t>(), w, h,
+            d_nbr.as<uint8_t>(), nw, nh, M, t, min_depth, max_depth, num_steps,
+            penalty1, penalty2, d_depth.as<float>())) != SMVS_OK)
+        return rc;
     SMVS_HIP_CHECK(hipDeviceSynchronize());
 
     if (depth != nullptr)
         SMVS_HIP_CHECK(hipMemcpy(depth, d_depth.p, sizeof(float) * npix,
             hipMemcpyDeviceToHost));
     if (argmin != nullptr)
-        SMVS_HIP_CHECK(hipMemcpy(argmin, d_argmin.p, sizeof(int32_t) * npix,
+        SMVS_HIP_CHECK(hipMemcpy(argmin, B.argmin.p, sizeof(int32_t) * npix,
             hipMemcpyDeviceToHost));
     if (sgm != nullptr)
-        SMVS_HIP_CHECK(hipMemcpy(sgm, d_sgm.p, sizeof(uint16_t) * vol,
+        SMVS_HIP_CHECK(hipMemcpy(sgm, B.sgm.p, sizeof(uint16_t) * vol,
             hipMemcpyDeviceToHost));
     if (cost != nullptr) {
         if ((rc = d_cost16.alloc(sizeof(uint16_t) * vol)))
             return rc;
-        hipLaunchKernelGGL(widen_u8_kernel, dim3(vblocks), dim3(256), 0, stream,
-            d_cost.as<uint8_t>(), d_cost16.as<uint16_t>(), vol);
+        hipLaunchKernelGGL(widen_u8_kernel, dim3((unsigned)((vol + 255) / 256)),
+            dim3(256), 0, stream, B.cost.as<uint8_t>(), d_cost16.as<uint16_t>(),
+            vol);
         SMVS_HIP_CHECK(hipGetLastError());
         SMVS_HIP_CHECK(hipMemcpy(cost, d_cost16.p, sizeof(uint16_t) * vol,
             hipMemcpyDeviceToHost));
     }
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
+    const smvs_sgm_neighbor *neighbors, int n_neighbors, int num_steps,
+    uint16_t penalty1, uint16_t penalty2, float *depth)
+{
+    SMVS_REQUIRE(main_img && neighbors && depth, "null argument");
+    SMVS_REQUIRE(n_neighbors >= 1 && n_neighbors <= 2,
+        "one or two neighbours (app/smvsrecon.cc:360-365)");
+    SMVS_REQUIRE(w > 10 && h > 8, "image too small");
+    for (int k = 0; k < n_neighbors; ++k)
+        SMVS_REQUIRE(neighbors[k].image && neighbors[k].width > 10
+            && neighbors[k].height > 8, "bad neighbour image");
+    int rc;
+    if ((rc = select_device(device)) != SMVS_OK)
+        return rc;
+    size_t const npix = (size_t)w * h;
+    SgmWorkspace B;
+    DevBuf d_main, d_nbr[2], d_fwd[2], d_bwd;
+    if ((rc = d_main.alloc(npix)))
+        return rc;
+    hipStream_t stream = nullptr;
+    SMVS_HIP_CHECK(hipMemcpyAsync(d_main.p, main_img, npix,
+        hipMemcpyHostToDevice, stream));
+    for (int k = 0; k < n_neighbors; ++k) {
+        smvs_sgm_neighbor const &N = neighbors[k];
+        size_t const nnpix = (size_t)N.width * N.height;
+        if ((rc = d_nbr[k].alloc(nnpix))
+            || (rc = d_fwd[k].alloc(sizeof(float) * npix))
+            || (rc = d_bwd.alloc(sizeof(float) * nnpix)))
+            return rc;
+        SMVS_HIP_CHECK(hipMemcpyAsync(d_nbr[k].p, N.image, nnpix,
+            hipMemcpyHostToDevice, stream));
+        // SGMStereo::reconstruct, sgm_stereo.cc:46-62: main -> neighbour,
+        // then neighbour -> main with the neighbour's own depth range
+        if ((rc = sgm_run_device(stream, B, d_main.as<uint8_t>(), w, h,
+                d_nbr[k].as<uint8_t>(), N.width, N.height, N.M_fwd, N.t_fwd,
+                N.range_main[0], N.range_main[1], num_steps, penalty1, penalty2,
+                d_fwd[k].as<float>())) != SMVS_OK)
+            return rc;
+        if ((rc = sgm_run_device(stream, B, d_nbr[k].as<uint8_t>(), N.width,
+                N.height, d_main.as<uint8_t>(), w, h, N.M_bwd, N.t_bwd,
+                N.range_neighbor[0], N.range_neighbor[1], num_steps, penalty1,
+                penalty2, d_bwd.as<float>())) != SMVS_OK)
+            return rc;
+        LrArgs L;
+        L.d_main = d_fwd[k].as<float>();
+        L.d_neig = d_bwd.as<float>();
+        L.w = w;
+        L.h = h;
+        L.nw = N.width;
+        L.nh = N.height;
+        L.cut = (int)(0.03 * (double)(N.width > N.height ? N.width : N.height));
+        for (int i = 0; i < 9; ++i)
+            L.M[i] = (double)N.M_fwd[i];
+        for (int i = 0; i < 3; ++i)
+            L.t[i] = (double)N.t_fwd[i];
+        hipLaunchKernelGGL(sgm_lr_check_kernel, dim3((w + 255) / 256, h),
+            dim3(256), 0, stream, L);
+        SMVS_HIP_CHECK(hipGetLastError());
+    }
+    if (n_neighbors > 1) {
+        hipLaunchKernelGGL(sgm_merge_kernel, dim3((unsigned)((npix + 255) / 256)),
+            dim3(256), 0, stream, d_fwd[0].as<float>(), d_fwd[1].as<float>(),
+            npix);
+        SMVS_HIP_CHECK(hipGetLastError());
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(depth, d_fwd[0].p, sizeof(float) * npix,
+        hipMemcpyDeviceToHost, stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(stream));
     return SMVS_OK;
 }
 

@@ -289,3 +289,65 @@ def bilateral_upsample(dm, ci, sigma=5.0, kernel_size=5, device=0):
     check(lib.smvs_bilateral_upsample(device, _p(dm, _fp), dw, dh, _p(ci, _fp),
           w, h, c, C.c_float(sigma), kernel_size, _p(out, _fp)))
     return out
+
+
+class SgmNeighbor(C.Structure):
+    """smvs_sgm_neighbor of include/smvs_hip.h."""
+    _fields_ = [("image", _u8p), ("width", C.c_int), ("height", C.c_int),
+                ("M_fwd", C.c_float * 9), ("t_fwd", C.c_float * 3),
+                ("M_bwd", C.c_float * 9), ("t_bwd", C.c_float * 3),
+                ("range_main", C.c_float * 2), ("range_neighbor", C.c_float * 2)]
+
+
+def sgm_depth_for_view(main_img, neighbors, num_steps=128, p1=6, p2=96, device=0):
+    """reconstruct_sgm_depth_for_view on the device.  neighbors: list of dicts
+    {image, M_fwd, t_fwd, M_bwd, t_bwd, range_main, range_neighbor} (SGM-scale
+    u8 images, float reprojections)."""
+    lib = _capi.load()
+    main_img = np.ascontiguousarray(main_img, dtype=np.uint8)
+    h, w = main_img.shape
+    keep = []
+    arr = (SgmNeighbor * len(neighbors))()
+    for k, nb in enumerate(neighbors):
+        img = np.ascontiguousarray(nb["image"], dtype=np.uint8)
+        keep.append(img)
+        arr[k].image = _p(img, _u8p)
+        arr[k].height, arr[k].width = img.shape
+        for name, n in (("M_fwd", 9), ("t_fwd", 3), ("M_bwd", 9), ("t_bwd", 3),
+                        ("range_main", 2), ("range_neighbor", 2)):
+            v = _f32(nb[name]).reshape(n)
+            for i in range(n):
+                getattr(arr[k], name)[i] = float(v[i])
+    depth = np.zeros((h, w), dtype=np.float32)
+    check(lib.smvs_sgm_depth_for_view(device, _p(main_img, _u8p), w, h, arr,
+          len(neighbors), num_steps, C.c_uint16(p1), C.c_uint16(p2), _p(depth, _fp)))
+    return depth
+
+
+class MeshView(C.Structure):
+    """smvs_mesh_view of include/smvs_hip.h."""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("flen", C.c_float),
+                ("rot", C.c_float * 9), ("trans", C.c_float * 3),
+                ("depth", _fp), ("normals", _fp)]
+
+
+def cut_depth_maps(cams, depths, normals, device=0):
+    """MeshGenerator::cut_depth_maps over all views on the device.  cams:
+    objects with .flen, .R, .t; depths[i] (h, w) ray-length depth; normals[i]
+    (h, w, 3) camera space.  Returns (cut depth maps, world-space normals)."""
+    lib = _capi.load()
+    n = len(cams)
+    d = [_f32(x).copy() for x in depths]
+    nm = [_f32(x).copy() for x in normals]
+    arr = (MeshView * n)()
+    for i in range(n):
+        arr[i].height, arr[i].width = d[i].shape
+        arr[i].flen = float(cams[i].flen)
+        for k, x in enumerate(np.asarray(cams[i].R, dtype=np.float32).reshape(9)):
+            arr[i].rot[k] = float(x)
+        for k, x in enumerate(np.asarray(cams[i].t, dtype=np.float32).reshape(3)):
+            arr[i].trans[k] = float(x)
+        arr[i].depth = _p(d[i], _fp)
+        arr[i].normals = _p(nm[i], _fp)
+    check(lib.smvs_cut_depth_maps(device, arr, n))
+    return d, nm

@@ -127,6 +127,24 @@ def depth_at(scene, cam, xs, ys):
     return (X @ cam.R.T + cam.t)[..., 2]
 
 
+def depth_and_normal_maps(scene, cams):
+    """Per camera: the depth map in MVE's convention (ray length, what
+    StereoView::write_depth_to_view stores) and the normal map in the
+    optimiser's camera-space convention (surface_derivative.cc:17-28: a
+    fronto-parallel surface has normal (0, 0, 1); mesh_generator.cc:199-207
+    turns (n0, -n1, -n2) into the world-space normal).  float32."""
+    depths, normals = [], []
+    for cam in cams:
+        ys, xs = np.mgrid[0:cam.height, 0:cam.width].astype(np.float64)
+        dirs = pixel_rays(cam, xs + 0.5, ys + 0.5)
+        X, hit = scene.intersect(cam.center, dirs)
+        depths.append(np.linalg.norm(X - cam.center, axis=-1).astype(np.float32))
+        c = scene.normal(X, hit) @ cam.R.T            # outward normal, camera space
+        normals.append(np.stack([c[..., 0], -c[..., 1], -c[..., 2]], axis=-1)
+                       .astype(np.float32))
+    return depths, normals
+
+
 def render(scene, cam, lighting=None):
     """u8 grey image (H, W); with `lighting` (16 SH coeffs) Lambert-like
     shading through the reference's scaled SH basis."""

@@ -1,0 +1,204 @@
+"""GPU parity of the callers either side of the Newton loop: the SGM front end
+(SGMStereo::reconstruct + merge, a19), the consumer of the depth maps
+(MeshGenerator::cut_depth_maps, f-3), and the whole optimiser at
+BASELINE.json's full size (configs[2] and [3]).  Integer / validity outputs
+must match exactly; float depth maps of the bit-exact integer SGM path must be
+array_equal; optimised depth within the north-star tolerance 1e-4 rel. L2.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import smvs_amd
+    if smvs_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on a GPU")
+    return smvs_amd
+
+
+@pytest.fixture()
+def oracle_threads(oracle):
+    """All host cores for the oracle's patch loops (results do not depend on
+    the thread count: tests/test_oracle_core.py)."""
+    n = max(1, min(os.cpu_count() or 1, 64))
+    oracle.lib().orc_set_threads(n)
+    yield n
+    oracle.lib().orc_set_threads(1)
+
+
+def _same_control_flow(a, b):
+    key = lambda e: (e["scale"], e["iter"], e["newton_steps"], e["valid_patches"])
+    return [key(e) for e in a] == [key(e) for e in b]
+
+
+# ------------------------------------------------------------ a19: SGM front
+@pytest.mark.parametrize("size,fixed_range", [((384, 256), None), ((250, 170), None),
+                                              ((384, 256), (2.0, 12.0))])
+def test_sgm_front_end_matches_oracle(hip, oracle, size, fixed_range):
+    """reconstruct_sgm_depth_for_view (app/smvsrecon.cc:346-384) through the
+    C++ host mirror -> smvs_sgm_depth_for_view (4 x run_sgm, L/R check, merge
+    on the device) against the oracle's own front end: depth range from the
+    bundle (sgm_stereo.cc:669-720) or fixed, L/R check (:64-91), merge --
+    array_equal (the SGM path is integer; the check's doubles follow the
+    reference's operation order)."""
+    from smvs_amd import synth, host
+    inputs = synth.pipeline_inputs("sphere", size[0], size[1], 3, flen=1.2)
+    lo, hi = fixed_range if fixed_range else (0.0, 0.0)
+    got = host.sgm_depth(inputs, sgm_scale=1, min_depth=lo, max_depth=hi)
+    want = oracle.sgm_depth_for_view(inputs, sgm_scale=1, min_depth=lo, max_depth=hi)
+    assert got.shape == want.shape
+    assert (want > 0).mean() > 0.3 and (want == 0).mean() > 0.01
+    assert np.array_equal(got, want)
+
+
+def test_device_lr_check_rejects_and_keeps(hip, oracle):
+    """smvs_sgm_depth_for_view with one neighbour against the oracle's pieces
+    (two run_sgm + orc_sgm_lr_check), on a pair whose second half is
+    inconsistent (the neighbour image is scrambled there)."""
+    rng = np.random.default_rng(5)
+    w, h = 112, 72
+    base = rng.integers(30, 220, size=(h + 8, w + 40)).astype(np.float32)
+    base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, -1, 1)) / 4
+    main = base[4:4 + h, 8:8 + w].astype(np.uint8)
+    nbr = base[4:4 + h, 11:11 + w].astype(np.uint8).copy()
+    nbr[:, w // 2:] = rng.integers(30, 220, size=(h, w - w // 2)).astype(np.uint8)
+    f = np.float32
+    M = np.eye(3, dtype=f).reshape(9)
+    t_fwd = np.array([-6.0, 0, 0], dtype=f)     # disparity 6 / depth
+    t_bwd = np.array([6.0, 0, 0], dtype=f)
+    rng_main, rng_nbr = (1.0, 12.0), (0.9, 11.0)
+    got = hip.sgm_depth_for_view(main, [dict(image=nbr, M_fwd=M, t_fwd=t_fwd, M_bwd=M,
+                                             t_bwd=t_bwd, range_main=rng_main,
+                                             range_neighbor=rng_nbr)], num_steps=64)
+
+    def run(a, b, t, lo, hi):
+        depths = oracle.sgm_depths(lo, hi, 64)
+        cost = oracle.sgm_cost_volume(a, b, M, t, depths)
+        sgm = oracle.sgm_aggregate(cost, 6, 96)
+        return oracle.sgm_depth_from_volume(sgm, a, depths)[0]
+
+    d_main = run(main, nbr, t_fwd, *rng_main)
+    d_neig = run(nbr, main, t_bwd, *rng_nbr)
+    want = oracle.sgm_lr_check(d_main, d_neig, M, t_fwd)
+    assert np.array_equal(got, want)
+    kept = want > 0
+    assert kept[:, : w // 2 - 12].mean() > 0.5          # consistent half survives
+    assert (d_main > 0).sum() > kept.sum()               # the check removed pixels
+
+
+# -------------------------------------------------------- f-3: cut_depth_maps
+@pytest.mark.parametrize("n_views,size", [(3, (192, 128)), (5, (160, 120)), (1, (96, 64))])
+def test_cut_depth_maps_matches_oracle(hip, oracle, n_views, size):
+    """smvs_cut_depth_maps against the restated MeshGenerator::cut_depth_maps
+    (mesh_generator.cc:24-158) on a synthetic sphere seen by n views, with a
+    block of one view pushed off the surface, holes and noise: cut maps and
+    world-space normals bit-identical."""
+    from smvs_amd import synth
+    inputs = synth.pipeline_inputs("sphere", size[0], size[1], max(n_views - 1, 1), flen=1.2)
+    cams = inputs["cams"][:n_views]
+    depths, normals = synth.depth_and_normal_maps(inputs["scene"], cams)
+    rng = np.random.default_rng(9)
+    for i in range(n_views):
+        depths[i] *= (1.0 + 0.002 * rng.standard_normal(depths[i].shape)).astype(np.float32)
+    depths[0][20:34, 40:60] *= np.float32(0.8)
+    if n_views > 1:
+        depths[1][5:9, 5:9] = 0.0
+        depths[1][50:60, 30:50] *= np.float32(1.3)
+    got_d, got_n = hip.cut_depth_maps(cams, depths, normals)
+    want_d, want_n = oracle.cut_depth_maps(cams, depths, normals)
+    for i in range(n_views):
+        assert np.array_equal(got_n[i], want_n[i])
+        assert np.array_equal(got_d[i], want_d[i])
+    if n_views > 1:
+        cut = sum(int(((d > 0) & (c == 0)).sum()) for d, c in zip(depths, want_d))
+        kept = sum(int((c > 0).sum()) for c in want_d)
+        assert cut > 100 and kept > cut
+    else:
+        assert np.array_equal(want_d[0], depths[0])
+
+
+def test_cut_depth_maps_rejects_bad_arguments(hip):
+    from smvs_amd._capi import SmvsError
+    with pytest.raises(SmvsError):
+        hip.cut_depth_maps([], [], [])
+
+
+# -------------------------------------------- bilateral at its production size
+def test_bilateral_upsample_full_size(hip, oracle, oracle_threads):
+    """K17 at the size the optimiser uses it: 960x540 SGM depth -> 1920x1080,
+    11x11 taps (depth_optimizer.cc:957-1004): float, 1e-5 of the depth range."""
+    rng = np.random.default_rng(17)
+    dh, dw, h, w = 540, 960, 1080, 1920
+    yy, xx = np.mgrid[0:dh, 0:dw].astype(np.float32)
+    dm = (4.0 + 0.5 * np.sin(xx / 70.0) + 0.3 * np.cos(yy / 45.0)).astype(np.float32)
+    dm[rng.random((dh, dw)) < 0.1] = 0.0
+    dm[200:260, 300:420] = 0.0
+    ci = rng.random((h, w, 3)).astype(np.float32)
+    ci = (ci + np.roll(ci, 1, 0) + np.roll(ci, 1, 1)) / 3
+    got = hip.bilateral_upsample(dm, ci)
+    want = oracle.bilateral_upsample(dm, ci)
+    assert np.array_equal(got > 0, want > 0)
+    assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+
+
+# ------------------------------------ configs[2] and [3] end to end, full size
+def _full_size_inputs(lighting=None):
+    from smvs_amd import synth
+    return synth.pipeline_inputs("sphere", 1920, 1080, 8, flen=1.2, lighting=lighting)
+
+
+def test_full_size_optimize_with_sgm_matches_oracle(hip, oracle, oracle_threads):
+    """BASELINE.json configs[2]: 1920x1080, 1 + 8 views, SGM initialisation
+    (960x540 x 128 planes, 8 paths, two neighbours, L/R check, merge) feeding
+    DepthOptimizer::optimize down to scale 2.  C++ host + HIP against the
+    oracle running its own SGM front end and optimiser on the same images:
+    the merged SGM depth is bit-identical, the batch log (scale, iteration,
+    Newton steps, valid patches) identical, the valid pixels identical and the
+    depth within 1e-4 relative L2."""
+    from smvs_amd import host
+    inputs = _full_size_inputs()
+    sgm = host.sgm_depth(inputs, sgm_scale=1)
+    sgm_o = oracle.sgm_depth_for_view(inputs, sgm_scale=1)
+    assert sgm.shape == (540, 960)
+    assert np.array_equal(sgm, sgm_o)
+    got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                        sgm_depth=sgm)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                           sgm_depth=oracle.sgm_depth_for_view(inputs, sgm_scale=1,
+                                                               roundtrip=True))
+    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert (want["depth"] > 0).mean() > 0.5
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
+    truth = inputs["truth"]
+    ok = want["depth"] > 0
+    assert np.median(np.abs(got["depth"][ok] - truth[ok]) / truth[ok]) < 5e-3
+
+
+def test_full_size_optimize_shading_aware_matches_oracle(hip, oracle, oracle_threads):
+    """BASELINE.json configs[3]: 1920x1080, 1 + 8 views, -S (GlobalLighting SH
+    fit at scales < 4 + shading residual), no SGM: identical batch log and
+    valid pixels, lighting coefficients to 1e-3, depth within 1e-4 rel. L2."""
+    from smvs_amd import host
+    rng = np.random.default_rng(3000)
+    lighting = np.zeros(16); lighting[0] = 0.9
+    lighting[1:4] = rng.uniform(-0.2, 0.2, 3)
+    inputs = _full_size_inputs(lighting)
+    got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                        use_shading=True)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                           use_shading=True)
+    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert got["lighting"] is not None and want["lighting"] is not None
+    assert _rel(got["lighting"], want["lighting"]) < 1e-3
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert _rel(got["depth"], want["depth"]) <= 1e-4

@@ -265,8 +265,9 @@ def test_host_optimize_matches_oracle_config1(hip, oracle):
 
 
 def test_host_optimize_with_sgm_and_shading_matches_oracle(hip, oracle):
-    """configs[2]/[3]-like: SGM initialisation (device SGM, host L/R check and
-    merge) feeding the optimizer with the shading term on."""
+    """configs[2]/[3]-like: SGM initialisation (run_sgm x 4, L/R check and
+    merge on the device) feeding the optimizer with the shading term on; each
+    side runs its own SGM front end."""
     from smvs_amd import synth, host
     rng = np.random.default_rng(3000)
     lighting = np.zeros(16); lighting[0] = 0.9
@@ -277,9 +278,12 @@ def test_host_optimize_with_sgm_and_shading_matches_oracle(hip, oracle):
     assert (sgm > 0).mean() > 0.3
     got = host.optimize(inputs, regularization=0.01, num_iterations=3, min_scale=2,
                         use_shading=True, sgm_depth=sgm)
+    # the oracle runs its OWN SGM front end (run_sgm x 4, L/R check, merge,
+    # write_depth_to_view / get_sgm_depth round trip) on the same images
+    sgm_o = oracle.sgm_depth_for_view(inputs, sgm_scale=1, roundtrip=True)
+    assert np.array_equal(got["sgm_roundtrip"], sgm_o)
     want = oracle.optimize(inputs, regularization=0.01, num_iterations=3,
-                           min_scale=2, use_shading=True,
-                           sgm_depth=got["sgm_roundtrip"])
+                           min_scale=2, use_shading=True, sgm_depth=sgm_o)
     assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
     assert got["lighting"] is not None and want["lighting"] is not None
     print("lighting rel %.3e" % _rel(got["lighting"], want["lighting"]))

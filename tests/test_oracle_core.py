@@ -241,3 +241,136 @@ def test_patch_subsampling_walk(oracle):
         assert np.all(pixels[:, 0] == 10 + (pids % size))
         assert np.all(pixels[:, 1] == 20 + (pids // size))
         assert np.allclose(depths, 1.0)
+
+
+# ------------------------------------------- remaining gtest_matrix_vector.cc
+def test_vector_ops_known_answers(oracle, known):
+    """SSEVectorTest add / subtract / multiply / multiply_add / multiply_sub
+    (gtest_matrix_vector.cc:55-196): the restated a +- b * f against the plain
+    expression, including the 1 M element cases."""
+    import ctypes as C
+    L = oracle.lib()
+
+    def axpy(a, b, f, sign):
+        a = np.ascontiguousarray(a, float); b = np.ascontiguousarray(b, float)
+        out = np.zeros_like(a)
+        L.orc_vec_multiply_add(a.ctypes.data_as(oracle.c_double_p),
+            b.ctypes.data_as(oracle.c_double_p), C.c_double(f), sign,
+            out.ctypes.data_as(oracle.c_double_p), C.c_size_t(a.size))
+        return out
+
+    for case in known["vec_ops"]["cases"]:
+        a = np.array(case["a"], float)
+        b = np.array(case.get("b", case["a"]), float)
+        f = case.get("factor", 1.0)
+        if case["op"] == "add":
+            assert np.array_equal(axpy(a, b, 1.0, +1), a + b)
+        elif case["op"] == "subtract":
+            assert np.array_equal(axpy(a, b, 1.0, -1), a - b)
+        elif case["op"] == "multiply":
+            assert np.array_equal(axpy(np.zeros(5), a, f, +1), a * f)
+        elif case["op"] == "multiply_add":
+            assert np.array_equal(axpy(a, b, f, +1), a + b * f)
+        else:
+            assert np.array_equal(axpy(a, b, f, -1), a - b * f)
+    big = known["vec_ops_large"]
+    i = np.arange(big["dim"])
+    a = (i % big["add"]["a_mod"]).astype(float); b = (i % big["add"]["b_mod"]).astype(float)
+    assert np.array_equal(axpy(a, b, big["factor"], +1), a + b * big["factor"])
+    a = (i % big["sub"]["a_mod"]).astype(float); b = (i % big["sub"]["b_mod"]).astype(float)
+    assert np.array_equal(axpy(a, b, big["factor"], -1), a - b * big["factor"])
+
+
+def _spmv(oracle, H9, present, x):
+    y = np.zeros_like(x)
+    n = H9.shape[0]
+    oracle.lib().orc_block_spmv(n, n, H9.ctypes.data_as(oracle.c_double_p),
+        present.ctypes.data_as(oracle.c_u8_p), x.ctypes.data_as(oracle.c_double_p),
+        y.ctypes.data_as(oracle.c_double_p))
+    return y
+
+
+def test_block_invert_known_answer(oracle, known):
+    """BlockSparseMatrixTest.BlockInvert (gtest_matrix_vector.cc:337-356): the
+    N = 2 blocks {2,0,0,2} sit in the leading 2x2 of 4x4 blocks whose other
+    diagonal entries are 1 (a zero pad would be a zero pivot, Q12)."""
+    case = known["block_invert"]
+    H9 = np.zeros((2, 9, 16)); present = np.zeros((2, 9), np.uint8)
+    for n in range(2):
+        blk = np.eye(4); blk[:2, :2] = np.array(case["block"], float).reshape(2, 2)
+        H9[n, 4] = oracle.ldl_inverse(blk).reshape(16)   # invert_blocks_inplace
+        present[n, 4] = 1
+    x = np.zeros(8); x[0:2] = 1; x[4:6] = 1
+    y = _spmv(oracle, H9, present, x)
+    got = list(y[0:2]) + list(y[4:6])
+    assert np.allclose(got, case["y"], atol=case["eps"], rtol=0)
+
+
+def test_triplets_multiply_known_answer(oracle, known):
+    """BlockSparseMatrixTest.SetFromTripletsMultiply (:292-335)."""
+    case = known["triplets_multiply"]
+
+    def build(trips):
+        H9 = np.zeros((2, 9, 16)); present = np.zeros((2, 9), np.uint8)
+        for r, c, v in trips:
+            br, bc = r // 2, c // 2
+            slot = 4 + (bc - br)
+            blk = H9[br, slot].reshape(4, 4)
+            blk[r % 2, c % 2] += v
+            present[br, slot] = 1
+        return H9, present
+
+    x = np.zeros(8); x[0:2] = case["x"][0:2]; x[4:6] = case["x"][2:4]
+    H9, present = build(case["triplets"])
+    y = _spmv(oracle, H9, present, x)
+    assert list(y[0:2]) + list(y[4:6]) == case["y"]
+    H9, present = build(case["triplets"] + case["extra"])
+    y = _spmv(oracle, H9, present, x)
+    assert list(y[0:2]) + list(y[4:6]) == case["y_extra"]
+
+
+# ------------------------- the reference's two builds against each other
+def test_k2_sse_branch_equals_scalar_branch(oracle):
+    """gauss_newton_step.cc holds two implementations of the photometric
+    accumulation: SSE4.1 (:252-333, what the reference build runs) and scalar
+    (:335-383).  The oracle restates both; they must agree to rounding, and the
+    SSE restatement with intrinsics must equal its lane-by-lane scalar form bit
+    for bit.  An independent check on the longest transcription."""
+    from smvs_amd import synth
+    L = oracle.lib()
+    prob = synth.make_problem(160, 128, 4, scale=2, noise=0.004, shading=True)
+    orc = oracle.OracleProblem(prob["surf"], prob["views"])
+    active = prob["surf"]["node_valid"]
+    lighting = np.zeros(16); lighting[0] = 0.8; lighting[2] = 0.3
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            L.orc_set_k2_mode(mode)
+            out[mode] = [orc.gn_construct(active, 0.01),
+                         orc.gn_construct(active, 0.01, light_reg=0.5, lighting=lighting)]
+    finally:
+        L.orc_set_k2_mode(0)
+    for k in range(2):
+        assert np.array_equal(out[0][k]["H9"], out[1][k]["H9"])
+        assert np.array_equal(out[0][k]["g"], out[1][k]["g"])
+        hs = np.abs(out[0][k]["H9"]).max(); gs = np.abs(out[0][k]["g"]).max()
+        assert np.abs(out[0][k]["H9"] - out[2][k]["H9"]).max() <= 1e-12 * hs
+        assert np.abs(out[0][k]["g"] - out[2][k]["g"]).max() <= 1e-12 * gs
+        assert np.array_equal(out[0][k]["present"], out[2][k]["present"])
+
+
+def test_construct_is_thread_count_invariant(oracle):
+    """The OpenMP patch loop scatters in ascending patch order: bit-identical
+    systems with 1 and 5 threads."""
+    from smvs_amd import synth
+    L = oracle.lib()
+    prob = synth.make_problem(160, 128, 3, scale=2, noise=0.004)
+    orc = oracle.OracleProblem(prob["surf"], prob["views"])
+    active = prob["surf"]["node_valid"]
+    try:
+        L.orc_set_threads(1); a = orc.gn_construct(active, 0.01)
+        L.orc_set_threads(5); b = orc.gn_construct(active, 0.01)
+    finally:
+        L.orc_set_threads(1)
+    assert np.array_equal(a["H9"], b["H9"]) and np.array_equal(a["g"], b["g"])
+    assert np.array_equal(a["P"], b["P"])

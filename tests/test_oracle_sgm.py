@@ -90,3 +90,102 @@ def test_bilateral_keeps_constant_depth(oracle):
     out = oracle.bilateral_upsample(dm, ci)
     assert out.shape == (32, 48)
     assert np.allclose(out, 3.5, atol=1e-5)
+
+
+def test_path_step_scalar_build_vs_sse_build(oracle):
+    """The reference holds two implementations of the path recurrence (Q18):
+    scalar (sgm_stereo.cc:310-346, penalty2 = max(P1*3/2, P2/(|dI|+1))) and SSE
+    (:361-406, constant penalty2).  Restated independently, they agree exactly
+    when the SSE form is given the scalar form's adapted penalty -- and
+    therefore with the plain P2 on a flat image, and differ elsewhere."""
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    D = 64
+    u16 = oracle.c_u16_p
+    differs = 0
+    for trial in range(200):
+        prev = rng.integers(0, 400, D).astype(np.uint16)
+        cost = rng.integers(0, 64, D).astype(np.uint16)
+        cost[rng.integers(0, D, 4)] = 255
+        i1, i2 = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+        if trial % 4 == 0:
+            i2 = i1
+        p1, p2 = 6, 96
+        a = np.zeros(D, np.uint16); b = np.zeros(D, np.uint16); c = np.zeros(D, np.uint16)
+        L.orc_sgm_path_step_scalar(prev.ctypes.data_as(u16), cost.ctypes.data_as(u16), D,
+            i1, i2, C.c_uint16(p1), C.c_uint16(p2), a.ctypes.data_as(u16))
+        p2_adapted = max(p1 * 3 // 2, p2 // (abs(i1 - i2) + 1))
+        L.orc_sgm_path_step_sse(prev.ctypes.data_as(u16), cost.ctypes.data_as(u16), D,
+            C.c_uint16(p1), C.c_uint16(p2_adapted), b.ctypes.data_as(u16))
+        assert np.array_equal(a, b), (i1, i2)
+        L.orc_sgm_path_step_sse(prev.ctypes.data_as(u16), cost.ctypes.data_as(u16), D,
+            C.c_uint16(p1), C.c_uint16(p2), c.ctypes.data_as(u16))
+        if i1 == i2:
+            assert np.array_equal(a, c)
+        else:
+            differs += int(not np.array_equal(a, c))
+    assert differs > 50   # the documented Q18 difference is real
+
+
+def test_depth_range_from_bundle(oracle):
+    """SGMStereo::fill_depth_range_for_view (sgm_stereo.cc:669-720): 0.7 x the
+    nearest feature, 5 x the 99th percentile; {0.3, 1.1} without features."""
+    from smvs_amd import synth
+    inputs = synth.pipeline_inputs("sphere", 96, 64, 2, flen=1.2, n_features=500)
+    r = oracle.sgm_depth_range(inputs, 0)
+    cam = inputs["cams"][0]
+    X = inputs["features"].astype(np.float32)
+    z = (X @ np.asarray(cam.R, np.float32).T + np.asarray(cam.t, np.float32))[:, 2]
+    z = np.sort(z[z > 0])
+    assert abs(r[0] - 0.7 * z[0]) < 1e-4 * z[0]
+    assert abs(r[1] - 5.0 * z[(len(z) * 99) // 100]) < 1e-3 * z[-1]
+    empty = dict(inputs); empty["features"] = np.zeros((0, 3), np.float32)
+    r = oracle.sgm_depth_range(empty, 0)
+    assert tuple(r) == (np.float32(0.3), np.float32(1.1))
+
+
+def test_front_end_merge_and_roundtrip(oracle):
+    """reconstruct_sgm_depth_for_view: the merged map equals the two checked
+    maps combined by app/smvsrecon.cc:366-377, and the write_depth_to_view /
+    get_sgm_depth round trip changes it by float rounding only."""
+    from smvs_amd import synth
+    inputs = synth.pipeline_inputs("sphere", 128, 96, 2, flen=1.2)
+    both = oracle.sgm_depth_for_view(inputs, sgm_scale=1)
+    one = dict(inputs)
+    first = oracle.sgm_depth_for_view(
+        dict(inputs, cams=inputs["cams"][:2], images=inputs["images"][:2],
+             view_ids=inputs["view_ids"][:2]), sgm_scale=1)
+    second = oracle.sgm_depth_for_view(
+        dict(inputs, cams=[inputs["cams"][0], inputs["cams"][2]],
+             images=[inputs["images"][0], inputs["images"][2]],
+             view_ids=[inputs["view_ids"][0], inputs["view_ids"][2]]), sgm_scale=1)
+    want = np.where(second == 0, first, np.where(first == 0, second,
+                    (first + second) * np.float32(0.5)))
+    assert np.array_equal(both, want)
+    assert (both > 0).mean() > 0.3
+    rt = oracle.sgm_depth_for_view(inputs, sgm_scale=1, roundtrip=True)
+    assert np.array_equal(rt > 0, both > 0)
+    assert np.max(np.abs(rt - both)) <= 2e-7 * both.max()
+
+
+def test_cut_depth_maps_cpu(oracle):
+    """MeshGenerator::cut_depth_maps restatement: consistent views keep their
+    surface, a view whose depth was pushed towards the camera in a block loses
+    exactly that block (the other views see free space there), holes stay."""
+    from smvs_amd import synth
+    scene_inputs = synth.pipeline_inputs("sphere", 96, 64, 3, flen=1.2)
+    cams = scene_inputs["cams"][:3]
+    depths, normals = synth.depth_and_normal_maps(scene_inputs["scene"], cams)
+    base, wn = oracle.cut_depth_maps(cams, depths, normals)
+    keep = [(b > 0).sum() / max((d > 0).sum(), 1) for b, d in zip(base, depths)]
+    assert min(keep) > 0.5
+    bad = [d.copy() for d in depths]
+    bad[0][20:30, 40:52] *= 0.8
+    bad[1][5:9, 5:9] = 0.0
+    cut, _ = oracle.cut_depth_maps(cams, bad, normals)
+    assert np.all(cut[0][22:28, 42:50] == 0)
+    assert np.all(cut[1][5:9, 5:9] == 0)
+    # world normals are unit vectors wherever the input normal was
+    n = np.linalg.norm(wn[0], axis=-1)
+    assert np.allclose(n[depths[0] > 0], 1.0, atol=1e-5)
