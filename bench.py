@@ -11,11 +11,28 @@ value = sum over timed steps of active patches / wall time, inputs resident
 in HBM.  One process per GPU; ranks work on independent reference views
 (weak scaling, no data-path collective).
 
+    python bench.py --gpus N --steps K --warmup W [--repeats R] [--config 1|5]
+
+With N > 1 and no torch.distributed environment the script re-executes itself
+under `python -m torch.distributed.run` with N ranks on 127.0.0.1.  After W
+warm-up steps the K-step region (barrier + device synchronisation on both
+sides, time = max over ranks) is measured R times; `value` / `ms_per_step` are
+the MEDIAN repeat, min and max are in "timing".
+
+--config 5 (BASELINE.json configs[4]): every rank holds --views-per-rank
+reference views (64 over 8 GPUs), shading-aware (-S): per view the
+GlobalLighting normal equations are accumulated on the device, optionally
+summed over the lock-step round of views with an RCCL all-reduce on the device
+buffers ("--shared-lighting"; the reference fits per view, which is the parity
+default), solved, and the Newton loop runs with the shading term.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import platform
+import subprocess
 import sys
 import time
 
@@ -28,15 +45,29 @@ W, H, NSUBS, SCALE = 1920, 1080, 8, 2
 REG = 0.01            # 0.01 * alpha (app/smvsrecon.cc:712), alpha = 1
 NOISE = 0.002
 
+# Assumed peaks (MI355X data sheet; MI355X_MICROARCH.md): what `frac` divides by.
+HBM_PEAK_GBPS = 8000.0
+FP64_PEAK_TFLOPS = 78.6
+# Per-unit algorithmic work:
+#  * per active patch, FP64 flops the factored construction executes at S = 8
+#    neighbours, P = 16 samples (SQ instruction counters, profiles/);
+#    SURVEY.md 8(d) prices the reference's unfactored rows at 0.50 MFLOP
+#  * per node and CG iteration, bytes of the upper-half block stencil + vectors
+FLOP_PER_PATCH = 0.132e6
+FLOP_PER_PATCH_SURVEY = 0.50e6
+BYTES_PER_PATCH = 4.2e3
+CG_BYTES = {"cg_spmv": 5 * 128 + 2 * 32 + 2 * 32,      # H upper half; z, d_old; Ad, d_new
+            "cg_update": 5 * 32 + 128 + 3 * 32 + 2}    # x d r Ad b; P; x r z; mask
 
-def make_problem(rank, small=False):
+
+def make_problem(rank, small=False, shading=False):
     from smvs_amd import synth
-    if small:
-        return synth.make_problem(480, 270, NSUBS, SCALE, noise=NOISE, seed=2000 + rank)
-    return synth.make_problem(W, H, NSUBS, SCALE, noise=NOISE, seed=2000 + rank)
+    w, h = (480, 270) if small else (W, H)
+    return synth.make_problem(w, h, NSUBS, SCALE, noise=NOISE, seed=2000 + rank,
+                              shading=shading)
 
 
-def run_steps(ctx, prob, steps):
+def run_steps(ctx, prob, steps, lighting=None):
     """Run exactly `steps` Newton steps; returns (active patch-steps, CG its)."""
     done = 0
     patch_steps = 0
@@ -45,8 +76,8 @@ def run_steps(ctx, prob, steps):
     while done < steps:
         if need_reset:
             ctx.set_nodes(prob["surf"]["nodes"])
-        st = ctx.run_loop(REG, max_newton_steps=min(200, steps - done),
-                          reset_active=True)
+        st = ctx.run_loop(REG, lighting=lighting,
+                          max_newton_steps=min(200, steps - done), reset_active=True)
         done += st["newton_steps"]
         patch_steps += st["active_patch_steps"]
         cg_its += st["linear_iterations"]
@@ -56,10 +87,31 @@ def run_steps(ctx, prob, steps):
     return patch_steps, cg_its
 
 
-def cpu_baseline(prob):
-    """Oracle (CPU restatement, 1 thread): one full Newton step of the same
-    workload with every valid node active (the first step of a batch),
-    about 15 s on one core."""
+# --------------------------------------------------------------- CPU baseline
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _oracle_flags():
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            for line in f:
+                if line.startswith("CFLAGS"):
+                    return "gcc " + line.split(":=", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _one_cpu_step(prob):
+    """One full Newton step of the workload with the oracle; seconds per phase."""
     from oracle import pyoracle
     surf = prob["surf"]
     active = np.ascontiguousarray(surf["node_valid"], dtype=np.uint8)
@@ -72,20 +124,229 @@ def cpu_baseline(prob):
     t2 = time.perf_counter()
     orc.update_and_reactivate(x, active)
     t3 = time.perf_counter()
-    return dict(value=ref["active_patches"] / (t3 - t0),
-                unit="active-patch-steps/s", cores=1, kind="port",
-                sample="1 Newton step, all %d patches active (first step of a batch "
-                       "of the %dx%d / %d-neighbour workload): construct %.2fs, "
-                       "PCG %d it %.2fs, update %.2fs"
-                       % (ref["active_patches"], W, H, NSUBS, t1 - t0, it,
-                          t2 - t1, t3 - t2))
+    return ref["active_patches"], it, (t1 - t0, t2 - t1, t3 - t2)
+
+
+def _cpu_worker(prob):
+    t = time.perf_counter()
+    patches, _, _ = _one_cpu_step(prob)
+    return patches, time.perf_counter() - t
+
+
+def cpu_baseline(prob, all_cores=True):
+    """The oracle (CPU restatement of the reference; SSE2 two-lane inner loop
+    like lib/gauss_newton_step.cc:252-333) timed on this host on ONE full
+    Newton step of the same workload with every valid node active (the first
+    step of a batch):
+      value     1 thread = the reference's per-view behaviour (it parallelises
+                over views, app/smvsrecon.cc:658-733, not inside one)
+      all_cores the same step as one process per view on many cores at once
+                (how the reference fills a host, app/smvsrecon.cc:49,558) and
+                with OpenMP inside one view."""
+    from oracle import pyoracle
+    L = pyoracle.lib()
+    nproc = os.cpu_count() or 1
+    L.orc_set_threads(1)
+    patches, it, (tc, ts, tu) = _one_cpu_step(prob)
+    one = patches / (tc + ts + tu)
+    out = dict(value=one, unit="active-patch-steps/s", cores=1, kind="port",
+               nproc=nproc, cpu_model=_cpu_model(), compiler_flags=_oracle_flags(),
+               sample="1 Newton step, all %d patches active (first step of a batch of the "
+                      "%dx%d / %d-neighbour workload): construct %.2fs, PCG %d it %.2fs, "
+                      "update %.2fs" % (patches, prob["surf"]["width"],
+                                        prob["surf"]["height"], NSUBS, tc, it, ts, tu))
+    if all_cores and nproc > 1:
+        # OpenMP over the patches of one view
+        th = min(nproc, 64)
+        L.orc_set_threads(th)
+        p2, _, (tc2, ts2, tu2) = _one_cpu_step(prob)
+        L.orc_set_threads(1)
+        out["openmp_one_view"] = dict(value=p2 / (tc2 + ts2 + tu2), threads=th,
+                                      construct_s=round(tc2, 3), pcg_s=round(ts2, 3),
+                                      update_s=round(tu2, 3))
+        # one view per core, like the reference's thread pool over views
+        import multiprocessing as mp
+        procs = min(max(nproc // 2, 1), 32)
+        t = time.perf_counter()
+        with mp.get_context("fork").Pool(procs) as pool:
+            res = pool.map(_cpu_worker, [prob] * procs)
+        wall = time.perf_counter() - t
+        out["all_cores"] = dict(value=sum(r[0] for r in res) / wall, processes=procs,
+                                wall_s=round(wall, 2),
+                                note="one view (one full Newton step) per process, "
+                                     "all at once")
+    return out
+
+
+# ------------------------------------------------------------------- roofline
+def measured_peaks():
+    """tools/peaks.py on this GPU (HBM copy / read, FP64 VALU and MFMA)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import peaks
+        r = peaks.run()
+        return dict(hbm_copy_GBps=round(r["hbm_copy_GBps"], 1),
+                    hbm_read_GBps=round(r["hbm_read_GBps"], 1),
+                    hbm_write_GBps=round(r["hbm_write_GBps"], 1),
+                    fp64_valu_fma_TFLOPs=round(r["fp64_valu_fma_TFLOPs"]["4"], 2),
+                    fp64_mfma_16x16x4_TFLOPs=round(r["fp64_mfma_16x16x4_TFLOPs"]["2"], 2),
+                    fp64_valu_and_mfma_share_one_pipe=bool(
+                        r["valu_plus_mfma_same_simd_ms"]["both"]
+                        > 0.9 * (r["valu_plus_mfma_same_simd_ms"]["valu_alone"]
+                                 + r["valu_plus_mfma_same_simd_ms"]["mfma_alone"])))
+    except Exception as e:  # the peaks are a report, never a reason to fail
+        return dict(error=str(e))
+
+
+def profile_pass(ctx, prob, steps, lighting=None):
+    """The same steps once more, one Newton step per call with HIP-event
+    timing of every kernel class on the context's stream: per-step active
+    sets, CG iterations and kernel times (untimed region)."""
+    surf = prob["surf"]
+    ctx.set_nodes(surf["nodes"])
+    ctx.set_active(None)
+    ctx.profile(True)
+    ctx.profile_reset()
+    n_init = int(surf["node_valid"].sum())
+    per_step = []
+    done = 0
+    n_act = n_init
+    while done < steps:
+        if n_act <= n_init // 20:
+            ctx.set_nodes(surf["nodes"])
+            ctx.set_active(None)
+            n_act = n_init
+        st = ctx.run_loop(REG, lighting=lighting, max_newton_steps=1, reset_active=False)
+        if st["newton_steps"] == 0:
+            raise RuntimeError("Newton loop made no progress")
+        per_step.append((n_act, st["active_patch_steps"], st["linear_iterations"]))
+        n_act = st["final_active_nodes"]
+        done += 1
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    return per_step, prof
+
+
+def roofline(ctx, prob, steps, ms_per_step, lighting=None):
+    per_step, prof = profile_pass(ctx, prob, steps, lighting)
+    kernels = {k: dict(ms=round(v[0], 3), launches=int(v[1]),
+                       avg_us=round(1e3 * v[0] / max(v[1], 1), 2))
+               for k, v in prof.items()}
+    name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+    n_nodes = ctx.num_nodes
+    patch_steps = sum(p for _, p, _ in per_step)
+    cg_its = sum(c for _, _, c in per_step)
+    traffic = None
+    for tf in ("traffic_r2.json", "traffic_r1.json"):
+        tfile = os.path.join(ROOT, "profiles", tf)
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get(name)
+            break
+    # ---- SURVEY.md 8(d): T_min of the whole step over the measured time ----
+    #   T_min = sum_steps [ max(F_construct / pi, B_construct / beta)
+    #                       + N_cg * B_cg / beta ]
+    # with the measured per-step active patches, active nodes and CG iterations;
+    # F = the flops the factored construction executes (the survey's 0.50 MFLOP
+    # per patch prices the unfactored rows and is reported beside it).
+    beta = HBM_PEAK_GBPS * 1e9
+    pi = FP64_PEAK_TFLOPS * 1e12
+    cg_bytes_node = CG_BYTES["cg_spmv"] + CG_BYTES["cg_update"]
+    t_min = t_min_survey = 0.0
+    for nodes_act, patches, its in per_step:
+        b_construct = patches * BYTES_PER_PATCH / beta
+        t_cg = its * cg_bytes_node * nodes_act / beta
+        t_min += max(patches * FLOP_PER_PATCH / pi, b_construct) + t_cg
+        t_min_survey += max(patches * FLOP_PER_PATCH_SURVEY / pi, b_construct) + t_cg
+    t_meas = ms_per_step * 1e-3 * steps
+    out = dict(kernel=name, traffic=traffic, kernels=kernels,
+               step_frac=round(t_min / t_meas, 4),
+               step_t_min_us=round(1e6 * t_min / steps, 1),
+               step_frac_with_survey_flops=round(t_min_survey / t_meas, 4),
+               step_note="step_frac = T_min / T per SURVEY.md 8(d) with the measured "
+                         "per-step active patches / nodes / CG iterations, %.3f MFLOP per "
+                         "patch (executed by the factored construction), %d B per active "
+                         "node and CG iteration, peaks %.0f GB/s and %.1f TFLOP/s; the "
+                         "survey's 0.50 MFLOP (unfactored rows) is not a lower bound and "
+                         "gives step_frac_with_survey_flops"
+                         % (FLOP_PER_PATCH / 1e6, cg_bytes_node, HBM_PEAK_GBPS,
+                            FP64_PEAK_TFLOPS),
+               peaks_assumed=dict(hbm_GBps=HBM_PEAK_GBPS, fp64_TFLOPs=FP64_PEAK_TFLOPS),
+               peaks_measured=measured_peaks())
+    if name == "cg_resident":
+        # one launch per solve; the matrix is read once and stays in registers:
+        # algorithmic HBM bytes = H upper half + P + g + b + x per node
+        bytes_per_launch = (5 * 128 + 128 + 32 + 32 + 32) * n_nodes
+        avg_s = ms * 1e-3 / max(cnt, 1)
+        achieved = bytes_per_launch / avg_s / 1e9
+        out.update(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
+                   unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                   bytes_per_launch=bytes_per_launch, avg_us=round(avg_s * 1e6, 2),
+                   note="whole PCG solve in one launch (%.1f iterations on average): "
+                        "after the one pass over H the kernel is bound by its two grid "
+                        "barriers per iteration, not by HBM" % (cg_its / max(cnt, 1)))
+    elif name in CG_BYTES:
+        # launches after convergence are no-ops: their time stays in the
+        # numerator, the denominator counts the launches that did work
+        bytes_per_launch = CG_BYTES[name] * n_nodes
+        work = max(cg_its, 1)
+        avg_s = ms * 1e-3 / work
+        achieved = bytes_per_launch / avg_s / 1e9
+        out.update(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
+                   unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                   bytes_per_launch=bytes_per_launch, avg_us=round(avg_s * 1e6, 2),
+                   launches_with_work=work)
+    else:
+        # gn_patch_kernel: FP64 arithmetic.  The vector FMA and v_mfma_f64 share
+        # one pipe on gfx950 (tools/peaks.py), so the bound is FP64 issue, and
+        # `frac` = executed FP64 flops / peak is a pipe UTILISATION (every
+        # executed instruction counts as useful): an upper bound on the useful
+        # fraction.
+        flops = FLOP_PER_PATCH * patch_steps / max(cnt, 1)
+        avg_s = ms * 1e-3 / max(cnt, 1)
+        achieved = flops / avg_s / 1e12
+        out.update(bound="fp64-issue", achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS,
+                   unit="TFLOP/s", frac=round(achieved / FP64_PEAK_TFLOPS, 4),
+                   fp64_util=round(achieved / FP64_PEAK_TFLOPS, 4),
+                   flops_per_launch=flops, avg_us=round(avg_s * 1e6, 2))
+    out["cg_iterations"] = cg_its
+    out["cg_launch_pairs"] = int(prof["cg_spmv"][1])
+    out["cg_resident_solves"] = int(prof.get("cg_resident", (0, 0))[1])
+    return out
+
+
+# ----------------------------------------------------------------------- main
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a torch.distributed environment:
+    become N ranks (one per GPU) on this node."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=30,
+                    help="how often the K-step region is measured (median reported)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 5),
+                    help="1: BASELINE configs[1] (headline); 5: configs[4], views sharded "
+                         "over the GPUs, shading-aware")
+    ap.add_argument("--views-per-rank", type=int, default=8, help="--config 5 only")
+    ap.add_argument("--shared-lighting", action="store_true",
+                    help="--config 5: RCCL all-reduce of the SH normal equations over "
+                         "the lock-step round (default: per-view lighting, the "
+                         "reference's behaviour)")
     ap.add_argument("--small", action="store_true", help="480x270 debug size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views-in-flight", type=int, default=1,
@@ -93,148 +354,160 @@ def main():
                          "stream and host thread each); the headline number uses 1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    shading = args.config == 5
+    prob = make_problem(rank, args.small, shading=shading)
+    # The CPU baseline forks one oracle process per view: run it before the
+    # HIP runtime (and its threads) exists in this process.
+    cpu = None
+    if rank == 0 and world == 1 and args.config == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(prob)
+
     import torch  # device plumbing + torch.distributed only
     import smvs_amd
+    from smvs_amd import shard
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if smvs_amd.device_count() < 1:
         raise RuntimeError("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
 
-    prob = make_problem(rank, args.small)
     surf = prob["surf"]
     w, h = surf["width"], surf["height"]
-    ctx = smvs_amd.ViewContext(w, h, NSUBS, device=local_rank)
-    ctx.set_views(prob["views"])
-    ctx.set_surface(surf)
+    n_views = max(args.views_per_rank, 1) if args.config == 5 else 1
+    n_views = max(n_views, max(args.views_in_flight, 1))
+
+    # The views of this rank: own context (device buffers + stream) each.  In
+    # --config 5 they are distinct reference views in cost: same image planes,
+    # individually perturbed start surfaces.
+    ctxs, starts = [], []
+    for v in range(n_views):
+        c = smvs_amd.ViewContext(w, h, NSUBS, device=local_rank)
+        c.set_views(prob["views"])
+        s = dict(surf)
+        if v > 0 and args.config == 5:
+            rng = np.random.default_rng(7000 + 97 * rank + v)
+            nodes = surf["nodes"].copy()
+            nodes[:, 0] *= 1.0 + 0.5 * NOISE * rng.standard_normal(nodes.shape[0])
+            s["nodes"] = nodes
+        c.set_surface(s)
+        ctxs.append(c)
+        starts.append(dict(prob, surf=s))
+    ctx = ctxs[0]
 
     def barrier():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    # optional: more reference views in flight on this GPU (same inputs, own
-    # context / stream / host thread each); every view runs the K steps
-    extra = []
-    for _ in range(max(args.views_in_flight, 1) - 1):
-        c = smvs_amd.ViewContext(w, h, NSUBS, device=local_rank)
-        c.set_views(prob["views"]); c.set_surface(surf)
-        extra.append(c)
+    def fit_lighting(round_ctxs):
+        """light_optimizer.cc:22-55 for the views of one lock-step round."""
+        ptrs = [c.light_accumulate_dev() for c in round_ctxs]
+        if args.shared_lighting:
+            shard.allreduce_lighting_device(ptrs, dist, device)
+        return [shard.solve_lighting(*c.light_download()) for c in round_ctxs]
 
     def run_all(steps):
+        """K steps on this rank: --config 1 on the (views-in-flight) contexts
+        concurrently, --config 5 view after view (lock step across ranks)."""
+        if args.config == 5:
+            done = ps = its = 0
+            v = 0
+            while done < steps:
+                c, p = ctxs[v % n_views], starts[v % n_views]
+                c.set_nodes(p["surf"]["nodes"])
+                lighting = fit_lighting([c])[0]
+                st = c.run_loop(REG, lighting=lighting,
+                                max_newton_steps=min(200, steps - done), reset_active=True)
+                if st["newton_steps"] == 0:
+                    raise RuntimeError("Newton loop made no progress")
+                done += st["newton_steps"]
+                ps += st["active_patch_steps"]
+                its += st["linear_iterations"]
+                v += 1
+            return ps, its
         import threading
-        res = [None] * (1 + len(extra))
+        use = ctxs[:max(args.views_in_flight, 1)]
+        res = [None] * len(use)
+
         def work(i, c):
-            res[i] = run_steps(c, prob, steps)
-        th = [threading.Thread(target=work, args=(i + 1, c)) for i, c in enumerate(extra)]
+            res[i] = run_steps(c, starts[i], steps)
+        th = [threading.Thread(target=work, args=(i, c)) for i, c in enumerate(use) if i > 0]
         [t.start() for t in th]
-        work(0, ctx)
+        work(0, use[0])
         [t.join() for t in th]
         return sum(r[0] for r in res), sum(r[1] for r in res)
 
     run_all(args.warmup)
-    for c in [ctx] + extra:
-        c.set_nodes(surf["nodes"])
-        c.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    patch_steps, cg_its = run_all(args.steps)
-    for c in extra:
-        c.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    for c in extra:
-        c.close()
+    repeats = []
+    for _ in range(max(args.repeats, 1)):
+        for c, p in zip(ctxs, starts):
+            c.set_nodes(p["surf"]["nodes"])
+        barrier()
+        t0 = time.perf_counter()
+        patch_steps, cg_its = run_all(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # whole-job aggregate: units summed over ranks, time = max over ranks
+        dev = device if dist is not None else None
+        units, secs = shard.aggregate_throughput(patch_steps, elapsed, dist, dev)
+        its, _ = shard.aggregate_throughput(cg_its, 0.0, dist, dev)
+        repeats.append((units / secs, secs, units, its))
+    repeats.sort(key=lambda r: r[0])
+    value, secs, units, cg_total = repeats[len(repeats) // 2]
 
-    # whole-job aggregate: units summed over ranks, time = max over ranks
-    from smvs_amd import shard
-    dev = torch.device("cuda", local_rank) if dist is not None else None
-    patch_steps, elapsed = shard.aggregate_throughput(patch_steps, elapsed, dist, dev)
-    cg_its, _ = shard.aggregate_throughput(cg_its, 0.0, dist, dev)
-
-    # ---- roofline of the dominant kernel: same steps, HIP-event timed ----
     roof = None
-    cpu = None
     if rank == 0:
-        ctx.set_nodes(surf["nodes"])
-        ctx.profile(True)
-        ctx.profile_reset()
-        prof_patch_steps, prof_cg_its = run_steps(ctx, prob, args.steps)
-        prof = ctx.profile_get()
-        ctx.profile(False)
-        name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
-        n_nodes = ctx.num_nodes
-        kernels = {k: dict(ms=round(v[0], 3), launches=int(v[1]),
-                           avg_us=round(1e3 * v[0] / max(v[1], 1), 2))
-                   for k, v in prof.items()}
-        # Algorithmic bytes / flops per launch.  The CG
-        # kernels are also launched as no-ops after convergence (the host
-        # learns the iteration count late): their average duration is taken
-        # over the launches that did work (= CG iterations of the profiled
-        # steps), with the no-op time left in the numerator.
-        per_node = {"cg_spmv": 5 * 128 + 2 * 32 + 2 * 32,      # H upper half; z, d_old; Ad, d_new
-                    "cg_update": 5 * 32 + 128 + 3 * 32 + 2}    # x d r Ad b; P; x r z; mask
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_r1.json")
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                traffic = json.load(f).get(name)
-        if name in per_node:
-            bytes_per_launch = per_node[name] * n_nodes
-            work_launches = max(prof_cg_its, 1)
-            avg_s = ms * 1e-3 / work_launches
-            achieved = bytes_per_launch / avg_s / 1e9
-            roof = dict(kernel=name, bound="hbm", achieved=round(achieved, 1),
-                        peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
-                        traffic=traffic, bytes_per_launch=bytes_per_launch,
-                        avg_us=round(avg_s * 1e6, 2), launches_with_work=work_launches,
-                        kernels=kernels)
-        else:
-            # gn_patch_kernel: FP64 arithmetic (VALU + v_mfma_f64).  0.132 MFLOP
-            # per active patch is what the factored formulation executes at
-            # S = 8 neighbours, P = 16 samples, counted from the SQ instruction
-            # counters (profiles/r1_patch_kernel_counters.txt);
-            # SURVEY 8(d)'s 0.50 MFLOP prices the reference's unfactored rows.
-            # Peak: 78.6 TFLOP/s, MI355X's FP64 rate (vector and matrix alike).
-            flops = 0.132e6 * prof_patch_steps / max(cnt, 1)
-            avg_s = ms * 1e-3 / cnt
-            achieved = flops / avg_s / 1e12
-            roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 3),
-                        peak=78.6, unit="TFLOP/s", frac=round(achieved / 78.6, 4),
-                        traffic=traffic, flops_per_launch=flops,
-                        avg_us=round(avg_s * 1e6, 2), kernels=kernels)
-        if not args.no_cpu_baseline and world == 1:   # N = 1 only
-            cpu = cpu_baseline(prob)
+        lighting = fit_lighting([ctx])[0] if args.config == 5 else None
+        if args.config == 5:
+            ctx.set_nodes(surf["nodes"])
+        roof = roofline(ctx, prob, args.steps, 1e3 * secs / args.steps, lighting)
 
     if rank == 0:
-        value = patch_steps / elapsed
+        views_in_flight = max(args.views_in_flight, 1) if args.config == 1 else 1
+        workload = ("configs[1]: %dx%d synthetic textured sphere, 1 ref + %d neighbours, -o2 "
+                    "(scale 2, %d patches), basic photometric optimizer, %s"
+                    % (w, h, NSUBS, int(surf["patch_valid"].sum()),
+                       "one reference view per GPU" if views_in_flight <= 1
+                       else "%d reference views in flight per GPU" % views_in_flight))
+        if args.config == 5:
+            workload = ("configs[4]: %d reference views x %d neighbours at %dx%d (%d per GPU), "
+                        "-S shading-aware (SH lighting fit per view%s + shading residual), "
+                        "scale 2, views sharded over the GPUs"
+                        % (n_views * world, NSUBS, w, h, n_views,
+                           ", normal equations all-reduced over the lock-step round with "
+                           "RCCL" if args.shared_lighting else ""))
         out = {
             "metric": "Gauss-Newton iters/sec x active patches, 1920x1080 ref view, 8 neighbours",
             "value": value, "unit": "active-patch-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * secs / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %dx%d synthetic textured sphere, 1 ref + %d "
-                                   "neighbours, -o2 (scale 2, %d patches), basic photometric "
-                                   "optimizer, %s"
-                                   % (w, h, NSUBS, int(surf["patch_valid"].sum()),
-                                      "one reference view per GPU" if args.views_in_flight <= 1
-                                      else "%d reference views in flight per GPU" % args.views_in_flight),
-                       "regularization": REG,
-                       "cg_iterations_per_step": cg_its / max(args.steps * world * max(args.views_in_flight, 1), 1),
-                       "views_in_flight_per_gpu": max(args.views_in_flight, 1)},
+            "config": {"workload": workload, "regularization": REG,
+                       "cg_iterations_per_step": cg_total / max(args.steps * world
+                                                                * views_in_flight, 1),
+                       "views_in_flight_per_gpu": views_in_flight},
+            "timing": {"repeats": len(repeats), "statistic": "median",
+                       "value_min": repeats[0][0], "value_max": repeats[-1][0],
+                       "ms_per_step_min": 1e3 * repeats[-1][1] / args.steps,
+                       "ms_per_step_max": 1e3 * repeats[0][1] / args.steps},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

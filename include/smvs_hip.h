@@ -203,6 +203,9 @@ int smvs_get_normal_map(smvs_ctx *ctx, float *normals);
  * device pointer. */
 int smvs_light_accumulate(smvs_ctx *ctx, double *A256, double *b16);
 int smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev);
+/* Reads the context's 272-double buffer back (after the caller's collective
+ * has summed it in place over the views that share their lighting). */
+int smvs_light_download(smvs_ctx *ctx, double *A256, double *b16);
 
 /* ------------------------------------------------------------------ */
 /* SGM                                                                */
@@ -329,6 +332,7 @@ enum {
     SMVS_K_CG_INIT,
     SMVS_K_REACTIVATE,    /* K9 */
     SMVS_K_MISC,
+    SMVS_K_CG_RESIDENT,   /* whole PCG solve in one launch, H in registers */
     SMVS_K_COUNT
 };
 int smvs_profile_enable(smvs_ctx *ctx, int on);

@@ -44,7 +44,7 @@ class LoopStats(C.Structure):
 
 
 K_NAMES = ["patch", "assemble", "cg_spmv", "cg_update", "cg_init",
-           "reactivate", "misc"]
+           "reactivate", "misc", "cg_resident"]
 
 
 def declared_symbols():

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmvs_hip.so")
-SOURCES = ["ctx.hip", "gn_construct.hip", "cg.hip", "update.hip", "sgm.hip",
+SOURCES = ["ctx.hip", "gn_construct.hip", "cg.hip", "cg_resident.hip", "update.hip", "sgm.hip",
            "scale.hip", "topology.hip", "mesh.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wall", "-Wno-unused-function"]

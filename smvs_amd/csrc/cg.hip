@@ -619,6 +619,22 @@ int
 cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info)
 {
+    // conjugate_gradient.h:123-125: the iteration counter starts at 1 and the
+    // loop runs while it is below max_iterations.  The launch index shares a
+    // 32-bit progress word with the solve id (16 bits each).
+    SMVS_REQUIRE(max_iterations >= 0 && max_iterations <= 0xFFFF,
+        "max_iterations must be in [0, 65535]");
+    SMVS_REQUIRE(q_tolerance >= 0.0, "negative q_tolerance");
+    {
+        // whole solve in one launch with H resident in registers when the
+        // node grid fits the chip (cg_resident.hip); otherwise, or when its
+        // workgroups could not all be resident, the streaming kernels below
+        bool ran = false;
+        int const rc = cg_resident_solve(ctx, max_iterations, error_tolerance,
+            q_tolerance, num_iterations, info, &ran);
+        if (rc != SMVS_OK || ran)
+            return rc;
+    }
     CgArgs A;
     A.H9 = ctx->H9;
     A.Pinv = ctx->Pinv;
@@ -664,6 +680,17 @@ cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
             ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
+
+    if (max_iterations <= 1) {
+        // The loop body never runs (conjugate_gradient.h:121-125, 198-199):
+        // x = 0, one "iteration", CG_MAX_ITERATIONS.  x was zeroed above.
+        ctx->last_cg_iterations = 1;
+        if (num_iterations != nullptr)
+            *num_iterations = 1;
+        if (info != nullptr)
+            *info = SMVS_CG_MAX_ITERATIONS;
+        return SMVS_OK;
+    }
 
     // A_k for k = 1 .. max_iterations (A_max only finishes iteration max-1),
     // B_k for k = 1 .. max_iterations - 1.
@@ -757,8 +784,6 @@ smvs_cg_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         set_error("smvs_cg_solve: no system constructed");
         return SMVS_ERR_STATE;
     }
-    SMVS_REQUIRE(max_iterations >= 0 && max_iterations <= 0xFFFF,
-        "max_iterations out of range");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     return cg_solve_launch(ctx, max_iterations, error_tolerance, q_tolerance,
         num_iterations, info);

@@ -1,0 +1,743 @@
+// Preconditioned conjugate gradient with the matrix resident on the chip.
+//
+// Same solver as cg.hip (ConjugateGradient::solve, lib/conjugate_gradient.h:72-202,
+// on the block stencil of BlockSparseMatrix<4>), different data movement.  The
+// streaming kernels of cg.hip read the matrix H (83 MB at 1920x1080, scale 2)
+// once per iteration: 150 MB per iteration through L2 / Infinity Cache and two
+// launches, ~33 us per iteration however small the active set is.  Here ONE
+// launch runs the whole solve:
+//
+//   * the node grid is cut into <= 256 tiles of <= 512 nodes, one workgroup
+//     (512 threads, one per node) per tile, one workgroup per CU;
+//   * a thread keeps its node's five stored blocks (diagonal + the four upper
+//     neighbours, 80 doubles = 160 VGPRs) in REGISTERS for the whole solve:
+//     the 128 MB register file holds the 83 MB matrix, H is read from HBM once
+//     per solve instead of once per iteration;
+//   * the product uses the symmetry the storage already exploits: thread m
+//     forms  B d  for its five blocks (its own rows) and  B^T d_m  for its four
+//     upper blocks (the rows of the upper neighbours, handed over through
+//     LDS); rows whose lower neighbour lives in another tile use a copy of
+//     that neighbour's block kept in LDS (the tile's rim, 18 KB);
+//   * per iteration only 32 bytes per rim node cross workgroups (z of the
+//     halo) plus 4 scalars per workgroup (the partial dot products), through
+//     write-through (agent-scope) stores and loads around two grid barriers
+//     (hierarchical counters, MI355X_MICROARCH.md "barrier-xcd"); every
+//     workgroup reduces the partial sums in the same fixed order, so all
+//     derive bit-identical alpha / beta and take the same branch.
+//
+// Numerics: the same operations as the reference except the association of
+// the sums (row sums collect the transposed contributions after the stored
+// ones; dot products are tree sums, as in cg.hip).  Deterministic: the result
+// does not depend on scheduling.  x, the iteration count and `info` are
+// checked against the oracle by the same tests as the streaming solver.
+//
+// Every spin is bounded: if the workgroups are not all resident (another
+// barrier kernel holds CUs, fewer CUs than tiles) the barrier times out, the
+// solve reports failure and the caller falls back to the streaming kernels.
+#include "common.h"
+
+#include <chrono>
+#include <cmath>
+#include <mutex>
+
+namespace smvs_hip {
+
+constexpr int RES_THREADS = 512;
+constexpr int RES_WAVES = RES_THREADS / 64;
+constexpr int RES_MAX_BLOCKS = 256;
+constexpr int RES_GROUPS = 8;           // barrier groups (blockIdx & 7: the XCD)
+
+typedef double double4_r __attribute__((ext_vector_type(4)));
+
+struct ResState {           // mirrors CgState of cg.hip
+    double rr, q0, tol, gnorm;
+    int iter, done, info, pad;
+};
+
+// barrier words (zeroed before every launch)
+struct ResBarrier {
+    unsigned cnt[RES_GROUPS];
+    unsigned gen[RES_GROUPS];
+    unsigned top;
+    unsigned timeout;
+};
+
+struct ResArgs {
+    const double *H9;        // [5][N][16]
+    const double *Pinv;      // [N][16]
+    const double *g;         // [N][4]
+    double *x, *b;           // [N][4], touched by the owning thread only
+    double *zx;              // [N][4] z, exchanged between workgroups
+    double *partA;           // [RES_MAX_BLOCKS]      d.Ad
+    double *partB;           // [3][RES_MAX_BLOCKS]   r.r, x.(b+r), z.r  (init: z.r, g.g)
+    ResBarrier *bar;
+    ResState *state;         // [2] (state[0] is written at the end)
+    int *status;
+    int *progress;           // pinned host words, see cg.hip
+    int solve_tag;
+    int num_nodes, stride, rows;
+    int tw, th, tiles_x, num_tiles;
+    int max_iterations;
+    double q_tolerance, fixed_tolerance;
+};
+
+__device__ __forceinline__ void
+st_agent(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+        (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double
+ld_agent(const double *p)
+{
+    unsigned long long const v = __hip_atomic_load(
+        reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)v);
+}
+
+// Grid barrier: arrivals per group, group leaders on a top counter, release
+// through per-group generation words.  The workgroup's write-through stores
+// are drained by every wave before its leader arrives.  Returns false after
+// a bounded wait (some workgroup is not resident / has given up).
+__device__ __forceinline__ bool
+grid_barrier(ResBarrier *bar, unsigned epoch, int nblocks, int *lds_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int const ngroups = nblocks < RES_GROUPS ? nblocks : RES_GROUPS;
+        int const group = (int)blockIdx.x % ngroups;
+        unsigned const members = (unsigned)((nblocks - group + ngroups - 1) / ngroups);
+        unsigned const a = __hip_atomic_fetch_add(&bar->cnt[group], 1u,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (a == epoch * members) {
+            unsigned const t = __hip_atomic_fetch_add(&bar->top, 1u,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (t == epoch * (unsigned)ngroups)
+                for (int gq = 0; gq < ngroups; ++gq)
+                    __hip_atomic_store(&bar->gen[gq], epoch, __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(&bar->gen[group], __ATOMIC_RELAXED,
+                   __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)
+                || ((spins & 1023u) == 0u
+                    && __hip_atomic_load(&bar->timeout, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(&bar->timeout, 1u, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *lds_flag = ok;
+    }
+    __syncthreads();
+    int const ok = *lds_flag;
+    __syncthreads();
+    return ok != 0;
+}
+
+// Sum K per-thread values over the workgroup in a fixed order; every thread
+// gets the result.
+template <int K>
+__device__ __forceinline__ void
+block_sum(double (&v)[K], double *red /*[K][RES_WAVES]*/)
+{
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            s += __shfl_xor(s, off);
+        if (lane == 0)
+            red[k * RES_WAVES + wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < RES_WAVES; ++wv)
+            s += red[k * RES_WAVES + wv];
+        v[k] = s;
+    }
+    __syncthreads();
+}
+
+// Sum the per-workgroup partials of K kinds (written before the barrier).
+template <int K>
+__device__ __forceinline__ void
+gather_partials(const double *part, int nblocks, double (&out)[K], double *red)
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        out[k] = (int)threadIdx.x < nblocks
+            ? ld_agent(part + (size_t)k * RES_MAX_BLOCKS + threadIdx.x) : 0.0;
+    block_sum<K>(out, red);
+}
+
+template <int K>
+__device__ __forceinline__ void
+publish_partials(double (&v)[K], double *part, double *red)
+{
+    block_sum<K>(v, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            st_agent(part + (size_t)k * RES_MAX_BLOCKS + blockIdx.x, v[k]);
+}
+
+__global__ void __launch_bounds__(RES_THREADS, 2)
+cg_resident_kernel(ResArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int const tw = A.tw, th = A.th;
+    int const LW = tw + 2, LH = th + 2;
+    int const tile_nodes = tw * th;
+    // LDS carve (doubles): direction tile with halo, contributions of the
+    // four upper blocks, rim blocks, reduction scratch, flag
+    double *dtile = lds;                                  // [LH*LW][4]
+    double *contrib = dtile + (size_t)LH * LW * 4;        // [4][tile_nodes][4]
+    double *fb = contrib + (size_t)4 * tile_nodes * 4;    // [3*tw + 3*th][16]
+    double *red = fb + (size_t)(3 * tw + 3 * th) * 16;    // [4][RES_WAVES]
+    int *flag = reinterpret_cast<int *>(red + 4 * RES_WAVES);
+
+    int const tid = threadIdx.x;
+    int const nblocks = (int)gridDim.x;
+    int const tile = (int)blockIdx.x;
+    int const ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    int const lx = tid % tw, ly = tid / tw;
+    int const gx = tx * tw + lx, gy = ty * th + ly;
+    bool const mine = tid < tile_nodes && gx < A.stride && gy < A.rows;
+    int const n = mine ? gy * A.stride + gx : 0;
+    int const lcore = (ly + 1) * LW + lx + 1;
+    size_t const N = (size_t)A.num_nodes;
+
+    // halo ring position served by this thread
+    int const ring = 2 * LW + 2 * th;
+    bool const has_halo = tid < ring;
+    int hx = 0, hy = 0;
+    if (tid < LW) {
+        hx = tid; hy = 0;
+    } else if (tid < 2 * LW) {
+        hx = tid - LW; hy = LH - 1;
+    } else if (tid < 2 * LW + th) {
+        hx = 0; hy = tid - 2 * LW + 1;
+    } else if (has_halo) {
+        hx = LW - 1; hy = tid - 2 * LW - th + 1;
+    }
+    int halo_node = -1;
+    if (has_halo) {
+        int const ix = tx * tw + hx - 1, iy = ty * th + hy - 1;
+        if (ix >= 0 && ix < A.stride && iy >= 0 && iy < A.rows)
+            halo_node = iy * A.stride + ix;
+    }
+    int const lhalo = hy * LW + hx;
+
+    // ---- the matrix: five stored blocks in registers, the rim in LDS ----
+    // (the diagonal block is symmetric, Q4: its upper triangle, 10 doubles)
+    double hd[10];
+    double hu[4][16];
+    {
+        const double4_r *src = reinterpret_cast<const double4_r *>(
+            A.H9 + (size_t)n * 16);
+        double4_r const zero4 = { 0, 0, 0, 0 };
+        double4_r const r0 = mine ? src[0] : zero4, r1 = mine ? src[1] : zero4,
+            r2 = mine ? src[2] : zero4, r3 = mine ? src[3] : zero4;
+        hd[0] = r0.x; hd[1] = r0.y; hd[2] = r0.z; hd[3] = r0.w;
+        hd[4] = r1.y; hd[5] = r1.z; hd[6] = r1.w;
+        hd[7] = r2.z; hd[8] = r2.w;
+        hd[9] = r3.w;
+    }
+#pragma unroll
+    for (int s = 1; s < 5; ++s) {
+        const double4_r *src = reinterpret_cast<const double4_r *>(
+            A.H9 + ((size_t)s * N + (size_t)n) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double4_r const v = mine ? src[q] : (double4_r){ 0, 0, 0, 0 };
+            hu[s - 1][4 * q + 0] = v.x; hu[s - 1][4 * q + 1] = v.y;
+            hu[s - 1][4 * q + 2] = v.z; hu[s - 1][4 * q + 3] = v.w;
+        }
+    }
+    // lower slot s = 0..3 <-> (dx, dy) = (-1,-1), (0,-1), (1,-1), (-1,0).
+    // fb_idx[s]: -2 neighbour outside the grid, -1 neighbour inside the tile
+    // (its contribution arrives through `contrib`), >= 0 index of the copy
+    // of the neighbour's block in the rim.
+    // `low` holds two bits per lower slot: 0 neighbour outside the grid,
+    // 1 neighbour inside the tile (its contribution arrives through
+    // `contrib`), 2 the neighbour's block sits in the rim; `up` one bit per
+    // upper slot: the neighbour's row lives in this tile.
+    auto rim_index = [&](int s) -> int {
+        int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
+        if (ly + dy < 0)
+            return s * tw + lx;
+        if (lx + dx < 0)
+            return 3 * tw + (s == 0 ? 0 : th) + ly;
+        return 3 * tw + 2 * th + ly;
+    };
+    unsigned low = 0u, up = 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
+        int const nx = gx + dx, ny = gy + dy;
+        if (mine && nx >= 0 && nx < A.stride && ny >= 0) {
+            int const mlx = lx + dx, mly = ly + dy;
+            bool const in_tile = mly >= 0 && mlx >= 0 && mlx < tw;
+            low |= (in_tile ? 1u : 2u) << (2 * s);
+            if (!in_tile) {
+                // block (row m, col n) is stored at m under its upper slot 8 - s
+                int const m = ny * A.stride + nx;
+                const double *src = A.H9 + ((size_t)(8 - s - 4) * N + (size_t)m) * 16;
+                double *dst = fb + (size_t)rim_index(s) * 16;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    dst[e] = src[e];
+            }
+        }
+    }
+    // upper slots 5..8 <-> (dx, dy) = (1,0), (-1,1), (0,1), (1,1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int const s = 5 + k;
+        int const dx = s % 3 - 1, dy = s / 3 - 1;
+        int const mlx = lx + dx, mly = ly + dy;
+        bool const in_tile = mine && mlx >= 0 && mlx < tw && mly < th
+            && gx + dx < A.stride && gy + dy < A.rows;
+        up |= (in_tile ? 1u : 0u) << k;
+    }
+    // zero the direction tile (out-of-grid halo stays zero for the whole solve)
+    for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
+        dtile[i] = 0.0;
+
+    // ---- x = 0, r = b = -g, z = P r  (conjugate_gradient.h:86-118) ----
+    double r[4], z[4];
+    {
+        double v0[2] = { 0.0, 0.0 };
+        if (mine) {
+            double4_r const gv = *reinterpret_cast<const double4_r *>(
+                A.g + (size_t)n * 4);
+            double const gg[4] = { gv.x, gv.y, gv.z, gv.w };
+            const double4_r *P = reinterpret_cast<const double4_r *>(
+                A.Pinv + (size_t)n * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = -gg[k];
+#pragma unroll
+            for (int row = 0; row < 4; ++row) {
+#pragma clang fp contract(off)
+                double4_r const p = P[row];
+                double zi = 0.0;
+                zi += p.x * r[0];
+                zi += p.y * r[1];
+                zi += p.z * r[2];
+                zi += p.w * r[3];
+                z[row] = zi;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                A.b[(size_t)n * 4 + k] = r[k];
+                A.x[(size_t)n * 4 + k] = 0.0;
+                st_agent(A.zx + (size_t)n * 4 + k, z[k]);
+                v0[0] += z[k] * r[k];
+                v0[1] += gg[k] * gg[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = z[k] = 0.0;
+        }
+        publish_partials<2>(v0, A.partB, red);
+    }
+    unsigned epoch = 1;
+    bool alive = grid_barrier(A.bar, epoch++, nblocks, flag);
+    ResState st;
+    {
+        double v0[2];
+        gather_partials<2>(A.partB, nblocks, v0, red);
+        st.rr = v0[0];
+        st.q0 = -0.0;
+        st.gnorm = sqrt(v0[1]);
+        st.tol = A.fixed_tolerance < 0.0 ? st.gnorm * 0.01 : A.fixed_tolerance;
+        st.iter = 1;
+        st.done = 0;
+        st.info = SMVS_CG_MAX_ITERATIONS;
+        st.pad = 0;
+    }
+
+    // ---- iterations (conjugate_gradient.h:123-198) ----
+    double beta = 0.0;
+    for (int k = 1; alive && k < A.max_iterations; ++k) {
+        // d_k = z + beta d_{k-1}: own node and halo, in LDS
+        {
+#pragma clang fp contract(off)
+            double4_r *dt = reinterpret_cast<double4_r *>(dtile);
+            if (mine) {
+                double4_r const old = dt[lcore];
+                dt[lcore] = (double4_r){ z[0] + beta * old.x, z[1] + beta * old.y,
+                    z[2] + beta * old.z, z[3] + beta * old.w };
+            }
+            if (halo_node >= 0) {
+                double zh[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    zh[q] = ld_agent(A.zx + (size_t)halo_node * 4 + q);
+                double4_r const old = dt[lhalo];
+                dt[lhalo] = (double4_r){ zh[0] + beta * old.x, zh[1] + beta * old.y,
+                    zh[2] + beta * old.z, zh[3] + beta * old.w };
+            }
+        }
+        __syncthreads();
+        // own rows: five stored blocks; transposed products for the rows of
+        // the four upper neighbours
+        double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+        double dself[4];
+        {
+            const double4_r *dt = reinterpret_cast<const double4_r *>(dtile);
+            double4_r const ds = dt[lcore];
+            dself[0] = ds.x; dself[1] = ds.y; dself[2] = ds.z; dself[3] = ds.w;
+            {
+                // diagonal block from its upper triangle
+                double const *d4 = dself;
+                acc[0] = hd[0] * d4[0] + hd[1] * d4[1] + hd[2] * d4[2] + hd[3] * d4[3];
+                acc[1] = hd[1] * d4[0] + hd[4] * d4[1] + hd[5] * d4[2] + hd[6] * d4[3];
+                acc[2] = hd[2] * d4[0] + hd[5] * d4[1] + hd[7] * d4[2] + hd[8] * d4[3];
+                acc[3] = hd[3] * d4[0] + hd[6] * d4[1] + hd[8] * d4[2] + hd[9] * d4[3];
+            }
+#pragma unroll
+            for (int s = 5; s < 9; ++s) {
+                int const dx = s % 3 - 1, dy = s / 3 - 1;
+                double4_r const dm = dt[lcore + dy * LW + dx];
+                double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
+#pragma unroll
+                for (int row = 0; row < 4; ++row)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[row] = __builtin_fma(hu[s - 5][row * 4 + c], dv[c],
+                            acc[row]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (!((up >> kk) & 1u))
+                    continue;
+                // the neighbour sees this block under its lower slot 8 - s
+                int const s = 5 + kk;
+                int const slot = 8 - s;
+                int const dx = s % 3 - 1, dy = s / 3 - 1;
+                int const target = (ly + dy) * tw + lx + dx;
+                double t[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int row = 0; row < 4; ++row)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        t[c] = __builtin_fma(hu[kk][row * 4 + c], dself[row],
+                            t[c]);
+                double4_r *dst = reinterpret_cast<double4_r *>(contrib
+                    + ((size_t)slot * tile_nodes + target) * 4);
+                *dst = (double4_r){ t[0], t[1], t[2], t[3] };
+            }
+        }
+        __syncthreads();
+        if (mine) {
+            const double4_r *dt = reinterpret_cast<const double4_r *>(dtile);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                unsigned const kind = (low >> (2 * s)) & 3u;
+                if (kind == 1u) {
+                    double4_r const cv = *reinterpret_cast<const double4_r *>(
+                        contrib + ((size_t)s * tile_nodes + (ly * tw + lx)) * 4);
+                    acc[0] += cv.x; acc[1] += cv.y; acc[2] += cv.z; acc[3] += cv.w;
+                } else if (kind == 2u) {
+                    int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
+                    double4_r const dm = dt[lcore + dy * LW + dx];
+                    double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
+                    const double *blk = fb + (size_t)rim_index(s) * 16;
+#pragma unroll
+                    for (int row = 0; row < 4; ++row)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[c] = __builtin_fma(blk[row * 4 + c], dv[row],
+                                acc[c]);
+                }
+            }
+        }
+        {
+            double v1[1] = { 0.0 };
+            if (mine)
+                v1[0] = dself[0] * acc[0] + dself[1] * acc[1]
+                    + dself[2] * acc[2] + dself[3] * acc[3];
+            publish_partials<1>(v1, A.partA, red);
+        }
+        if (!(alive = grid_barrier(A.bar, epoch++, nblocks, flag)))
+            break;
+        double dad[1];
+        gather_partials<1>(A.partA, nblocks, dad, red);
+        double const alpha = st.rr / dad[0];
+        // x += alpha d, r -= alpha Ad, z = P r.  (x, b and P are this thread's
+        // own lines in L2; holding them across the barrier would cost 48 of
+        // the 256 registers the matrix leaves 96 of.)
+        double v3[3] = { 0.0, 0.0, 0.0 };
+        if (mine) {
+#pragma clang fp contract(off)
+            double4_r const xv = *reinterpret_cast<const double4_r *>(
+                A.x + (size_t)n * 4);
+            double4_r const bv = *reinterpret_cast<const double4_r *>(
+                A.b + (size_t)n * 4);
+            double const xn[4] = { xv.x + alpha * dself[0], xv.y + alpha * dself[1],
+                xv.z + alpha * dself[2], xv.w + alpha * dself[3] };
+            double const bo[4] = { bv.x, bv.y, bv.z, bv.w };
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                r[q] = r[q] - alpha * acc[q];
+            const double4_r *P = reinterpret_cast<const double4_r *>(
+                A.Pinv + (size_t)n * 16);
+#pragma unroll
+            for (int row = 0; row < 4; ++row) {
+                double4_r const p = P[row];
+                double zi = 0.0;
+                zi += p.x * r[0];
+                zi += p.y * r[1];
+                zi += p.z * r[2];
+                zi += p.w * r[3];
+                z[row] = zi;
+            }
+            *reinterpret_cast<double4_r *>(A.x + (size_t)n * 4)
+                = (double4_r){ xn[0], xn[1], xn[2], xn[3] };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                st_agent(A.zx + (size_t)n * 4 + q, z[q]);
+                v3[0] += r[q] * r[q];
+                v3[1] += xn[q] * (bo[q] + r[q]);
+                v3[2] += z[q] * r[q];
+            }
+        }
+        publish_partials<3>(v3, A.partB, red);
+        if (!(alive = grid_barrier(A.bar, epoch++, nblocks, flag)))
+            break;
+        gather_partials<3>(A.partB, nblocks, v3, red);
+        // termination tests of iteration k (conjugate_gradient.h:136-198)
+        double const new_rr = v3[0];
+        double const Q1 = -1.0 * v3[1];
+        int done = 0, info = SMVS_CG_MAX_ITERATIONS, iter_out = k + 1;
+        if (new_rr < st.tol) {
+            done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
+        } else {
+            double const zeta = k * (Q1 - st.q0) / Q1;
+            if (zeta < A.q_tolerance) {
+                done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
+            } else if (k + 1 >= A.max_iterations) {
+                done = 1;
+            }
+        }
+        beta = v3[2] / st.rr;
+        st.rr = v3[2];
+        st.q0 = Q1;
+        st.iter = iter_out;
+        st.done = done;
+        st.info = info;
+        if (done)
+            break;
+    }
+
+    if (blockIdx.x == 0 && tid == 0) {
+        int const failed = alive ? 0 : 1;
+        if (!st.done && !failed) {
+            // max_iterations <= 1 never reaches here (handled by the host)
+            st.done = 1;
+        }
+        A.state[0] = st;
+        A.status[I_DONE] = failed ? 0 : 1;
+        A.status[I_INFO] = st.info;
+        A.status[I_ITER] = st.iter;
+        __hip_atomic_store(A.progress + 2, st.info, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.progress + 3, st.iter, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.progress + 4, failed, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.progress + 1, A.solve_tag | 1, __ATOMIC_RELEASE,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Tile shape: tw * th <= 512 nodes, at most max_tiles tiles, smallest rim.
+static bool
+choose_tiling(int stride, int rows, int max_tiles, int *tw_out, int *th_out)
+{
+    long best = -1;
+    for (int tw = 4; tw <= 128 && tw <= RES_THREADS; ++tw) {
+        int const th = RES_THREADS / tw;
+        if (th < 2)
+            continue;
+        for (int t2 = th; t2 >= 2 && t2 >= th - 8; --t2) {
+            long const tiles = (long)((stride + tw - 1) / tw)
+                * ((rows + t2 - 1) / t2);
+            if (tiles > max_tiles)
+                continue;
+            // prefer few idle threads, then a short rim
+            long const waste = tiles * (long)(tw * t2) - (long)stride * rows;
+            long const score = waste * 4 + tiles * (tw + t2);
+            if (best < 0 || score < best) {
+                best = score;
+                *tw_out = tw;
+                *th_out = t2;
+            }
+        }
+    }
+    return best >= 0;
+}
+
+static std::mutex g_resident_mutex[16];   // one barrier kernel per device at a time
+
+// Returns SMVS_OK with *ran = false when the resident solver does not apply
+// (grid too large for the chip, disabled, or it failed to synchronise) -- the
+// caller then runs the streaming kernels.
+int
+cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
+    double q_tolerance, int *num_iterations, int *info, bool *ran)
+{
+    *ran = false;
+    if (ctx->resident_disabled || max_iterations <= 1)
+        return SMVS_OK;
+    static int const env_off = [] {
+        const char *e = std::getenv("SMVS_CG_RESIDENT");
+        return e != nullptr && e[0] == '0' ? 1 : 0;
+    }();
+    if (env_off)
+        return SMVS_OK;
+    int const stride = ctx->node_stride;
+    int const rows = ctx->num_nodes / stride;
+    if (ctx->resident_cus == 0) {
+        hipDeviceProp_t prop;
+        SMVS_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+        ctx->resident_cus = prop.multiProcessorCount;
+        ctx->resident_lds = (int)prop.sharedMemPerBlock;
+        int max_dyn = 0;
+        if (hipDeviceGetAttribute(&max_dyn,
+                hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess
+            && max_dyn > ctx->resident_lds)
+            ctx->resident_lds = max_dyn;
+    }
+    int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
+        ? ctx->resident_cus : RES_MAX_BLOCKS;
+    int tw = 0, th = 0;
+    if (!choose_tiling(stride, rows, max_tiles, &tw, &th))
+        return SMVS_OK;
+    int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
+    int const num_tiles = tiles_x * tiles_y;
+    size_t const lds_bytes = ((size_t)(tw + 2) * (th + 2) * 4
+        + (size_t)4 * tw * th * 4 + (size_t)(3 * tw + 3 * th) * 16
+        + 4 * RES_WAVES + 2) * sizeof(double);
+    if (lds_bytes > (size_t)160 * 1024)
+        return SMVS_OK;
+    if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32)
+        return SMVS_OK;
+
+    int rc;
+    if (ctx->res_work == nullptr) {
+        // zx [cap_nodes][4], partA, partB[3], barrier words
+        if ((rc = device_alloc(&ctx->res_work,
+                 (size_t)4 * RES_MAX_BLOCKS + 64)) != SMVS_OK)
+            return rc;
+    }
+    if (ctx->res_zx_cap < (size_t)ctx->num_nodes) {
+        if ((rc = device_alloc(&ctx->res_zx, ctx->cap_nodes * 4)) != SMVS_OK) {
+            ctx->res_zx_cap = 0;
+            return rc;
+        }
+        ctx->res_zx_cap = ctx->cap_nodes;
+    }
+    static bool attr_set[16] = { false };
+    if (ctx->device < 16 && !attr_set[ctx->device]) {
+        SMVS_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(cg_resident_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[ctx->device] = true;
+    }
+
+    ResArgs A;
+    A.H9 = ctx->H9;
+    A.Pinv = ctx->Pinv;
+    A.g = ctx->g;
+    A.x = ctx->x;
+    A.b = ctx->b;
+    A.zx = ctx->res_zx;
+    A.partA = ctx->res_work;
+    A.partB = ctx->res_work + RES_MAX_BLOCKS;
+    A.bar = reinterpret_cast<ResBarrier *>(ctx->res_work + 4 * RES_MAX_BLOCKS);
+    A.state = reinterpret_cast<ResState *>(ctx->cg_state);
+    A.status = ctx->status;
+    A.progress = ctx->cg_progress;
+    ctx->cg_solve_id = (ctx->cg_solve_id + 1) & 0x7FFF;
+    if (ctx->cg_solve_id == 0)
+        ctx->cg_solve_id = 1;
+    A.solve_tag = ctx->cg_solve_id << 16;
+    A.num_nodes = ctx->num_nodes;
+    A.stride = stride;
+    A.rows = rows;
+    A.tw = tw;
+    A.th = th;
+    A.tiles_x = tiles_x;
+    A.num_tiles = num_tiles;
+    A.max_iterations = max_iterations;
+    A.q_tolerance = q_tolerance;
+    A.fixed_tolerance = error_tolerance;
+
+    // one barrier kernel at a time per device: two of them started together
+    // could each hold half of the CUs and wait for the other half for ever
+    std::lock_guard<std::mutex> guard(g_resident_mutex[ctx->device & 15]);
+    SMVS_HIP_CHECK(hipMemsetAsync(A.bar, 0, sizeof(ResBarrier), ctx->stream));
+    {
+        ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
+        hipLaunchKernelGGL(cg_resident_kernel, dim3(num_tiles),
+            dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+
+    volatile int *progress = ctx->cg_progress;
+    auto const t_start = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) != (A.solve_tag | 1)) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            hipError_t const q = hipStreamQuery(ctx->stream);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                SMVS_HIP_CHECK(q);
+            if (q == hipSuccess
+                && __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE)
+                    != (A.solve_tag | 1)) {
+                set_error("cg_resident_solve: kernel ended without a result");
+                return SMVS_ERR_STATE;
+            }
+            if (std::chrono::steady_clock::now() - t_start
+                > std::chrono::seconds(60)) {
+                set_error("cg_resident_solve: timed out waiting for the device");
+                return SMVS_ERR_STATE;
+            }
+        }
+    }
+    // (every workgroup has passed its last barrier when the result appears:
+    // the kernel is draining and cannot block a barrier kernel started now)
+    if (progress[4] != 0) {
+        // not all workgroups were resident: never try again on this context
+        ctx->resident_disabled = true;
+        return SMVS_OK;
+    }
+    ctx->last_cg_iterations = progress[3];
+    if (num_iterations != nullptr)
+        *num_iterations = progress[3];
+    if (info != nullptr)
+        *info = progress[2];
+    *ran = true;
+    return SMVS_OK;
+}
+
+} // namespace smvs_hip

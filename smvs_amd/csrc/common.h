@@ -144,6 +144,14 @@ struct smvs_ctx {
     double *lightAb = nullptr;      // [272] lighting normal equations
     float *stage = nullptr;         // upload staging (3-channel planes)
     size_t stage_cap = 0;
+    // resident PCG (cg_resident.hip)
+    double *res_work = nullptr;     // partial sums + barrier words
+    double *res_zx = nullptr;       // [cap_nodes][4] z exchanged between workgroups
+    size_t res_zx_cap = 0;
+    int resident_cus = 0, resident_lds = 0;
+    bool resident_disabled = false;
+    float *map_scratch = nullptr;   // depth / normal map output, W*H*3 floats
+    double *light_partial = nullptr;  // per-block lighting sums (update.hip)
 
     // scale space on the device (scale.hip): float images of the views
     struct ViewImage { int w = 0, h = 0, c = 0; float *data = nullptr; };
@@ -216,5 +224,7 @@ int gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
 int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info);
 int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization);
+int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
+    double q_tolerance, int *num_iterations, int *info, bool *ran);
 
 } // namespace smvs_hip

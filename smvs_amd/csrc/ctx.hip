@@ -142,9 +142,12 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         smvs_ctx_destroy(ctx);
         return rc;
     }
-    if (hipHostMalloc((void **)&ctx->cg_progress, sizeof(int) * 8) != hipSuccess
-        || hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM) != hipSuccess
-        || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM) != hipSuccess) {
+    // coherent (fine-grained) pinned memory: the CG kernels publish their
+    // progress with system-scope stores that the host polls while they run
+    unsigned const host_flags = hipHostMallocCoherent | hipHostMallocMapped;
+    if (hipHostMalloc((void **)&ctx->cg_progress, sizeof(int) * 8, host_flags) != hipSuccess
+        || hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM, host_flags) != hipSuccess
+        || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM, host_flags) != hipSuccess) {
         set_error("hipHostMalloc failed");
         smvs_ctx_destroy(ctx);
         return SMVS_ERR_NOMEM;
@@ -171,7 +174,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->Hp, ctx->gp, ctx->H9, ctx->Pinv, ctx->g, ctx->lighting, ctx->x,
         ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->d2, ctx->b, ctx->partials,
         ctx->cg_state, ctx->scalars,
-        ctx->status, ctx->lightAb, ctx->stage };
+        ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
+        ctx->light_partial, ctx->res_work, ctx->res_zx };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -291,11 +295,17 @@ smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
     SubPlanes &sp = ctx->subs[sub];
     size_t const npix = (size_t)width * height;
     int rc;
-    if (sp.width != width || sp.height != height || sp.grad == nullptr) {
-        if ((rc = device_alloc(&sp.grad, npix)) != SMVS_OK)
+    if (sp.width != width || sp.height != height || sp.grad == nullptr
+        || sp.hess == nullptr) {
+        // a failed allocation leaves the planes marked absent, so that the
+        // next call allocates both again
+        sp.width = sp.height = 0;
+        if ((rc = device_alloc(&sp.grad, npix)) != SMVS_OK
+            || (rc = device_alloc(&sp.hess, npix)) != SMVS_OK) {
+            (void)device_alloc(&sp.grad, 0);
+            (void)device_alloc(&sp.hess, 0);
             return rc;
-        if ((rc = device_alloc(&sp.hess, npix)) != SMVS_OK)
-            return rc;
+        }
         sp.width = width;
         sp.height = height;
     }
@@ -377,6 +387,11 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
     int rc = SMVS_OK;
     if (N > ctx->cap_nodes) {
         size_t const cap = N + N / 8;
+        // (a failure below leaves the context without a surface and with a
+        // zero capacity: the next call allocates everything again)
+        ctx->cap_nodes = 0;
+        ctx->has_surface = false;
+        ctx->has_system = false;
         if ((rc = device_alloc(&ctx->nodes, cap * 4)) != SMVS_OK
             || (rc = device_alloc(&ctx->node_valid, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->active, cap)) != SMVS_OK
@@ -397,6 +412,9 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
     }
     if (P > ctx->cap_patches) {
         size_t const cap = P + P / 8;
+        ctx->cap_patches = 0;
+        ctx->has_surface = false;
+        ctx->has_system = false;
         if ((rc = device_alloc(&ctx->patch_valid, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->patch_vis, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->Hp, cap * 256)) != SMVS_OK

@@ -1037,6 +1037,19 @@ int
 gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     bool use_lighting)
 {
+    // Shared by smvs_gn_construct and smvs_gn_run_loop: the patch kernel
+    // dereferences every neighbour's planes and the main gradient.
+    for (int j = 0; j < ctx->n_subs; ++j)
+        if (ctx->subs[j].grad == nullptr || ctx->subs[j].hess == nullptr) {
+            set_error("gn_construct: sub view %d has no gradient / Hessian "
+                "planes (smvs_ctx_upload_sub or smvs_ctx_set_scale first)", j);
+            return SMVS_ERR_STATE;
+        }
+    if (use_lighting && !ctx->has_shading) {
+        set_error("gn_construct: lighting given but no shading planes");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_REQUIRE(reg >= 0.0 && light_reg >= 0.0, "negative regularization");
     PatchKernelArgs A;
     A.nodes = ctx->nodes;
     A.patch_valid = ctx->patch_valid;
@@ -1131,15 +1144,6 @@ smvs_gn_construct(smvs_ctx *ctx, double regularization,
     SMVS_REQUIRE(ctx != nullptr, "null context");
     if (!ctx->has_surface || !ctx->has_cameras) {
         set_error("smvs_gn_construct: cameras and surface must be set first");
-        return SMVS_ERR_STATE;
-    }
-    for (int j = 0; j < ctx->n_subs; ++j)
-        if (ctx->subs[j].grad == nullptr) {
-            set_error("smvs_gn_construct: sub view %d has no planes", j);
-            return SMVS_ERR_STATE;
-        }
-    if (lighting16 != nullptr && !ctx->has_shading) {
-        set_error("smvs_gn_construct: lighting given but no shading planes");
         return SMVS_ERR_STATE;
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));

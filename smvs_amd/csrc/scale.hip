@@ -238,9 +238,13 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
         } else {
             SubPlanes &sp = ctx->subs[v - 1];
             size_t const npix = (size_t)vi.w * vi.h;
-            if (sp.width != vi.w || sp.height != vi.h || sp.grad == nullptr) {
+            if (sp.width != vi.w || sp.height != vi.h || sp.grad == nullptr
+                || sp.hess == nullptr) {
+                sp.width = sp.height = 0;   // absent until both planes exist
                 if ((rc = device_alloc(&sp.grad, npix)) != SMVS_OK
                     || (rc = device_alloc(&sp.hess, npix)) != SMVS_OK) {
+                    (void)device_alloc(&sp.grad, 0);
+                    (void)device_alloc(&sp.hess, 0);
                     (void)hipFree(kernel_dev);
                     return rc;
                 }

@@ -458,10 +458,11 @@ smvs_update_and_reactivate(smvs_ctx *ctx, double threshold,
         *num_active = ctx->status_host[I_NUM_ACTIVE];
     if (nan_flag != nullptr)
         *nan_flag = ctx->status_host[I_NAN];
+    // sum / count like depth_optimizer.cc:277-282: NaN when no patch is seen
+    // by any neighbour (0 / 0), which the caller's `update < 0.01` rejects
     if (mean_delta != nullptr)
-        *mean_delta = ctx->scalars_host[S_COUNT_DIFF] > 0.0
-            ? ctx->scalars_host[S_SUMDIFF] / ctx->scalars_host[S_COUNT_DIFF]
-            : 0.0;
+        *mean_delta = ctx->scalars_host[S_SUMDIFF]
+            / ctx->scalars_host[S_COUNT_DIFF];
     return SMVS_OK;
 }
 
@@ -478,6 +479,12 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         set_error("smvs_gn_run_loop: lighting requested without shading planes");
         return SMVS_ERR_STATE;
     }
+    SMVS_REQUIRE(prm->max_newton_steps >= 0, "max_newton_steps is negative");
+    SMVS_REQUIRE(prm->active_threshold >= 0.0 && prm->full_opt_threshold >= 0.0
+        && prm->cg_q_tolerance >= 0.0, "negative threshold");
+    // (neighbour planes and cg_max_iterations are checked by
+    // gn_construct_launch / cg_solve_launch, shared with the stand-alone
+    // entry points)
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     memset(stats, 0, sizeof(*stats));
     int rc;
@@ -534,9 +541,11 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             break;
         }
         if (prm->full_optimization) {
-            double const cnt = ctx->scalars_host[S_COUNT_DIFF];
-            double const update = cnt > 0.0
-                ? ctx->scalars_host[S_SUMDIFF] / cnt : 0.0;
+            // depth_optimizer.cc:277-288: sum_diff / size; with no
+            // reprojection term at all this is 0 / 0 = NaN, the comparison is
+            // false and the loop goes on to its step limit like the reference
+            double const update = ctx->scalars_host[S_SUMDIFF]
+                / ctx->scalars_host[S_COUNT_DIFF];
             if (update < prm->full_opt_threshold)
                 break;
             continue;
@@ -546,6 +555,16 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     stats->newton_steps = newton_step;
     stats->final_active_nodes = num_active;
     return SMVS_OK;
+}
+
+// W*H*3 floats of output scratch owned by the context (no allocation per call)
+static int
+ensure_map_scratch(smvs_ctx *ctx)
+{
+    if (ctx->map_scratch != nullptr)
+        return SMVS_OK;
+    return device_alloc(&ctx->map_scratch,
+        (size_t)ctx->width * ctx->height * 3);
 }
 
 extern "C" int
@@ -558,10 +577,10 @@ smvs_get_depth_map(smvs_ctx *ctx, float *depth)
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
-    float *buf = nullptr;
-    int rc = device_alloc(&buf, npix);
+    int rc = ensure_map_scratch(ctx);
     if (rc != SMVS_OK)
         return rc;
+    float *buf = ctx->map_scratch;
     hipError_t e = hipMemsetAsync(buf, 0, npix * sizeof(float), ctx->stream);
     if (e == hipSuccess)
         rc = launch_maps(ctx, buf, nullptr);
@@ -570,7 +589,6 @@ smvs_get_depth_map(smvs_ctx *ctx, float *depth)
             hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(buf);
     if (e != hipSuccess) {
         set_error("smvs_get_depth_map: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
@@ -588,10 +606,10 @@ smvs_get_normal_map(smvs_ctx *ctx, float *normals)
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const n = (size_t)ctx->width * ctx->height * 3;
-    float *buf = nullptr;
-    int rc = device_alloc(&buf, n);
+    int rc = ensure_map_scratch(ctx);
     if (rc != SMVS_OK)
         return rc;
+    float *buf = ctx->map_scratch;
     hipError_t e = hipMemsetAsync(buf, 0, n * sizeof(float), ctx->stream);
     if (e == hipSuccess)
         rc = launch_maps(ctx, nullptr, buf);
@@ -600,7 +618,6 @@ smvs_get_normal_map(smvs_ctx *ctx, float *normals)
             hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(buf);
     if (e != hipSuccess) {
         set_error("smvs_get_normal_map: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
@@ -618,15 +635,15 @@ smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev)
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
-    float *normals = nullptr;
-    double *partial = nullptr;
-    int rc = device_alloc(&normals, npix * 3);
+    int rc = ensure_map_scratch(ctx);
     if (rc != SMVS_OK)
         return rc;
-    if ((rc = device_alloc(&partial, (size_t)LIGHT_BLOCKS * 152)) != SMVS_OK) {
-        (void)hipFree(normals);
+    if (ctx->light_partial == nullptr
+        && (rc = device_alloc(&ctx->light_partial,
+                (size_t)LIGHT_BLOCKS * 152)) != SMVS_OK)
         return rc;
-    }
+    float *normals = ctx->map_scratch;
+    double *partial = ctx->light_partial;
     hipError_t e = hipMemsetAsync(normals, 0, npix * 3 * sizeof(float),
         ctx->stream);
     if (e == hipSuccess)
@@ -642,8 +659,6 @@ smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev)
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(normals);
-    (void)hipFree(partial);
     if (e != hipSuccess) {
         set_error("smvs_light_accumulate: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
@@ -660,6 +675,19 @@ smvs_light_accumulate(smvs_ctx *ctx, double *A256, double *b16)
     int rc = smvs_light_accumulate_dev(ctx, nullptr);
     if (rc != SMVS_OK)
         return rc;
+    double host[272];
+    SMVS_HIP_CHECK(hipMemcpy(host, ctx->lightAb, sizeof(host),
+        hipMemcpyDeviceToHost));
+    memcpy(A256, host, 256 * sizeof(double));
+    memcpy(b16, host + 256, 16 * sizeof(double));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_light_download(smvs_ctx *ctx, double *A256, double *b16)
+{
+    SMVS_REQUIRE(ctx && A256 && b16, "null argument");
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     double host[272];
     SMVS_HIP_CHECK(hipMemcpy(host, ctx->lightAb, sizeof(host),
         hipMemcpyDeviceToHost));

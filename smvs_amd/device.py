@@ -218,6 +218,18 @@ class ViewContext:
         check(self.lib.smvs_light_accumulate(self.handle, _p(A, _dp), _p(b, _dp)))
         return A, b
 
+    def light_accumulate_dev(self):
+        """Leaves A (256) + b (16) doubles in the context's device buffer and
+        returns its device address (for an in-place RCCL all-reduce)."""
+        ptr = C.c_void_p()
+        check(self.lib.smvs_light_accumulate_dev(self.handle, C.byref(ptr)))
+        return ptr.value
+
+    def light_download(self):
+        A = np.zeros((16, 16)); b = np.zeros(16)
+        check(self.lib.smvs_light_download(self.handle, _p(A, _dp), _p(b, _dp)))
+        return A, b
+
     # ------------------------------------------------------------ topology
     def topology_subviews(self, sgm_depth=None, use_ncc=True):
         """create_subview_surfaces' per-(patch, neighbour) tests -> bit masks."""

@@ -49,6 +49,50 @@ def allreduce_lighting(A, b, dist=None, device=None):
     return buf[:256].reshape(16, 16), buf[256:]
 
 
+class _DevicePointer:
+    """Zero-copy view of `count` doubles at a raw device address for
+    torch.as_tensor (the __cuda_array_interface__ protocol)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, count, device):
+    """torch float64 tensor aliasing libsmvs_hip's device buffer (no copy)."""
+    import torch
+    return torch.as_tensor(_DevicePointer(ptr, count), device=device)
+
+
+def allreduce_lighting_device(ptrs, dist=None, device=None):
+    """Shared-lighting collective directly on the buffers
+    smvs_light_accumulate_dev left on the device (272 doubles each: A then b).
+    `ptrs`: the device addresses of the views this rank processes in the
+    current lock-step round.  They are summed on the device, all-reduced over
+    the ranks in place with RCCL (no host hop) and the result is written back
+    to every buffer, so that each view's smvs_light_download returns the sum
+    over all views of the round."""
+    import torch
+    ts = [device_tensor(p, 272, device) for p in ptrs]
+    if not ts:
+        return
+    total = ts[0]
+    for t in ts[1:]:
+        total += t
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    for t in ts[1:]:
+        t.copy_(total)
+    torch.cuda.synchronize(device)
+
+
+def solve_lighting(A, b):
+    """params = pinv(A) b (light_optimizer.cc:50-52), singular values below
+    1e-12 of the largest dropped."""
+    return np.linalg.pinv(np.asarray(A, dtype=np.float64), rcond=1e-12,
+                          hermitian=True) @ np.asarray(b, dtype=np.float64)
+
+
 def aggregate_throughput(units, seconds, dist=None, device=None):
     """Whole-job numbers of one timed region: work units summed over ranks,
     time = max over ranks.  Returns (total_units, max_seconds)."""

@@ -202,3 +202,54 @@ def test_full_size_optimize_shading_aware_matches_oracle(hip, oracle, oracle_thr
     assert _rel(got["lighting"], want["lighting"]) < 1e-3
     assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
     assert _rel(got["depth"], want["depth"]) <= 1e-4
+
+
+# ------------------------- configs[4] code path (views sharded, shading-aware)
+def test_config5_lighting_round_on_device_buffers(hip, oracle):
+    """The --config 5 path of bench.py on one rank with two views in a
+    lock-step round (light_optimizer.cc:32-55): per-view mode
+    (the reference's behaviour) = each view's own normal equations; shared
+    mode = the device buffers of smvs_light_accumulate_dev summed in place by
+    shard.allreduce_lighting_device (RCCL when world > 1, no host hop) against
+    the oracle summing A, b over the round; then a shading-aware construction
+    with the solved lighting against the oracle."""
+    import torch
+    from smvs_amd import synth, shard
+    prob = synth.make_problem(256, 192, 3, 2, shading=True, noise=0.003)
+    surfs = [prob["surf"], dict(prob["surf"])]
+    rng = np.random.default_rng(77)
+    nodes = prob["surf"]["nodes"].copy()
+    nodes[:, 0] *= 1.0 + 0.002 * rng.standard_normal(nodes.shape[0])
+    surfs[1]["nodes"] = nodes
+    ctxs, refs = [], []
+    for s in surfs:
+        c = hip.ViewContext(256, 192, 3)
+        c.set_views(prob["views"]); c.set_surface(s)
+        ctxs.append(c)
+        orc = oracle.OracleProblem(s, prob["views"])
+        refs.append(oracle.light_accumulate(orc.normal_map(), prob["views"]["shading"]))
+    device = torch.device("cuda", 0)
+    # per-view lighting (parity mode)
+    for c, (A_ref, b_ref) in zip(ctxs, refs):
+        c.light_accumulate_dev()
+        A, b = c.light_download()
+        assert _rel(A, A_ref) < 1e-10 and _rel(b, b_ref) < 1e-10
+    # shared lighting over the round
+    ptrs = [c.light_accumulate_dev() for c in ctxs]
+    shard.allreduce_lighting_device(ptrs, None, device)
+    A_sum = refs[0][0] + refs[1][0]; b_sum = refs[0][1] + refs[1][1]
+    for c in ctxs:
+        A, b = c.light_download()
+        assert _rel(A, A_sum) < 1e-10 and _rel(b, b_sum) < 1e-10
+    lighting = shard.solve_lighting(A_sum, b_sum)
+    want = oracle.light_solve(A_sum, b_sum)
+    assert _rel(lighting, want) < 1e-3        # 16x16 SH system is ill-conditioned
+    # the Newton step consumes it
+    n = ctxs[1].gn_construct(0.01, 0.0, lighting)
+    H9, g, P = ctxs[1].gn_download()
+    ref = oracle.OracleProblem(surfs[1], prob["views"]).gn_construct(
+        surfs[1]["node_valid"], 0.01, 0.0, lighting)
+    assert n == ref["active_patches"]
+    assert _rel(H9, ref["H9"]) < 1e-9 and _rel(g, ref["g"]) < 1e-9
+    for c in ctxs:
+        c.close()
