@@ -1207,6 +1207,32 @@ log_push(orc_opt_log *log, int scale, int iter, int steps, int patches,
     log->cg_iterations[i] = cg_iterations;
 }
 
+/* Debug aid: with ORC_DUMP_DIR set, the surface state at the stages of a
+ * Newton batch goes to <dir>/s<scale>_i<iter>_<tag>.bin (ints scale, npx, npy;
+ * nodes, node_valid, patch_valid, patch_vis) for tools/compare_dumps.py. */
+static void
+opt_dump(const OOpt *O, int iter, const char *tag)
+{
+    const char *dir = getenv("ORC_DUMP_DIR");
+    if (dir == NULL)
+        return;
+    const orc_surface *s = &O->surf.s;
+    char path[512];
+    snprintf(path, sizeof(path), "%s/s%d_i%d_%s.bin", dir, s->scale, iter, tag);
+    FILE *f = fopen(path, "wb");
+    if (f == NULL)
+        return;
+    int const hdr[3] = { s->scale, s->npx, s->npy };
+    size_t const nn = (size_t)(s->npx + 1) * (s->npy + 1);
+    size_t const np = (size_t)s->npx * s->npy;
+    fwrite(hdr, sizeof(int), 3, f);
+    fwrite(s->nodes, sizeof(double), 4 * nn, f);
+    fwrite(s->node_valid, 1, nn, f);
+    fwrite(s->patch_valid, 1, np, f);
+    fwrite(s->patch_vis, sizeof(uint32_t), np, f);
+    fclose(f);
+}
+
 /* depth_optimizer.cc:164-358 */
 static void
 opt_run_newton_iterations(OOpt *O, int num_iters)
@@ -1276,11 +1302,13 @@ opt_run_newton_iterations(OOpt *O, int num_iters)
         free(active);
         log_push(O->log, S->s.scale, iter, (int)newton_step, num_valid_patches,
             cg_total);
+        opt_dump(O, iter, "newton");
         if (finished)
             break;
         int deleted = 0x7fffffff;
         while (deleted > 10)
             deleted = opt_cut_boundaries(O);
+        opt_dump(O, iter, "cut");
         if (!O->opts->use_sgm)
         {
             surf_expand(S);

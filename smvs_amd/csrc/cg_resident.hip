@@ -45,7 +45,6 @@ namespace smvs_hip {
 constexpr int RES_THREADS = 512;
 constexpr int RES_WAVES = RES_THREADS / 64;
 constexpr int RES_MAX_BLOCKS = 256;
-constexpr int RES_GROUPS = 8;           // barrier groups (blockIdx & 7: the XCD)
 
 typedef double double4_r __attribute__((ext_vector_type(4)));
 
@@ -54,11 +53,13 @@ struct ResState {           // mirrors CgState of cg.hip
     int iter, done, info, pad;
 };
 
-// barrier words (zeroed before every launch)
-struct ResBarrier {
-    unsigned cnt[RES_GROUPS];
-    unsigned gen[RES_GROUPS];
-    unsigned top;
+// Exchange area (zeroed before every launch).  A double travels as two
+// 8-byte granules {tag = epoch, 32 data bits}: the data is its own flag
+// (cdna_hip_programming.md Guideline 16, form R2), so one sweep over the
+// granules of all workgroups is barrier and all-reduce at once.
+constexpr int RES_KINDS = 3;                 // doubles per all-reduce, at most
+struct ResExchange {
+    unsigned long long gran[2][2 * RES_KINDS][RES_MAX_BLOCKS];   // [parity][..][wg]
     unsigned timeout;
 };
 
@@ -68,9 +69,7 @@ struct ResArgs {
     const double *g;         // [N][4]
     double *x, *b;           // [N][4], touched by the owning thread only
     double *zx;              // [N][4] z, exchanged between workgroups
-    double *partA;           // [RES_MAX_BLOCKS]      d.Ad
-    double *partB;           // [3][RES_MAX_BLOCKS]   r.r, x.(b+r), z.r  (init: z.r, g.g)
-    ResBarrier *bar;
+    ResExchange *ex;
     ResState *state;         // [2] (state[0] is written at the end)
     int *status;
     int *progress;           // pinned host words, see cg.hip
@@ -96,52 +95,6 @@ ld_agent(const double *p)
         reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
     return __longlong_as_double((long long)v);
-}
-
-// Grid barrier: arrivals per group, group leaders on a top counter, release
-// through per-group generation words.  The workgroup's write-through stores
-// are drained by every wave before its leader arrives.  Returns false after
-// a bounded wait (some workgroup is not resident / has given up).
-__device__ __forceinline__ bool
-grid_barrier(ResBarrier *bar, unsigned epoch, int nblocks, int *lds_flag)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int const ngroups = nblocks < RES_GROUPS ? nblocks : RES_GROUPS;
-        int const group = (int)blockIdx.x % ngroups;
-        unsigned const members = (unsigned)((nblocks - group + ngroups - 1) / ngroups);
-        unsigned const a = __hip_atomic_fetch_add(&bar->cnt[group], 1u,
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        if (a == epoch * members) {
-            unsigned const t = __hip_atomic_fetch_add(&bar->top, 1u,
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (t == epoch * (unsigned)ngroups)
-                for (int gq = 0; gq < ngroups; ++gq)
-                    __hip_atomic_store(&bar->gen[gq], epoch, __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT);
-        }
-        int ok = 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(&bar->gen[group], __ATOMIC_RELAXED,
-                   __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 20)
-                || ((spins & 1023u) == 0u
-                    && __hip_atomic_load(&bar->timeout, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                __hip_atomic_store(&bar->timeout, 1u, __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        *lds_flag = ok;
-    }
-    __syncthreads();
-    int const ok = *lds_flag;
-    __syncthreads();
-    return ok != 0;
 }
 
 // Sum K per-thread values over the workgroup in a fixed order; every thread
@@ -172,27 +125,93 @@ block_sum(double (&v)[K], double *red /*[K][RES_WAVES]*/)
     __syncthreads();
 }
 
-// Sum the per-workgroup partials of K kinds (written before the barrier).
+// All-reduce of K doubles over the workgroups of the grid, and the grid-wide
+// synchronisation point of the phase: every workgroup publishes its K sums as
+// tagged granules AFTER its write-through stores of the phase have drained;
+// wave 0 of every workgroup sweeps the granules of all workgroups until every
+// tag carries this epoch, then all sum them in the same fixed order.  Seeing a
+// workgroup's granule implies seeing the z it stored before.  The slots are
+// double-buffered by epoch parity: a workgroup can publish epoch e + 2 only
+// after everybody published e + 1, i.e. after everybody finished reading e.
+// Returns false after a bounded wait (a workgroup is not resident / gave up).
 template <int K>
-__device__ __forceinline__ void
-gather_partials(const double *part, int nblocks, double (&out)[K], double *red)
+__device__ __forceinline__ bool
+grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
+    double *red, int *lds_flag)
 {
+    block_sum<K>(v, red);          // (ends with a workgroup barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned const par = epoch & 1u;
+    if (threadIdx.x < 2 * K) {
+        int const k = threadIdx.x >> 1, half = threadIdx.x & 1;
+        unsigned long long const bits = (unsigned long long)__double_as_longlong(v[k]);
+        unsigned const word = half ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(&ex->gran[par][threadIdx.x][blockIdx.x],
+            ((unsigned long long)epoch << 32) | word, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int const wave = threadIdx.x >> 6;
+    if (wave < K) {
+        // wave k sweeps kind k (the K sweeps run side by side)
+        int const lane = threadIdx.x & 63;
+        constexpr int PER_LANE = RES_MAX_BLOCKS / 64;
+        unsigned lo[PER_LANE], hi[PER_LANE];
+        bool ok = true;
+        for (unsigned spins = 0;; ++spins) {
+            bool all = true;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        out[k] = (int)threadIdx.x < nblocks
-            ? ld_agent(part + (size_t)k * RES_MAX_BLOCKS + threadIdx.x) : 0.0;
-    block_sum<K>(out, red);
-}
-
-template <int K>
-__device__ __forceinline__ void
-publish_partials(double (&v)[K], double *part, double *red)
-{
-    block_sum<K>(v, red);
-    if (threadIdx.x == 0)
+            for (int j = 0; j < PER_LANE; ++j) {
+                int const blk = lane + 64 * j;
+                unsigned long long g0 = (unsigned long long)epoch << 32, g1 = g0;
+                if (blk < nblocks) {
+                    g0 = __hip_atomic_load(&ex->gran[par][2 * wave][blk],
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g1 = __hip_atomic_load(&ex->gran[par][2 * wave + 1][blk],
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                lo[j] = (unsigned)g0;
+                hi[j] = (unsigned)g1;
+                all &= (unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch;
+            }
+            if (__all(all))
+                break;
+            if (spins > (1u << 18)
+                || ((spins & 255u) == 255u
+                    && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        // fixed order: workgroups lane, lane + 64, ... per lane, then the tree
+        double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            st_agent(part + (size_t)k * RES_MAX_BLOCKS + blockIdx.x, v[k]);
+        for (int j = 0; j < PER_LANE; ++j) {
+            unsigned long long const bits = ((unsigned long long)hi[j] << 32) | lo[j];
+            sum += (lane + 64 * j) < nblocks
+                ? __longlong_as_double((long long)bits) : 0.0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            sum += __shfl_xor(sum, off);
+        if (lane == 0) {
+            red[wave] = sum;
+            lds_flag[wave] = ok ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[k] = red[k];
+        ok = ok && lds_flag[k] != 0;
+    }
+    __syncthreads();
+    return ok;
 }
 
 __global__ void __launch_bounds__(RES_THREADS, 2)
@@ -320,6 +339,9 @@ cg_resident_kernel(ResArgs A)
 
     // ---- x = 0, r = b = -g, z = P r  (conjugate_gradient.h:86-118) ----
     double r[4], z[4];
+    unsigned epoch = 1;
+    bool alive = true;
+    ResState st;
     {
         double v0[2] = { 0.0, 0.0 };
         if (mine) {
@@ -355,14 +377,7 @@ cg_resident_kernel(ResArgs A)
             for (int k = 0; k < 4; ++k)
                 r[k] = z[k] = 0.0;
         }
-        publish_partials<2>(v0, A.partB, red);
-    }
-    unsigned epoch = 1;
-    bool alive = grid_barrier(A.bar, epoch++, nblocks, flag);
-    ResState st;
-    {
-        double v0[2];
-        gather_partials<2>(A.partB, nblocks, v0, red);
+        alive = grid_allreduce<2>(A.ex, epoch++, nblocks, v0, red, flag);
         st.rr = v0[0];
         st.q0 = -0.0;
         st.gnorm = sqrt(v0[1]);
@@ -469,17 +484,12 @@ cg_resident_kernel(ResArgs A)
                 }
             }
         }
-        {
-            double v1[1] = { 0.0 };
-            if (mine)
-                v1[0] = dself[0] * acc[0] + dself[1] * acc[1]
-                    + dself[2] * acc[2] + dself[3] * acc[3];
-            publish_partials<1>(v1, A.partA, red);
-        }
-        if (!(alive = grid_barrier(A.bar, epoch++, nblocks, flag)))
+        double dad[1] = { 0.0 };
+        if (mine)
+            dad[0] = dself[0] * acc[0] + dself[1] * acc[1]
+                + dself[2] * acc[2] + dself[3] * acc[3];
+        if (!(alive = grid_allreduce<1>(A.ex, epoch++, nblocks, dad, red, flag)))
             break;
-        double dad[1];
-        gather_partials<1>(A.partA, nblocks, dad, red);
         double const alpha = st.rr / dad[0];
         // x += alpha d, r -= alpha Ad, z = P r.  (x, b and P are this thread's
         // own lines in L2; holding them across the barrier would cost 48 of
@@ -519,10 +529,8 @@ cg_resident_kernel(ResArgs A)
                 v3[2] += z[q] * r[q];
             }
         }
-        publish_partials<3>(v3, A.partB, red);
-        if (!(alive = grid_barrier(A.bar, epoch++, nblocks, flag)))
+        if (!(alive = grid_allreduce<3>(A.ex, epoch++, nblocks, v3, red, flag)))
             break;
-        gather_partials<3>(A.partB, nblocks, v3, red);
         // termination tests of iteration k (conjugate_gradient.h:136-198)
         double const new_rr = v3[0];
         double const Q1 = -1.0 * v3[1];
@@ -643,9 +651,8 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
 
     int rc;
     if (ctx->res_work == nullptr) {
-        // zx [cap_nodes][4], partA, partB[3], barrier words
         if ((rc = device_alloc(&ctx->res_work,
-                 (size_t)4 * RES_MAX_BLOCKS + 64)) != SMVS_OK)
+                 sizeof(ResExchange) / sizeof(double) + 8)) != SMVS_OK)
             return rc;
     }
     if (ctx->res_zx_cap < (size_t)ctx->num_nodes) {
@@ -670,9 +677,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.x = ctx->x;
     A.b = ctx->b;
     A.zx = ctx->res_zx;
-    A.partA = ctx->res_work;
-    A.partB = ctx->res_work + RES_MAX_BLOCKS;
-    A.bar = reinterpret_cast<ResBarrier *>(ctx->res_work + 4 * RES_MAX_BLOCKS);
+    A.ex = reinterpret_cast<ResExchange *>(ctx->res_work);
     A.state = reinterpret_cast<ResState *>(ctx->cg_state);
     A.status = ctx->status;
     A.progress = ctx->cg_progress;
@@ -694,7 +699,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     // one barrier kernel at a time per device: two of them started together
     // could each hold half of the CUs and wait for the other half for ever
     std::lock_guard<std::mutex> guard(g_resident_mutex[ctx->device & 15]);
-    SMVS_HIP_CHECK(hipMemsetAsync(A.bar, 0, sizeof(ResBarrier), ctx->stream));
+    SMVS_HIP_CHECK(hipMemsetAsync(A.ex, 0, sizeof(ResExchange), ctx->stream));
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
         hipLaunchKernelGGL(cg_resident_kernel, dim3(num_tiles),

@@ -61,6 +61,7 @@ enum {
     I_NUM_ACTIVE,    // active nodes after re-activation
     I_ACTIVE_PATCHES,
     I_TOPO_DELETED,  // patches deleted by one cut_boundaries pass
+    I_LIVE_PATCHES,  // entries of the compacted live-patch list
     I_NUM = 16
 };
 
@@ -116,6 +117,7 @@ struct smvs_ctx {
     uint8_t *patch_valid = nullptr;
     uint32_t *patch_vis = nullptr;
     uint8_t *active = nullptr, *active_next = nullptr;
+    int *live_list = nullptr;       // [P] patches with an active node, compacted
     uint16_t *cg_mask = nullptr;    // per node: stencil slots present in the CG matrix
     double *hermite_tab = nullptr;  // [ps][12] 1-D Hermite basis table
     int hermite_tab_ps = 0;
@@ -219,11 +221,16 @@ xcd_band_block(unsigned bid, unsigned nblocks)
 }
 
 // internal entry points used by the fused loop
+// known_live: entries of the live-patch list the previous reactivate_launch
+// of the same Newton loop built (its count read back by the host), or -1 to
+// build the list here.
 int gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
-    bool use_lighting);
+    bool use_lighting, int known_live = -1);
+int live_patch_list_launch(smvs_ctx *ctx);
 int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info);
-int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization);
+int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
+    bool build_live_list = false);
 int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info, bool *ran);
 

@@ -175,7 +175,7 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->d2, ctx->b, ctx->partials,
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
-        ctx->light_partial, ctx->res_work, ctx->res_zx };
+        ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -416,6 +416,7 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
         ctx->has_surface = false;
         ctx->has_system = false;
         if ((rc = device_alloc(&ctx->patch_valid, cap)) != SMVS_OK
+            || (rc = device_alloc(&ctx->live_list, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->patch_vis, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->Hp, cap * 256)) != SMVS_OK
             || (rc = device_alloc(&ctx->gp, cap * 16)) != SMVS_OK)

@@ -43,6 +43,7 @@ struct PatchKernelArgs {
     const uint8_t *patch_valid;
     const uint32_t *patch_vis;
     const uint8_t *active;
+    const int *live_list;        // compacted ids of the patches to evaluate
     const double *hermite_tab;   // [ps][12]
     const float2 *main_grad;
     const float *main_shading;
@@ -657,8 +658,18 @@ gn_patch_kernel(PatchKernelArgs A)
     double *tabs = lds + scratch_rows * 64;  // [spr][12] sampled coordinates
 
     int const lane = threadIdx.x;
-    unsigned const wv = xcd_band_block(blockIdx.x, gridDim.x);
-    int const patch_base = (int)wv * PPW;
+    // Work = the compacted list of live patches (a patch with an active node,
+    // gauss_newton_step.cc:73-79): a sparse step launches / occupies waves in
+    // proportion to its active set.  The list's blocks are dealt to the XCDs
+    // in contiguous bands (neighbouring patches share texels: one image
+    // region per L2); blocks beyond the list leave at once.
+    int const live_count = A.status[I_LIVE_PATCHES];
+    unsigned const live_blocks = (unsigned)((live_count + PPW - 1) / PPW);
+    unsigned const band = (live_blocks + 7u) >> 3;
+    unsigned const wv = (blockIdx.x & 7u) * band + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= band || wv >= live_blocks)
+        return;
+    int const slot_base = (int)wv * PPW;
 
     for (int i = lane; i < A.spr * 12; i += 64) {
         int const row = i / 12, e = i - row * 12;
@@ -668,36 +679,26 @@ gn_patch_kernel(PatchKernelArgs A)
     // the patch this lane works for in phase 1
     int const q1 = lane / SLOTS;
     int const sidx = lane - q1 * SLOTS;
-    int const patch1 = patch_base + q1;
-    bool live = false;
+    bool const live = slot_base + q1 < live_count;
+    int const patch1 = live ? A.live_list[slot_base + q1] : 0;
     double theta[16];
     uint32_t vis = 0;
     int pox = 0, poy = 0;
-    if (patch1 < A.num_patches && A.patch_valid[patch1]) {
+    if (live) {
         int const ix = patch1 % A.npx, iy = patch1 / A.npx;
         int const n00 = iy * A.stride + ix;
         int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
-        live = (A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
-            | A.active[ids[3]]) != 0;
-        if (live) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const double *src = A.nodes + 4 * (size_t)ids[n];
+        for (int n = 0; n < 4; ++n) {
+            const double *src = A.nodes + 4 * (size_t)ids[n];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    theta[4 * n + k] = src[k];
-            }
-            vis = A.patch_vis[patch1];
-            pox = A.start_x + ix * A.ps;
-            poy = A.start_y + iy * A.ps;
+            for (int k = 0; k < 4; ++k)
+                theta[4 * n + k] = src[k];
         }
+        vis = A.patch_vis[patch1];
+        pox = A.start_x + ix * A.ps;
+        poy = A.start_y + iy * A.ps;
     }
-    // the assembly kernel, which runs next, counts the live patches
-    if (blockIdx.x == 0 && lane == 0)
-        A.status[I_ACTIVE_PATCHES] = 0;
-    // wave-uniform early exit: nothing to do for any of the PPW patches
-    if (__ballot(live) == 0ull)
-        return;
 
     // phase 2 roles
     int const kg = lane >> 4, col = lane & 15;
@@ -803,12 +804,12 @@ gn_patch_kernel(PatchKernelArgs A)
     // ---- phase 3: store the per-patch systems ----
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-        int const patch = patch_base + q;
         double gv = gacc[q];
         gv += __shfl_xor(gv, 16);
         gv += __shfl_xor(gv, 32);
-        if (patch >= A.num_patches)
+        if (slot_base + q >= live_count)
             continue;
+        int const patch = A.live_list[slot_base + q];
         // Packed store: only the 10 node blocks (bi <= bj) of the upper block
         // triangle, 16 doubles each (the assembly mirrors the rest); the 16
         // lanes of a block write one 128-byte line.
@@ -959,25 +960,12 @@ gn_assemble_kernel(AssembleArgs A)
     if (in_range && r == 0)
         A.active_next[n] = 0;
     if (gid == 0) {
+        // patches the construction touched (gauss_newton_step.cc:73-79) = the
+        // length of the live list the patch kernel has just worked through
+        A.status[I_ACTIVE_PATCHES] = A.status[I_LIVE_PATCHES];
         A.status[I_NUM_ACTIVE] = 0;
         A.scalars[S_SUMDIFF] = 0.0;
         A.scalars[S_COUNT_DIFF] = 0.0;
-    }
-
-    // number of patches the construction touched (a patch with at least one
-    // active node, gauss_newton_step.cc:146-149): counted at the patch's
-    // top-left node
-    {
-        bool live = false;
-        if (in_range && r == 0 && ix < A.npx && iy < A.npy) {
-            int const p = iy * A.npx + ix;
-            live = A.patch_valid[p]
-                && (A.active[n] | A.active[n + 1] | A.active[n + A.stride]
-                    | A.active[n + A.stride + 1]) != 0;
-        }
-        int const cnt = __syncthreads_count(live);
-        if (threadIdx.x == 0 && cnt != 0)
-            atomicAdd(&A.status[I_ACTIVE_PATCHES], cnt);
     }
 
     if (in_range) {
@@ -1021,6 +1009,59 @@ gn_assemble_kernel(AssembleArgs A)
     }
 }
 
+// Compacted list of the patches the construction has to evaluate: valid
+// patches with at least one active node (gauss_newton_step.cc:73-79).  The
+// order inside a block of 256 patches is kept, blocks land in the order of
+// their atomic (neighbouring patches stay together for texel locality; which
+// wave evaluates which patch has no effect on the result).
+__global__ void __launch_bounds__(256)
+live_patch_list_kernel(const uint8_t *__restrict__ patch_valid,
+    const uint8_t *__restrict__ active, int npx, int stride, int num_patches,
+    int *__restrict__ list, int *__restrict__ status)
+{
+    int const p = blockIdx.x * 256 + threadIdx.x;
+    bool live = false;
+    if (p < num_patches && patch_valid[p]) {
+        int const ix = p % npx, iy = p / npx;
+        int const n00 = iy * stride + ix;
+        live = (active[n00] | active[n00 + 1] | active[n00 + stride]
+            | active[n00 + stride + 1]) != 0;
+    }
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long const ballot = __ballot(live);
+    int const before = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0)
+        wave_cnt[wave] = __popcll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int const total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        base = total > 0 ? atomicAdd(&status[I_LIVE_PATCHES], total) : 0;
+    }
+    __syncthreads();
+    if (live) {
+        int off = base + before;
+        for (int wv = 0; wv < wave; ++wv)
+            off += wave_cnt[wv];
+        list[off] = p;
+    }
+}
+
+int
+live_patch_list_launch(smvs_ctx *ctx)
+{
+    SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_LIVE_PATCHES, 0, sizeof(int),
+        ctx->stream));
+    ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+    hipLaunchKernelGGL(live_patch_list_kernel,
+        dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0,
+        ctx->stream, ctx->patch_valid, ctx->active, ctx->npx, ctx->node_stride,
+        ctx->num_patches, ctx->live_list, ctx->status);
+    SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
 static int
 sampling_for_scale(int scale)
 {
@@ -1035,7 +1076,7 @@ sampling_for_scale(int scale)
 
 int
 gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
-    bool use_lighting)
+    bool use_lighting, int known_live)
 {
     // Shared by smvs_gn_construct and smvs_gn_run_loop: the patch kernel
     // dereferences every neighbour's planes and the main gradient.
@@ -1055,6 +1096,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     A.patch_valid = ctx->patch_valid;
     A.patch_vis = ctx->patch_vis;
     A.active = ctx->active;
+    A.live_list = ctx->live_list;
     A.hermite_tab = ctx->hermite_tab;
     A.main_grad = ctx->main_grad;
     A.main_shading = ctx->main_shading;
@@ -1092,8 +1134,21 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12) * sizeof(double);
     bool const four = A.P <= 16;
     int const ppw = four ? 4 : 1;
-    unsigned const blocks = (unsigned)((ctx->num_patches + ppw - 1) / ppw);
-    {
+    // grid = the live list when the host knows its length (read back after the
+    // previous step of the same Newton loop), otherwise every patch (the
+    // surplus blocks leave at once)
+    int live = ctx->num_patches;
+    if (known_live >= 0) {
+        live = known_live;
+    } else {
+        int const rc = live_patch_list_launch(ctx);
+        if (rc != SMVS_OK)
+            return rc;
+    }
+    // (8 XCD bands of ceil(blocks / 8) blocks each)
+    unsigned const live_blocks = (unsigned)((live + ppw - 1) / ppw);
+    unsigned const blocks = ((live_blocks + 7u) >> 3) << 3;
+    if (blocks > 0) {
         ScopedKernelTimer timer(ctx, SMVS_K_PATCH);
         if (four)
             hipLaunchKernelGGL((gn_patch_kernel<4>), dim3(blocks), dim3(64), lds,

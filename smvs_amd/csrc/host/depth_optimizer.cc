@@ -126,6 +126,36 @@ solve_psd16(double const* A_in, double const* b, double* x)
 
 } // namespace
 
+// Debug aid: with SMVS_DUMP_DIR set, the surface state at the stages of a
+// Newton batch goes to <dir>/s<scale>_i<iter>_<tag>.bin in the layout of the
+// oracle's ORC_DUMP_DIR files (tools/compare_dumps.py).
+void
+DepthOptimizer::dump_state(int iter, char const* tag) const
+{
+    char const* dir = std::getenv("SMVS_DUMP_DIR");
+    if (dir == nullptr)
+        return;
+    std::string const path = std::string(dir) + "/s"
+        + std::to_string(surface->get_scale()) + "_i" + std::to_string(iter)
+        + "_" + tag + ".bin";
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (f == nullptr)
+        return;
+    int const hdr[3] = { surface->get_scale(), surface->get_num_patches_x(),
+        surface->get_num_patches_y() };
+    std::size_t const nn = surface->get_num_nodes();
+    std::size_t const np = surface->get_num_patches();
+    std::vector<uint32_t> vis(np, 0);
+    for (std::size_t p = 0; p < np && p < subsurfaces.size(); ++p)
+        vis[p] = subsurfaces[p];
+    std::fwrite(hdr, sizeof(int), 3, f);
+    std::fwrite(surface->node_values().data(), sizeof(double), 4 * nn, f);
+    std::fwrite(surface->node_validity().data(), 1, nn, f);
+    std::fwrite(surface->patch_validity().data(), 1, np, f);
+    std::fwrite(vis.data(), sizeof(uint32_t), np, f);
+    std::fclose(f);
+}
+
 void
 DepthOptimizer::check(int status, char const* what) const
 {
@@ -374,6 +404,7 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         }
         log.push_back({ surface->get_scale(), iter, stats.newton_steps,
             num_valid_patches, stats.linear_iterations });
+        this->dump_state(iter, "newton");
 
         if (finished)
             break;
@@ -381,6 +412,7 @@ DepthOptimizer::run_newton_iterations(int num_iters)
             ScopedHostTimer timer("cut_boundaries");
             this->cut_boundaries_until_stable();
         }
+        this->dump_state(iter, "cut");
         if (!opts.use_sgm) {
             {
                 ScopedHostTimer timer("expand");

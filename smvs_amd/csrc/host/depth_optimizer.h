@@ -73,6 +73,7 @@ private:
     void set_scale_everywhere(int scale);
     void upload_surface(void);
     void check(int status, char const* what) const;
+    void dump_state(int iter, char const* tag) const;
 
 private:
     Options const& opts;

@@ -548,6 +548,12 @@ struct BilateralArgs {
     float sigma;
 };
 
+__device__ __forceinline__ float
+exp_rounded(float x)
+{
+    return (float)exp((double)x);
+}
+
 __global__ void __launch_bounds__(256)
 bilateral_kernel(BilateralArgs A)
 {
@@ -570,14 +576,19 @@ bilateral_kernel(BilateralArgs A)
             float const dv = A.dm[(size_t)dm_y * A.dm_w + dm_x];
             if (dv == 0.0f)
                 continue;
+            // math::gaussian / gaussian_2d are std::exp on floats: the host's
+            // expf is correctly rounded (glibc), the device's float expf is
+            // not, so the exponential is taken in double and rounded once.
+            // The initial surface then matches the CPU path bit for bit.
             float weight = 1.0f;
-            weight *= expf(-((float)kx * (float)kx / (2.0f * A.sigma * A.sigma)
+            weight *= exp_rounded(-((float)kx * (float)kx
+                / (2.0f * A.sigma * A.sigma)
                 + (float)ky * (float)ky / (2.0f * A.sigma * A.sigma)));
             for (int c = 0; c < A.channels; ++c) {
                 float const diff =
                     A.ci[((size_t)ci_y * A.w + ci_x) * A.channels + c]
                     - A.ci[((size_t)y * A.w + x) * A.channels + c];
-                weight *= expf(-(diff * diff) / (2.0f * 0.1f * 0.1f));
+                weight *= exp_rounded(-(diff * diff) / (2.0f * 0.1f * 0.1f));
             }
             acc_v += dv * weight;
             acc_w += weight;

@@ -210,7 +210,8 @@ apply_update_kernel(double *nodes, const double *x, const uint8_t *node_valid,
 }
 
 int
-reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization)
+reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
+    bool build_live_list)
 {
     int const N = ctx->num_nodes;
     // (the assembly kernel of the same Newton step has already cleared the
@@ -259,6 +260,9 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization)
             ctx->active, ctx->active_next, N, full_optimization, ctx->status);
     }
     SMVS_HIP_CHECK(hipGetLastError());
+    // the next construction's work list, from the new active set
+    if (build_live_list)
+        return live_patch_list_launch(ctx);
     return SMVS_OK;
 }
 
@@ -500,12 +504,14 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         return rc;
     int num_active = num_initial;
     int newton_step = 0;
+    int known_live = -1;   // length of the live-patch list once read back
     // depth_optimizer.cc:219-220
     while (newton_step < prm->max_newton_steps
         && num_active > num_initial / 20) {
         newton_step += 1;
         if ((rc = gn_construct_launch(ctx, prm->regularization,
-                prm->light_surf_regularization, prm->use_lighting != 0)) != SMVS_OK)
+                prm->light_surf_regularization, prm->use_lighting != 0,
+                known_live)) != SMVS_OK)
             return rc;
         int iters = 0, info = 0;
         if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
@@ -513,7 +519,7 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             return rc;
         stats->linear_iterations += iters;
         if ((rc = reactivate_launch(ctx, prm->active_threshold,
-                prm->full_optimization)) != SMVS_OK)
+                prm->full_optimization, true)) != SMVS_OK)
             return rc;
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
             sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
@@ -536,6 +542,7 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             SMVS_HIP_CHECK(q);
         }
         stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
+        known_live = ctx->status_host[I_LIVE_PATCHES];
         if (ctx->status_host[I_NAN]) {
             stats->nan_break = 1;
             break;

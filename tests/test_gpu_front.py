@@ -135,7 +135,7 @@ def test_cut_depth_maps_rejects_bad_arguments(hip):
 # -------------------------------------------- bilateral at its production size
 def test_bilateral_upsample_full_size(hip, oracle, oracle_threads):
     """K17 at the size the optimiser uses it: 960x540 SGM depth -> 1920x1080,
-    11x11 taps (depth_optimizer.cc:957-1004): float, 1e-5 of the depth range."""
+    11x11 taps (depth_optimizer.cc:957-1004)."""
     rng = np.random.default_rng(17)
     dh, dw, h, w = 540, 960, 1080, 1920
     yy, xx = np.mgrid[0:dh, 0:dw].astype(np.float32)
@@ -147,7 +147,11 @@ def test_bilateral_upsample_full_size(hip, oracle, oracle_threads):
     got = hip.bilateral_upsample(dm, ci)
     want = oracle.bilateral_upsample(dm, ci)
     assert np.array_equal(got > 0, want > 0)
-    assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+    # correctly rounded exponentials on both sides, same float operation
+    # order: the upsampled depth is bit-identical but for the rare weight
+    # whose double exponential lies within 2^-29 of a float rounding boundary
+    assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+    assert (got != want).mean() < 1e-3
 
 
 # ------------------------------------ configs[2] and [3] end to end, full size
