@@ -179,6 +179,15 @@ DepthOptimizer::DepthOptimizer(StereoView::Ptr main_view,
         "smvs_ctx_set_cameras");
 }
 
+DepthOptimizer::DepthOptimizer(StereoView::Ptr main_view,
+    std::vector<StereoView::Ptr> const& sub_views, Surface::Ptr surface,
+    Options const& opts)
+    : DepthOptimizer(main_view, sub_views, Bundle::ConstPtr(), opts)
+{
+    // lib/depth_optimizer.h:127-134
+    this->surface = surface;
+}
+
 DepthOptimizer::~DepthOptimizer(void)
 {
     if (ctx != nullptr)
@@ -228,8 +237,12 @@ DepthOptimizer::create_initial_surface(void)
         init = depthmap_bilateral_filter(init, main_view->get_image());
         this->surface = Surface::create(bundle, main_view, init_scale, init);
         this->sgm_depth = init;
-    } else
+    } else {
+        if (bundle == nullptr)
+            throw std::invalid_argument("DepthOptimizer: no bundle to "
+                "initialise the surface from (use_sgm is off)");
         this->surface = Surface::create(bundle, main_view, init_scale + 1);
+    }
 }
 
 void

@@ -42,6 +42,15 @@ public:
     DepthOptimizer(StereoView::Ptr main_view,
         std::vector<StereoView::Ptr> const& sub_views,
         Bundle::ConstPtr bundle, Options const& options);
+    // lib/depth_optimizer.h:53-56, 127-134: takes an existing surface and
+    // leaves the bundle null.  As in the reference, optimize() then rebuilds
+    // the surface (lib/depth_optimizer.cc:56 -> :35-51), which without a bundle
+    // only works with use_sgm (the reference dereferences the null bundle
+    // otherwise; here that case throws std::invalid_argument); get_depth() /
+    // get_normals() evaluate the surface that was passed in.
+    DepthOptimizer(StereoView::Ptr main_view,
+        std::vector<StereoView::Ptr> const& sub_views,
+        Surface::Ptr surface, Options const& options);
     ~DepthOptimizer(void);
     DepthOptimizer(DepthOptimizer const&) = delete;
     DepthOptimizer& operator=(DepthOptimizer const&) = delete;
