@@ -87,3 +87,43 @@ def test_single_process_paths_are_identity():
     sA, sb = shard.allreduce_lighting(A, b, None)
     assert np.array_equal(sA, A) and np.array_equal(sb, b)
     assert shard.aggregate_throughput(7, 2.0) == (7.0, 2.0)
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a torch.distributed environment
+    re-executes itself under torch.distributed.run with N ranks on 127.0.0.1
+    (the driver's own N > 1 command sets RANK and skips this)."""
+    import argparse
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        seen["env"] = env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    rc = bench.respawn_under_torchrun(argparse.Namespace(gpus=4))
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_device_pointer_protocol():
+    """shard.device_tensor wraps a raw device address through
+    __cuda_array_interface__ (no copy): shape, type and address are what torch
+    reads."""
+    from smvs_amd import shard
+    p = shard._DevicePointer(0x7f0000001000, 272)
+    cai = p.__cuda_array_interface__
+    assert cai["shape"] == (272,) and cai["typestr"] == "<f8"
+    assert cai["data"] == (0x7f0000001000, False) and cai["version"] == 2
+    A = np.diag(np.arange(1.0, 17.0)); b = np.arange(16.0)
+    assert np.allclose(shard.solve_lighting(A, b), b / np.arange(1.0, 17.0))
