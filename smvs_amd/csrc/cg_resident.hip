@@ -68,7 +68,7 @@ struct ResArgs {
     const double *Pinv;      // [N][16]
     const double *g;         // [N][4]
     double *x, *b;           // [N][4], touched by the owning thread only
-    double *zx;              // [N][4] z, exchanged between workgroups
+    unsigned long long *zg;  // [N][4][2] z of the rim nodes as tagged granules
     ResExchange *ex;
     ResState *state;         // [2] (state[0] is written at the end)
     int *status;
@@ -78,7 +78,10 @@ struct ResArgs {
     int tw, th, tiles_x, num_tiles;
     int max_iterations;
     double q_tolerance, fixed_tolerance;
+    long long *trace;        // debug: cycle stamps of workgroup 0 (or nullptr)
 };
+
+constexpr int TRACE_ITERS = 12, TRACE_POINTS = 8;
 
 __device__ __forceinline__ void
 st_agent(double *p, double v)
@@ -86,6 +89,19 @@ st_agent(double *p, double v)
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
         (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A double that crosses workgroups travels as two 8-byte granules {tag, 32
+// data bits} (Guideline 16, form R2): the reader polls until both tags carry
+// the value it expects, no release / drain on the writer's side.
+__device__ __forceinline__ void
+st_granules(unsigned long long *g, unsigned tag, double v)
+{
+    unsigned long long const bits = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | (bits & 0xFFFFFFFFull),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, ((unsigned long long)tag << 32) | (bits >> 32),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ double
@@ -140,8 +156,8 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
     double *red, int *lds_flag)
 {
     block_sum<K>(v, red);          // (ends with a workgroup barrier)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // (nothing to drain: everything that crosses workgroups is a granule, the
+    // vectors of the solve live in registers and LDS)
     unsigned const par = epoch & 1u;
     if (threadIdx.x < 2 * K) {
         int const k = threadIdx.x >> 1, half = threadIdx.x & 1;
@@ -151,9 +167,11 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
             ((unsigned long long)epoch << 32) | word, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_AGENT);
     }
-    int const wave = threadIdx.x >> 6;
-    if (wave < K) {
-        // wave k sweeps kind k (the K sweeps run side by side)
+    // Waves 3 .. 3 + K - 1 sweep (kind k each, side by side): they hold the
+    // middle rows of the tile and have next to no rim stores of their own in
+    // flight, which a wave's loads would have to wait behind (one counter).
+    int const wave = (int)(threadIdx.x >> 6) - 3;
+    if (wave >= 0 && wave < K) {
         int const lane = threadIdx.x & 63;
         constexpr int PER_LANE = RES_MAX_BLOCKS / 64;
         unsigned lo[PER_LANE], hi[PER_LANE];
@@ -200,6 +218,10 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
             sum += __shfl_xor(sum, off);
         if (lane == 0) {
             red[wave] = sum;
+            // (a halo wait that gave up raises the same flag)
+            if (wave == 0 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                ok = false;
             lds_flag[wave] = ok ? 1 : 0;
         }
     }
@@ -224,9 +246,12 @@ cg_resident_kernel(ResArgs A)
     // LDS carve (doubles): direction tile with halo, contributions of the
     // four upper blocks, rim blocks, reduction scratch, flag
     double *dtile = lds;                                  // [LH*LW][4]
-    double *contrib = dtile + (size_t)LH * LW * 4;        // [4][tile_nodes][4]
-    double *fb = contrib + (size_t)4 * tile_nodes * 4;    // [3*tw + 3*th][16]
-    double *red = fb + (size_t)(3 * tw + 3 * th) * 16;    // [4][RES_WAVES]
+    double *yl = dtile + (size_t)LH * LW * 4;             // [tile_nodes][4] row sums from below
+    double *Pl = yl + (size_t)tile_nodes * 4;             // [4][tile_nodes][4] P, row-major planes
+    double *fb = Pl + (size_t)4 * tile_nodes * 4;         // [3*tw + 3*th][16]
+    double *xl = fb + (size_t)(3 * tw + 3 * th) * 16;     // [tile_nodes][4] x
+    double *bl = xl + (size_t)tile_nodes * 4;             // [tile_nodes][4] b
+    double *red = bl + (size_t)tile_nodes * 4;            // [4][RES_WAVES]
     int *flag = reinterpret_cast<int *>(red + 4 * RES_WAVES);
 
     int const tid = threadIdx.x;
@@ -238,6 +263,9 @@ cg_resident_kernel(ResArgs A)
     bool const mine = tid < tile_nodes && gx < A.stride && gy < A.rows;
     int const n = mine ? gy * A.stride + gx : 0;
     int const lcore = (ly + 1) * LW + lx + 1;
+    int const li = ly * tw + lx;             // index in the tile
+    // the z of a rim node is read by the neighbouring tiles
+    bool const rim = mine && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
     size_t const N = (size_t)A.num_nodes;
 
     // halo ring position served by this thread
@@ -261,6 +289,8 @@ cg_resident_kernel(ResArgs A)
     }
     int const lhalo = hy * LW + hx;
 
+    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+        A.trace[0] = (long long)__builtin_readcyclecounter();
     // ---- the matrix: five stored blocks in registers, the rim in LDS ----
     // (the diagonal block is symmetric, Q4: its upper triangle, 10 doubles)
     double hd[10];
@@ -289,11 +319,11 @@ cg_resident_kernel(ResArgs A)
     }
     // lower slot s = 0..3 <-> (dx, dy) = (-1,-1), (0,-1), (1,-1), (-1,0).
     // fb_idx[s]: -2 neighbour outside the grid, -1 neighbour inside the tile
-    // (its contribution arrives through `contrib`), >= 0 index of the copy
+    // (its contribution arrives through `yl`), >= 0 index of the copy
     // of the neighbour's block in the rim.
     // `low` holds two bits per lower slot: 0 neighbour outside the grid,
     // 1 neighbour inside the tile (its contribution arrives through
-    // `contrib`), 2 the neighbour's block sits in the rim; `up` one bit per
+    // `yl`), 2 the neighbour's block sits in the rim; `up` one bit per
     // upper slot: the neighbour's row lives in this tile.
     auto rim_index = [&](int s) -> int {
         int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
@@ -315,10 +345,12 @@ cg_resident_kernel(ResArgs A)
             if (!in_tile) {
                 // block (row m, col n) is stored at m under its upper slot 8 - s
                 int const m = ny * A.stride + nx;
-                const double *src = A.H9 + ((size_t)(8 - s - 4) * N + (size_t)m) * 16;
-                double *dst = fb + (size_t)rim_index(s) * 16;
+                const double4_r *src = reinterpret_cast<const double4_r *>(
+                    A.H9 + ((size_t)(8 - s - 4) * N + (size_t)m) * 16);
+                double4_r *dst = reinterpret_cast<double4_r *>(
+                    fb + (size_t)rim_index(s) * 16);
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
+                for (int e = 0; e < 4; ++e)
                     dst[e] = src[e];
             }
         }
@@ -337,6 +369,8 @@ cg_resident_kernel(ResArgs A)
     for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
         dtile[i] = 0.0;
 
+    // tag of the z granules: the solve id and the iteration that reads them
+    unsigned const ztag = (unsigned)A.solve_tag;
     // ---- x = 0, r = b = -g, z = P r  (conjugate_gradient.h:86-118) ----
     double r[4], z[4];
     unsigned epoch = 1;
@@ -357,6 +391,8 @@ cg_resident_kernel(ResArgs A)
             for (int row = 0; row < 4; ++row) {
 #pragma clang fp contract(off)
                 double4_r const p = P[row];
+                *reinterpret_cast<double4_r *>(
+                    Pl + ((size_t)row * tile_nodes + li) * 4) = p;
                 double zi = 0.0;
                 zi += p.x * r[0];
                 zi += p.y * r[1];
@@ -364,11 +400,14 @@ cg_resident_kernel(ResArgs A)
                 zi += p.w * r[3];
                 z[row] = zi;
             }
+            *reinterpret_cast<double4_r *>(bl + (size_t)li * 4)
+                = (double4_r){ r[0], r[1], r[2], r[3] };
+            *reinterpret_cast<double4_r *>(xl + (size_t)li * 4)
+                = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                A.b[(size_t)n * 4 + k] = r[k];
-                A.x[(size_t)n * 4 + k] = 0.0;
-                st_agent(A.zx + (size_t)n * 4 + k, z[k]);
+                if (rim)
+                    st_granules(A.zg + ((size_t)n * 4 + k) * 2, ztag + 1u, z[k]);
                 v0[0] += z[k] * r[k];
                 v0[1] += gg[k] * gg[k];
             }
@@ -388,9 +427,15 @@ cg_resident_kernel(ResArgs A)
         st.pad = 0;
     }
 
+    auto stamp = [&](int k, int point) {
+        if (A.trace != nullptr && blockIdx.x == 0 && tid == 0 && k <= TRACE_ITERS)
+            A.trace[k * TRACE_POINTS + point] = (long long)__builtin_readcyclecounter();
+    };
+    stamp(0, 1);
     // ---- iterations (conjugate_gradient.h:123-198) ----
     double beta = 0.0;
     for (int k = 1; alive && k < A.max_iterations; ++k) {
+        stamp(k, 0);
         // d_k = z + beta d_{k-1}: own node and halo, in LDS
         {
 #pragma clang fp contract(off)
@@ -399,18 +444,45 @@ cg_resident_kernel(ResArgs A)
                 double4_r const old = dt[lcore];
                 dt[lcore] = (double4_r){ z[0] + beta * old.x, z[1] + beta * old.y,
                     z[2] + beta * old.z, z[3] + beta * old.w };
+                *reinterpret_cast<double4_r *>(yl + (size_t)li * 4)
+                    = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
             }
             if (halo_node >= 0) {
-                double zh[4];
+                // the neighbour's z of the previous iteration: poll its eight
+                // granules until all carry this iteration's tag
+                double zh[4] = { 0.0, 0.0, 0.0, 0.0 };
+                const unsigned long long *src = A.zg + (size_t)halo_node * 8;
+                unsigned const want = ztag + (unsigned)k;
+                for (unsigned spins = 0;; ++spins) {
+                    unsigned long long g[8];
+                    bool ok = true;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    zh[q] = ld_agent(A.zx + (size_t)halo_node * 4 + q);
+                    for (int q = 0; q < 8; ++q) {
+                        g[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(g[q] >> 32) == want;
+                    }
+                    if (ok) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            zh[q] = __longlong_as_double((long long)(
+                                (g[2 * q + 1] << 32) | (g[2 * q] & 0xFFFFFFFFull)));
+                        break;
+                    }
+                    if (spins > (1u << 18)) {
+                        __hip_atomic_store(&A.ex->timeout, 1u, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
                 double4_r const old = dt[lhalo];
                 dt[lhalo] = (double4_r){ zh[0] + beta * old.x, zh[1] + beta * old.y,
                     zh[2] + beta * old.z, zh[3] + beta * old.w };
             }
         }
         __syncthreads();
+        stamp(k, 1);
         // own rows: five stored blocks; transposed products for the rows of
         // the four upper neighbours
         double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -439,13 +511,15 @@ cg_resident_kernel(ResArgs A)
                         acc[row] = __builtin_fma(hu[s - 5][row * 4 + c], dv[c],
                             acc[row]);
             }
+        }
+        // transposed products for the rows of the four upper neighbours, one
+        // direction at a time: within a direction every row receives exactly
+        // one contribution, so the adds into yl need no atomics and the
+        // order of the sum is fixed
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (!((up >> kk) & 1u))
-                    continue;
-                // the neighbour sees this block under its lower slot 8 - s
+        for (int kk = 0; kk < 4; ++kk) {
+            if ((up >> kk) & 1u) {
                 int const s = 5 + kk;
-                int const slot = 8 - s;
                 int const dx = s % 3 - 1, dy = s / 3 - 1;
                 int const target = (ly + dy) * tw + lx + dx;
                 double t[4] = { 0.0, 0.0, 0.0, 0.0 };
@@ -455,32 +529,41 @@ cg_resident_kernel(ResArgs A)
                     for (int c = 0; c < 4; ++c)
                         t[c] = __builtin_fma(hu[kk][row * 4 + c], dself[row],
                             t[c]);
-                double4_r *dst = reinterpret_cast<double4_r *>(contrib
-                    + ((size_t)slot * tile_nodes + target) * 4);
-                *dst = (double4_r){ t[0], t[1], t[2], t[3] };
+                double4_r *dst = reinterpret_cast<double4_r *>(
+                    yl + (size_t)target * 4);
+                double4_r const cur = *dst;
+                *dst = (double4_r){ cur.x + t[0], cur.y + t[1], cur.z + t[2],
+                    cur.w + t[3] };
             }
+            if (kk < 3)
+                __syncthreads();
         }
         __syncthreads();
+        stamp(k, 2);
         if (mine) {
             const double4_r *dt = reinterpret_cast<const double4_r *>(dtile);
+            {
+                double4_r const cv = *reinterpret_cast<const double4_r *>(
+                    yl + (size_t)li * 4);
+                acc[0] += cv.x; acc[1] += cv.y; acc[2] += cv.z; acc[3] += cv.w;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 unsigned const kind = (low >> (2 * s)) & 3u;
-                if (kind == 1u) {
-                    double4_r const cv = *reinterpret_cast<const double4_r *>(
-                        contrib + ((size_t)s * tile_nodes + (ly * tw + lx)) * 4);
-                    acc[0] += cv.x; acc[1] += cv.y; acc[2] += cv.z; acc[3] += cv.w;
-                } else if (kind == 2u) {
+                if (kind == 2u) {
                     int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
                     double4_r const dm = dt[lcore + dy * LW + dx];
                     double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
-                    const double *blk = fb + (size_t)rim_index(s) * 16;
+                    const double4_r *blk = reinterpret_cast<const double4_r *>(
+                        fb + (size_t)rim_index(s) * 16);
 #pragma unroll
-                    for (int row = 0; row < 4; ++row)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[c] = __builtin_fma(blk[row * 4 + c], dv[row],
-                                acc[c]);
+                    for (int row = 0; row < 4; ++row) {
+                        double4_r const br = blk[row];
+                        acc[0] = __builtin_fma(br.x, dv[row], acc[0]);
+                        acc[1] = __builtin_fma(br.y, dv[row], acc[1]);
+                        acc[2] = __builtin_fma(br.z, dv[row], acc[2]);
+                        acc[3] = __builtin_fma(br.w, dv[row], acc[3]);
+                    }
                 }
             }
         }
@@ -488,30 +571,31 @@ cg_resident_kernel(ResArgs A)
         if (mine)
             dad[0] = dself[0] * acc[0] + dself[1] * acc[1]
                 + dself[2] * acc[2] + dself[3] * acc[3];
+        stamp(k, 3);
         if (!(alive = grid_allreduce<1>(A.ex, epoch++, nblocks, dad, red, flag)))
             break;
+        stamp(k, 4);
         double const alpha = st.rr / dad[0];
-        // x += alpha d, r -= alpha Ad, z = P r.  (x, b and P are this thread's
-        // own lines in L2; holding them across the barrier would cost 48 of
-        // the 256 registers the matrix leaves 96 of.)
+        // x += alpha d, r -= alpha Ad, z = P r: x, b and P in LDS; only the rim
+        // publishes its z (as granules: nothing to drain before the all-reduce)
         double v3[3] = { 0.0, 0.0, 0.0 };
         if (mine) {
 #pragma clang fp contract(off)
-            double4_r const xv = *reinterpret_cast<const double4_r *>(
-                A.x + (size_t)n * 4);
+            double4_r *xp = reinterpret_cast<double4_r *>(xl + (size_t)li * 4);
+            double4_r const xv = *xp;
             double4_r const bv = *reinterpret_cast<const double4_r *>(
-                A.b + (size_t)n * 4);
+                bl + (size_t)li * 4);
             double const xn[4] = { xv.x + alpha * dself[0], xv.y + alpha * dself[1],
                 xv.z + alpha * dself[2], xv.w + alpha * dself[3] };
             double const bo[4] = { bv.x, bv.y, bv.z, bv.w };
+            *xp = (double4_r){ xn[0], xn[1], xn[2], xn[3] };
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 r[q] = r[q] - alpha * acc[q];
-            const double4_r *P = reinterpret_cast<const double4_r *>(
-                A.Pinv + (size_t)n * 16);
 #pragma unroll
             for (int row = 0; row < 4; ++row) {
-                double4_r const p = P[row];
+                double4_r const p = *reinterpret_cast<const double4_r *>(
+                    Pl + ((size_t)row * tile_nodes + li) * 4);
                 double zi = 0.0;
                 zi += p.x * r[0];
                 zi += p.y * r[1];
@@ -519,18 +603,20 @@ cg_resident_kernel(ResArgs A)
                 zi += p.w * r[3];
                 z[row] = zi;
             }
-            *reinterpret_cast<double4_r *>(A.x + (size_t)n * 4)
-                = (double4_r){ xn[0], xn[1], xn[2], xn[3] };
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                st_agent(A.zx + (size_t)n * 4 + q, z[q]);
+                if (rim)
+                    st_granules(A.zg + ((size_t)n * 4 + q) * 2,
+                        ztag + (unsigned)k + 1u, z[q]);
                 v3[0] += r[q] * r[q];
                 v3[1] += xn[q] * (bo[q] + r[q]);
                 v3[2] += z[q] * r[q];
             }
         }
+        stamp(k, 5);
         if (!(alive = grid_allreduce<3>(A.ex, epoch++, nblocks, v3, red, flag)))
             break;
+        stamp(k, 6);
         // termination tests of iteration k (conjugate_gradient.h:136-198)
         double const new_rr = v3[0];
         double const Q1 = -1.0 * v3[1];
@@ -555,6 +641,13 @@ cg_resident_kernel(ResArgs A)
             break;
     }
 
+    // the solution (and b, which the streaming solver also leaves) go to HBM
+    if (mine) {
+        *reinterpret_cast<double4_r *>(A.x + (size_t)n * 4)
+            = *reinterpret_cast<const double4_r *>(xl + (size_t)li * 4);
+        *reinterpret_cast<double4_r *>(A.b + (size_t)n * 4)
+            = *reinterpret_cast<const double4_r *>(bl + (size_t)li * 4);
+    }
     if (blockIdx.x == 0 && tid == 0) {
         int const failed = alive ? 0 : 1;
         if (!st.done && !failed) {
@@ -642,7 +735,8 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
     int const num_tiles = tiles_x * tiles_y;
     size_t const lds_bytes = ((size_t)(tw + 2) * (th + 2) * 4
-        + (size_t)4 * tw * th * 4 + (size_t)(3 * tw + 3 * th) * 16
+        + (size_t)tw * th * 4 + (size_t)4 * tw * th * 4
+        + (size_t)(3 * tw + 3 * th) * 16 + (size_t)2 * tw * th * 4
         + 4 * RES_WAVES + 2) * sizeof(double);
     if (lds_bytes > (size_t)160 * 1024)
         return SMVS_OK;
@@ -656,10 +750,12 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
             return rc;
     }
     if (ctx->res_zx_cap < (size_t)ctx->num_nodes) {
-        if ((rc = device_alloc(&ctx->res_zx, ctx->cap_nodes * 4)) != SMVS_OK) {
+        if ((rc = device_alloc(&ctx->res_zx, ctx->cap_nodes * 8)) != SMVS_OK) {
             ctx->res_zx_cap = 0;
             return rc;
         }
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0,
+            ctx->cap_nodes * 8 * sizeof(double), ctx->stream));
         ctx->res_zx_cap = ctx->cap_nodes;
     }
     static bool attr_set[16] = { false };
@@ -676,7 +772,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.g = ctx->g;
     A.x = ctx->x;
     A.b = ctx->b;
-    A.zx = ctx->res_zx;
+    A.zg = reinterpret_cast<unsigned long long *>(ctx->res_zx);
     A.ex = reinterpret_cast<ResExchange *>(ctx->res_work);
     A.state = reinterpret_cast<ResState *>(ctx->cg_state);
     A.status = ctx->status;
@@ -695,6 +791,17 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.max_iterations = max_iterations;
     A.q_tolerance = q_tolerance;
     A.fixed_tolerance = error_tolerance;
+    A.trace = nullptr;
+    // debug aid (tools/cg_trace.py): cycle stamps of workgroup 0
+    static const char *trace_path = std::getenv("SMVS_CG_TRACE");
+    long long *trace_dev = nullptr;
+    size_t const trace_n = (size_t)(TRACE_ITERS + 1) * TRACE_POINTS;
+    if (trace_path != nullptr) {
+        SMVS_HIP_CHECK(hipMalloc((void **)&trace_dev, trace_n * sizeof(long long)));
+        SMVS_HIP_CHECK(hipMemsetAsync(trace_dev, 0, trace_n * sizeof(long long),
+            ctx->stream));
+        A.trace = trace_dev;
+    }
 
     // one barrier kernel at a time per device: two of them started together
     // could each hold half of the CUs and wait for the other half for ever
@@ -727,6 +834,23 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                 set_error("cg_resident_solve: timed out waiting for the device");
                 return SMVS_ERR_STATE;
             }
+        }
+    }
+    if (trace_dev != nullptr) {
+        std::vector<long long> tr(trace_n);
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        SMVS_HIP_CHECK(hipMemcpy(tr.data(), trace_dev, trace_n * sizeof(long long),
+            hipMemcpyDeviceToHost));
+        (void)hipFree(trace_dev);
+        if (FILE *f = std::fopen(trace_path, "a")) {
+            std::fprintf(f, "solve nodes=%d tiles=%d its=%d\n", ctx->num_nodes,
+                num_tiles, progress[3]);
+            for (int k = 0; k <= TRACE_ITERS; ++k) {
+                for (int q = 0; q < TRACE_POINTS; ++q)
+                    std::fprintf(f, "%lld ", tr[(size_t)k * TRACE_POINTS + q]);
+                std::fprintf(f, "\n");
+            }
+            std::fclose(f);
         }
     }
     // (every workgroup has passed its last barrier when the result appears:
