@@ -227,7 +227,7 @@ def profile_pass(ctx, prob, steps, lighting=None):
     return per_step, prof
 
 
-def roofline(ctx, prob, steps, ms_per_step, lighting=None):
+def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     per_step, prof = profile_pass(ctx, prob, steps, lighting)
     kernels = {k: dict(ms=round(v[0], 3), launches=int(v[1]),
                        avg_us=round(1e3 * v[0] / max(v[1], 1), 2))
@@ -272,7 +272,7 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None):
                          % (FLOP_PER_PATCH / 1e6, cg_bytes_node, HBM_PEAK_GBPS,
                             FP64_PEAK_TFLOPS),
                peaks_assumed=dict(hbm_GBps=HBM_PEAK_GBPS, fp64_TFLOPs=FP64_PEAK_TFLOPS),
-               peaks_measured=measured_peaks())
+               peaks_measured=measured_peaks() if with_peaks else None)
     if name == "cg_resident":
         # one launch per solve; the matrix is read once and stays in registers:
         # algorithmic HBM bytes = H upper half + P + g + b + x per node
@@ -349,6 +349,8 @@ def main():
                          "reference's behaviour)")
     ap.add_argument("--small", action="store_true", help="480x270 debug size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-peaks", action="store_true",
+                    help="skip the peak microbenchmarks (profiling runs)")
     ap.add_argument("--views-in-flight", type=int, default=1,
                     help="reference views processed concurrently per GPU (own context, "
                          "stream and host thread each); the headline number uses 1")
@@ -472,7 +474,8 @@ def main():
         lighting = fit_lighting([ctx])[0] if args.config == 5 else None
         if args.config == 5:
             ctx.set_nodes(surf["nodes"])
-        roof = roofline(ctx, prob, args.steps, 1e3 * secs / args.steps, lighting)
+        roof = roofline(ctx, prob, args.steps, 1e3 * secs / args.steps, lighting,
+                        with_peaks=not args.no_peaks)
 
     if rank == 0:
         views_in_flight = max(args.views_in_flight, 1) if args.config == 1 else 1

@@ -4,12 +4,25 @@
 # passes (--pmc with --kernel-trace only), as MI355X_MICROARCH.md prescribes.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_${1:-r1}
+OUT=$ROOT/gpurun_out/prof_${1:-r2}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-peaks"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- $CMD > "$OUT/write.log" 2>&1
 ls -R "$OUT" | head -30
-python $ROOT/tools/summarise_profiles.py "$OUT" "$OUT/summary" "${1:-r1}"
+python $ROOT/tools/summarise_profiles.py "$OUT" "$OUT/summary" "${1:-r2}"
+# the whole pipeline of one reference view (SGM front end, bilateral upsample,
+# scale space, topology kernels, Newton loops) and the depth-map cut
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipeline" -o run -- python $ROOT/tools/pipeline_profile.py > "$OUT/pipeline.log" 2>&1
+python - <<PY
+import csv, glob
+rows = list(csv.DictReader(open(glob.glob("$OUT/pipeline/**/*kernel_stats.csv", recursive=True)[0])))
+with open("$OUT/summary/${1:-r2}_pipeline_kernel_stats.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+PY
+tail -5 "$OUT/pipeline.log"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counter passes over the construct-only helper (patch kernel analysis)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/patch_pmc
+OUT=$ROOT/gpurun_out/patch_pmc_r2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > $OUT/sq_counters.txt

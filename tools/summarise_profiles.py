@@ -16,6 +16,7 @@ import os
 import sys
 
 SHORT = [("gn_patch_kernel", "patch"), ("gn_assemble_kernel", "assemble"),
+         ("cg_resident_kernel", "cg_resident"), ("live_patch_list_kernel", "live_patch_list"),
          ("cg_spmv_kernel", "cg_spmv"), ("cg_update_kernel", "cg_update"),
          ("cg_init_kernel", "cg_init"), ("reactivate_kernel", "reactivate"),
          ("apply_update_kernel", "apply_update"), ("prepare_update_kernel", "prepare_update")]
@@ -70,7 +71,7 @@ def main(src, dst, tag):
             avg / 1e6, mx / 1e6))
     with open(os.path.join(dst, "%s_hbm_traffic.txt" % tag), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of\n"
-                "# `python bench.py --steps 20 --warmup 3 --no-cpu-baseline`; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024\n"
+                "# `python bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-peaks`; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024\n"
                 "# averages are over launches that moved data (CG launches after convergence are no-ops)\n")
         f.write("\n".join(lines) + "\n")
     with open(os.path.join(dst, "traffic_%s.json" % tag), "w") as f:
