@@ -79,7 +79,122 @@ struct ResArgs {
     int max_iterations;
     double q_tolerance, fixed_tolerance;
     long long *trace;        // debug: cycle stamps of workgroup 0 (or nullptr)
+    // fused assembly (the Newton loop): per-patch systems instead of H / g / P
+    const double *Hp;        // [P][10][16]
+    const double *gp;        // [P][16]
+    const uint8_t *patch_valid;
+    const uint8_t *active;
+    uint8_t *active_next;    // cleared for the node update of this step
+    double *scalars;
+    int npx, npy;
 };
+
+// GaussNewtonStep::construct's scatter (gauss_newton_step.cc:88-142) in gather
+// form for ONE node, as gn_assemble_kernel does it with four lanes: the <= 4
+// incident patches in ascending patch id, local node order 0 (ix, iy),
+// 1 (ix+1, iy), 2 (ix, iy+1), 3 (ix+1, iy+1); only stored slots (other node
+// >= this node), blocks towards inactive nodes omitted (Q6).
+struct NodeSystem {
+    double hd[10];      // diagonal block, upper triangle (Q4)
+    double hu[4][16];   // slots 5..8
+    double g[4];
+};
+
+__device__ __forceinline__ void
+assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
+{
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+        S.hd[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            S.hu[k][i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        S.g[i] = 0.0;
+    if (!on || !A.active[iy * A.stride + ix])
+        return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int const pxq = ix - (1 - (q & 1));
+        int const pyq = iy - (1 - (q >> 1));
+        int const ln = 3 - q;   // local index of the node in that patch
+        if (pxq < 0 || pxq >= A.npx || pyq < 0 || pyq >= A.npy)
+            continue;
+        int const p = pyq * A.npx + pxq;
+        if (!A.patch_valid[p])
+            continue;
+        const double *Hl = A.Hp + (size_t)p * PATCH_H_STRIDE;
+        int const n00 = pyq * A.stride + pxq;
+#pragma unroll
+        for (int lm = 0; lm < 4; ++lm) {
+            if (lm < ln)
+                continue;
+            int const m = n00 + (lm & 1) + (lm >> 1) * A.stride;
+            if (!A.active[m])
+                continue;
+            const double4_r *blk = reinterpret_cast<const double4_r *>(
+                Hl + upper_block(ln, lm) * 16);
+            double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
+            if (lm == ln) {
+                S.hd[0] += b0.x; S.hd[1] += b0.y; S.hd[2] += b0.z; S.hd[3] += b0.w;
+                S.hd[4] += b1.y; S.hd[5] += b1.z; S.hd[6] += b1.w;
+                S.hd[7] += b2.z; S.hd[8] += b2.w;
+                S.hd[9] += b3.w;
+            } else {
+                int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
+                int const k = (dy + 1) * 3 + dx + 1 - 5;
+                S.hu[k][0] += b0.x; S.hu[k][1] += b0.y; S.hu[k][2] += b0.z; S.hu[k][3] += b0.w;
+                S.hu[k][4] += b1.x; S.hu[k][5] += b1.y; S.hu[k][6] += b1.z; S.hu[k][7] += b1.w;
+                S.hu[k][8] += b2.x; S.hu[k][9] += b2.y; S.hu[k][10] += b2.z; S.hu[k][11] += b2.w;
+                S.hu[k][12] += b3.x; S.hu[k][13] += b3.y; S.hu[k][14] += b3.z; S.hu[k][15] += b3.w;
+            }
+        }
+        double4_r const gv = *reinterpret_cast<const double4_r *>(
+            A.gp + (size_t)p * 16 + 4 * ln);
+        S.g[0] += gv.x; S.g[1] += gv.y; S.g[2] += gv.z; S.g[3] += gv.w;
+    }
+}
+
+// One stored block of another node: row node (mx, my), its upper slot 5..8.
+__device__ __forceinline__ void
+assemble_block(ResArgs const &A, int mx, int my, int slot, double *out16)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        out16[i] = 0.0;
+    if (!A.active[my * A.stride + mx])
+        return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int const ln = 3 - q;
+#pragma unroll
+        for (int lm = 0; lm < 4; ++lm) {
+            if (lm <= ln)
+                continue;
+            int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
+            if ((dy + 1) * 3 + dx + 1 != slot)
+                continue;
+            int const pxq = mx - (1 - (q & 1));
+            int const pyq = my - (1 - (q >> 1));
+            if (pxq < 0 || pxq >= A.npx || pyq < 0 || pyq >= A.npy)
+                continue;
+            int const p = pyq * A.npx + pxq;
+            if (!A.patch_valid[p])
+                continue;
+            int const m = pyq * A.stride + pxq + (lm & 1) + (lm >> 1) * A.stride;
+            if (!A.active[m])
+                continue;
+            const double *blk = A.Hp + (size_t)p * PATCH_H_STRIDE
+                + upper_block(ln, lm) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                out16[i] += blk[i];
+        }
+    }
+}
 
 constexpr int TRACE_ITERS = 12, TRACE_POINTS = 8;
 
@@ -236,6 +351,7 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
     return ok;
 }
 
+template <bool FUSED>
 __global__ void __launch_bounds__(RES_THREADS, 2)
 cg_resident_kernel(ResArgs A)
 {
@@ -295,27 +411,57 @@ cg_resident_kernel(ResArgs A)
     // (the diagonal block is symmetric, Q4: its upper triangle, 10 doubles)
     double hd[10];
     double hu[4][16];
-    {
-        const double4_r *src = reinterpret_cast<const double4_r *>(
-            A.H9 + (size_t)n * 16);
-        double4_r const zero4 = { 0, 0, 0, 0 };
-        double4_r const r0 = mine ? src[0] : zero4, r1 = mine ? src[1] : zero4,
-            r2 = mine ? src[2] : zero4, r3 = mine ? src[3] : zero4;
-        hd[0] = r0.x; hd[1] = r0.y; hd[2] = r0.z; hd[3] = r0.w;
-        hd[4] = r1.y; hd[5] = r1.z; hd[6] = r1.w;
-        hd[7] = r2.z; hd[8] = r2.w;
-        hd[9] = r3.w;
-    }
+    double gnode[4];          // gradient of the node
+    if (FUSED) {
+        // assembled here from the per-patch systems: H, g and P never go to
+        // HBM.  Also what the assembly kernel does for the step's node update.
+        NodeSystem S;
+        assemble_node(A, gx, gy, mine, S);
 #pragma unroll
-    for (int s = 1; s < 5; ++s) {
-        const double4_r *src = reinterpret_cast<const double4_r *>(
-            A.H9 + ((size_t)s * N + (size_t)n) * 16);
+        for (int i = 0; i < 10; ++i)
+            hd[i] = S.hd[i];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double4_r const v = mine ? src[q] : (double4_r){ 0, 0, 0, 0 };
-            hu[s - 1][4 * q + 0] = v.x; hu[s - 1][4 * q + 1] = v.y;
-            hu[s - 1][4 * q + 2] = v.z; hu[s - 1][4 * q + 3] = v.w;
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                hu[k][i] = S.hu[k][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gnode[i] = S.g[i];
+        if (mine)
+            A.active_next[n] = 0;
+        if (blockIdx.x == 0 && tid == 0) {
+            A.status[I_ACTIVE_PATCHES] = A.status[I_LIVE_PATCHES];
+            A.status[I_NUM_ACTIVE] = 0;
+            A.scalars[S_SUMDIFF] = 0.0;
+            A.scalars[S_COUNT_DIFF] = 0.0;
         }
+    } else {
+        {
+            const double4_r *src = reinterpret_cast<const double4_r *>(
+                A.H9 + (size_t)n * 16);
+            double4_r const zero4 = { 0, 0, 0, 0 };
+            double4_r const r0 = mine ? src[0] : zero4, r1 = mine ? src[1] : zero4,
+                r2 = mine ? src[2] : zero4, r3 = mine ? src[3] : zero4;
+            hd[0] = r0.x; hd[1] = r0.y; hd[2] = r0.z; hd[3] = r0.w;
+            hd[4] = r1.y; hd[5] = r1.z; hd[6] = r1.w;
+            hd[7] = r2.z; hd[8] = r2.w;
+            hd[9] = r3.w;
+        }
+#pragma unroll
+        for (int s = 1; s < 5; ++s) {
+            const double4_r *src = reinterpret_cast<const double4_r *>(
+                A.H9 + ((size_t)s * N + (size_t)n) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double4_r const v = mine ? src[q] : (double4_r){ 0, 0, 0, 0 };
+                hu[s - 1][4 * q + 0] = v.x; hu[s - 1][4 * q + 1] = v.y;
+                hu[s - 1][4 * q + 2] = v.z; hu[s - 1][4 * q + 3] = v.w;
+            }
+        }
+        double4_r const gv = mine ? *reinterpret_cast<const double4_r *>(
+            A.g + (size_t)n * 4) : (double4_r){ 0, 0, 0, 0 };
+        gnode[0] = gv.x; gnode[1] = gv.y; gnode[2] = gv.z; gnode[3] = gv.w;
     }
     // lower slot s = 0..3 <-> (dx, dy) = (-1,-1), (0,-1), (1,-1), (-1,0).
     // fb_idx[s]: -2 neighbour outside the grid, -1 neighbour inside the tile
@@ -344,14 +490,21 @@ cg_resident_kernel(ResArgs A)
             low |= (in_tile ? 1u : 2u) << (2 * s);
             if (!in_tile) {
                 // block (row m, col n) is stored at m under its upper slot 8 - s
-                int const m = ny * A.stride + nx;
-                const double4_r *src = reinterpret_cast<const double4_r *>(
-                    A.H9 + ((size_t)(8 - s - 4) * N + (size_t)m) * 16);
-                double4_r *dst = reinterpret_cast<double4_r *>(
-                    fb + (size_t)rim_index(s) * 16);
+                double *dst = fb + (size_t)rim_index(s) * 16;
+                if (FUSED) {
+                    double blk[16];
+                    assemble_block(A, nx, ny, 8 - s, blk);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    dst[e] = src[e];
+                    for (int e = 0; e < 16; ++e)
+                        dst[e] = blk[e];
+                } else {
+                    int const m = ny * A.stride + nx;
+                    const double4_r *src = reinterpret_cast<const double4_r *>(
+                        A.H9 + ((size_t)(8 - s - 4) * N + (size_t)m) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        reinterpret_cast<double4_r *>(dst)[e] = src[e];
+                }
             }
         }
     }
@@ -379,18 +532,43 @@ cg_resident_kernel(ResArgs A)
     {
         double v0[2] = { 0.0, 0.0 };
         if (mine) {
-            double4_r const gv = *reinterpret_cast<const double4_r *>(
-                A.g + (size_t)n * 4);
-            double const gg[4] = { gv.x, gv.y, gv.z, gv.w };
-            const double4_r *P = reinterpret_cast<const double4_r *>(
-                A.Pinv + (size_t)n * 16);
+            double const gg[4] = { gnode[0], gnode[1], gnode[2], gnode[3] };
+            // block-Jacobi preconditioner (block_sparse_matrix.h:300-316): the
+            // inverted diagonal block, kept un-inverted on NaN / zero pivot (Q12)
+            double Pfull[16];
+            if (FUSED) {
+                double const full[16] = { hd[0], hd[1], hd[2], hd[3],
+                    hd[1], hd[4], hd[5], hd[6], hd[2], hd[5], hd[7], hd[8],
+                    hd[3], hd[6], hd[8], hd[9] };
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    Pfull[i] = full[i];
+                ldl_inverse4(Pfull);
+                bool nancheck = false;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    nancheck |= isnan(Pfull[i]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    Pfull[i] = nancheck ? full[i] : Pfull[i];
+            } else {
+                const double4_r *P = reinterpret_cast<const double4_r *>(
+                    A.Pinv + (size_t)n * 16);
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    double4_r const p = P[row];
+                    Pfull[row * 4 + 0] = p.x; Pfull[row * 4 + 1] = p.y;
+                    Pfull[row * 4 + 2] = p.z; Pfull[row * 4 + 3] = p.w;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 r[k] = -gg[k];
 #pragma unroll
             for (int row = 0; row < 4; ++row) {
 #pragma clang fp contract(off)
-                double4_r const p = P[row];
+                double4_r const p = { Pfull[row * 4 + 0], Pfull[row * 4 + 1],
+                    Pfull[row * 4 + 2], Pfull[row * 4 + 3] };
                 *reinterpret_cast<double4_r *>(
                     Pl + ((size_t)row * tile_nodes + li) * 4) = p;
                 double zi = 0.0;
@@ -696,6 +874,47 @@ choose_tiling(int stride, int rows, int max_tiles, int *tw_out, int *th_out)
     return best >= 0;
 }
 
+static size_t
+resident_lds_bytes(int tw, int th)
+{
+    return ((size_t)(tw + 2) * (th + 2) * 4 + (size_t)tw * th * 4
+        + (size_t)4 * tw * th * 4 + (size_t)(3 * tw + 3 * th) * 16
+        + (size_t)2 * tw * th * 4 + 4 * RES_WAVES + 2) * sizeof(double);
+}
+
+// Does the resident solver take this system?  (grid fits the chip's CUs and
+// LDS, not disabled by SMVS_CG_RESIDENT=0 or by an earlier failure)
+bool
+cg_resident_applies(smvs_ctx *ctx, int max_iterations)
+{
+    if (ctx->resident_disabled || max_iterations <= 1 || !ctx->has_surface)
+        return false;
+    static int const env_off = [] {
+        const char *e = std::getenv("SMVS_CG_RESIDENT");
+        return e != nullptr && e[0] == '0' ? 1 : 0;
+    }();
+    if (env_off)
+        return false;
+    if (ctx->resident_cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess)
+            return false;
+        ctx->resident_cus = prop.multiProcessorCount;
+    }
+    int const stride = ctx->node_stride;
+    int const rows = ctx->num_nodes / stride;
+    int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
+        ? ctx->resident_cus : RES_MAX_BLOCKS;
+    int tw = 0, th = 0;
+    if (!choose_tiling(stride, rows, max_tiles, &tw, &th))
+        return false;
+    if (resident_lds_bytes(tw, th) > (size_t)160 * 1024)
+        return false;
+    if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32)
+        return false;
+    return true;
+}
+
 static std::mutex g_resident_mutex[16];   // one barrier kernel per device at a time
 
 // Returns SMVS_OK with *ran = false when the resident solver does not apply
@@ -703,45 +922,20 @@ static std::mutex g_resident_mutex[16];   // one barrier kernel per device at a 
 // caller then runs the streaming kernels.
 int
 cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
-    double q_tolerance, int *num_iterations, int *info, bool *ran)
+    double q_tolerance, int *num_iterations, int *info, bool *ran, bool fused)
 {
     *ran = false;
-    if (ctx->resident_disabled || max_iterations <= 1)
-        return SMVS_OK;
-    static int const env_off = [] {
-        const char *e = std::getenv("SMVS_CG_RESIDENT");
-        return e != nullptr && e[0] == '0' ? 1 : 0;
-    }();
-    if (env_off)
+    if (!cg_resident_applies(ctx, max_iterations))
         return SMVS_OK;
     int const stride = ctx->node_stride;
     int const rows = ctx->num_nodes / stride;
-    if (ctx->resident_cus == 0) {
-        hipDeviceProp_t prop;
-        SMVS_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
-        ctx->resident_cus = prop.multiProcessorCount;
-        ctx->resident_lds = (int)prop.sharedMemPerBlock;
-        int max_dyn = 0;
-        if (hipDeviceGetAttribute(&max_dyn,
-                hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess
-            && max_dyn > ctx->resident_lds)
-            ctx->resident_lds = max_dyn;
-    }
     int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
         ? ctx->resident_cus : RES_MAX_BLOCKS;
     int tw = 0, th = 0;
-    if (!choose_tiling(stride, rows, max_tiles, &tw, &th))
-        return SMVS_OK;
+    (void)choose_tiling(stride, rows, max_tiles, &tw, &th);
     int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
     int const num_tiles = tiles_x * tiles_y;
-    size_t const lds_bytes = ((size_t)(tw + 2) * (th + 2) * 4
-        + (size_t)tw * th * 4 + (size_t)4 * tw * th * 4
-        + (size_t)(3 * tw + 3 * th) * 16 + (size_t)2 * tw * th * 4
-        + 4 * RES_WAVES + 2) * sizeof(double);
-    if (lds_bytes > (size_t)160 * 1024)
-        return SMVS_OK;
-    if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32)
-        return SMVS_OK;
+    size_t const lds_bytes = resident_lds_bytes(tw, th);
 
     int rc;
     if (ctx->res_work == nullptr) {
@@ -761,7 +955,10 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     static bool attr_set[16] = { false };
     if (ctx->device < 16 && !attr_set[ctx->device]) {
         SMVS_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(cg_resident_kernel),
+            reinterpret_cast<const void *>(cg_resident_kernel<false>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SMVS_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(cg_resident_kernel<true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device] = true;
     }
@@ -791,6 +988,14 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.max_iterations = max_iterations;
     A.q_tolerance = q_tolerance;
     A.fixed_tolerance = error_tolerance;
+    A.Hp = ctx->Hp;
+    A.gp = ctx->gp;
+    A.patch_valid = ctx->patch_valid;
+    A.active = ctx->active;
+    A.active_next = ctx->active_next;
+    A.scalars = ctx->scalars;
+    A.npx = ctx->npx;
+    A.npy = ctx->npy;
     A.trace = nullptr;
     // debug aid (tools/cg_trace.py): cycle stamps of workgroup 0
     static const char *trace_path = std::getenv("SMVS_CG_TRACE");
@@ -809,8 +1014,12 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     SMVS_HIP_CHECK(hipMemsetAsync(A.ex, 0, sizeof(ResExchange), ctx->stream));
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
-        hipLaunchKernelGGL(cg_resident_kernel, dim3(num_tiles),
-            dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+        if (fused)
+            hipLaunchKernelGGL(cg_resident_kernel<true>, dim3(num_tiles),
+                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+        else
+            hipLaunchKernelGGL(cg_resident_kernel<false>, dim3(num_tiles),
+                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
 

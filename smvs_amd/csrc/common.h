@@ -220,18 +220,90 @@ xcd_band_block(unsigned bid, unsigned nblocks)
     return (bid & 7u) * per + (bid >> 3);
 }
 
+// Per-patch normal equations as stored between the two kernels: the 10 node
+// blocks (bi <= bj) of the upper block triangle, [block][4][4] doubles.
+constexpr int PATCH_H_STRIDE = 160;
+__host__ __device__ __forceinline__ constexpr int
+upper_block(int bi, int bj)
+{
+    return bi * 4 - bi * (bi - 1) / 2 + (bj - bi);
+}
+
+
+// lib/ldl_decomposition.h:43-92 for a 4x4 block, same operation order.
+__device__ __forceinline__ void
+ldl_inverse4(double A[16])
+{
+#pragma clang fp contract(off)
+    double L[16], D[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        L[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        D[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        D[j] = A[j * 4 + j];
+        L[j * 4 + j] = 1.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+            D[j] -= (L[j * 4 + k] * L[j * 4 + k]) * D[k];
+        if (D[j] == 0.0)
+            return;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            L[i * 4 + j] = A[i * 4 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k)
+                L[i * 4 + j] -= L[i * 4 + k] * D[k] * L[j * 4 + k];
+            L[i * 4 + j] /= D[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int k = i; k < j; ++k)
+                sum -= L[j * 4 + k] * L[k * 4 + i];
+            L[j * 4 + i] = sum;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        D[i] = 1.0 / D[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        A[i] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2)
+                A[c1 * 4 + c2] += L[r * 4 + c2] * L[r * 4 + c1] * D[r];
+}
+
 // internal entry points used by the fused loop
 // known_live: entries of the live-patch list the previous reactivate_launch
 // of the same Newton loop built (its count read back by the host), or -1 to
 // build the list here.
+// skip_assembly: leave the per-patch systems unassembled (the resident solver
+// gathers them itself, cg_resident_solve(..., fused = true)).
 int gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
-    bool use_lighting, int known_live = -1);
+    bool use_lighting, int known_live = -1, bool skip_assembly = false);
+int gn_assemble_launch(smvs_ctx *ctx);
 int live_patch_list_launch(smvs_ctx *ctx);
 int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info);
 int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
     bool build_live_list = false);
+// fused: assemble H, g, P from the per-patch systems inside the kernel (the
+// caller has NOT run the assembly kernel); *ran = false means nothing was done.
 int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
-    double q_tolerance, int *num_iterations, int *info, bool *ran);
+    double q_tolerance, int *num_iterations, int *info, bool *ran,
+    bool fused = false);
+bool cg_resident_applies(smvs_ctx *ctx, int max_iterations);
 
 } // namespace smvs_hip

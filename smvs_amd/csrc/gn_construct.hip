@@ -24,16 +24,6 @@
 
 namespace smvs_hip {
 
-// Per-patch normal equations as stored between the two kernels: the 10 node
-// blocks (bi <= bj) of the upper block triangle, [block][4][4] doubles.
-constexpr int PATCH_H_STRIDE = 160;
-__host__ __device__ __forceinline__ constexpr int
-upper_block(int bi, int bj)
-{
-    return bi * 4 - bi * (bi - 1) / 2 + (bj - bi);
-}
-
-
 #define R_FACTOR 1e-4  // gauss_newton_step.cc:17
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -845,61 +835,6 @@ struct AssembleArgs {
     double *scalars;
 };
 
-// lib/ldl_decomposition.h:43-92 for a 4x4 block, same operation order.
-__device__ __forceinline__ void
-ldl_inverse4(double A[16])
-{
-#pragma clang fp contract(off)
-    double L[16], D[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        L[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        D[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        D[j] = A[j * 4 + j];
-        L[j * 4 + j] = 1.0;
-#pragma unroll
-        for (int k = 0; k < j; ++k)
-            D[j] -= (L[j * 4 + k] * L[j * 4 + k]) * D[k];
-        if (D[j] == 0.0)
-            return;
-#pragma unroll
-        for (int i = j + 1; i < 4; ++i) {
-            L[i * 4 + j] = A[i * 4 + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k)
-                L[i * 4 + j] -= L[i * 4 + k] * D[k] * L[j * 4 + k];
-            L[i * 4 + j] /= D[j];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i + 1; j < 4; ++j) {
-            double sum = 0.0;
-#pragma unroll
-            for (int k = i; k < j; ++k)
-                sum -= L[j * 4 + k] * L[k * 4 + i];
-            L[j * 4 + i] = sum;
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        D[i] = 1.0 / D[i];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        A[i] = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c1 = 0; c1 < 4; ++c1)
-#pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2)
-                A[c1 * 4 + c2] += L[r * 4 + c2] * L[r * 4 + c1] * D[r];
-}
-
 __global__ void __launch_bounds__(256)
 gn_assemble_kernel(AssembleArgs A)
 {
@@ -1076,7 +1011,7 @@ sampling_for_scale(int scale)
 
 int
 gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
-    bool use_lighting, int known_live)
+    bool use_lighting, int known_live, bool skip_assembly)
 {
     // Shared by smvs_gn_construct and smvs_gn_run_loop: the patch kernel
     // dereferences every neighbour's planes and the main gradient.
@@ -1159,6 +1094,20 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
+    if (skip_assembly) {
+        // the resident solver assembles H, g, P from the per-patch systems
+        // itself; nothing is materialised for smvs_gn_download
+        ctx->has_system = false;
+        ctx->cg_use_active = true;
+        ctx->update_prepared = true;
+        return SMVS_OK;
+    }
+    return gn_assemble_launch(ctx);
+}
+
+int
+gn_assemble_launch(smvs_ctx *ctx)
+{
     AssembleArgs B;
     B.Hp = ctx->Hp;
     B.gp = ctx->gp;

@@ -509,14 +509,27 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     while (newton_step < prm->max_newton_steps
         && num_active > num_initial / 20) {
         newton_step += 1;
+        // With the resident solver the assembly happens inside the solve
+        // (H, g and P never travel through HBM); if it cannot run -- or gives
+        // up because its workgroups were not all resident -- the assembly
+        // kernel and the streaming solver take over.
+        bool const fused = cg_resident_applies(ctx, prm->cg_max_iterations);
         if ((rc = gn_construct_launch(ctx, prm->regularization,
                 prm->light_surf_regularization, prm->use_lighting != 0,
-                known_live)) != SMVS_OK)
+                known_live, fused)) != SMVS_OK)
             return rc;
         int iters = 0, info = 0;
-        if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
-                prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
+        bool solved = false;
+        if (fused && (rc = cg_resident_solve(ctx, prm->cg_max_iterations, -1.0,
+                prm->cg_q_tolerance, &iters, &info, &solved, true)) != SMVS_OK)
             return rc;
+        if (!solved) {
+            if (fused && (rc = gn_assemble_launch(ctx)) != SMVS_OK)
+                return rc;
+            if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
+                    prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
+                return rc;
+        }
         stats->linear_iterations += iters;
         if ((rc = reactivate_launch(ctx, prm->active_threshold,
                 prm->full_optimization, true)) != SMVS_OK)
