@@ -267,9 +267,12 @@ block_sum(double (&v)[K], double *red /*[K][RES_WAVES]*/)
 // Returns false after a bounded wait (a workgroup is not resident / gave up).
 template <int K>
 __device__ __forceinline__ bool
-grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
-    double *red, int *lds_flag)
+grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
+    double (&v)[K], double *red, int *lds_flag)
 {
+    // tags carry the solve id: granules of earlier solves never match, so the
+    // exchange area needs no clearing between solves
+    unsigned const tag = solve_tag | epoch;
     block_sum<K>(v, red);          // (ends with a workgroup barrier)
     // (nothing to drain: everything that crosses workgroups is a granule, the
     // vectors of the solve live in registers and LDS)
@@ -279,7 +282,7 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
         unsigned long long const bits = (unsigned long long)__double_as_longlong(v[k]);
         unsigned const word = half ? (unsigned)(bits >> 32) : (unsigned)bits;
         __hip_atomic_store(&ex->gran[par][threadIdx.x][blockIdx.x],
-            ((unsigned long long)epoch << 32) | word, __ATOMIC_RELAXED,
+            ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_AGENT);
     }
     // Waves 3 .. 3 + K - 1 sweep (kind k each, side by side): they hold the
@@ -296,7 +299,7 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
 #pragma unroll
             for (int j = 0; j < PER_LANE; ++j) {
                 int const blk = lane + 64 * j;
-                unsigned long long g0 = (unsigned long long)epoch << 32, g1 = g0;
+                unsigned long long g0 = (unsigned long long)tag << 32, g1 = g0;
                 if (blk < nblocks) {
                     g0 = __hip_atomic_load(&ex->gran[par][2 * wave][blk],
                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -305,7 +308,7 @@ grid_allreduce(ResExchange *ex, unsigned epoch, int nblocks, double (&v)[K],
                 }
                 lo[j] = (unsigned)g0;
                 hi[j] = (unsigned)g1;
-                all &= (unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch;
+                all &= (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
             }
             if (__all(all))
                 break;
@@ -594,7 +597,7 @@ cg_resident_kernel(ResArgs A)
             for (int k = 0; k < 4; ++k)
                 r[k] = z[k] = 0.0;
         }
-        alive = grid_allreduce<2>(A.ex, epoch++, nblocks, v0, red, flag);
+        alive = grid_allreduce<2>(A.ex, ztag, epoch++, nblocks, v0, red, flag);
         st.rr = v0[0];
         st.q0 = -0.0;
         st.gnorm = sqrt(v0[1]);
@@ -750,7 +753,7 @@ cg_resident_kernel(ResArgs A)
             dad[0] = dself[0] * acc[0] + dself[1] * acc[1]
                 + dself[2] * acc[2] + dself[3] * acc[3];
         stamp(k, 3);
-        if (!(alive = grid_allreduce<1>(A.ex, epoch++, nblocks, dad, red, flag)))
+        if (!(alive = grid_allreduce<1>(A.ex, ztag, epoch++, nblocks, dad, red, flag)))
             break;
         stamp(k, 4);
         double const alpha = st.rr / dad[0];
@@ -792,7 +795,7 @@ cg_resident_kernel(ResArgs A)
             }
         }
         stamp(k, 5);
-        if (!(alive = grid_allreduce<3>(A.ex, epoch++, nblocks, v3, red, flag)))
+        if (!(alive = grid_allreduce<3>(A.ex, ztag, epoch++, nblocks, v3, red, flag)))
             break;
         stamp(k, 6);
         // termination tests of iteration k (conjugate_gradient.h:136-198)
@@ -942,6 +945,8 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         if ((rc = device_alloc(&ctx->res_work,
                  sizeof(ResExchange) / sizeof(double) + 8)) != SMVS_OK)
             return rc;
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
+            ctx->stream));
     }
     if (ctx->res_zx_cap < (size_t)ctx->num_nodes) {
         if ((rc = device_alloc(&ctx->res_zx, ctx->cap_nodes * 8)) != SMVS_OK) {
@@ -1011,7 +1016,6 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     // one barrier kernel at a time per device: two of them started together
     // could each hold half of the CUs and wait for the other half for ever
     std::lock_guard<std::mutex> guard(g_resident_mutex[ctx->device & 15]);
-    SMVS_HIP_CHECK(hipMemsetAsync(A.ex, 0, sizeof(ResExchange), ctx->stream));
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
         if (fused)
@@ -1066,6 +1070,8 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     // the kernel is draining and cannot block a barrier kernel started now)
     if (progress[4] != 0) {
         // not all workgroups were resident: never try again on this context
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
+            ctx->stream));
         ctx->resident_disabled = true;
         return SMVS_OK;
     }

@@ -62,6 +62,7 @@ enum {
     I_ACTIVE_PATCHES,
     I_TOPO_DELETED,  // patches deleted by one cut_boundaries pass
     I_LIVE_PATCHES,  // entries of the compacted live-patch list
+    I_TICKET,        // arrivals of finish_step_kernel's workgroups
     I_NUM = 16
 };
 
@@ -141,6 +142,8 @@ struct smvs_ctx {
     int *status = nullptr;          // [I_NUM]
     int *status_host = nullptr;     // pinned
     int *cg_progress = nullptr;     // pinned, written by the CG kernels (cg.hip)
+    int *step_words = nullptr;      // pinned, written by finish_step_kernel (update.hip)
+    int step_seq = 0;
     int cg_solve_id = 0;
     double *scalars_host = nullptr; // pinned
     double *lightAb = nullptr;      // [272] lighting normal equations
@@ -297,8 +300,11 @@ int gn_assemble_launch(smvs_ctx *ctx);
 int live_patch_list_launch(smvs_ctx *ctx);
 int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info);
+// known_live >= 0: walk the live list (its length as read back by the host);
+// publish_seq != 0: the Newton loop's fused end of step (finish_step_kernel
+// publishes the result words tagged with this sequence number).
 int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
-    bool build_live_list = false);
+    bool build_live_list = false, int known_live = -1, int publish_seq = 0);
 // fused: assemble H, g, P from the per-patch systems inside the kernel (the
 // caller has NOT run the assembly kernel); *ran = false means nothing was done.
 int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,

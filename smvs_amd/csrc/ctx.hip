@@ -146,6 +146,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     // progress with system-scope stores that the host polls while they run
     unsigned const host_flags = hipHostMallocCoherent | hipHostMallocMapped;
     if (hipHostMalloc((void **)&ctx->cg_progress, sizeof(int) * 8, host_flags) != hipSuccess
+        || hipHostMalloc((void **)&ctx->step_words, sizeof(int) * 8, host_flags) != hipSuccess
         || hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM, host_flags) != hipSuccess
         || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM, host_flags) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -154,8 +155,10 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     }
     (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
     (void)hipMemsetAsync(ctx->status, 0, sizeof(int) * I_NUM, ctx->stream);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
         ctx->cg_progress[i] = 0;
+        ctx->step_words[i] = 0;
+    }
     *out = ctx;
     return SMVS_OK;
 }
@@ -205,6 +208,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         (void)hipHostFree(ctx->status_host);
     if (ctx->cg_progress)
         (void)hipHostFree(ctx->cg_progress);
+    if (ctx->step_words)
+        (void)hipHostFree(ctx->step_words);
     if (ctx->scalars_host)
         (void)hipHostFree(ctx->scalars_host);
     for (auto &p : ctx->prof.pending) {

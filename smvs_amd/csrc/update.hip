@@ -56,6 +56,9 @@ struct ReactivateArgs {
     int npx, stride, ps, start_x, start_y, n_subs, num_patches;
     double threshold;
     int full_optimization;
+    const int *live_list;   // the step's live patches, or nullptr: all patches
+    int live_count;
+    int zero_step_words;    // the Newton loop: reset the words of finish_step_kernel
 };
 
 // One thread per (patch, full-resolution pixel): project with the old and
@@ -69,8 +72,17 @@ reactivate_kernel(ReactivateArgs A)
         return;
     int const pp = A.ps * A.ps;
     long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int const patch = (int)(gid / pp);
-    int const pid = (int)(gid - (long long)patch * pp);
+    if (gid == 0 && A.zero_step_words) {
+        // (the construction has consumed the list length; finish_step_kernel
+        // counts the next list and its arrivals from zero)
+        A.status[I_LIVE_PATCHES] = 0;
+        A.status[I_TICKET] = 0;
+    }
+    int const slot = (int)(gid / pp);
+    int const pid = (int)(gid - (long long)slot * pp);
+    int patch = slot;
+    if (A.live_list != nullptr)
+        patch = slot < A.live_count ? A.live_list[slot] : A.num_patches;
     double sum = 0.0, cnt = 0.0;
     if (patch < A.num_patches && A.patch_valid[patch]) {
         int const ix = patch % A.npx, iy = patch / A.npx;
@@ -209,9 +221,113 @@ apply_update_kernel(double *nodes, const double *x, const uint8_t *node_valid,
         atomicAdd(&status[I_NUM_ACTIVE], cnt);
 }
 
+// End of a Newton step inside smvs_gn_run_loop, one launch instead of node
+// update + list build + two device-to-host copies: thread c owns node c
+// (nodes += delta, adopt the new active flag, count it, surface.cc:957-981,
+// depth_optimizer.cc:291-303) and, where c is also the top-left node of a
+// patch, that patch's entry in the next step's live list.  The last
+// workgroup to finish publishes the step's result words in pinned host
+// memory, which the host polls (no stream query, no copies).
+struct FinishArgs {
+    double *nodes;
+    const double *x;
+    const uint8_t *node_valid;
+    const uint8_t *patch_valid;
+    uint8_t *active;
+    const uint8_t *active_next;
+    int *list;
+    int *status;
+    const double *scalars;
+    int *host_words;       // pinned: [0] sequence tag, [1] active nodes, [2] NaN,
+                           //         [3] active patches of the step, [4] next list length
+    double *host_scalars;  // pinned: [0] sum of shifts, [1] number of terms
+    int npx, npy, stride, num_nodes;
+    int full_optimization;
+    int seq;
+};
+
+__global__ void __launch_bounds__(256)
+finish_step_kernel(FinishArgs A)
+{
+    bool const skip = isnan(A.x[0]);   // depth_optimizer.cc:267: nothing is updated
+    bool const keep = skip || A.full_optimization != 0;
+    int const c = blockIdx.x * blockDim.x + threadIdx.x;
+    bool on = false, live = false;
+    int patch = 0;
+    if (c < A.num_nodes) {
+        if (!skip && A.node_valid[c]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                A.nodes[4 * (size_t)c + k] += A.x[4 * (size_t)c + k];
+        }
+        // (other threads read active_next, never the flag adopted here)
+        uint8_t const flag = keep ? A.active[c] : A.active_next[c];
+        if (!keep)
+            A.active[c] = flag;
+        on = flag == 1;
+        int const ix = c % A.stride, iy = c / A.stride;
+        if (ix < A.npx && iy < A.npy) {
+            patch = iy * A.npx + ix;
+            const uint8_t *f = keep ? A.active : A.active_next;
+            live = A.patch_valid[patch]
+                && (flag | f[c + 1] | f[c + A.stride] | f[c + A.stride + 1]) != 0;
+        }
+    }
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    __shared__ int last;
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long const ballot = __ballot(live);
+    int const before = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0)
+        wave_cnt[wave] = __popcll(ballot);
+    int const cnt_on = __syncthreads_count(on);
+    if (threadIdx.x == 0) {
+        int const total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        base = total > 0 ? atomicAdd(&A.status[I_LIVE_PATCHES], total) : 0;
+        if (cnt_on != 0)
+            atomicAdd(&A.status[I_NUM_ACTIVE], cnt_on);
+    }
+    __syncthreads();
+    if (live) {
+        int off = base + before;
+        for (int wv = 0; wv < wave; ++wv)
+            off += wave_cnt[wv];
+        A.list[off] = patch;
+    }
+    // publish from the last workgroup.  No fences (a release per workgroup
+    // writes back a whole L2): the counters are device-scope atomics, thread 0
+    // waits for its own to be acknowledged before it draws its ticket, and the
+    // publisher reads them back with atomic loads.
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = atomicAdd(&A.status[I_TICKET], 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        int const num_active = __hip_atomic_load(&A.status[I_NUM_ACTIVE],
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int const next_live = __hip_atomic_load(&A.status[I_LIVE_PATCHES],
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A.status[I_NAN] = skip ? 1 : 0;
+        __hip_atomic_store(A.host_words + 1, num_active, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.host_words + 2, skip ? 1 : 0, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.host_words + 3, A.status[I_ACTIVE_PATCHES],
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.host_words + 4, next_live, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        A.host_scalars[0] = A.scalars[S_SUMDIFF];
+        A.host_scalars[1] = A.scalars[S_COUNT_DIFF];
+        __hip_atomic_store(A.host_words + 0, A.seq, __ATOMIC_RELEASE,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 int
 reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
-    bool build_live_list)
+    bool build_live_list, int known_live, int publish_seq)
 {
     int const N = ctx->num_nodes;
     // (the assembly kernel of the same Newton step has already cleared the
@@ -245,14 +361,47 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
     A.num_patches = ctx->num_patches;
     A.threshold = threshold;
     A.full_optimization = full_optimization;
-    long long const items = (long long)ctx->num_patches * ctx->patchsize
-        * ctx->patchsize;
+    // the live list of this step (built at the end of the previous one) when
+    // the host knows its length
+    A.live_list = known_live >= 0 ? ctx->live_list : nullptr;
+    A.live_count = known_live;
+    A.zero_step_words = publish_seq != 0 ? 1 : 0;
+    long long const items = (long long)(known_live >= 0 ? known_live
+        : ctx->num_patches) * ctx->patchsize * ctx->patchsize;
     {
         ScopedKernelTimer timer(ctx, SMVS_K_REACTIVATE);
-        hipLaunchKernelGGL(reactivate_kernel, dim3((unsigned)((items + 255) / 256)),
+        hipLaunchKernelGGL(reactivate_kernel,
+            dim3((unsigned)((items + 255) / 256 > 0 ? (items + 255) / 256 : 1)),
             dim3(256), 0, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
+    if (publish_seq != 0) {
+        // the Newton loop: node update, next live list and the result words
+        // in one launch
+        FinishArgs F;
+        F.nodes = ctx->nodes;
+        F.x = ctx->x;
+        F.node_valid = ctx->node_valid;
+        F.patch_valid = ctx->patch_valid;
+        F.active = ctx->active;
+        F.active_next = ctx->active_next;
+        F.list = ctx->live_list;
+        F.status = ctx->status;
+        F.scalars = ctx->scalars;
+        F.host_words = ctx->step_words;
+        F.host_scalars = ctx->scalars_host;
+        F.npx = ctx->npx;
+        F.npy = ctx->npy;
+        F.stride = ctx->node_stride;
+        F.num_nodes = N;
+        F.full_optimization = full_optimization;
+        F.seq = publish_seq;
+        ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+        hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)((N + 255) / 256)),
+            dim3(256), 0, ctx->stream, F);
+        SMVS_HIP_CHECK(hipGetLastError());
+        return SMVS_OK;
+    }
     {
         ScopedKernelTimer timer(ctx, SMVS_K_MISC);
         hipLaunchKernelGGL(apply_update_kernel, dim3((unsigned)((N + 255) / 256)),
@@ -531,32 +680,42 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
                 return rc;
         }
         stats->linear_iterations += iters;
+        ctx->step_seq = (ctx->step_seq % 0x3FFFFFFF) + 1;
         if ((rc = reactivate_launch(ctx, prm->active_threshold,
-                prm->full_optimization, true)) != SMVS_OK)
+                prm->full_optimization, true, known_live, ctx->step_seq)) != SMVS_OK)
             return rc;
-        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host, ctx->status,
-            sizeof(int) * I_NUM, hipMemcpyDeviceToHost, ctx->stream));
-        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->scalars_host, ctx->scalars,
-            sizeof(double) * S_NUM, hipMemcpyDeviceToHost, ctx->stream));
-        // spin instead of a blocking wait: the next step's launches should
-        // follow the end of this one within microseconds
+        // the last workgroup of the step publishes its result words in pinned
+        // host memory; spin on them so that the next step's launches follow
+        // the end of this one within microseconds
         {
-            hipError_t q;
+            volatile int *words = ctx->step_words;
             auto const t_start = std::chrono::steady_clock::now();
             long spins = 0;
-            while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) {
+            while (__atomic_load_n(&words[0], __ATOMIC_ACQUIRE) != ctx->step_seq) {
                 __builtin_ia32_pause();
-                if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now()
-                    - t_start > std::chrono::seconds(60)) {
-                    set_error("smvs_gn_run_loop: timed out waiting for the device");
-                    return SMVS_ERR_STATE;
+                if ((++spins & 0xFFFF) == 0) {
+                    hipError_t const q = hipStreamQuery(ctx->stream);
+                    if (q != hipSuccess && q != hipErrorNotReady)
+                        SMVS_HIP_CHECK(q);
+                    if (q == hipSuccess && __atomic_load_n(&words[0],
+                            __ATOMIC_ACQUIRE) != ctx->step_seq) {
+                        set_error("smvs_gn_run_loop: the step ended without "
+                            "publishing its result");
+                        return SMVS_ERR_STATE;
+                    }
+                    if (std::chrono::steady_clock::now() - t_start
+                        > std::chrono::seconds(60)) {
+                        set_error("smvs_gn_run_loop: timed out waiting for the device");
+                        return SMVS_ERR_STATE;
+                    }
                 }
             }
-            SMVS_HIP_CHECK(q);
         }
-        stats->active_patch_steps += ctx->status_host[I_ACTIVE_PATCHES];
-        known_live = ctx->status_host[I_LIVE_PATCHES];
-        if (ctx->status_host[I_NAN]) {
+        int const step_active = ctx->step_words[1];
+        int const step_nan = ctx->step_words[2];
+        stats->active_patch_steps += ctx->step_words[3];
+        known_live = ctx->step_words[4];
+        if (step_nan) {
             stats->nan_break = 1;
             break;
         }
@@ -564,13 +723,12 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             // depth_optimizer.cc:277-288: sum_diff / size; with no
             // reprojection term at all this is 0 / 0 = NaN, the comparison is
             // false and the loop goes on to its step limit like the reference
-            double const update = ctx->scalars_host[S_SUMDIFF]
-                / ctx->scalars_host[S_COUNT_DIFF];
+            double const update = ctx->scalars_host[0] / ctx->scalars_host[1];
             if (update < prm->full_opt_threshold)
                 break;
             continue;
         }
-        num_active = ctx->status_host[I_NUM_ACTIVE];
+        num_active = step_active;
     }
     stats->newton_steps = newton_step;
     stats->final_active_nodes = num_active;
