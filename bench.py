@@ -76,7 +76,7 @@ def run_steps(ctx, prob, steps, lighting=None):
     need_reset = False
     while done < steps:
         if need_reset:
-            ctx.set_nodes(prob["surf"]["nodes"])
+            ctx.restore_nodes()   # the start surface, resident in HBM
         st = ctx.run_loop(REG, lighting=lighting,
                           max_newton_steps=min(200, steps - done), reset_active=True)
         done += st["newton_steps"]
@@ -403,6 +403,7 @@ def main():
             nodes[:, 0] *= 1.0 + 0.5 * NOISE * rng.standard_normal(nodes.shape[0])
             s["nodes"] = nodes
         c.set_surface(s)
+        c.save_nodes()   # the start surface stays resident in HBM
         ctxs.append(c)
         starts.append(dict(prob, surf=s))
     ctx = ctxs[0]
@@ -429,7 +430,7 @@ def main():
             v = 0
             while done < steps:
                 c, p = ctxs[v % n_views], starts[v % n_views]
-                c.set_nodes(p["surf"]["nodes"])
+                c.restore_nodes()
                 lighting = fit_lighting([c])[0]
                 st = c.run_loop(REG, lighting=lighting,
                                 max_newton_steps=min(200, steps - done), reset_active=True)
@@ -455,8 +456,8 @@ def main():
     run_all(args.warmup)
     repeats = []
     for _ in range(max(args.repeats, 1)):
-        for c, p in zip(ctxs, starts):
-            c.set_nodes(p["surf"]["nodes"])
+        for c in ctxs:
+            c.restore_nodes()
         barrier()
         t0 = time.perf_counter()
         patch_steps, cg_its = run_all(args.steps)

@@ -114,6 +114,14 @@ int smvs_ctx_set_active(smvs_ctx *ctx, const uint8_t *active);
 int smvs_get_active(smvs_ctx *ctx, uint8_t *active, int *num_active);
 int smvs_get_nodes(smvs_ctx *ctx, double *nodes);
 int smvs_set_nodes(smvs_ctx *ctx, const double *nodes);
+/* Device-resident copy of the nodes (not in the reference, whose surface lives
+ * in host memory): save keeps the current nodes in HBM, restore brings them
+ * back on the context's stream without a transfer -- a caller that reruns the
+ * optimisation from one start (bench.py, parameter sweeps) uploads it once.
+ * restore without a save, or after smvs_ctx_set_surface changed the grid,
+ * returns SMVS_ERR_STATE. */
+int smvs_ctx_save_nodes(smvs_ctx *ctx);
+int smvs_ctx_restore_nodes(smvs_ctx *ctx);
 
 /* ------------------------------------------------------------------ */
 /* Gauss-Newton step                                                  */

@@ -79,6 +79,8 @@ struct ResArgs {
     int max_iterations;
     double q_tolerance, fixed_tolerance;
     long long *trace;        // debug: cycle stamps of workgroup 0 (or nullptr)
+    int pipelined;           // bit 0: launch-ahead Newton loop (update.hip), bit 1:
+                             // report a failure (test hook)
     // fused assembly (the Newton loop): per-patch systems instead of H / g / P
     const double *Hp;        // [P][10][16]
     const double *gp;        // [P][16]
@@ -359,6 +361,10 @@ __global__ void __launch_bounds__(RES_THREADS, 2)
 cg_resident_kernel(ResArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // launch-ahead Newton loop: the loop ended (or a solve gave up) while this
+    // launch was already enqueued -- every workgroup reads the same words
+    if (A.pipelined && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
+        return;
     int const tw = A.tw, th = A.th;
     int const LW = tw + 2, LH = th + 2;
     int const tile_nodes = tw * th;
@@ -830,7 +836,7 @@ cg_resident_kernel(ResArgs A)
             = *reinterpret_cast<const double4_r *>(bl + (size_t)li * 4);
     }
     if (blockIdx.x == 0 && tid == 0) {
-        int const failed = alive ? 0 : 1;
+        int const failed = alive && !(A.pipelined & 2) ? 0 : 1;   // (bit 1: test hook)
         if (!st.done && !failed) {
             // max_iterations <= 1 never reaches here (handled by the host)
             st.done = 1;
@@ -839,6 +845,8 @@ cg_resident_kernel(ResArgs A)
         A.status[I_DONE] = failed ? 0 : 1;
         A.status[I_INFO] = st.info;
         A.status[I_ITER] = st.iter;
+        if (failed && A.pipelined)
+            A.status[I_STEP_ABORT] = ABORT_SOLVER;   // the enqueued steps do nothing
         __hip_atomic_store(A.progress + 2, st.info, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(A.progress + 3, st.iter, __ATOMIC_RELAXED,
@@ -920,16 +928,24 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
 
 static std::mutex g_resident_mutex[16];   // one barrier kernel per device at a time
 
-// Returns SMVS_OK with *ran = false when the resident solver does not apply
-// (grid too large for the chip, disabled, or it failed to synchronise) -- the
-// caller then runs the streaming kernels.
-int
-cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
-    double q_tolerance, int *num_iterations, int *info, bool *ran, bool fused)
+// one barrier kernel at a time per device: two of them started together
+// could each hold half of the CUs and wait for the other half for ever
+std::mutex &
+cg_resident_mutex(int device)
 {
-    *ran = false;
-    if (!cg_resident_applies(ctx, max_iterations))
-        return SMVS_OK;
+    return g_resident_mutex[device & 15];
+}
+
+// Launches the solver (the caller holds cg_resident_mutex and has checked
+// cg_resident_applies).  pipelined: the Newton loop's launch-ahead mode -- the
+// kernel leaves at once when status[I_STOP] / [I_STEP_ABORT] is set, raises
+// I_STEP_ABORT itself when it gives up, and nobody waits on the progress words.
+// *solve_tag_out: the tag the progress words will carry.
+static int
+resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
+    double q_tolerance, bool fused, bool pipelined, long long *trace_dev,
+    int *solve_tag_out, int *num_tiles_out, bool test_give_up = false)
+{
     int const stride = ctx->node_stride;
     int const rows = ctx->num_nodes / stride;
     int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
@@ -1001,21 +1017,10 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.scalars = ctx->scalars;
     A.npx = ctx->npx;
     A.npy = ctx->npy;
-    A.trace = nullptr;
-    // debug aid (tools/cg_trace.py): cycle stamps of workgroup 0
-    static const char *trace_path = std::getenv("SMVS_CG_TRACE");
-    long long *trace_dev = nullptr;
-    size_t const trace_n = (size_t)(TRACE_ITERS + 1) * TRACE_POINTS;
-    if (trace_path != nullptr) {
-        SMVS_HIP_CHECK(hipMalloc((void **)&trace_dev, trace_n * sizeof(long long)));
-        SMVS_HIP_CHECK(hipMemsetAsync(trace_dev, 0, trace_n * sizeof(long long),
-            ctx->stream));
-        A.trace = trace_dev;
-    }
-
-    // one barrier kernel at a time per device: two of them started together
-    // could each hold half of the CUs and wait for the other half for ever
-    std::lock_guard<std::mutex> guard(g_resident_mutex[ctx->device & 15]);
+    A.trace = trace_dev;
+    A.pipelined = pipelined ? (test_give_up ? 3 : 1) : 0;
+    *solve_tag_out = A.solve_tag;
+    *num_tiles_out = num_tiles;
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
         if (fused)
@@ -1026,11 +1031,54 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                 dim3(RES_THREADS), lds_bytes, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
+size_t
+cg_resident_exchange_bytes(void)
+{
+    return sizeof(ResExchange);
+}
+
+int
+cg_resident_enqueue(smvs_ctx *ctx, int max_iterations, double q_tolerance,
+    bool test_give_up)
+{
+    int tag = 0, tiles = 0;
+    return resident_enqueue(ctx, max_iterations, -1.0, q_tolerance, true, true,
+        nullptr, &tag, &tiles, test_give_up);
+}
+
+// Returns SMVS_OK with *ran = false when the resident solver does not apply
+// (grid too large for the chip, disabled, or it failed to synchronise) -- the
+// caller then runs the streaming kernels.
+int
+cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
+    double q_tolerance, int *num_iterations, int *info, bool *ran, bool fused)
+{
+    *ran = false;
+    if (!cg_resident_applies(ctx, max_iterations))
+        return SMVS_OK;
+    // debug aid (tools/cg_trace.py): cycle stamps of workgroup 0
+    static const char *trace_path = std::getenv("SMVS_CG_TRACE");
+    long long *trace_dev = nullptr;
+    size_t const trace_n = (size_t)(TRACE_ITERS + 1) * TRACE_POINTS;
+    if (trace_path != nullptr) {
+        SMVS_HIP_CHECK(hipMalloc((void **)&trace_dev, trace_n * sizeof(long long)));
+        SMVS_HIP_CHECK(hipMemsetAsync(trace_dev, 0, trace_n * sizeof(long long),
+            ctx->stream));
+    }
+    std::lock_guard<std::mutex> guard(cg_resident_mutex(ctx->device));
+    int solve_tag = 0, num_tiles = 0;
+    int const rc = resident_enqueue(ctx, max_iterations, error_tolerance,
+        q_tolerance, fused, false, trace_dev, &solve_tag, &num_tiles);
+    if (rc != SMVS_OK)
+        return rc;
 
     volatile int *progress = ctx->cg_progress;
     auto const t_start = std::chrono::steady_clock::now();
     long spins = 0;
-    while (__atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) != (A.solve_tag | 1)) {
+    while (__atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) != (solve_tag | 1)) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFF) == 0) {
             hipError_t const q = hipStreamQuery(ctx->stream);
@@ -1038,7 +1086,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                 SMVS_HIP_CHECK(q);
             if (q == hipSuccess
                 && __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE)
-                    != (A.solve_tag | 1)) {
+                    != (solve_tag | 1)) {
                 set_error("cg_resident_solve: kernel ended without a result");
                 return SMVS_ERR_STATE;
             }

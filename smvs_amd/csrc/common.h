@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -62,7 +63,10 @@ enum {
     I_ACTIVE_PATCHES,
     I_TOPO_DELETED,  // patches deleted by one cut_boundaries pass
     I_LIVE_PATCHES,  // entries of the compacted live-patch list
-    I_TICKET,        // arrivals of finish_step_kernel's workgroups
+    I_NUM_INITIAL,   // active nodes at the start of the Newton loop (finish_step_kernel, begin)
+    I_STOP,          // pipelined Newton loop: the loop has ended, enqueued steps do nothing
+    I_STEP_ABORT,    // pipelined Newton loop: this step was abandoned (ABORT_*); it and
+                     // the steps enqueued behind it change nothing
     I_NUM = 16
 };
 
@@ -142,7 +146,12 @@ struct smvs_ctx {
     int *status = nullptr;          // [I_NUM]
     int *status_host = nullptr;     // pinned
     int *cg_progress = nullptr;     // pinned, written by the CG kernels (cg.hip)
-    int *step_words = nullptr;      // pinned, written by finish_step_kernel (update.hip)
+    int *step_words = nullptr;      // pinned ring of STEP_SLOTS result slots, written by
+                                    // finish_step_kernel (update.hip)
+    unsigned long long *step_counter = nullptr;   // device, its packed counters
+    double *nodes_saved = nullptr;  // smvs_ctx_save_nodes
+    size_t nodes_saved_cap = 0;
+    int nodes_saved_count = 0, nodes_saved_stride = 0;
     int step_seq = 0;
     int cg_solve_id = 0;
     double *scalars_host = nullptr; // pinned
@@ -288,6 +297,21 @@ ldl_inverse4(double A[16])
                 A[c1 * 4 + c2] += L[r * 4 + c2] * L[r * 4 + c1] * D[r];
 }
 
+// reasons in status[I_STEP_ABORT]; finish_step_kernel reports 1 + reason
+constexpr int ABORT_SOLVER = 1;   // the resident solver gave up (workgroups not co-resident)
+constexpr int ABORT_GRID = 2;     // a launch was sized for a shorter live list
+constexpr int STEP_SLOTS = 4;        // steps whose result words can coexist
+constexpr int STEP_SLOT_INTS = 16;   // one 64-byte line per slot
+
+// Launch-ahead mode of the Newton loop: the launches of a step are sized and
+// enqueued before the previous step's result is known; the kernels read the
+// list length and the loop's stop word on the device.
+struct StepPipeline {
+    int seq;             // sequence tag finish_step_kernel publishes (never 0)
+    int grid_live;       // list length the launches are sized for
+    double full_opt_threshold;
+};
+
 // internal entry points used by the fused loop
 // known_live: entries of the live-patch list the previous reactivate_launch
 // of the same Newton loop built (its count read back by the host), or -1 to
@@ -295,7 +319,8 @@ ldl_inverse4(double A[16])
 // skip_assembly: leave the per-patch systems unassembled (the resident solver
 // gathers them itself, cg_resident_solve(..., fused = true)).
 int gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
-    bool use_lighting, int known_live = -1, bool skip_assembly = false);
+    bool use_lighting, int known_live = -1, bool skip_assembly = false,
+    bool check_stop = false);
 int gn_assemble_launch(smvs_ctx *ctx);
 int live_patch_list_launch(smvs_ctx *ctx);
 int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
@@ -304,12 +329,20 @@ int cg_solve_launch(smvs_ctx *ctx, int max_iterations, double error_tolerance,
 // publish_seq != 0: the Newton loop's fused end of step (finish_step_kernel
 // publishes the result words tagged with this sequence number).
 int reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
-    bool build_live_list = false, int known_live = -1, int publish_seq = 0);
+    bool build_live_list = false, int known_live = -1, int publish_seq = 0,
+    const StepPipeline *pipe = nullptr);
 // fused: assemble H, g, P from the per-patch systems inside the kernel (the
 // caller has NOT run the assembly kernel); *ran = false means nothing was done.
 int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info, bool *ran,
     bool fused = false);
 bool cg_resident_applies(smvs_ctx *ctx, int max_iterations);
+// The launch-ahead Newton loop (update.hip): holds cg_resident_mutex for the
+// whole loop and enqueues fused solves without waiting for them.
+std::mutex &cg_resident_mutex(int device);
+int cg_resident_enqueue(smvs_ctx *ctx, int max_iterations, double q_tolerance,
+    bool test_give_up = false);
+size_t cg_resident_exchange_bytes(void);   // size of ctx->res_work
+
 
 } // namespace smvs_hip

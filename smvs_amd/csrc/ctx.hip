@@ -138,6 +138,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || (rc = device_alloc(&ctx->lighting, 16)) != SMVS_OK
         || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK
         || (rc = device_alloc(&ctx->partials, 4 * 1024)) != SMVS_OK
+        || (rc = device_alloc(&ctx->step_counter, 2)) != SMVS_OK
         || (rc = device_alloc(reinterpret_cast<char **>(&ctx->cg_state), 256)) != SMVS_OK) {
         smvs_ctx_destroy(ctx);
         return rc;
@@ -146,7 +147,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     // progress with system-scope stores that the host polls while they run
     unsigned const host_flags = hipHostMallocCoherent | hipHostMallocMapped;
     if (hipHostMalloc((void **)&ctx->cg_progress, sizeof(int) * 8, host_flags) != hipSuccess
-        || hipHostMalloc((void **)&ctx->step_words, sizeof(int) * 8, host_flags) != hipSuccess
+        || hipHostMalloc((void **)&ctx->step_words, sizeof(int) * STEP_SLOTS * STEP_SLOT_INTS, host_flags) != hipSuccess
         || hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM, host_flags) != hipSuccess
         || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM, host_flags) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -155,10 +156,11 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     }
     (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
     (void)hipMemsetAsync(ctx->status, 0, sizeof(int) * I_NUM, ctx->stream);
-    for (int i = 0; i < 8; ++i) {
+    (void)hipMemsetAsync(ctx->step_counter, 0, sizeof(unsigned long long), ctx->stream);
+    for (int i = 0; i < 8; ++i)
         ctx->cg_progress[i] = 0;
+    for (int i = 0; i < STEP_SLOTS * STEP_SLOT_INTS; ++i)
         ctx->step_words[i] = 0;
-    }
     *out = ctx;
     return SMVS_OK;
 }
@@ -178,7 +180,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->d2, ctx->b, ctx->partials,
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
-        ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list };
+        ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list,
+        ctx->step_counter, ctx->nodes_saved };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -543,6 +546,51 @@ smvs_set_nodes(smvs_ctx *ctx, const double *nodes)
         (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyHostToDevice,
         ctx->stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_save_nodes(smvs_ctx *ctx)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface) {
+        set_error("smvs_ctx_save_nodes: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const n = (size_t)ctx->num_nodes * 4;
+    if (ctx->nodes_saved_cap < n) {
+        if (ctx->nodes_saved != nullptr)
+            (void)hipFree(ctx->nodes_saved);
+        ctx->nodes_saved = nullptr;
+        ctx->nodes_saved_cap = 0;
+        ctx->nodes_saved_count = 0;
+        int const rc = device_alloc(&ctx->nodes_saved, n);
+        if (rc != SMVS_OK)
+            return rc;
+        ctx->nodes_saved_cap = n;
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes_saved, ctx->nodes, n * sizeof(double),
+        hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->nodes_saved_count = ctx->num_nodes;
+    ctx->nodes_saved_stride = ctx->node_stride;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_restore_nodes(smvs_ctx *ctx)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (!ctx->has_surface || ctx->nodes_saved == nullptr
+        || ctx->nodes_saved_count != ctx->num_nodes
+        || ctx->nodes_saved_stride != ctx->node_stride) {
+        set_error("smvs_ctx_restore_nodes: no saved nodes for this surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes, ctx->nodes_saved,
+        (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyDeviceToDevice,
+        ctx->stream));
     return SMVS_OK;
 }
 

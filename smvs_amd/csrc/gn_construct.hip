@@ -54,6 +54,7 @@ struct PatchKernelArgs {
     double reg, light_reg;
     int use_lighting;
     int *status;
+    int check_stop;   // leave at once when status[I_STOP] / [I_STEP_ABORT] is set
 };
 
 // 1 / x to ~1 ulp: hardware estimate (2^-26 or better) + two Newton steps.
@@ -648,6 +649,10 @@ gn_patch_kernel(PatchKernelArgs A)
     double *tabs = lds + scratch_rows * 64;  // [spr][12] sampled coordinates
 
     int const lane = threadIdx.x;
+    // a pipelined Newton loop enqueues steps before it knows whether the loop
+    // goes on (update.hip): once it has ended they do nothing
+    if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
+        return;
     // Work = the compacted list of live patches (a patch with an active node,
     // gauss_newton_step.cc:73-79): a sparse step launches / occupies waves in
     // proportion to its active set.  The list's blocks are dealt to the XCDs
@@ -656,6 +661,14 @@ gn_patch_kernel(PatchKernelArgs A)
     int const live_count = A.status[I_LIVE_PATCHES];
     unsigned const live_blocks = (unsigned)((live_count + PPW - 1) / PPW);
     unsigned const band = (live_blocks + 7u) >> 3;
+    if (band > (gridDim.x >> 3)) {
+        // the pipelined loop sized this launch before the list existed and
+        // the list came out longer: the whole step is abandoned (every
+        // workgroup takes this branch) and the host enqueues it again
+        if (blockIdx.x == 0 && lane == 0)
+            A.status[I_STEP_ABORT] = ABORT_GRID;
+        return;
+    }
     unsigned const wv = (blockIdx.x & 7u) * band + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= band || wv >= live_blocks)
         return;
@@ -1011,7 +1024,7 @@ sampling_for_scale(int scale)
 
 int
 gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
-    bool use_lighting, int known_live, bool skip_assembly)
+    bool use_lighting, int known_live, bool skip_assembly, bool check_stop)
 {
     // Shared by smvs_gn_construct and smvs_gn_run_loop: the patch kernel
     // dereferences every neighbour's planes and the main gradient.
@@ -1064,6 +1077,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     A.light_reg = light_reg;
     A.use_lighting = use_lighting ? 1 : 0;
     A.status = ctx->status;
+    A.check_stop = check_stop ? 1 : 0;
 
     int const scratch_rows = 5 * (ctx->n_subs - 1) > 27 ? 5 * (ctx->n_subs - 1) : 27;
     size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12) * sizeof(double);

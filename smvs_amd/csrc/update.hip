@@ -58,7 +58,7 @@ struct ReactivateArgs {
     int full_optimization;
     const int *live_list;   // the step's live patches, or nullptr: all patches
     int live_count;
-    int zero_step_words;    // the Newton loop: reset the words of finish_step_kernel
+    int check_stop;
 };
 
 // One thread per (patch, full-resolution pixel): project with the old and
@@ -67,22 +67,32 @@ struct ReactivateArgs {
 __global__ void __launch_bounds__(256)
 reactivate_kernel(ReactivateArgs A)
 {
+    long long const gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // the pipelined Newton loop: the loop has already ended / the solver of
+    // this step gave up (finish_step_kernel reports it)
+    if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
+        return;
+    int const pp = A.ps * A.ps;
+    // the list length is read on the device when the launch was sized before
+    // it was known (live_count < 0)
+    int const live_count = A.live_list == nullptr ? A.num_patches
+        : (A.live_count >= 0 ? A.live_count : A.status[I_LIVE_PATCHES]);
+    if ((long long)live_count * pp > (long long)gridDim.x * blockDim.x) {
+        // (cannot happen behind a patch kernel of the same step, which is
+        // sized for the same length and would have abandoned the step)
+        if (gid0 == 0)
+            A.status[I_STEP_ABORT] = ABORT_GRID;
+        return;
+    }
     // NaN guard of the reference on delta[0] (depth_optimizer.cc:267)
     if (isnan(A.x[0]))
         return;
-    int const pp = A.ps * A.ps;
-    long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid == 0 && A.zero_step_words) {
-        // (the construction has consumed the list length; finish_step_kernel
-        // counts the next list and its arrivals from zero)
-        A.status[I_LIVE_PATCHES] = 0;
-        A.status[I_TICKET] = 0;
-    }
+    long long const gid = gid0;
     int const slot = (int)(gid / pp);
     int const pid = (int)(gid - (long long)slot * pp);
-    int patch = slot;
-    if (A.live_list != nullptr)
-        patch = slot < A.live_count ? A.live_list[slot] : A.num_patches;
+    int patch = A.num_patches;
+    if (slot < live_count)
+        patch = A.live_list != nullptr ? A.live_list[slot] : slot;
     double sum = 0.0, cnt = 0.0;
     if (patch < A.num_patches && A.patch_valid[patch]) {
         int const ix = patch % A.npx, iy = patch / A.npx;
@@ -237,45 +247,79 @@ struct FinishArgs {
     const uint8_t *active_next;
     int *list;
     int *status;
+    unsigned long long *counter;   // bits 0-23 list length, 24-47 active nodes,
+                                   // 48-63 workgroups arrived: ONE atomic per workgroup
     const double *scalars;
-    int *host_words;       // pinned: [0] sequence tag, [1] active nodes, [2] NaN,
-                           //         [3] active patches of the step, [4] next list length
-    double *host_scalars;  // pinned: [0] sum of shifts, [1] number of terms
+    int *host_words;       // pinned slot (STEP_SLOT_INTS ints): [0] sequence tag,
+                           // [1] active nodes, [2] NaN, [3] active patches of the
+                           // step, [4] next list length, [5] 0 ran / 1 skipped (the
+                           // loop had ended) / 1 + ABORT_* (the step was abandoned),
+                           // [6] CG iterations, [7] the loop ends after this step,
+                           // [8..11] two doubles: sum of shifts, number of terms
     int npx, npy, stride, num_nodes;
     int full_optimization;
     int seq;
+    int check_stop;        // launch-ahead mode: obey / maintain status[I_STOP]
+    double full_opt_threshold;
+    int begin;             // 1: the start of a loop instead of the end of a step --
+                           // no node update; count the active set into
+                           // status[I_NUM_INITIAL], build the first live list,
+                           // clear the stop / abort words
+    int reset_active;      // begin: active := valid nodes first (surface.cc:37-44)
 };
 
-__global__ void __launch_bounds__(256)
+constexpr int FINISH_THREADS = 1024;
+
+__global__ void __launch_bounds__(FINISH_THREADS)
 finish_step_kernel(FinishArgs A)
 {
-    bool const skip = isnan(A.x[0]);   // depth_optimizer.cc:267: nothing is updated
-    bool const keep = skip || A.full_optimization != 0;
+    if (A.check_stop && !A.begin) {
+        // enqueued before the loop was known to have ended / the solver to
+        // have given up: report it, touch nothing
+        int const abort = A.status[I_STEP_ABORT];
+        int const gate = A.status[I_STOP] != 0 ? 1 : (abort != 0 ? 1 + abort : 0);
+        if (gate != 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                __hip_atomic_store(A.host_words + 5, gate, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(A.host_words + 0, A.seq, __ATOMIC_RELEASE,
+                    __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+    bool const begin = A.begin != 0;
+    // depth_optimizer.cc:267: nothing is updated
+    bool const skip = begin ? false : isnan(A.x[0]);
+    bool const keep = begin ? A.reset_active == 0 : (skip || A.full_optimization != 0);
+    // the flags the new active set comes from when it is not kept
+    const uint8_t *incoming = begin ? A.node_valid : A.active_next;
     int const c = blockIdx.x * blockDim.x + threadIdx.x;
     bool on = false, live = false;
     int patch = 0;
     if (c < A.num_nodes) {
-        if (!skip && A.node_valid[c]) {
+        if (!begin && !skip && A.node_valid[c]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 A.nodes[4 * (size_t)c + k] += A.x[4 * (size_t)c + k];
         }
-        // (other threads read active_next, never the flag adopted here)
-        uint8_t const flag = keep ? A.active[c] : A.active_next[c];
+        // (other threads read `incoming`, never the flag adopted here)
+        uint8_t const flag = keep ? A.active[c] : (incoming[c] != 0 ? 1 : 0);
         if (!keep)
             A.active[c] = flag;
         on = flag == 1;
         int const ix = c % A.stride, iy = c / A.stride;
         if (ix < A.npx && iy < A.npy) {
             patch = iy * A.npx + ix;
-            const uint8_t *f = keep ? A.active : A.active_next;
+            const uint8_t *f = keep ? A.active : incoming;
             live = A.patch_valid[patch]
                 && (flag | f[c + 1] | f[c + A.stride] | f[c + A.stride + 1]) != 0;
         }
     }
-    __shared__ int wave_cnt[4];
+    constexpr int WAVES = FINISH_THREADS / 64;
+    __shared__ int wave_cnt[WAVES];
     __shared__ int base;
-    __shared__ int last;
+    __shared__ unsigned long long seen;
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long const ballot = __ballot(live);
     int const before = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -283,10 +327,16 @@ finish_step_kernel(FinishArgs A)
         wave_cnt[wave] = __popcll(ballot);
     int const cnt_on = __syncthreads_count(on);
     if (threadIdx.x == 0) {
-        int const total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        base = total > 0 ? atomicAdd(&A.status[I_LIVE_PATCHES], total) : 0;
-        if (cnt_on != 0)
-            atomicAdd(&A.status[I_NUM_ACTIVE], cnt_on);
+        int total = 0;
+        for (int wv = 0; wv < WAVES; ++wv)
+            total += wave_cnt[wv];
+        // one device-scope atomic per workgroup (atomics on one address are
+        // served one after the other): list slots, active nodes and arrival
+        unsigned long long const add = (unsigned long long)total
+            | ((unsigned long long)cnt_on << 24) | (1ull << 48);
+        unsigned long long const old = atomicAdd(A.counter, add);
+        base = (int)(old & 0xFFFFFFull);
+        seen = old + add;
     }
     __syncthreads();
     if (live) {
@@ -295,21 +345,20 @@ finish_step_kernel(FinishArgs A)
             off += wave_cnt[wv];
         A.list[off] = patch;
     }
-    // publish from the last workgroup.  No fences (a release per workgroup
-    // writes back a whole L2): the counters are device-scope atomics, thread 0
-    // waits for its own to be acknowledged before it draws its ticket, and the
-    // publisher reads them back with atomic loads.
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = atomicAdd(&A.status[I_TICKET], 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        int const num_active = __hip_atomic_load(&A.status[I_NUM_ACTIVE],
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int const next_live = __hip_atomic_load(&A.status[I_LIVE_PATCHES],
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the workgroup that arrives last publishes the step (no fences: the
+    // counters travelled in the atomic itself)
+    if (threadIdx.x == 0 && (seen >> 48) == (unsigned long long)gridDim.x) {
+        int const next_live = (int)(seen & 0xFFFFFFull);
+        int const num_active = (int)((seen >> 24) & 0xFFFFFFull);
+        *A.counter = 0ull;   // (nobody else touches it any more) for the next launch
+        if (begin) {
+            A.status[I_NUM_INITIAL] = num_active;
+            A.status[I_STEP_ABORT] = 0;
+            A.status[I_ACTIVE_PATCHES] = 0;
+        }
         A.status[I_NAN] = skip ? 1 : 0;
+        A.status[I_NUM_ACTIVE] = num_active;
+        A.status[I_LIVE_PATCHES] = next_live;
         __hip_atomic_store(A.host_words + 1, num_active, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(A.host_words + 2, skip ? 1 : 0, __ATOMIC_RELAXED,
@@ -318,17 +367,89 @@ finish_step_kernel(FinishArgs A)
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(A.host_words + 4, next_live, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
-        A.host_scalars[0] = A.scalars[S_SUMDIFF];
-        A.host_scalars[1] = A.scalars[S_COUNT_DIFF];
+        double const sum_diff = A.scalars[S_SUMDIFF];
+        double const count_diff = A.scalars[S_COUNT_DIFF];
+        // does the loop go on?  (depth_optimizer.cc:219-220, 267-268, 277-288;
+        // the step limit is the host's business)
+        bool stop = skip;
+        if (A.full_optimization && !begin)
+            stop = stop || sum_diff / count_diff < A.full_opt_threshold;
+        else
+            stop = stop || !(num_active > A.status[I_NUM_INITIAL] / 20);
+        if (A.check_stop || begin)
+            A.status[I_STOP] = stop ? 1 : 0;
+        __hip_atomic_store(A.host_words + 5, 0, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.host_words + 6, begin ? 0 : A.status[I_ITER], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.host_words + 7, stop ? 1 : 0, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_SYSTEM);
+        double *host_scalars = reinterpret_cast<double *>(A.host_words + 8);
+        host_scalars[0] = sum_diff;
+        host_scalars[1] = count_diff;
         __hip_atomic_store(A.host_words + 0, A.seq, __ATOMIC_RELEASE,
             __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
+static FinishArgs
+finish_args(smvs_ctx *ctx, int seq)
+{
+    FinishArgs F;
+    F.nodes = ctx->nodes;
+    F.x = ctx->x;
+    F.node_valid = ctx->node_valid;
+    F.patch_valid = ctx->patch_valid;
+    F.active = ctx->active;
+    F.active_next = ctx->active_next;
+    F.list = ctx->live_list;
+    F.status = ctx->status;
+    F.counter = ctx->step_counter;
+    F.scalars = ctx->scalars;
+    F.host_words = ctx->step_words + (seq & (STEP_SLOTS - 1)) * STEP_SLOT_INTS;
+    F.npx = ctx->npx;
+    F.npy = ctx->npy;
+    F.stride = ctx->node_stride;
+    F.num_nodes = ctx->num_nodes;
+    F.full_optimization = 0;
+    F.seq = seq;
+    F.check_stop = 0;
+    F.full_opt_threshold = 0.0;
+    F.begin = 0;
+    F.reset_active = 0;
+    return F;
+}
+
+// Start of a Newton loop (depth_optimizer.cc:214-220) without a host round
+// trip: optionally active := valid nodes, count the active set into
+// status[I_NUM_INITIAL], build the first live-patch list, clear the stop /
+// abort words, publish the counts under `seq`.
+static int
+loop_begin_launch(smvs_ctx *ctx, bool reset_active, int seq)
+{
+    FinishArgs F = finish_args(ctx, seq);
+    F.begin = 1;
+    F.reset_active = reset_active ? 1 : 0;
+    if (reset_active)
+        ctx->cg_use_active = false;   // as smvs_ctx_set_active
+    int const N = ctx->num_nodes;
+    ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+    hipLaunchKernelGGL(finish_step_kernel,
+        dim3((unsigned)((N + FINISH_THREADS - 1) / FINISH_THREADS)),
+        dim3(FINISH_THREADS), 0, ctx->stream, F);
+    SMVS_HIP_CHECK(hipGetLastError());
+    return SMVS_OK;
+}
+
 int
 reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
-    bool build_live_list, int known_live, int publish_seq)
+    bool build_live_list, int known_live, int publish_seq,
+    const StepPipeline *pipe)
 {
+    if (pipe != nullptr) {
+        publish_seq = pipe->seq;
+        known_live = pipe->grid_live;
+    }
     int const N = ctx->num_nodes;
     // (the assembly kernel of the same Newton step has already cleared the
     // flags and counters when the system came from smvs_gn_construct)
@@ -364,8 +485,8 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
     // the live list of this step (built at the end of the previous one) when
     // the host knows its length
     A.live_list = known_live >= 0 ? ctx->live_list : nullptr;
-    A.live_count = known_live;
-    A.zero_step_words = publish_seq != 0 ? 1 : 0;
+    A.live_count = pipe != nullptr ? -1 : known_live;   // -1: read on the device
+    A.check_stop = pipe != nullptr ? 1 : 0;
     long long const items = (long long)(known_live >= 0 ? known_live
         : ctx->num_patches) * ctx->patchsize * ctx->patchsize;
     {
@@ -378,27 +499,14 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
     if (publish_seq != 0) {
         // the Newton loop: node update, next live list and the result words
         // in one launch
-        FinishArgs F;
-        F.nodes = ctx->nodes;
-        F.x = ctx->x;
-        F.node_valid = ctx->node_valid;
-        F.patch_valid = ctx->patch_valid;
-        F.active = ctx->active;
-        F.active_next = ctx->active_next;
-        F.list = ctx->live_list;
-        F.status = ctx->status;
-        F.scalars = ctx->scalars;
-        F.host_words = ctx->step_words;
-        F.host_scalars = ctx->scalars_host;
-        F.npx = ctx->npx;
-        F.npy = ctx->npy;
-        F.stride = ctx->node_stride;
-        F.num_nodes = N;
+        FinishArgs F = finish_args(ctx, publish_seq);
         F.full_optimization = full_optimization;
-        F.seq = publish_seq;
+        F.check_stop = pipe != nullptr ? 1 : 0;
+        F.full_opt_threshold = pipe != nullptr ? pipe->full_opt_threshold : 0.0;
         ScopedKernelTimer timer(ctx, SMVS_K_MISC);
-        hipLaunchKernelGGL(finish_step_kernel, dim3((unsigned)((N + 255) / 256)),
-            dim3(256), 0, ctx->stream, F);
+        hipLaunchKernelGGL(finish_step_kernel,
+            dim3((unsigned)((N + FINISH_THREADS - 1) / FINISH_THREADS)),
+            dim3(FINISH_THREADS), 0, ctx->stream, F);
         SMVS_HIP_CHECK(hipGetLastError());
         return SMVS_OK;
     }
@@ -619,6 +727,277 @@ smvs_update_and_reactivate(smvs_ctx *ctx, double threshold,
     return SMVS_OK;
 }
 
+// State of one smvs_gn_run_loop call
+struct LoopState {
+    int num_initial = 0;
+    int num_active = 0;
+    int newton_step = 0;
+    int known_live = -1;   // length of the live-patch list once read back
+    bool ended = false;    // a break of depth_optimizer.cc:267-268 / :284-288
+    int begin_seq = 0;     // tag of the loop-begin words while they are unread
+};
+
+static bool
+loop_goes_on(const smvs_gn_loop_params *prm, LoopState const &L)
+{
+    // depth_optimizer.cc:219-220
+    return !L.ended && L.newton_step < prm->max_newton_steps
+        && L.num_active > L.num_initial / 20;
+}
+
+// Spins on a result slot until finish_step_kernel has published `seq` there:
+// the next launches follow the end of the step within microseconds (no stream
+// query, no copies).
+static int
+wait_step_words(smvs_ctx *ctx, int seq, const int **slot_out)
+{
+    const int *words = ctx->step_words + (seq & (STEP_SLOTS - 1)) * STEP_SLOT_INTS;
+    auto const t_start = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(&words[0], __ATOMIC_ACQUIRE) != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFF) == 0) {
+            hipError_t const q = hipStreamQuery(ctx->stream);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                SMVS_HIP_CHECK(q);
+            if (q == hipSuccess
+                && __atomic_load_n(&words[0], __ATOMIC_ACQUIRE) != seq) {
+                set_error("smvs_gn_run_loop: the step ended without "
+                    "publishing its result");
+                return SMVS_ERR_STATE;
+            }
+            if (std::chrono::steady_clock::now() - t_start
+                > std::chrono::seconds(60)) {
+                set_error("smvs_gn_run_loop: timed out waiting for the device");
+                return SMVS_ERR_STATE;
+            }
+        }
+    }
+    *slot_out = words;
+    return SMVS_OK;
+}
+
+// The counts loop_begin_launch published: the initial active set and the
+// length of the first live list.
+static int
+read_loop_begin(smvs_ctx *ctx, LoopState &L)
+{
+    const int *words = nullptr;
+    int const rc = wait_step_words(ctx, L.begin_seq, &words);
+    if (rc != SMVS_OK)
+        return rc;
+    L.num_initial = L.num_active = words[1];
+    L.known_live = words[4];
+    L.begin_seq = 0;
+    return SMVS_OK;
+}
+
+// The bookkeeping of depth_optimizer.cc:267-303 on a step's result words.
+static void
+account_step(const smvs_gn_loop_params *prm, smvs_gn_loop_stats *stats,
+    LoopState &L, const int *words, int cg_iterations)
+{
+    L.newton_step += 1;
+    stats->linear_iterations += cg_iterations;
+    stats->active_patch_steps += words[3];
+    L.known_live = words[4];
+    if (words[2] != 0) {
+        stats->nan_break = 1;
+        L.ended = true;
+        return;
+    }
+    if (prm->full_optimization) {
+        // depth_optimizer.cc:277-288: sum_diff / size; with no reprojection
+        // term at all this is 0 / 0 = NaN, the comparison is false and the
+        // loop goes on to its step limit like the reference
+        const double *sc = reinterpret_cast<const double *>(words + 8);
+        if (sc[0] / sc[1] < prm->full_opt_threshold)
+            L.ended = true;
+        return;
+    }
+    L.num_active = words[1];
+}
+
+static int
+next_step_seq(smvs_ctx *ctx)
+{
+    ctx->step_seq = (ctx->step_seq % 0x3FFFFFFF) + 1;
+    return ctx->step_seq;
+}
+
+// One Newton step with the assembly kernel and the streaming solver; the host
+// waits for its result before it launches the next one.
+static int
+run_step_streaming(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
+    smvs_gn_loop_stats *stats, LoopState &L)
+{
+    int rc;
+    if ((rc = gn_construct_launch(ctx, prm->regularization,
+            prm->light_surf_regularization, prm->use_lighting != 0,
+            L.known_live, false)) != SMVS_OK)
+        return rc;
+    int iters = 0, info = 0;
+    if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
+            prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
+        return rc;
+    int const seq = next_step_seq(ctx);
+    if ((rc = reactivate_launch(ctx, prm->active_threshold,
+            prm->full_optimization, true, L.known_live, seq)) != SMVS_OK)
+        return rc;
+    const int *words = nullptr;
+    if ((rc = wait_step_words(ctx, seq, &words)) != SMVS_OK)
+        return rc;
+    account_step(prm, stats, L, words, iters);
+    return SMVS_OK;
+}
+
+// The Newton loop with the fused resident solver, launch-ahead: step k + 1 is
+// enqueued before the result of step k is known, so the GPU never waits for
+// the host between steps.  The kernels size themselves from the device-side
+// list length; finish_step_kernel evaluates the loop condition into
+// status[I_STOP], and a step enqueued behind the end of the loop does nothing
+// but report that it was skipped.  Returns with L.ended set, or -- when the
+// solver gave up -- with the context's resident solver disabled and L at the
+// last completed step (the caller goes on with run_step_streaming).
+static int
+run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
+    smvs_gn_loop_stats *stats, LoopState &L)
+{
+    // barrier kernels of two loops must not interleave on one device
+    std::lock_guard<std::mutex> guard(cg_resident_mutex(ctx->device));
+    static_assert(I_STEP_ABORT == I_STOP + 1, "cleared together");
+    static int const test_mode = [] {
+        const char *e = std::getenv("SMVS_LOOP_TEST");
+        if (e == nullptr)
+            return 0;
+        return std::strcmp(e, "undersize") == 0 ? 1
+            : (std::strcmp(e, "solver") == 0 ? 2 : 0);
+    }();
+    int rc;
+    int seqs[2] = { 0, 0 };      // tags of the steps in flight, oldest first
+    int in_flight = 0;
+    int enqueued = L.newton_step;   // steps enqueued so far (absolute number)
+    auto enqueue = [&]() -> int {
+        StepPipeline P;
+        P.seq = next_step_seq(ctx);
+        // The launches are sized for the newest list length the host has
+        // seen -- one step old when the launch is ahead -- plus some slack
+        // (the surplus workgroups leave at once; a list that still came out
+        // longer makes the step abandon itself, below), for every patch
+        // before the first count has come back.  Multiples of 32 patches:
+        // the patch kernel's 8 bands of 4-patch workgroups.
+        long long want = ctx->num_patches;
+        if (L.known_live >= 0 && L.known_live + L.known_live / 16 + 64 < want)
+            want = L.known_live + L.known_live / 16 + 64;
+        // test hooks (tests/test_gpu_parity.py): SMVS_LOOP_TEST=undersize
+        // sizes every launch-ahead step for half the list, =solver makes the
+        // second solve of a loop report that it gave up
+        if (test_mode == 1 && in_flight >= 1 && L.known_live >= 0)
+            want = L.known_live / 2;
+        P.grid_live = (int)((want + 31) / 32 * 32);
+        P.full_opt_threshold = prm->full_opt_threshold;
+        int r = gn_construct_launch(ctx, prm->regularization,
+            prm->light_surf_regularization, prm->use_lighting != 0,
+            P.grid_live, true, true);
+        if (r == SMVS_OK)
+            r = cg_resident_enqueue(ctx, prm->cg_max_iterations,
+                prm->cg_q_tolerance, test_mode == 2 && enqueued == 1);
+        if (r == SMVS_OK)
+            r = reactivate_launch(ctx, prm->active_threshold,
+                prm->full_optimization, true, -1, 0, &P);
+        if (r == SMVS_OK) {
+            seqs[in_flight++] = P.seq;
+            enqueued += 1;
+        }
+        return r;
+    };
+    // every enqueued step is waited for before this function returns (the
+    // result slots and the stop words are then quiet)
+    auto drain = [&]() -> int {
+        int r = SMVS_OK;
+        while (in_flight > 0) {
+            const int *words = nullptr;
+            int const q = wait_step_words(ctx, seqs[0], &words);
+            if (q != SMVS_OK && r == SMVS_OK)
+                r = q;
+            seqs[0] = seqs[1];
+            in_flight -= 1;
+            if (q != SMVS_OK)
+                break;
+        }
+        return r;
+    };
+    if ((rc = enqueue()) != SMVS_OK) {
+        (void)drain();
+        return rc;
+    }
+    for (;;) {
+        if (enqueued < prm->max_newton_steps && in_flight < 2)
+            if ((rc = enqueue()) != SMVS_OK) {
+                (void)drain();
+                return rc;
+            }
+        if (L.begin_seq != 0) {
+            // (published long before the first step ends)
+            if ((rc = read_loop_begin(ctx, L)) != SMVS_OK)
+                return rc;
+            if (!loop_goes_on(prm, L)) {
+                // no active node: the steps in flight report themselves skipped
+                L.ended = true;
+                return drain();
+            }
+        }
+        const int *words = nullptr;
+        if ((rc = wait_step_words(ctx, seqs[0], &words)) != SMVS_OK)
+            return rc;
+        seqs[0] = seqs[1];
+        in_flight -= 1;
+        if (words[5] == 1 + ABORT_SOLVER || words[5] == 1 + ABORT_GRID) {
+            // this step and the one behind it did nothing
+            bool const solver = words[5] == 1 + ABORT_SOLVER;
+            if ((rc = drain()) != SMVS_OK)
+                return rc;
+            SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_STOP, 0,
+                2 * sizeof(int), ctx->stream));
+            enqueued = L.newton_step;
+            if (solver) {
+                // its workgroups were not all resident: never try again on
+                // this context, the caller goes on with the streaming solver
+                SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0,
+                    cg_resident_exchange_bytes(), ctx->stream));
+                ctx->resident_disabled = true;
+                return SMVS_OK;
+            }
+            // the live list outgrew the launch: again, sized for the list
+            // length that has come back in the meantime
+            if ((rc = enqueue()) != SMVS_OK)
+                return rc;
+            continue;
+        }
+        if (words[5] != 0) {
+            set_error("smvs_gn_run_loop: a step was skipped before the loop ended");
+            (void)drain();
+            return SMVS_ERR_STATE;
+        }
+        ctx->last_cg_iterations = words[6];
+        account_step(prm, stats, L, words, words[6]);
+        if (!L.ended && !(L.num_active > L.num_initial / 20))
+            L.ended = true;
+        if (L.ended != (words[7] != 0)) {
+            set_error("smvs_gn_run_loop: host and device disagree on the end "
+                "of the loop");
+            (void)drain();
+            return SMVS_ERR_STATE;
+        }
+        if (L.ended || L.newton_step >= prm->max_newton_steps)
+            break;
+    }
+    // (a step enqueued behind the end reports itself skipped)
+    rc = drain();
+    L.ended = true;
+    return rc;
+}
+
 extern "C" int
 smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     smvs_gn_loop_stats *stats)
@@ -641,95 +1020,49 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     memset(stats, 0, sizeof(*stats));
     int rc;
-    if (prm->reset_active)
-        if ((rc = smvs_ctx_set_active(ctx, nullptr)) != SMVS_OK)
-            return rc;
     if (prm->use_lighting)
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->lighting, prm->lighting,
             16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 
-    int num_initial = 0;
-    if ((rc = smvs_get_active(ctx, nullptr, &num_initial)) != SMVS_OK)
-        return rc;
-    int num_active = num_initial;
-    int newton_step = 0;
-    int known_live = -1;   // length of the live-patch list once read back
-    // depth_optimizer.cc:219-220
-    while (newton_step < prm->max_newton_steps
-        && num_active > num_initial / 20) {
-        newton_step += 1;
-        // With the resident solver the assembly happens inside the solve
-        // (H, g and P never travel through HBM); if it cannot run -- or gives
-        // up because its workgroups were not all resident -- the assembly
-        // kernel and the streaming solver take over.
-        bool const fused = cg_resident_applies(ctx, prm->cg_max_iterations);
-        if ((rc = gn_construct_launch(ctx, prm->regularization,
-                prm->light_surf_regularization, prm->use_lighting != 0,
-                known_live, fused)) != SMVS_OK)
+    LoopState L;
+    if (prm->max_newton_steps == 0) {
+        // nothing to run: only the count of the active set is reported
+        int num_initial = 0;
+        if (prm->reset_active
+            && (rc = smvs_ctx_set_active(ctx, nullptr)) != SMVS_OK)
             return rc;
-        int iters = 0, info = 0;
-        bool solved = false;
-        if (fused && (rc = cg_resident_solve(ctx, prm->cg_max_iterations, -1.0,
-                prm->cg_q_tolerance, &iters, &info, &solved, true)) != SMVS_OK)
+        if ((rc = smvs_get_active(ctx, nullptr, &num_initial)) != SMVS_OK)
             return rc;
-        if (!solved) {
-            if (fused && (rc = gn_assemble_launch(ctx)) != SMVS_OK)
+        L.num_initial = L.num_active = num_initial;
+    } else {
+        // the start of the loop happens on the device (no round trip before
+        // the first step): active set, its size, the first live list
+        L.begin_seq = next_step_seq(ctx);
+        if ((rc = loop_begin_launch(ctx, prm->reset_active != 0, L.begin_seq))
+                != SMVS_OK)
+            return rc;
+    }
+    while (L.begin_seq != 0 || loop_goes_on(prm, L)) {
+        // With the resident solver the assembly happens inside the solve (H,
+        // g and P never travel through HBM) and the steps are enqueued ahead
+        // of their predecessors' results; if it cannot run -- or gives up
+        // because its workgroups were not all resident -- the assembly kernel
+        // and the streaming solver take over, one step at a time.
+        if (cg_resident_applies(ctx, prm->cg_max_iterations)) {
+            if ((rc = run_steps_pipelined(ctx, prm, stats, L)) != SMVS_OK)
                 return rc;
-            if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
-                    prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
-                return rc;
-        }
-        stats->linear_iterations += iters;
-        ctx->step_seq = (ctx->step_seq % 0x3FFFFFFF) + 1;
-        if ((rc = reactivate_launch(ctx, prm->active_threshold,
-                prm->full_optimization, true, known_live, ctx->step_seq)) != SMVS_OK)
-            return rc;
-        // the last workgroup of the step publishes its result words in pinned
-        // host memory; spin on them so that the next step's launches follow
-        // the end of this one within microseconds
-        {
-            volatile int *words = ctx->step_words;
-            auto const t_start = std::chrono::steady_clock::now();
-            long spins = 0;
-            while (__atomic_load_n(&words[0], __ATOMIC_ACQUIRE) != ctx->step_seq) {
-                __builtin_ia32_pause();
-                if ((++spins & 0xFFFF) == 0) {
-                    hipError_t const q = hipStreamQuery(ctx->stream);
-                    if (q != hipSuccess && q != hipErrorNotReady)
-                        SMVS_HIP_CHECK(q);
-                    if (q == hipSuccess && __atomic_load_n(&words[0],
-                            __ATOMIC_ACQUIRE) != ctx->step_seq) {
-                        set_error("smvs_gn_run_loop: the step ended without "
-                            "publishing its result");
-                        return SMVS_ERR_STATE;
-                    }
-                    if (std::chrono::steady_clock::now() - t_start
-                        > std::chrono::seconds(60)) {
-                        set_error("smvs_gn_run_loop: timed out waiting for the device");
-                        return SMVS_ERR_STATE;
-                    }
-                }
-            }
-        }
-        int const step_active = ctx->step_words[1];
-        int const step_nan = ctx->step_words[2];
-        stats->active_patch_steps += ctx->step_words[3];
-        known_live = ctx->step_words[4];
-        if (step_nan) {
-            stats->nan_break = 1;
-            break;
-        }
-        if (prm->full_optimization) {
-            // depth_optimizer.cc:277-288: sum_diff / size; with no
-            // reprojection term at all this is 0 / 0 = NaN, the comparison is
-            // false and the loop goes on to its step limit like the reference
-            double const update = ctx->scalars_host[0] / ctx->scalars_host[1];
-            if (update < prm->full_opt_threshold)
-                break;
             continue;
         }
-        num_active = step_active;
+        if (L.begin_seq != 0) {
+            if ((rc = read_loop_begin(ctx, L)) != SMVS_OK)
+                return rc;
+            continue;
+        }
+        if ((rc = run_step_streaming(ctx, prm, stats, L)) != SMVS_OK)
+            return rc;
     }
+    int const newton_step = L.newton_step;
+    int const num_active = L.num_active;
     stats->newton_steps = newton_step;
     stats->final_active_nodes = num_active;
     return SMVS_OK;

@@ -129,6 +129,14 @@ class ViewContext:
         assert nodes.shape[0] == self.num_nodes
         check(self.lib.smvs_set_nodes(self.handle, _p(nodes, _dp)))
 
+    def save_nodes(self):
+        """Keep a device-resident copy of the nodes (restore_nodes brings it
+        back without a transfer)."""
+        check(self.lib.smvs_ctx_save_nodes(self.handle))
+
+    def restore_nodes(self):
+        check(self.lib.smvs_ctx_restore_nodes(self.handle))
+
     # ------------------------------------------------------------ GN step
     def gn_construct(self, regularization, light_reg=0.0, lighting=None):
         lt = _f64(lighting) if lighting is not None else None
@@ -179,7 +187,8 @@ class ViewContext:
 
     def run_loop(self, regularization, light_reg=0.0, lighting=None,
                  full_optimization=False, max_newton_steps=200,
-                 cg_max_iterations=200, reset_active=True):
+                 cg_max_iterations=200, reset_active=True,
+                 active_threshold=0.15, full_opt_threshold=0.01):
         p = LoopParams()
         p.regularization = regularization
         p.light_surf_regularization = light_reg
@@ -187,8 +196,8 @@ class ViewContext:
         p.max_newton_steps = max_newton_steps
         p.cg_max_iterations = cg_max_iterations
         p.cg_q_tolerance = 1e-3
-        p.active_threshold = 0.15
-        p.full_opt_threshold = 0.01
+        p.active_threshold = active_threshold
+        p.full_opt_threshold = full_opt_threshold
         p.use_lighting = 1 if lighting is not None else 0
         if lighting is not None:
             for i in range(16):

@@ -666,3 +666,83 @@ def test_host_optimize_matches_oracle_960x540(hip, oracle):
     assert len(got["log"]) >= 8
     assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
     assert _rel(got["depth"], want["depth"]) <= 1e-4
+
+
+_LOOP_PROBE = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime, see conftest.py)
+sys.path.insert(0, sys.argv[1])
+import smvs_amd
+from smvs_amd import synth
+prob = synth.make_problem(256, 192, 4, 2, noise=0.01)
+ctx = smvs_amd.ViewContext(256, 192, 4)
+ctx.set_views(prob["views"])
+ctx.set_surface(prob["surf"])
+ctx.profile(True)
+stats = ctx.run_loop(0.01, max_newton_steps=6, active_threshold=0.002)
+launches = {k: int(v[1]) for k, v in ctx.profile_get().items()}
+np.save(sys.argv[2], ctx.get_nodes())
+print(json.dumps(dict(stats={k: int(v) for k, v in stats.items()}, launches=launches)))
+"""
+
+
+@pytest.mark.parametrize("mode", ["undersize", "solver"])
+def test_gn_loop_abandoned_steps_are_redone(hip, mode, tmp_path):
+    """The launch-ahead Newton loop abandons a step whose launches were sized
+    for a shorter live list (and re-enqueues it) or whose resident solver gave
+    up (and goes on with the streaming solver).  SMVS_LOOP_TEST forces either
+    case in a child process; the result has to be the one of the undisturbed
+    loop: bit for bit when only launches were redone, to 1e-9 when the other
+    solver (another summation order) finished the loop."""
+    import json, os, subprocess, sys
+    from smvs_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "nodes.npy")
+    env = dict(os.environ, SMVS_LOOP_TEST=mode)
+    res = subprocess.run([sys.executable, "-c", _LOOP_PROBE, root, out], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    reply = json.loads(res.stdout.strip().splitlines()[-1])
+    child, launches = reply["stats"], reply["launches"]
+    # the hook fired: launches were repeated / the streaming solver ran
+    if mode == "undersize":
+        assert launches["patch"] > child["newton_steps"] + 1
+    else:
+        assert launches["cg_spmv"] > 0 and 2 <= launches["cg_resident"] <= 3
+    prob = synth.make_problem(256, 192, 4, 2, noise=0.01)
+    ctx = hip.ViewContext(256, 192, 4)
+    ctx.set_views(prob["views"])
+    ctx.set_surface(prob["surf"])
+    stats = ctx.run_loop(0.01, max_newton_steps=6, active_threshold=0.002)
+    assert stats["newton_steps"] >= 4   # (long enough for the hooks to fire)
+    nodes = ctx.get_nodes()
+    ctx.close()
+    child_nodes = np.load(out)
+    for key in ("newton_steps", "active_patch_steps", "final_active_nodes", "nan_break"):
+        assert child[key] == int(stats[key]), key
+    if mode == "undersize":
+        assert child["linear_iterations"] == int(stats["linear_iterations"])
+        assert np.array_equal(child_nodes, nodes)
+    else:
+        assert _rel(child_nodes, nodes) <= 1e-9
+
+
+def test_save_and_restore_nodes(hip, oracle):
+    """smvs_ctx_save_nodes / smvs_ctx_restore_nodes: the saved start surface
+    comes back bit for bit after a Newton loop, a second loop from it repeats
+    the first one exactly, and restoring without a save is an error."""
+    prob, ctx, _ = _setup(hip, oracle, 192, 128, 3, 2, noise=0.01)
+    with pytest.raises(RuntimeError):
+        ctx.restore_nodes()
+    start = ctx.get_nodes()
+    ctx.save_nodes()
+    s1 = ctx.run_loop(0.01, max_newton_steps=4)
+    n1 = ctx.get_nodes()
+    assert not np.array_equal(n1, start)
+    ctx.restore_nodes()
+    assert np.array_equal(ctx.get_nodes(), start)
+    s2 = ctx.run_loop(0.01, max_newton_steps=4)
+    assert s1 == s2
+    assert np.array_equal(ctx.get_nodes(), n1)
+    ctx.close()
