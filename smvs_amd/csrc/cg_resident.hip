@@ -89,6 +89,7 @@ struct ResArgs {
     uint8_t *active_next;    // cleared for the node update of this step
     double *scalars;
     int npx, npy;
+    const double *zeros;     // 16 doubles of +0.0 (a block that does not contribute)
 };
 
 // GaussNewtonStep::construct's scatter (gauss_newton_step.cc:88-142) in gather
@@ -102,6 +103,13 @@ struct NodeSystem {
     double g[4];
 };
 
+// The loads below are unconditional: a block that does not contribute (patch
+// outside the grid / invalid, other node inactive) is read from a block of
+// zeros instead, so that all flag loads, then all block loads, are
+// independent and in flight together -- with a branch per block every one of
+// them cost a full memory latency, ~25 in a row at 2 waves per SIMD.  Adding
+// +0.0 in place of an omitted term leaves every sum bit-identical (the sums
+// start at +0.0 and can never be -0.0).
 __device__ __forceinline__ void
 assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
 {
@@ -116,29 +124,46 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         S.g[i] = 0.0;
-    if (!on || !A.active[iy * A.stride + ix])
+    if (!on)
         return;
+    int const n = iy * A.stride + ix;
+    int const rows = A.npy + 1;
+    // flags of the 3 x 3 nodes around (ix, iy) and of the four incident patches
+    bool act[3][3], pv[4];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            int const jx = ix + dx, jy = iy + dy;
+            bool const inside = jx >= 0 && jx < A.stride && jy >= 0 && jy < rows;
+            uint8_t const f = A.active[inside ? jy * A.stride + jx : n];
+            act[dy + 1][dx + 1] = inside && f != 0;
+        }
+    int pidx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int const pxq = ix - (1 - (q & 1));
         int const pyq = iy - (1 - (q >> 1));
+        bool const inside = pxq >= 0 && pxq < A.npx && pyq >= 0 && pyq < A.npy;
+        pidx[q] = inside ? pyq * A.npx + pxq : 0;
+        uint8_t const f = A.patch_valid[pidx[q]];
+        pv[q] = inside && f != 0;
+    }
+    if (!act[1][1])
+        return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         int const ln = 3 - q;   // local index of the node in that patch
-        if (pxq < 0 || pxq >= A.npx || pyq < 0 || pyq >= A.npy)
-            continue;
-        int const p = pyq * A.npx + pxq;
-        if (!A.patch_valid[p])
-            continue;
-        const double *Hl = A.Hp + (size_t)p * PATCH_H_STRIDE;
-        int const n00 = pyq * A.stride + pxq;
+        const double *Hl = A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE;
 #pragma unroll
         for (int lm = 0; lm < 4; ++lm) {
             if (lm < ln)
                 continue;
-            int const m = n00 + (lm & 1) + (lm >> 1) * A.stride;
-            if (!A.active[m])
-                continue;
+            // the other node, relative to this one
+            int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
+            bool const use = pv[q] && act[dy + 1][dx + 1];
             const double4_r *blk = reinterpret_cast<const double4_r *>(
-                Hl + upper_block(ln, lm) * 16);
+                use ? Hl + upper_block(ln, lm) * 16 : A.zeros);
             double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
             if (lm == ln) {
                 S.hd[0] += b0.x; S.hd[1] += b0.y; S.hd[2] += b0.z; S.hd[3] += b0.w;
@@ -146,7 +171,6 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
                 S.hd[7] += b2.z; S.hd[8] += b2.w;
                 S.hd[9] += b3.w;
             } else {
-                int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
                 int const k = (dy + 1) * 3 + dx + 1 - 5;
                 S.hu[k][0] += b0.x; S.hu[k][1] += b0.y; S.hu[k][2] += b0.z; S.hu[k][3] += b0.w;
                 S.hu[k][4] += b1.x; S.hu[k][5] += b1.y; S.hu[k][6] += b1.z; S.hu[k][7] += b1.w;
@@ -155,20 +179,22 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
             }
         }
         double4_r const gv = *reinterpret_cast<const double4_r *>(
-            A.gp + (size_t)p * 16 + 4 * ln);
+            pv[q] ? A.gp + (size_t)pidx[q] * 16 + 4 * ln : A.zeros);
         S.g[0] += gv.x; S.g[1] += gv.y; S.g[2] += gv.z; S.g[3] += gv.w;
     }
 }
 
-// One stored block of another node: row node (mx, my), its upper slot 5..8.
+// One stored block of another node: row node (mx, my), its upper slot 5..8
+// (a compile-time constant at every call: the loops fold to the <= 2 patches
+// that hold both nodes).
 __device__ __forceinline__ void
 assemble_block(ResArgs const &A, int mx, int my, int slot, double *out16)
 {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         out16[i] = 0.0;
-    if (!A.active[my * A.stride + mx])
-        return;
+    int const mrow = my * A.stride + mx;
+    bool const act_row = A.active[mrow] != 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int const ln = 3 - q;
@@ -181,24 +207,91 @@ assemble_block(ResArgs const &A, int mx, int my, int slot, double *out16)
                 continue;
             int const pxq = mx - (1 - (q & 1));
             int const pyq = my - (1 - (q >> 1));
-            if (pxq < 0 || pxq >= A.npx || pyq < 0 || pyq >= A.npy)
-                continue;
-            int const p = pyq * A.npx + pxq;
-            if (!A.patch_valid[p])
-                continue;
-            int const m = pyq * A.stride + pxq + (lm & 1) + (lm >> 1) * A.stride;
-            if (!A.active[m])
-                continue;
-            const double *blk = A.Hp + (size_t)p * PATCH_H_STRIDE
-                + upper_block(ln, lm) * 16;
+            bool const inside = pxq >= 0 && pxq < A.npx && pyq >= 0 && pyq < A.npy;
+            int const p = inside ? pyq * A.npx + pxq : 0;
+            int const m = inside
+                ? pyq * A.stride + pxq + (lm & 1) + (lm >> 1) * A.stride : mrow;
+            uint8_t const fp = A.patch_valid[p];
+            uint8_t const fm = A.active[m];
+            bool const use = act_row && inside && fp != 0 && fm != 0;
+            const double4_r *blk = reinterpret_cast<const double4_r *>(use
+                ? A.Hp + (size_t)p * PATCH_H_STRIDE + upper_block(ln, lm) * 16
+                : A.zeros);
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                out16[i] += blk[i];
+            for (int i = 0; i < 4; ++i) {
+                double4_r const v = blk[i];
+                out16[4 * i + 0] += v.x; out16[4 * i + 1] += v.y;
+                out16[4 * i + 2] += v.z; out16[4 * i + 3] += v.w;
+            }
         }
     }
 }
 
+// A rim block for the tile's LDS: the stored block of row node (mx, my)
+// towards its neighbour of LOWER slot s seen from the tile node (i.e. the row
+// node's upper slot 8 - s), s chosen at run time so that one thread per rim
+// block can do the work.  The <= 2 patches holding both nodes, in ascending
+// patch id as in assemble_block:
+//   s = 0 (slot 8): q 3 (ln 0, lm 3)
+//   s = 1 (slot 7): q 2 (ln 1, lm 3), q 3 (ln 0, lm 2)
+//   s = 2 (slot 6): q 2 (ln 1, lm 2)
+//   s = 3 (slot 5): q 1 (ln 2, lm 3), q 3 (ln 0, lm 1)
+// Flags in one batch, the two blocks in one batch (a missing contribution is
+// read from the block of zeros).
+__device__ __forceinline__ void
+assemble_rim_block(ResArgs const &A, int mx, int my, int s, double *dst16)
+{
+    int const q[2] = { s == 0 ? 3 : (s == 3 ? 1 : 2), 3 };
+    int const ln[2] = { s == 0 ? 0 : (s == 3 ? 2 : 1), 0 };
+    int const lm[2] = { s == 2 ? 2 : 3, s == 1 ? 2 : 1 };
+    bool const two = s == 1 || s == 3;
+    int const mrow = my * A.stride + mx;
+    uint8_t const frow = A.active[mrow];
+    const double4_r *src[2];
+    uint8_t fp[2], fm[2];
+    bool inside[2];
+    int p[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        int const pxq = mx - (1 - (q[e] & 1));
+        int const pyq = my - (1 - (q[e] >> 1));
+        inside[e] = (e == 0 || two) && pxq >= 0 && pxq < A.npx && pyq >= 0
+            && pyq < A.npy;
+        p[e] = inside[e] ? pyq * A.npx + pxq : 0;
+        int const m = inside[e]
+            ? pyq * A.stride + pxq + (lm[e] & 1) + (lm[e] >> 1) * A.stride : mrow;
+        fp[e] = A.patch_valid[p[e]];
+        fm[e] = A.active[m];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        bool const use = frow != 0 && inside[e] && fp[e] != 0 && fm[e] != 0;
+        src[e] = reinterpret_cast<const double4_r *>(use
+            ? A.Hp + (size_t)p[e] * PATCH_H_STRIDE + upper_block(ln[e], lm[e]) * 16
+            : A.zeros);
+    }
+    double4_r v0[4], v1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v0[i] = src[0][i];
+        v1[i] = src[1][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // (0 + first) + second, as assemble_block
+        double4_r r;
+        r.x = (0.0 + v0[i].x) + v1[i].x;
+        r.y = (0.0 + v0[i].y) + v1[i].y;
+        r.z = (0.0 + v0[i].z) + v1[i].z;
+        r.w = (0.0 + v0[i].w) + v1[i].w;
+        reinterpret_cast<double4_r *>(dst16)[i] = r;
+    }
+}
+
 constexpr int TRACE_ITERS = 12, TRACE_POINTS = 8;
+// after the iteration rows: four prologue stamps of every workgroup
+constexpr int TRACE_BLOCK_BASE = (TRACE_ITERS + 1) * TRACE_POINTS;
+constexpr int TRACE_TOTAL = TRACE_BLOCK_BASE + 4 * RES_MAX_BLOCKS;
 
 __device__ __forceinline__ void
 st_agent(double *p, double v)
@@ -416,6 +509,8 @@ cg_resident_kernel(ResArgs A)
 
     if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
         A.trace[0] = (long long)__builtin_readcyclecounter();
+    if (A.trace != nullptr && tid == 0)
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 0] = (long long)__builtin_readcyclecounter();
     // ---- the matrix: five stored blocks in registers, the rim in LDS ----
     // (the diagonal block is symmetric, Q4: its upper triangle, 10 doubles)
     double hd[10];
@@ -488,6 +583,10 @@ cg_resident_kernel(ResArgs A)
             return 3 * tw + (s == 0 ? 0 : th) + ly;
         return 3 * tw + 2 * th + ly;
     };
+    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+        A.trace[2] = (long long)__builtin_readcyclecounter();   // own blocks in registers
+    if (A.trace != nullptr && tid == 0)
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 1] = (long long)__builtin_readcyclecounter();
     unsigned low = 0u, up = 0u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -501,11 +600,7 @@ cg_resident_kernel(ResArgs A)
                 // block (row m, col n) is stored at m under its upper slot 8 - s
                 double *dst = fb + (size_t)rim_index(s) * 16;
                 if (FUSED) {
-                    double blk[16];
-                    assemble_block(A, nx, ny, 8 - s, blk);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        dst[e] = blk[e];
+                    // (assembled below, one thread per rim block)
                 } else {
                     int const m = ny * A.stride + nx;
                     const double4_r *src = reinterpret_cast<const double4_r *>(
@@ -517,6 +612,38 @@ cg_resident_kernel(ResArgs A)
             }
         }
     }
+    if (FUSED) {
+        // The rim blocks, one thread each (with the tile node's own thread
+        // doing up to three of them one after the other this phase was a
+        // chain of ~8 memory latencies for a handful of threads).  The index
+        // decodes as rim_index encodes: top row, left column (two slots),
+        // right column.
+        for (int r = tid; r < 3 * tw + 3 * th; r += RES_THREADS) {
+            int rs, rlx, rly;
+            if (r < 3 * tw) {
+                rs = r / tw; rlx = r - rs * tw; rly = 0;
+            } else if (r < 3 * tw + th) {
+                rs = 0; rlx = 0; rly = r - 3 * tw;
+            } else if (r < 3 * tw + 2 * th) {
+                rs = 3; rlx = 0; rly = r - 3 * tw - th;
+            } else {
+                rs = 2; rlx = tw - 1; rly = r - 3 * tw - 2 * th;
+            }
+            int const dx = rs == 3 ? -1 : rs - 1, dy = rs == 3 ? 0 : -1;
+            int const ngx = tx * tw + rlx, ngy = ty * th + rly;   // the tile node
+            int const nx = ngx + dx, ny = ngy + dy;               // the row node
+            bool const tile_node = ngx < A.stride && ngy < A.rows;
+            bool const in_tile = rly + dy >= 0 && rlx + dx >= 0 && rlx + dx < tw;
+            // (the column entries with rly = 0 belong to the top row's indices)
+            bool const dup = r >= 3 * tw && r != 3 * tw + th && rly == 0;
+            if (tile_node && !in_tile && !dup && nx >= 0 && nx < A.stride && ny >= 0)
+                assemble_rim_block(A, nx, ny, rs, fb + (size_t)r * 16);
+        }
+    }
+    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+        A.trace[3] = (long long)__builtin_readcyclecounter();   // rim blocks in LDS
+    if (A.trace != nullptr && tid == 0)
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 2] = (long long)__builtin_readcyclecounter();
     // upper slots 5..8 <-> (dx, dy) = (1,0), (-1,1), (0,1), (1,1)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -603,6 +730,10 @@ cg_resident_kernel(ResArgs A)
             for (int k = 0; k < 4; ++k)
                 r[k] = z[k] = 0.0;
         }
+        if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+            A.trace[4] = (long long)__builtin_readcyclecounter();   // P, r, z done
+        if (A.trace != nullptr && tid == 0)
+            A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 3] = (long long)__builtin_readcyclecounter();
         alive = grid_allreduce<2>(A.ex, ztag, epoch++, nblocks, v0, red, flag);
         st.rr = v0[0];
         st.q0 = -0.0;
@@ -1017,6 +1148,7 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.scalars = ctx->scalars;
     A.npx = ctx->npx;
     A.npy = ctx->npy;
+    A.zeros = ctx->zero_block;
     A.trace = trace_dev;
     A.pipelined = pipelined ? (test_give_up ? 3 : 1) : 0;
     *solve_tag_out = A.solve_tag;
@@ -1062,7 +1194,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     // debug aid (tools/cg_trace.py): cycle stamps of workgroup 0
     static const char *trace_path = std::getenv("SMVS_CG_TRACE");
     long long *trace_dev = nullptr;
-    size_t const trace_n = (size_t)(TRACE_ITERS + 1) * TRACE_POINTS;
+    size_t const trace_n = (size_t)TRACE_TOTAL;
     if (trace_path != nullptr) {
         SMVS_HIP_CHECK(hipMalloc((void **)&trace_dev, trace_n * sizeof(long long)));
         SMVS_HIP_CHECK(hipMemsetAsync(trace_dev, 0, trace_n * sizeof(long long),
@@ -1111,6 +1243,10 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                     std::fprintf(f, "%lld ", tr[(size_t)k * TRACE_POINTS + q]);
                 std::fprintf(f, "\n");
             }
+            for (int b = 0; b < num_tiles; ++b)
+                std::fprintf(f, "block %d %lld %lld %lld %lld\n", b,
+                    tr[TRACE_BLOCK_BASE + 4 * b], tr[TRACE_BLOCK_BASE + 4 * b + 1],
+                    tr[TRACE_BLOCK_BASE + 4 * b + 2], tr[TRACE_BLOCK_BASE + 4 * b + 3]);
             std::fclose(f);
         }
     }

@@ -139,6 +139,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK
         || (rc = device_alloc(&ctx->partials, 4 * 1024)) != SMVS_OK
         || (rc = device_alloc(&ctx->step_counter, 2)) != SMVS_OK
+        || (rc = device_alloc(&ctx->zero_block, 16)) != SMVS_OK
         || (rc = device_alloc(reinterpret_cast<char **>(&ctx->cg_state), 256)) != SMVS_OK) {
         smvs_ctx_destroy(ctx);
         return rc;
@@ -157,6 +158,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
     (void)hipMemsetAsync(ctx->status, 0, sizeof(int) * I_NUM, ctx->stream);
     (void)hipMemsetAsync(ctx->step_counter, 0, sizeof(unsigned long long), ctx->stream);
+    (void)hipMemsetAsync(ctx->zero_block, 0, 16 * sizeof(double), ctx->stream);
     for (int i = 0; i < 8; ++i)
         ctx->cg_progress[i] = 0;
     for (int i = 0; i < STEP_SLOTS * STEP_SLOT_INTS; ++i)
@@ -181,7 +183,7 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
         ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list,
-        ctx->step_counter, ctx->nodes_saved };
+        ctx->step_counter, ctx->nodes_saved, ctx->zero_block };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);

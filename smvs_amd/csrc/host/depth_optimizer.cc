@@ -149,7 +149,8 @@ DepthOptimizer::dump_state(int iter, char const* tag) const
     for (std::size_t p = 0; p < np && p < subsurfaces.size(); ++p)
         vis[p] = subsurfaces[p];
     std::fwrite(hdr, sizeof(int), 3, f);
-    std::fwrite(surface->node_values().data(), sizeof(double), 4 * nn, f);
+    std::fwrite(static_cast<Surface const&>(*surface).node_values().data(),
+        sizeof(double), 4 * nn, f);
     std::fwrite(surface->node_validity().data(), 1, nn, f);
     std::fwrite(surface->patch_validity().data(), 1, np, f);
     std::fwrite(vis.data(), sizeof(uint32_t), np, f);
@@ -297,19 +298,34 @@ DepthOptimizer::download_scale_planes(void)
 void
 DepthOptimizer::upload_surface(void)
 {
-    check(smvs_ctx_set_surface(ctx, surface->get_scale(),
-        surface->get_num_patches_x(), surface->get_num_patches_y(),
-        surface->get_pixel_start_x(), surface->get_pixel_start_y(),
-        surface->node_values().data(), surface->node_validity().data(),
-        surface->patch_validity().data(), subsurfaces.data()),
+    // Nothing to do when the device already holds exactly this surface (the
+    // same object at the same revision with the same visibility masks): the
+    // Newton loop's result is downloaded into the host surface, so the
+    // cut_boundaries / get_depth / get_normals that follow it find the
+    // device copy current.
+    Surface const& s = *surface;
+    if (uploaded_surface == surface.get() && uploaded_rev == s.revision()
+        && uploaded_subs_rev == subs_rev)
+        return;
+    check(smvs_ctx_set_surface(ctx, s.get_scale(),
+        s.get_num_patches_x(), s.get_num_patches_y(),
+        s.get_pixel_start_x(), s.get_pixel_start_y(),
+        s.node_values().data(), s.node_validity().data(),
+        s.patch_validity().data(), subsurfaces.data()),
         "smvs_ctx_set_surface");
+    uploaded_surface = surface.get();
+    uploaded_rev = s.revision();
+    uploaded_subs_rev = subs_rev;
 }
 
 void
 DepthOptimizer::fit_lighting(void)
 {
     // LightOptimizer::fit_lighting_to_image, lib/light_optimizer.cc:22-55
-    subsurfaces.resize(surface->get_num_patches(), 0);
+    if (subsurfaces.size() != (std::size_t)surface->get_num_patches()) {
+        subsurfaces.resize(surface->get_num_patches(), 0);
+        subs_rev += 1;
+    }
     upload_surface();
     double A[256], b[16];
     check(smvs_light_accumulate(ctx, A, b), "smvs_light_accumulate");
@@ -414,6 +430,9 @@ DepthOptimizer::run_newton_iterations(int num_iters)
             check(smvs_gn_run_loop(ctx, &prm, &stats), "smvs_gn_run_loop");
             check(smvs_get_nodes(ctx, surface->node_values().data()),
                 "smvs_get_nodes");
+            // host and device nodes are the same again
+            if (uploaded_surface == surface.get())
+                uploaded_rev = surface->revision();
         }
         log.push_back({ surface->get_scale(), iter, stats.newton_steps,
             num_valid_patches, stats.linear_iterations });
@@ -484,10 +503,12 @@ DepthOptimizer::create_subview_surfaces(void)
     // (smvs_topology_subviews); deleting the patches nobody sees stays here.
     std::size_t const num_patches = surface->get_num_patches();
     subsurfaces.assign(num_patches, 0);
+    subs_rev += 1;
     this->upload_surface();
     check(smvs_topology_subviews(ctx,
         opts.use_sgm ? sgm_depth->begin() : nullptr, opts.use_sgm ? 0 : 1,
         subsurfaces.data()), "smvs_topology_subviews");
+    subs_rev += 1;   // (the device still holds the masks that were uploaded)
 
     std::size_t removed = 0;
     for (std::size_t p = 0; p < num_patches; ++p)

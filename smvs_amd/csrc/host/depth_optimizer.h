@@ -93,6 +93,9 @@ private:
     FloatImage::ConstPtr sgm_depth;
     Surface::Ptr surface;
     std::vector<uint32_t> subsurfaces;   // bit j: neighbour j sees the patch
+    // what the device context holds (upload_surface skips a repeat)
+    Surface const* uploaded_surface = nullptr;
+    unsigned long uploaded_rev = 0, uploaded_subs_rev = 0, subs_rev = 1;
     bool lit = false;
     bool images_uploaded = false;
     double lighting[16];

@@ -4,10 +4,18 @@
 #include "surface.h"
 #include "topo_math.h"
 
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 
 namespace smvs_amd {
+
+unsigned long
+Surface::next_revision(void)
+{
+    static std::atomic<unsigned long> counter{ 0 };
+    return ++counter;
+}
 
 
 PatchEval::PatchEval(double const* nodes16)
@@ -139,6 +147,7 @@ Surface::patch_origin(std::size_t patch_id, int* px, int* py) const
 int
 Surface::fill_holes(void)
 {
+    touch();
     // lib/surface.cc:630-651
     int filled = 0;
     for (int x = 0; x < npx; ++x)
@@ -157,6 +166,7 @@ Surface::fill_holes(void)
 void
 Surface::remove_nodes_without_patch(void)
 {
+    touch();
     // lib/surface.cc:762-869: a node lives while one incident patch lives
     int const stride = npx + 1;
     for (std::size_t i = 0; i < node_valid.size(); ++i) {
@@ -172,6 +182,7 @@ Surface::remove_nodes_without_patch(void)
 void
 Surface::remove_isolated_patches(void)
 {
+    touch();
     // lib/surface.cc:887-927
     for (int x = 0; x < npx; ++x)
         for (int y = 0; y < npy; ++y) {
@@ -191,6 +202,7 @@ Surface::remove_isolated_patches(void)
 void
 Surface::initialize_node_from_depth(int idx, int idy)
 {
+    touch();
     // lib/surface.cc:667-760
     int const stride = npx + 1;
     std::size_t const id = (size_t)idy * stride + idx;
@@ -245,6 +257,7 @@ Surface::initialize_node_from_depth(int idx, int idy)
 void
 Surface::fill_patches_from_depth(void)
 {
+    touch();
     // lib/surface.cc:140-152
     for (int i = 0; i < npx + 1; ++i)
         for (int j = 0; j < npy + 1; ++j)
@@ -307,6 +320,7 @@ Surface::get_normal_map(float inv_flen) const
 void
 Surface::update_nodes(std::vector<double> const& delta)
 {
+    touch();
     // lib/surface.cc:957-981
     for (std::size_t i = 0; i < node_valid.size(); ++i) {
         if (!node_valid[i])
@@ -319,6 +333,7 @@ Surface::update_nodes(std::vector<double> const& delta)
 void
 Surface::subdivide_patches(void)
 {
+    touch();
     // lib/surface.cc:983-1107
     int const old_npx = npx, old_npy = npy, old_stride = npx + 1;
     scale -= 1;
@@ -388,6 +403,7 @@ Surface::subdivide_patches(void)
 int
 Surface::expand(void)
 {
+    touch();
     // lib/surface.cc:482-628: two rounds of extrapolating new nodes from
     // complete triples of neighbours; a later candidate replaces an earlier
     // one only when it is more than 1/0.9 deeper (check_swap_nodes :472-480)

@@ -66,12 +66,17 @@ public:
     bool node_exists(int idx, int idy) const;
     bool patch_exists(int idx, int idy) const;
 
-    void delete_patch(std::size_t patch_id) { patch_valid[patch_id] = 0; }
+    void delete_patch(std::size_t patch_id) { patch_valid[patch_id] = 0; touch(); }
     void remove_isolated_patches(void);
     void remove_nodes_without_patch(void);
 
+    // Counts the changes to nodes / validity: every mutating operation bumps
+    // it (handing out the writable node array counts as one), so the device
+    // mirror knows when its copy is stale (host/depth_optimizer.cc).
+    unsigned long revision(void) const { return rev; }
+
     // raw arrays (what the device context consumes)
-    std::vector<double>& node_values(void) { return nodes; }
+    std::vector<double>& node_values(void) { touch(); return nodes; }
     std::vector<double> const& node_values(void) const { return nodes; }
     std::vector<uint8_t> const& node_validity(void) const { return node_valid; }
     std::vector<uint8_t> const& patch_validity(void) const { return patch_valid; }
@@ -90,6 +95,11 @@ private:
     std::vector<double> nodes;        // 4 per node
     std::vector<uint8_t> node_valid;
     std::vector<uint8_t> patch_valid;
+    // (unique over all surfaces of the process: a new surface at a recycled
+    // address never looks like the one the device holds)
+    void touch(void) { rev = next_revision(); }
+    static unsigned long next_revision(void);
+    unsigned long rev = next_revision();
 };
 
 } // namespace smvs_amd

@@ -825,21 +825,50 @@ next_step_seq(smvs_ctx *ctx)
     return ctx->step_seq;
 }
 
-// One Newton step with the assembly kernel and the streaming solver; the host
-// waits for its result before it launches the next one.
+// SMVS_LOOP_TEST (tests/test_gpu_parity.py, tools/cg_trace.py): "undersize"
+// sizes every launch-ahead step for half the list, "solver" makes the second
+// solve of a loop report that it gave up, "unpipelined" runs the fused steps
+// one at a time (the host waits for each solve: what SMVS_CG_TRACE needs).
+static int
+loop_test_mode(void)
+{
+    static int const mode = [] {
+        const char *e = std::getenv("SMVS_LOOP_TEST");
+        if (e == nullptr)
+            return 0;
+        return std::strcmp(e, "undersize") == 0 ? 1
+            : std::strcmp(e, "solver") == 0 ? 2
+            : std::strcmp(e, "unpipelined") == 0 ? 3 : 0;
+    }();
+    return mode;
+}
+
+// One Newton step, the host waits for its result before it launches the next
+// one: with the assembly kernel and the streaming solver, or (test mode
+// "unpipelined") with the fused resident solver.
 static int
 run_step_streaming(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     smvs_gn_loop_stats *stats, LoopState &L)
 {
     int rc;
+    bool const fused = loop_test_mode() == 3
+        && cg_resident_applies(ctx, prm->cg_max_iterations);
     if ((rc = gn_construct_launch(ctx, prm->regularization,
             prm->light_surf_regularization, prm->use_lighting != 0,
-            L.known_live, false)) != SMVS_OK)
+            L.known_live, fused)) != SMVS_OK)
         return rc;
     int iters = 0, info = 0;
-    if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
-            prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
+    bool solved = false;
+    if (fused && (rc = cg_resident_solve(ctx, prm->cg_max_iterations, -1.0,
+            prm->cg_q_tolerance, &iters, &info, &solved, true)) != SMVS_OK)
         return rc;
+    if (!solved) {
+        if (fused && (rc = gn_assemble_launch(ctx)) != SMVS_OK)
+            return rc;
+        if ((rc = cg_solve_launch(ctx, prm->cg_max_iterations, -1.0,
+                prm->cg_q_tolerance, &iters, &info)) != SMVS_OK)
+            return rc;
+    }
     int const seq = next_step_seq(ctx);
     if ((rc = reactivate_launch(ctx, prm->active_threshold,
             prm->full_optimization, true, L.known_live, seq)) != SMVS_OK)
@@ -866,13 +895,7 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     // barrier kernels of two loops must not interleave on one device
     std::lock_guard<std::mutex> guard(cg_resident_mutex(ctx->device));
     static_assert(I_STEP_ABORT == I_STOP + 1, "cleared together");
-    static int const test_mode = [] {
-        const char *e = std::getenv("SMVS_LOOP_TEST");
-        if (e == nullptr)
-            return 0;
-        return std::strcmp(e, "undersize") == 0 ? 1
-            : (std::strcmp(e, "solver") == 0 ? 2 : 0);
-    }();
+    int const test_mode = loop_test_mode();
     int rc;
     int seqs[2] = { 0, 0 };      // tags of the steps in flight, oldest first
     int in_flight = 0;
@@ -889,9 +912,7 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         long long want = ctx->num_patches;
         if (L.known_live >= 0 && L.known_live + L.known_live / 16 + 64 < want)
             want = L.known_live + L.known_live / 16 + 64;
-        // test hooks (tests/test_gpu_parity.py): SMVS_LOOP_TEST=undersize
-        // sizes every launch-ahead step for half the list, =solver makes the
-        // second solve of a loop report that it gave up
+        // (test hooks, see loop_test_mode)
         if (test_mode == 1 && in_flight >= 1 && L.known_live >= 0)
             want = L.known_live / 2;
         P.grid_live = (int)((want + 31) / 32 * 32);
@@ -1048,7 +1069,8 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         // of their predecessors' results; if it cannot run -- or gives up
         // because its workgroups were not all resident -- the assembly kernel
         // and the streaming solver take over, one step at a time.
-        if (cg_resident_applies(ctx, prm->cg_max_iterations)) {
+        if (loop_test_mode() != 3
+            && cg_resident_applies(ctx, prm->cg_max_iterations)) {
             if ((rc = run_steps_pipelined(ctx, prm, stats, L)) != SMVS_OK)
                 return rc;
             continue;
