@@ -274,18 +274,54 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
                             FP64_PEAK_TFLOPS),
                peaks_assumed=dict(hbm_GBps=HBM_PEAK_GBPS, fp64_TFLOPs=FP64_PEAK_TFLOPS),
                peaks_measured=measured_peaks() if with_peaks else None)
-    if name == "cg_resident":
-        # one launch per solve; the matrix is read once and stays in registers:
-        # algorithmic HBM bytes = H upper half + P + g + b + x per node
-        bytes_per_launch = (5 * 128 + 128 + 32 + 32 + 32) * n_nodes
-        avg_s = ms * 1e-3 / max(cnt, 1)
+    def cg_resident_line():
+        # One launch per solve.  Inside the Newton loop the kernel assembles H,
+        # g, P itself from the per-patch systems (1,280 + 128 B per live patch,
+        # read once) and writes x and b; through smvs_cg_solve it reads the
+        # assembled upper half of H, P and g instead.  Either way the matrix
+        # then stays in registers.
+        ms_k, cnt_k = prof["cg_resident"]
+        fused = prof["assemble"][1] == 0
+        if fused:
+            bytes_per_launch = (1280 + 128) * patch_steps / max(cnt_k, 1) + 64 * n_nodes
+        else:
+            bytes_per_launch = (5 * 128 + 128 + 32 + 32 + 32) * n_nodes
+        avg_s = ms_k * 1e-3 / max(cnt_k, 1)
         achieved = bytes_per_launch / avg_s / 1e9
-        out.update(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
-                   unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                   bytes_per_launch=bytes_per_launch, avg_us=round(avg_s * 1e6, 2),
-                   note="whole PCG solve in one launch (%.1f iterations on average): "
-                        "after the one pass over H the kernel is bound by its two grid "
-                        "barriers per iteration, not by HBM" % (cg_its / max(cnt, 1)))
+        return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                    bytes_per_launch=int(bytes_per_launch), avg_us=round(avg_s * 1e6, 2),
+                    note="whole PCG solve in one launch (%.1f iterations on average, "
+                         "system assembled in the kernel: %s): after the one pass over "
+                         "its input the kernel is bound by the latency of its two "
+                         "grid-wide exchanges per iteration (~15 us per iteration), "
+                         "not by HBM" % (cg_its / max(cnt_k, 1), "yes" if fused else "no"))
+
+    def patch_line():
+        # gn_patch_kernel: FP64 arithmetic.  The vector FMA and v_mfma_f64 share
+        # one pipe on gfx950 (tools/peaks.py), so the bound is FP64 issue, and
+        # `frac` = executed FP64 flops / peak is a pipe UTILISATION (every
+        # executed instruction counts as useful): an upper bound on the useful
+        # fraction.
+        ms_k, cnt_k = prof["patch"]
+        flops = FLOP_PER_PATCH * patch_steps / max(cnt_k, 1)
+        avg_s = ms_k * 1e-3 / max(cnt_k, 1)
+        achieved = flops / avg_s / 1e12
+        return dict(bound="fp64-issue", achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / FP64_PEAK_TFLOPS, 4),
+                    fp64_util=round(achieved / FP64_PEAK_TFLOPS, 4),
+                    flops_per_launch=flops, avg_us=round(avg_s * 1e6, 2))
+
+    # the two kernels that share a Newton step about evenly are both described;
+    # the top-level fields are those of the one with the larger share
+    lines = {}
+    if prof["patch"][1] > 0:
+        lines["patch"] = patch_line()
+    if prof.get("cg_resident", (0, 0))[1] > 0:
+        lines["cg_resident"] = cg_resident_line()
+    out["per_kernel"] = lines
+    if name in lines:
+        out.update(lines[name])
     elif name in CG_BYTES:
         # launches after convergence are no-ops: their time stays in the
         # numerator, the denominator counts the launches that did work
@@ -297,19 +333,6 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                    bytes_per_launch=bytes_per_launch, avg_us=round(avg_s * 1e6, 2),
                    launches_with_work=work)
-    else:
-        # gn_patch_kernel: FP64 arithmetic.  The vector FMA and v_mfma_f64 share
-        # one pipe on gfx950 (tools/peaks.py), so the bound is FP64 issue, and
-        # `frac` = executed FP64 flops / peak is a pipe UTILISATION (every
-        # executed instruction counts as useful): an upper bound on the useful
-        # fraction.
-        flops = FLOP_PER_PATCH * patch_steps / max(cnt, 1)
-        avg_s = ms * 1e-3 / max(cnt, 1)
-        achieved = flops / avg_s / 1e12
-        out.update(bound="fp64-issue", achieved=round(achieved, 3), peak=FP64_PEAK_TFLOPS,
-                   unit="TFLOP/s", frac=round(achieved / FP64_PEAK_TFLOPS, 4),
-                   fp64_util=round(achieved / FP64_PEAK_TFLOPS, 4),
-                   flops_per_launch=flops, avg_us=round(avg_s * 1e6, 2))
     out["cg_iterations"] = cg_its
     out["cg_launch_pairs"] = int(prof["cg_spmv"][1])
     out["cg_resident_solves"] = int(prof.get("cg_resident", (0, 0))[1])

@@ -78,7 +78,7 @@ struct ResArgs {
     int tw, th, tiles_x, num_tiles;
     int max_iterations;
     double q_tolerance, fixed_tolerance;
-    long long *trace;        // debug: cycle stamps of workgroup 0 (or nullptr)
+    long long *trace;        // debug: 100 MHz wall-clock stamps (or nullptr)
     int pipelined;           // bit 0: launch-ahead Newton loop (update.hip), bit 1:
                              // report a failure (test hook)
     // fused assembly (the Newton loop): per-patch systems instead of H / g / P
@@ -508,9 +508,9 @@ cg_resident_kernel(ResArgs A)
     int const lhalo = hy * LW + hx;
 
     if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
-        A.trace[0] = (long long)__builtin_readcyclecounter();
+        A.trace[0] = (long long)wall_clock64();
     if (A.trace != nullptr && tid == 0)
-        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 0] = (long long)__builtin_readcyclecounter();
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 0] = (long long)wall_clock64();
     // ---- the matrix: five stored blocks in registers, the rim in LDS ----
     // (the diagonal block is symmetric, Q4: its upper triangle, 10 doubles)
     double hd[10];
@@ -584,9 +584,9 @@ cg_resident_kernel(ResArgs A)
         return 3 * tw + 2 * th + ly;
     };
     if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
-        A.trace[2] = (long long)__builtin_readcyclecounter();   // own blocks in registers
+        A.trace[2] = (long long)wall_clock64();   // own blocks in registers
     if (A.trace != nullptr && tid == 0)
-        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 1] = (long long)__builtin_readcyclecounter();
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 1] = (long long)wall_clock64();
     unsigned low = 0u, up = 0u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -641,9 +641,9 @@ cg_resident_kernel(ResArgs A)
         }
     }
     if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
-        A.trace[3] = (long long)__builtin_readcyclecounter();   // rim blocks in LDS
+        A.trace[3] = (long long)wall_clock64();   // rim blocks in LDS
     if (A.trace != nullptr && tid == 0)
-        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 2] = (long long)__builtin_readcyclecounter();
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 2] = (long long)wall_clock64();
     // upper slots 5..8 <-> (dx, dy) = (1,0), (-1,1), (0,1), (1,1)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -731,9 +731,9 @@ cg_resident_kernel(ResArgs A)
                 r[k] = z[k] = 0.0;
         }
         if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
-            A.trace[4] = (long long)__builtin_readcyclecounter();   // P, r, z done
+            A.trace[4] = (long long)wall_clock64();   // P, r, z done
         if (A.trace != nullptr && tid == 0)
-            A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 3] = (long long)__builtin_readcyclecounter();
+            A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 3] = (long long)wall_clock64();
         alive = grid_allreduce<2>(A.ex, ztag, epoch++, nblocks, v0, red, flag);
         st.rr = v0[0];
         st.q0 = -0.0;
@@ -747,7 +747,7 @@ cg_resident_kernel(ResArgs A)
 
     auto stamp = [&](int k, int point) {
         if (A.trace != nullptr && blockIdx.x == 0 && tid == 0 && k <= TRACE_ITERS)
-            A.trace[k * TRACE_POINTS + point] = (long long)__builtin_readcyclecounter();
+            A.trace[k * TRACE_POINTS + point] = (long long)wall_clock64();
     };
     stamp(0, 1);
     // ---- iterations (conjugate_gradient.h:123-198) ----

@@ -150,6 +150,7 @@ struct smvs_ctx {
                                     // finish_step_kernel (update.hip)
     unsigned long long *step_counter = nullptr;   // device, its packed counters
     double *zero_block = nullptr;   // 16 doubles of +0.0 (cg_resident.hip)
+    int last_loop_steps = 1 << 30;  // Newton steps of the previous smvs_gn_run_loop (launch-ahead heuristic)
     double *nodes_saved = nullptr;  // smvs_ctx_save_nodes
     size_t nodes_saved_cap = 0;
     int nodes_saved_count = 0, nodes_saved_stride = 0;

@@ -952,8 +952,26 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         (void)drain();
         return rc;
     }
+    // A step enqueued behind the end of the loop costs four empty launches
+    // (~20 us); a step that was not enqueued ahead costs the host's turn-around
+    // (~25 us) once its predecessor has ended.  So the next step is enqueued
+    // ahead only while the loop is likely to go on: the active set (one step
+    // old) is still well above the level at which the loop stops, the mean
+    // shift of full optimisation well above its threshold, and -- before the
+    // first result -- the previous loop on this context ran that far.
+    double last_update = -1.0;   // full optimisation: mean shift of the newest step
+    auto likely_to_go_on = [&]() -> bool {
+        if (test_mode == 1)
+            return true;
+        if (L.newton_step == 0)
+            return ctx->last_loop_steps > enqueued;
+        if (prm->full_optimization)
+            return !(last_update < 4.0 * prm->full_opt_threshold);
+        return L.num_active / 4 > L.num_initial / 20;
+    };
     for (;;) {
-        if (enqueued < prm->max_newton_steps && in_flight < 2)
+        if (enqueued < prm->max_newton_steps
+            && (in_flight == 0 || (in_flight < 2 && likely_to_go_on())))
             if ((rc = enqueue()) != SMVS_OK) {
                 (void)drain();
                 return rc;
@@ -1002,6 +1020,10 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         }
         ctx->last_cg_iterations = words[6];
         account_step(prm, stats, L, words, words[6]);
+        if (prm->full_optimization) {
+            const double *sc = reinterpret_cast<const double *>(words + 8);
+            last_update = sc[0] / sc[1];
+        }
         if (!L.ended && !(L.num_active > L.num_initial / 20))
             L.ended = true;
         if (L.ended != (words[7] != 0)) {
@@ -1016,6 +1038,7 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     // (a step enqueued behind the end reports itself skipped)
     rc = drain();
     L.ended = true;
+    ctx->last_loop_steps = L.newton_step;
     return rc;
 }
 

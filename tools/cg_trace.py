@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where an iteration of the resident PCG spends its time: cycle stamps of
-workgroup 0 (SMVS_CG_TRACE) on the first Newton step of the bench workload."""
+"""Where the resident PCG spends a solve: 100 MHz wall-clock stamps (SMVS_CG_TRACE) of
+workgroup 0 per iteration and of every workgroup in the prologue, on the three Newton
+steps of a batch of the bench workload (SMVS_LOOP_TEST=unpipelined: the host waits
+for each solve)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/cg_trace.txt"
@@ -23,13 +25,16 @@ for block in open(path).read().split("solve")[1:]:
                       dtype=np.int64)
     lines = [l for l in lines if not l.startswith("block")]
     if len(blocks):
-        t00 = blocks[:, 1].min()
-        rel = (blocks[:, 1:] - t00) / 100.0
-        print("  prologue over the %d workgroups (units of this tool, relative to the first start):" % len(blocks))
+        # (wall_clock64: one 100 MHz counter for the whole device)
+        rel = (blocks[:, 1:] - blocks[:, 1].min()) / 100.0
+        print("  prologue over the %d workgroups, us after the first workgroup started:" % len(blocks))
         for name, col in (("start", 0), ("own blocks done", 1), ("rim blocks done", 2), ("before all-reduce", 3)):
             v = rel[:, col]
-            print("    %-18s min %8.2f  median %8.2f  max %8.2f  (workgroup %d)"
+            print("    %-18s min %7.2f  median %7.2f  max %7.2f  (workgroup %d)"
                   % (name, v.min(), np.median(v), v.max(), int(blocks[np.argmax(v), 0])))
+        own = (blocks[:, 4] - blocks[:, 1]) / 100.0
+        print("    a workgroup's own prologue (start -> before all-reduce): median %.2f, max %.2f us"
+              % (np.median(own), own.max()))
     print("solve", lines[0])
     rows = np.array([[int(x) for x in l.split()] for l in lines[1:]], dtype=np.int64)
     t0 = rows[0, 0]

@@ -12,6 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- $CMD > "$OUT/write.log" 2>&1
 ls -R "$OUT" | head -30
+# per-step timeline of the Newton loop (kernel durations and the gaps between them)
+python $ROOT/tools/step_timeline.py $(find "$OUT/stats" -name "*kernel_trace.csv" | head -1) > "$OUT/step_timeline.txt" 2>&1
+# where the resident solver spends a solve (cycle stamps; the host waits for each solve)
+python $ROOT/tools/cg_trace.py "$OUT/cg_trace_raw.txt" > "$OUT/cg_trace.txt" 2>&1
 python $ROOT/tools/summarise_profiles.py "$OUT" "$OUT/summary" "${1:-r2}"
 # the whole pipeline of one reference view (SGM front end, bilateral upsample,
 # scale space, topology kernels, Newton loops) and the depth-map cut

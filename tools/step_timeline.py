@@ -18,23 +18,36 @@ while i + 3 < len(rows):
             and names[2] == "reactivate_kernel" and names[3] == "finish_step_kernel"):
         # (a step enqueued behind the end of its loop does nothing: leave it out)
         if rows[i + 1][1] - rows[i + 1][0] > 20000:
-            steps.append(rows[i:i + 4])
+            steps.append(rows[i:i + 4] + [i])
         i += 4
     else:
         i += 1
 print("fused steps found:", len(steps))
 dur = collections.defaultdict(list)
 gap = collections.defaultdict(list)
+index = [st[4] for st in steps]
+steps = [st[:4] for st in steps]
+loops = 1
 for k, st in enumerate(steps):
     for s, e, n in st:
         dur[n].append(e - s)
     for a, b in zip(st, st[1:]):
         gap[a[2] + " -> " + b[2]].append(b[0] - a[1])
-    if k + 1 < len(steps) and steps[k + 1][0][0] - st[-1][1] < 200000:
-        gap["finish_step_kernel -> next patch (host turn-around)"].append(steps[k + 1][0][0] - st[-1][1])
+    if k + 1 < len(steps):
+        if index[k + 1] == index[k] + 4:
+            # the next step of the same loop (nothing launched in between)
+            gap["finish_step_kernel -> next step of the loop"].append(steps[k + 1][0][0] - st[-1][1])
+        else:
+            loops += 1
+            if steps[k + 1][0][0] - st[-1][1] < 500000:
+                gap["end of a loop -> first patch kernel of the next (restore, loop begin, skipped step)"].append(
+                    steps[k + 1][0][0] - st[-1][1])
 tot = 0.0
+print("loops: %d (%.2f steps per loop)" % (loops, len(steps) / max(loops, 1)))
 for n, d in dur.items():
     print("%-28s n=%4d mean %8.2f us" % (n, len(d), sum(d) / len(d) / 1e3)); tot += sum(d) / len(d)
 for n, g in gap.items():
-    print("%-60s n=%4d mean %7.2f us" % (n, len(g), sum(g) / len(g) / 1e3)); tot += sum(g) / len(g)
-print("sum of the means: %.1f us per step" % (tot / 1e3))
+    print("%-60s n=%4d mean %7.2f us" % (n, len(g), sum(g) / len(g) / 1e3))
+    if not n.startswith("end of a loop"):
+        tot += sum(g) / len(g)
+print("sum of the in-loop means: %.1f us per step" % (tot / 1e3))

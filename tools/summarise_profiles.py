@@ -19,7 +19,8 @@ SHORT = [("gn_patch_kernel", "patch"), ("gn_assemble_kernel", "assemble"),
          ("cg_resident_kernel", "cg_resident"), ("live_patch_list_kernel", "live_patch_list"),
          ("cg_spmv_kernel", "cg_spmv"), ("cg_update_kernel", "cg_update"),
          ("cg_init_kernel", "cg_init"), ("reactivate_kernel", "reactivate"),
-         ("apply_update_kernel", "apply_update"), ("prepare_update_kernel", "prepare_update")]
+         ("apply_update_kernel", "apply_update"), ("prepare_update_kernel", "prepare_update"),
+         ("finish_step_kernel", "finish_step")]
 
 
 def short(name):
