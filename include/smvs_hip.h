@@ -167,8 +167,13 @@ int smvs_update_and_reactivate(smvs_ctx *ctx, double threshold,
     int full_optimization, int *num_active, double *mean_delta,
     int *nan_flag);
 
-/* The whole Newton loop of one outer iteration, depth_optimizer.cc:204-304,
- * without host round trips inside a step. */
+/* The whole Newton loop of one outer iteration, depth_optimizer.cc:204-304:
+ * four launches per step, no host round trip inside a step, and the next step
+ * is enqueued before the previous one has ended (the loop condition of
+ * :219-220 / :267-268 / :284-288 is evaluated on the device).
+ * The call returns when the loop has ended and the stream is idle.  Between
+ * the call's steps nothing is materialised for smvs_gn_download (H, g, P live
+ * in registers); smvs_cg_download_x holds the last step's delta. */
 typedef struct {
     double regularization;             /* DepthOptimizer::Options */
     double light_surf_regularization;
