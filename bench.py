@@ -54,7 +54,7 @@ FP64_PEAK_TFLOPS = 78.6
 #    profiles/r2_patch_kernel_counters.txt);
 #    SURVEY.md 8(d) prices the reference's unfactored rows at 0.50 MFLOP
 #  * per node and CG iteration, bytes of the upper-half block stencil + vectors
-FLOP_PER_PATCH = 0.126e6
+FLOP_PER_PATCH = 0.114e6
 FLOP_PER_PATCH_SURVEY = 0.50e6
 BYTES_PER_PATCH = 4.2e3
 CG_BYTES = {"cg_spmv": 5 * 128 + 2 * 32 + 2 * 32,      # H upper half; z, d_old; Ad, d_new

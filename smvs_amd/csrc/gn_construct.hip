@@ -705,10 +705,20 @@ gn_patch_kernel(PatchKernelArgs A)
 
     // phase 2 roles
     int const kg = lane >> 4, col = lane & 15;
-    int ex, ey;
-    col_functions(col, &ex, &ey);
+    // Only the 10 node blocks (bi <= bj) of the symmetric 16 x 16 system are
+    // needed: three v_mfma_f64_4x4x4 (four independent 4 x 4 blocks each)
+    // instead of one 16x16x4 (all 16 blocks).  Lane (kg, col) feeds pixel kg,
+    // column col; in block slot b = col >> 2 the B operand T = M6 D6 is this
+    // lane's own column in all three instructions, the A operand is D6 of the
+    // column rotated left by 0, 4, 8 within the 16:
+    //   variant 0: blocks (b, b);  1: ((b - 1) & 3, b), slot 0 holding (3, 0) =
+    //   (0, 3) transposed;  2: ((b - 2) & 3, b), slots 2 and 3 = (0, 2), (1, 3).
+    int ex[3], ey[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+        col_functions((col - 4 * v) & 15, &ex[v], &ey[v]);
 
-    double4_t acc[PPW];
+    double acc[PPW][3];
     double gacc[PPW];
     // PPW == 4 means P <= 16 = SLOTS: a single chunk, so the accumulators are
     // only live in phase 2
@@ -745,7 +755,7 @@ gn_patch_kernel(PatchKernelArgs A)
         if (c == 0) {
 #pragma unroll
             for (int q = 0; q < PPW; ++q) {
-                acc[q] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+                acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
                 gacc[q] = 0.0;
             }
         }
@@ -753,54 +763,68 @@ gn_patch_kernel(PatchKernelArgs A)
         // With PPW == 4 and 4 x 4 samples per patch, pixel slot
         // pl = 16 qq + 4 tt + kg is sample (sx, sy) = (kg, tt) of patch qq:
         // the x-functions of a lane are loop invariant, the y-functions
-        // depend on tt only.
+        // depend on tt only -- so tt is the outer loop and the three column
+        // variants of D6 are formed once for the four patches.
         bool const grid4 = PPW == 4 && A.spr == 4;
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        double xv[3][3];
         if (grid4) {
-            const double *X = tabs + kg * 12 + ex * 3;
-            x0 = X[0]; x1 = X[1]; x2 = X[2];
-        }
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            int const q = PPW == 1 ? 0 : qq;
-            double4_t accq = acc[q];
-            double gsum = gacc[q];
+            for (int v = 0; v < 3; ++v) {
+                const double *X = tabs + kg * 12 + ex[v] * 3;
+                xv[v][0] = X[0]; xv[v][1] = X[1]; xv[v][2] = X[2];
+            }
+        }
 #pragma unroll 1
-            for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < 4; ++tt) {
+            double D[3][6];
+            if (grid4) {
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const double *Y = tabs + tt * 12 + ey[v] * 3;
+                    double const y0 = Y[0], y1 = Y[1], y2 = Y[2];
+                    D[v][0] = xv[v][0] * y0; D[v][1] = xv[v][1] * y0;
+                    D[v][2] = xv[v][0] * y1; D[v][3] = xv[v][1] * y1;
+                    D[v][4] = xv[v][2] * y0; D[v][5] = xv[v][0] * y2;
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                int const q = PPW == 1 ? 0 : qq;
                 int const pl = 4 * (4 * qq + tt) + kg;  // pixel slot in the wave
-                double y0, y1, y2;
-                if (grid4) {
-                    const double *Y = tabs + tt * 12 + ey * 3;
-                    y0 = Y[0]; y1 = Y[1]; y2 = Y[2];
-                } else {
+                if (!grid4) {
                     int si = c * SLOTS + (pl & (SLOTS - 1));
                     si = min(si, A.P - 1);
                     int const sy = si / A.spr, sx = si - sy * A.spr;
-                    const double *X = tabs + sx * 12 + ex * 3;
-                    const double *Y = tabs + sy * 12 + ey * 3;
-                    x0 = X[0]; x1 = X[1]; x2 = X[2];
-                    y0 = Y[0]; y1 = Y[1]; y2 = Y[2];
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const double *X = tabs + sx * 12 + ex[v] * 3;
+                        const double *Y = tabs + sy * 12 + ey[v] * 3;
+                        double const x0 = X[0], x1 = X[1], x2 = X[2];
+                        double const y0 = Y[0], y1 = Y[1], y2 = Y[2];
+                        D[v][0] = x0 * y0; D[v][1] = x1 * y0; D[v][2] = x0 * y1;
+                        D[v][3] = x1 * y1; D[v][4] = x2 * y0; D[v][5] = x0 * y2;
+                    }
                 }
-                double D[6];
-                D[0] = x0 * y0; D[1] = x1 * y0; D[2] = x0 * y1;
-                D[3] = x1 * y1; D[4] = x2 * y0; D[5] = x0 * y2;
                 double Mx[21];
 #pragma unroll
                 for (int i = 0; i < 21; ++i)
                     Mx[i] = Msh[i * 64 + pl];
+                double a0 = acc[q][0], a1 = acc[q][1], a2 = acc[q][2];
+                double gsum = gacc[q];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     double T = 0.0;
 #pragma unroll
                     for (int b = 0; b < 6; ++b)
-                        T = __builtin_fma(Mx[sym6(a, b)], D[b], T);
-                    accq = __builtin_amdgcn_mfma_f64_16x16x4f64(D[a], T, accq,
-                        0, 0, 0);
-                    gsum = __builtin_fma(Msh[(21 + a) * 64 + pl], D[a], gsum);
+                        T = __builtin_fma(Mx[sym6(a, b)], D[0][b], T);
+                    a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(D[0][a], T, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(D[1][a], T, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(D[2][a], T, a2, 0, 0, 0);
+                    gsum = __builtin_fma(Msh[(21 + a) * 64 + pl], D[0][a], gsum);
                 }
+                acc[q][0] = a0; acc[q][1] = a1; acc[q][2] = a2;
+                gacc[q] = gsum;
             }
-            acc[q] = accq;
-            gacc[q] = gsum;
         }
     }
 
@@ -813,15 +837,19 @@ gn_patch_kernel(PatchKernelArgs A)
         if (slot_base + q >= live_count)
             continue;
         int const patch = A.live_list[slot_base + q];
-        // Packed store: only the 10 node blocks (bi <= bj) of the upper block
-        // triangle, 16 doubles each (the assembly mirrors the rest); the 16
-        // lanes of a block write one 128-byte line.
+        // Packed store: the 10 node blocks (bi <= bj) of the upper block
+        // triangle, 16 doubles each, row-major (the assembly mirrors the
+        // rest).  v_mfma_f64_4x4x4 leaves element (i, j) of block slot b in
+        // lane 16 i + 4 b + j, i.e. in lane (kg, col) = (i, 4 b + j).
         double *Hout = A.Hp + (size_t)patch * PATCH_H_STRIDE;
-        int const bj = col >> 2, jc = col & 3;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            if (rr <= bj)
-                Hout[upper_block(rr, bj) * 16 + kg * 4 + jc] = acc[q][rr];
+        int const bs = col >> 2, jc = col & 3;
+        Hout[upper_block(bs, bs) * 16 + kg * 4 + jc] = acc[q][0];
+        if (bs >= 1)
+            Hout[upper_block(bs - 1, bs) * 16 + kg * 4 + jc] = acc[q][1];
+        else   // block (3, 0): the transpose of the stored block (0, 3)
+            Hout[upper_block(0, 3) * 16 + jc * 4 + kg] = acc[q][1];
+        if (bs >= 2)
+            Hout[upper_block(bs - 2, bs) * 16 + kg * 4 + jc] = acc[q][2];
         if (lane < 16)
             A.gp[(size_t)patch * 16 + lane] = gv;
     }
