@@ -1058,9 +1058,11 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     SMVS_REQUIRE(prm->max_newton_steps >= 0, "max_newton_steps is negative");
     SMVS_REQUIRE(prm->active_threshold >= 0.0 && prm->full_opt_threshold >= 0.0
         && prm->cg_q_tolerance >= 0.0, "negative threshold");
-    // (neighbour planes and cg_max_iterations are checked by
-    // gn_construct_launch / cg_solve_launch, shared with the stand-alone
-    // entry points)
+    // (the iteration number travels in the low 16 bits of the solvers' tags,
+    // as in cg_solve_launch; the neighbour planes are checked by
+    // gn_construct_launch, shared with the stand-alone entry point)
+    SMVS_REQUIRE(prm->cg_max_iterations >= 0 && prm->cg_max_iterations <= 0xFFFF,
+        "cg_max_iterations out of range [0, 65535]");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     memset(stats, 0, sizeof(*stats));
     int rc;

@@ -329,6 +329,27 @@ def test_call_order_errors(hip):
     ctx.close()
 
 
+def test_loop_argument_errors(hip, oracle):
+    """smvs_gn_run_loop rejects what its kernels cannot carry (the iteration
+    number travels in 16 bits of the solvers' tags) and a loop of zero steps
+    only reports the active set."""
+    from smvs_amd._capi import SmvsError
+    prob, ctx, _ = _setup(hip, oracle, 128, 96, 2, 2)
+    with pytest.raises(SmvsError):
+        ctx.run_loop(0.01, cg_max_iterations=70000)
+    with pytest.raises(SmvsError):
+        ctx.run_loop(0.01, max_newton_steps=-1)
+    before = ctx.get_nodes()
+    stats = ctx.run_loop(0.01, max_newton_steps=0)
+    assert stats["newton_steps"] == 0
+    assert stats["final_active_nodes"] == int(prob["surf"]["node_valid"].sum())
+    assert np.array_equal(ctx.get_nodes(), before)
+    # one CG iteration allowed: conjugate_gradient.h:121-123 returns x = 0
+    stats = ctx.run_loop(0.01, max_newton_steps=2, cg_max_iterations=1)
+    assert stats["newton_steps"] >= 1 and np.array_equal(ctx.get_nodes(), before)
+    ctx.close()
+
+
 def test_device_bicubic_matches_reference_known_answers(hip):
     """The reference's own known-answer vectors for BicubicPatch
     (tests/gtest_bicubic_patch.cc:16-162, tests/golden/) through the device
