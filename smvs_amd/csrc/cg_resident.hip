@@ -1127,8 +1127,17 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.status = ctx->status;
     A.progress = ctx->cg_progress;
     ctx->cg_solve_id = (ctx->cg_solve_id + 1) & 0x7FFF;
-    if (ctx->cg_solve_id == 0)
+    if (ctx->cg_solve_id == 0) {
+        // The 15-bit solve id starts over: a granule that no solve has
+        // overwritten since the id was last used (a slot of an epoch only a
+        // longer solve reaches) would carry a matching tag.  Clear both
+        // exchange areas, once per 32,767 solves.
         ctx->cg_solve_id = 1;
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
+            ctx->stream));
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0,
+            ctx->res_zx_cap * 8 * sizeof(double), ctx->stream));
+    }
     A.solve_tag = ctx->cg_solve_id << 16;
     A.num_nodes = ctx->num_nodes;
     A.stride = stride;

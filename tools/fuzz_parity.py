@@ -22,7 +22,7 @@ for case in range(n_cases):
     n_subs = int(rng.integers(1, 9))
     shading = bool(rng.integers(0, 2))
     light_reg = float(rng.choice([0.0, 0.5])) if shading else 0.0
-    prob = synth.make_problem(w, h, n_subs, scale, shading=shading, noise=0.01, seed=int(rng.integers(1, 10000)))
+    prob = synth.make_problem(w, h, n_subs, scale, shading=shading, noise=float(rng.choice([0.01, 0.03])), seed=int(rng.integers(1, 10000)))
     surf = prob["surf"]
     if surf["patch_valid"].sum() < 4:
         print("case %d skipped (no valid patches)" % case); continue
@@ -52,5 +52,29 @@ for case in range(n_cases):
     assert eH < 1e-8 and eg < 1e-8 and eP < 1e-5 and ex < 1e-8 and ok_it and same_active, case
     for k, v in (("H", eH), ("g", eg), ("P", eP), ("x", ex)):
         worst[k] = max(worst[k], v)
+    # ---- the whole Newton loop (fused assembly + resident solver, launch-ahead)
+    # against the oracle's loop run step by step: same control flow, same CG
+    # iteration total, depth to 1e-6
+    ctx.set_surface(surf)
+    orc = oracle.OracleProblem(surf, prob["views"])
+    max_steps = int(rng.integers(1, 7))
+    stats = ctx.run_loop(0.01, light_reg, lighting, max_newton_steps=max_steps)
+    act = surf["node_valid"].copy()
+    n_init = int(act.sum()); n_act = n_init; steps = 0; its = 0; psteps = 0
+    while steps < max_steps and n_act > n_init // 20:
+        steps += 1
+        ref = orc.gn_construct(act, 0.01, light_reg, lighting)
+        psteps += ref["active_patches"]
+        xr, itr, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
+                                  0.01 * np.linalg.norm(ref["g"]), 1e-3)
+        its += itr
+        act, n_act, _ = orc.update_and_reactivate(xr, act)
+    ed = rel(ctx.depth_map(), orc.depth_map())
+    same = (stats["newton_steps"], stats["active_patch_steps"], stats["final_active_nodes"],
+            stats["linear_iterations"]) == (steps, psteps, n_act, its)
+    print("         loop: %d steps (max %d), %d CG iterations, depth %.1e, control flow %s"
+          % (steps, max_steps, its, ed, same))
+    assert same and ed < 1e-6, (case, stats, steps, psteps, n_act, its)
+    worst["loop_depth"] = max(worst.get("loop_depth", 0), ed)
     ctx.close()
 print("worst", worst)
