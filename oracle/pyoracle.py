@@ -702,3 +702,46 @@ class TopologyProblem:
         return lib().orc_topology_cut_boundaries(C.byref(self.surf), C.byref(self.main),
                                                  self.subs, self.n_subs, _p(self.M, c_double_p),
                                                  _p(self.t, c_double_p))
+
+
+# ------------------------------------------------ scene level: view selection
+class SceneView(C.Structure):
+    _fields_ = [("present", C.c_int), ("id", C.c_int), ("flen", C.c_float),
+                ("rot", C.c_float * 9), ("trans", C.c_float * 3),
+                ("has_image", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+def select_neighbors(scene, view, num_neighbors=6, use_bundle=True):
+    """ViewSelection::get_neighbors_for_view (lib/view_selection.cc:14-161).
+    scene: dict(views=[dict(present, id, flen, rot, trans, has_image, width,
+    height)], features=(F, 3) float32, refs=[list of view ids per feature])."""
+    keep = []
+    n = len(scene["views"])
+    views = (SceneView * n)()
+    for i, v in enumerate(scene["views"]):
+        views[i].present = 1 if v.get("present", True) else 0
+        views[i].id = int(v["id"])
+        views[i].flen = float(v["flen"])
+        for k, x in enumerate(np.asarray(v["rot"], dtype=np.float32).reshape(9)):
+            views[i].rot[k] = float(x)
+        for k, x in enumerate(np.asarray(v["trans"], dtype=np.float32).reshape(3)):
+            views[i].trans[k] = float(x)
+        views[i].has_image = 1 if v.get("has_image", True) else 0
+        views[i].width, views[i].height = int(v["width"]), int(v["height"])
+    bundle = None
+    if use_bundle:
+        feats = f32(scene["features"]).reshape(-1, 3)
+        offsets = np.zeros(len(scene["refs"]) + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum([len(r) for r in scene["refs"]])
+        flat = np.asarray([i for r in scene["refs"] for i in r], dtype=np.int32)
+        if flat.size == 0:
+            flat = np.zeros(1, dtype=np.int32)
+        keep += [feats, offsets, flat]
+        bundle = Bundle(feats.shape[0], _p(feats, c_float_p), _p(offsets, c_i32_p),
+                        _p(flat, c_i32_p))
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    f = lib().orc_select_neighbors
+    f.restype = C.c_int
+    count = f(C.c_int(n), views, C.byref(bundle) if bundle is not None else None,
+              C.c_int(view), C.c_int(num_neighbors), _p(out, c_i32_p))
+    return [int(x) for x in out[:count]]

@@ -113,6 +113,23 @@ int orc_sgm_depth_for_view(const orc_view_input *main_view,
     int sgm_scale, float min_depth, float max_depth, int num_steps,
     int penalty1, int penalty2, int roundtrip, float *depth_out, int *out_w,
     int *out_h);
+/* what ViewSelection reads of an mve::View (view_selection.cc:23-159) */
+typedef struct {
+    int present;                   /* 0: a null entry of the scene's view list */
+    int id;                        /* mve::View::get_id() */
+    float flen;
+    float rot[9], trans[3];
+    int has_image;                 /* has_image(opts.embedding) */
+    int width, height;             /* of that embedding */
+} orc_scene_view;
+
+/* smvs::ViewSelection::get_neighbors_for_view (view_selection.cc:14-161):
+ * bundle-based with a bundle, position-based with NULL.  out: indices into
+ * the view list (the reference's ids-as-indices included), best first;
+ * room for n_views entries.  Returns the number of neighbours. */
+int orc_select_neighbors(int n_views, const orc_scene_view *views,
+    const orc_bundle *bundle, int view, int num_neighbors, int *out);
+
 /* generate_mesh's normal preparation (mesh_generator.cc:189-208) and
  * MeshGenerator::cut_depth_maps (:24-158); depth[i] (ray length) and
  * normals[i] (camera space) are overwritten with the cut maps / world-space

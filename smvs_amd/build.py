@@ -24,7 +24,7 @@ def _stale():
 HOST_DIR = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libsmvs_host.so")
 HOST_SOURCES = ["camera.cc", "stereo_view.cc", "surface.cc", "sgm_stereo.cc",
-                "depth_optimizer.cc", "host_capi.cc"]
+                "depth_optimizer.cc", "view_selection.cc", "host_capi.cc"]
 
 
 def _host_stale():

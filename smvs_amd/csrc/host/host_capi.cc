@@ -3,10 +3,12 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 
 #include "depth_optimizer.h"
 #include "sgm_stereo.h"
+#include "view_selection.h"
 
 using namespace smvs_amd;
 
@@ -136,6 +138,44 @@ smvs_host_sgm_depth(const smvs_host_view *main_in, const smvs_host_view *subs_in
         if (depth_out != nullptr)
             std::memcpy(depth_out, d->begin(),
                 sizeof(float) * d->get_pixel_amount());
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_select_neighbors(const smvs_host_view *views_in, int n_views,
+    const smvs_host_bundle *bundle_in, int view, int num_neighbors, int *out,
+    int *n_out)
+{
+    try {
+        if (views_in == nullptr || out == nullptr || n_out == nullptr
+            || view < 0 || view >= n_views || num_neighbors < 0)
+            throw std::invalid_argument("smvs_host_select_neighbors: bad argument");
+        ViewSelection::ViewList views((std::size_t)n_views);
+        for (int i = 0; i < n_views; ++i) {
+            smvs_host_view const& v = views_in[i];
+            ViewSelection::ViewInfo& info = views[i];
+            info.present = v.width > 0;
+            info.id = v.view_id;
+            info.cam.flen = v.flen;
+            std::copy(v.rot, v.rot + 9, info.cam.rot);
+            std::copy(v.trans, v.trans + 3, info.cam.trans);
+            info.has_image = v.bytes != nullptr;
+            info.width = v.width;
+            info.height = v.height;
+        }
+        ViewSelection::Options opts;
+        opts.num_neighbors = (std::size_t)num_neighbors;
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        ViewSelection selection(opts, views, bundle);
+        std::vector<std::size_t> const chosen
+            = selection.get_neighbors_for_view((std::size_t)view);
+        *n_out = (int)chosen.size();
+        for (std::size_t k = 0; k < chosen.size(); ++k)
+            out[k] = (int)chosen[k];
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();

@@ -67,6 +67,15 @@ int smvs_host_sgm_depth(const smvs_host_view *main_view,
     int sgm_scale, float min_depth, float max_depth, int device,
     float *depth_out, int *out_w, int *out_h);
 
+/* smvs::ViewSelection(opts, views, bundle).get_neighbors_for_view(view)
+ * (lib/view_selection.cc:14-161; bundle may be NULL: position-based).
+ * A view whose `bytes` is NULL has no image in the embedding; width <= 0
+ * marks a hole in the view list (a null View::Ptr).  out: room for n_views
+ * indices; *n_out receives how many were written. */
+int smvs_host_select_neighbors(const smvs_host_view *views, int n_views,
+    const smvs_host_bundle *bundle, int view, int num_neighbors, int *out,
+    int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

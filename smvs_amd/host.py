@@ -136,3 +136,46 @@ def sgm_depth(inputs, sgm_scale=1, min_depth=0.0, max_depth=0.0, device=0):
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
     assert (ow.value, oh.value) == (w, h)
     return out
+
+
+def select_neighbors(scene, view, num_neighbors=6, use_bundle=True):
+    """smvs_amd::ViewSelection (csrc/host/view_selection.cc, mirror of
+    lib/view_selection.cc:14-161) on a scene description: dict(views=[dict(
+    present, id, flen, rot, trans, has_image, width, height)], features=(F, 3),
+    refs=[view ids per feature]).  Returns indices into the view list."""
+    lib = load()
+    keep = []
+    n = len(scene["views"])
+    views = (HostView * n)()
+    dummy = np.zeros(1, dtype=np.uint8)
+    for i, v in enumerate(scene["views"]):
+        present = v.get("present", True)
+        views[i].width = int(v["width"]) if present else 0
+        views[i].height = int(v["height"]) if present else 0
+        views[i].channels = 1
+        views[i].bytes = dummy.ctypes.data_as(_u8p) if v.get("has_image", True) else None
+        views[i].flen = float(v["flen"])
+        for k, x in enumerate(np.asarray(v["rot"], dtype=np.float32).reshape(9)):
+            views[i].rot[k] = float(x)
+        for k, x in enumerate(np.asarray(v["trans"], dtype=np.float32).reshape(3)):
+            views[i].trans[k] = float(x)
+        views[i].view_id = int(v["id"])
+    bundle = None
+    if use_bundle:
+        feats = np.ascontiguousarray(scene["features"], dtype=np.float32).reshape(-1, 3)
+        offsets = np.zeros(len(scene["refs"]) + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum([len(r) for r in scene["refs"]])
+        flat = np.asarray([i for r in scene["refs"] for i in r], dtype=np.int32)
+        if flat.size == 0:
+            flat = np.zeros(1, dtype=np.int32)
+        keep += [feats, offsets, flat]
+        bundle = HostBundle(feats.shape[0], feats.ctypes.data_as(_fp),
+                            offsets.ctypes.data_as(_i32p), flat.ctypes.data_as(_i32p))
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    n_out = C.c_int(0)
+    rc = lib.smvs_host_select_neighbors(views, C.c_int(n),
+        C.byref(bundle) if bundle is not None else None, C.c_int(view),
+        C.c_int(num_neighbors), out.ctypes.data_as(_i32p), C.byref(n_out))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return [int(x) for x in out[:n_out.value]]
