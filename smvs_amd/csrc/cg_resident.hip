@@ -348,7 +348,8 @@ block_sum(double (&v)[K], double *red /*[K][RES_WAVES]*/)
             s += red[k * RES_WAVES + wv];
         v[k] = s;
     }
-    __syncthreads();
+    // (no barrier: the partials are next written by the following block_sum,
+    // and every thread passes the caller's barrier behind the sweep first)
 }
 
 // All-reduce of K doubles over the workgroups of the grid, and the grid-wide
@@ -368,7 +369,8 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
     // tags carry the solve id: granules of earlier solves never match, so the
     // exchange area needs no clearing between solves
     unsigned const tag = solve_tag | epoch;
-    block_sum<K>(v, red);          // (ends with a workgroup barrier)
+    double *res = red + 4 * RES_WAVES;   // [4] results, behind the partial sums
+    block_sum<K>(v, red);
     // (nothing to drain: everything that crosses workgroups is a granule, the
     // vectors of the solve live in registers and LDS)
     unsigned const par = epoch & 1u;
@@ -430,7 +432,7 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
         for (int off = 32; off > 0; off >>= 1)
             sum += __shfl_xor(sum, off);
         if (lane == 0) {
-            red[wave] = sum;
+            res[wave] = sum;
             // (a halo wait that gave up raises the same flag)
             if (wave == 0 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT) != 0u)
@@ -439,13 +441,16 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
         }
     }
     __syncthreads();
+    // The results live apart from the partial sums, so two workgroup barriers
+    // per all-reduce are enough (one inside block_sum, this one): results and
+    // flags are next written behind the next all-reduce's first barrier, which
+    // every thread reaches only after it has read these.
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        v[k] = red[k];
+        v[k] = res[k];
         ok = ok && lds_flag[k] != 0;
     }
-    __syncthreads();
     return ok;
 }
 
@@ -469,8 +474,8 @@ cg_resident_kernel(ResArgs A)
     double *fb = Pl + (size_t)4 * tile_nodes * 4;         // [3*tw + 3*th][16]
     double *xl = fb + (size_t)(3 * tw + 3 * th) * 16;     // [tile_nodes][4] x
     double *bl = xl + (size_t)tile_nodes * 4;             // [tile_nodes][4] b
-    double *red = bl + (size_t)tile_nodes * 4;            // [4][RES_WAVES]
-    int *flag = reinterpret_cast<int *>(red + 4 * RES_WAVES);
+    double *red = bl + (size_t)tile_nodes * 4;            // [4][RES_WAVES] partials + [4] results
+    int *flag = reinterpret_cast<int *>(red + 4 * RES_WAVES + 4);
 
     int const tid = threadIdx.x;
     int const nblocks = (int)gridDim.x;
@@ -1021,7 +1026,7 @@ resident_lds_bytes(int tw, int th)
 {
     return ((size_t)(tw + 2) * (th + 2) * 4 + (size_t)tw * th * 4
         + (size_t)4 * tw * th * 4 + (size_t)(3 * tw + 3 * th) * 16
-        + (size_t)2 * tw * th * 4 + 4 * RES_WAVES + 2) * sizeof(double);
+        + (size_t)2 * tw * th * 4 + 4 * RES_WAVES + 4 + 2) * sizeof(double);
 }
 
 // Does the resident solver take this system?  (grid fits the chip's CUs and
