@@ -54,6 +54,7 @@ struct ReactivateArgs {
     double *scalars;
     int *status;
     int npx, stride, ps, start_x, start_y, n_subs, num_patches;
+    int ps_log2;            // ps = 1 << ps_log2 (Surface: patchsize = 2^scale)
     double threshold;
     int full_optimization;
     const int *live_list;   // the step's live patches, or nullptr: all patches
@@ -72,12 +73,12 @@ reactivate_kernel(ReactivateArgs A)
     // this step gave up (finish_step_kernel reports it)
     if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
         return;
-    int const pp = A.ps * A.ps;
     // the list length is read on the device when the launch was sized before
     // it was known (live_count < 0)
     int const live_count = A.live_list == nullptr ? A.num_patches
         : (A.live_count >= 0 ? A.live_count : A.status[I_LIVE_PATCHES]);
-    if ((long long)live_count * pp > (long long)gridDim.x * blockDim.x) {
+    if (((long long)live_count << (2 * A.ps_log2))
+        > (long long)gridDim.x * blockDim.x) {
         // (cannot happen behind a patch kernel of the same step, which is
         // sized for the same length and would have abandoned the step)
         if (gid0 == 0)
@@ -87,9 +88,13 @@ reactivate_kernel(ReactivateArgs A)
     // NaN guard of the reference on delta[0] (depth_optimizer.cc:267)
     if (isnan(A.x[0]))
         return;
-    long long const gid = gid0;
-    int const slot = (int)(gid / pp);
-    int const pid = (int)(gid - (long long)slot * pp);
+    // (the patch size is a power of two: shifts instead of 64-bit divisions,
+    // which cost more than the arithmetic of a pixel)
+    // (measured: one thread per 16-pixel chunk, loading the nodes once per
+    // chunk, is slower -- 40 instead of 25 us: too few waves to hide the
+    // latency of its serial pixels)
+    int const slot = (int)(gid0 >> (2 * A.ps_log2));
+    int const pid = (int)(gid0 & (long long)((1 << (2 * A.ps_log2)) - 1));
     int patch = A.num_patches;
     if (slot < live_count)
         patch = A.live_list != nullptr ? A.live_list[slot] : slot;
@@ -110,16 +115,16 @@ reactivate_kernel(ReactivateArgs A)
                     th0[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
                     thd[4 * n + k] = A.x[4 * (size_t)ids[n] + k];
                 }
-            int const ci = pid % A.ps, cj = pid / A.ps;
+            uint32_t const vis = A.patch_vis[patch];
+            double const th2 = A.threshold * A.threshold;
+            bool moved = false;
+            int const ci = pid & (A.ps - 1), cj = pid >> A.ps_log2;
             double w0, dw, dum0, dum1;
             eval_patch(A.hermite_tab, ci, cj, th0, &w0, &dum0, &dum1);
             eval_patch(A.hermite_tab, ci, cj, thd, &dw, &dum0, &dum1);
             double const w1 = w0 + dw;
             double const u = (double)(A.start_x + ix * A.ps + ci);
             double const v = (double)(A.start_y + iy * A.ps + cj);
-            uint32_t const vis = A.patch_vis[patch];
-            double const th2 = A.threshold * A.threshold;
-            bool moved = false;
             for (int j = 0; j < A.n_subs; ++j) {
                 if (!((vis >> j) & 1u))
                     continue;
@@ -476,6 +481,7 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
     A.npx = ctx->npx;
     A.stride = ctx->node_stride;
     A.ps = ctx->patchsize;
+    A.ps_log2 = ctx->scale;
     A.start_x = ctx->start_x;
     A.start_y = ctx->start_y;
     A.n_subs = ctx->n_subs;
