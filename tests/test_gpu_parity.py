@@ -767,3 +767,38 @@ def test_save_and_restore_nodes(hip, oracle):
     assert s1 == s2
     assert np.array_equal(ctx.get_nodes(), n1)
     ctx.close()
+
+
+@pytest.mark.parametrize("full_optimization", [False, True])
+def test_gn_loop_from_a_partial_active_set(hip, oracle, full_optimization):
+    """smvs_gn_run_loop with reset_active = 0: the loop starts from the active
+    set the caller uploaded (the loop-begin kernel counts it and builds the
+    first live list from it) -- against the oracle's loop from the same set."""
+    prob, ctx, orc = _setup(hip, oracle, 224, 160, 3, 2, noise=0.02)
+    rng = np.random.default_rng(5)
+    valid = prob["surf"]["node_valid"]
+    active = (valid & (rng.random(valid.size) < 0.4)).astype(np.uint8)
+    ctx.set_active(active)
+    stats = ctx.run_loop(0.01, max_newton_steps=5, reset_active=False,
+                         full_optimization=full_optimization)
+    n_init = int(active.sum()); n_act = n_init; steps = 0; patch_steps = 0; its = 0
+    act = active.copy()
+    while steps < 5 and n_act > n_init // 20:
+        steps += 1
+        ref = orc.gn_construct(act, 0.01)
+        patch_steps += ref["active_patches"]
+        x, it, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
+                                0.01 * np.linalg.norm(ref["g"]), 1e-3)
+        its += it
+        new_act, n_new, mean = orc.update_and_reactivate(x, act, full_optimization)
+        if full_optimization:
+            if mean < 0.01:
+                break
+        else:
+            act, n_act = new_act, n_new
+    assert stats["newton_steps"] == steps
+    assert stats["active_patch_steps"] == patch_steps
+    assert stats["linear_iterations"] == its
+    assert stats["final_active_nodes"] == n_act
+    assert _rel(ctx.depth_map(), orc.depth_map()) <= 1e-5
+    ctx.close()
