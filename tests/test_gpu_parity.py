@@ -726,6 +726,9 @@ def test_gn_loop_abandoned_steps_are_redone(hip, mode, tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     reply = json.loads(res.stdout.strip().splitlines()[-1])
     child, launches = reply["stats"], reply["launches"]
+    if launches["cg_resident"] == 0:
+        pytest.skip("the resident solver does not apply on this device (fewer CUs "
+                    "than tiles, or SMVS_CG_RESIDENT=0): the launch-ahead loop is not used")
     # the hook fired: launches were repeated / the streaming solver ran
     if mode == "undersize":
         assert launches["patch"] > child["newton_steps"] + 1
