@@ -1069,6 +1069,10 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     // gn_construct_launch, shared with the stand-alone entry point)
     SMVS_REQUIRE(prm->cg_max_iterations >= 0 && prm->cg_max_iterations <= 0xFFFF,
         "cg_max_iterations out of range [0, 65535]");
+    // (finish_step_kernel packs the list length and the active-node count
+    // into 24 bits each of one atomic)
+    SMVS_REQUIRE(ctx->num_nodes < (1 << 24),
+        "surface too large for the Newton loop (2^24 nodes)");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     memset(stats, 0, sizeof(*stats));
     int rc;
