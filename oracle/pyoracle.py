@@ -745,3 +745,33 @@ def select_neighbors(scene, view, num_neighbors=6, use_bundle=True):
     count = f(C.c_int(n), views, C.byref(bundle) if bundle is not None else None,
               C.c_int(view), C.c_int(num_neighbors), _p(out, c_i32_p))
     return [int(x) for x in out[:count]]
+
+
+# ------------------------------------------------ Surface operations on their own
+def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3):
+    """lib/surface.cc: Surface::create + a script of operations (1 expand,
+    2 subdivide_patches, 3 fill_patches_from_depth, 4 remove_isolated_patches,
+    5 delete every delete_every-th valid patch + remove_nodes_without_patch).
+    inputs as for optimize(); returns dict(scale, npx, npy, start_x, start_y,
+    nodes, node_valid, patch_valid)."""
+    keep = []
+    main = _view_input(inputs["images"][0], inputs["cams"][0], inputs["view_ids"][0], keep)
+    bundle = _bundle(inputs, keep)
+    h, w = np.asarray(inputs["images"][0]).shape[:2]
+    cap_n, cap_p = (w + 2) * (h + 2), (w + 1) * (h + 1)
+    nodes = np.zeros(cap_n * 4); nv = np.zeros(cap_n, np.uint8); pv = np.zeros(cap_p, np.uint8)
+    info = np.zeros(5, np.int32)
+    ops_a = np.asarray(list(ops) + [0], dtype=np.int32)
+    depth = None if init_depth is None else f32(init_depth)
+    f = lib().orc_surface_script
+    f.restype = C.c_int
+    rc = f(C.byref(main), C.byref(bundle), _p(depth, c_float_p) if depth is not None else None,
+           C.c_int(init_scale), _p(ops_a, c_i32_p), C.c_int(len(ops)), C.c_int(delete_every),
+           _p(info, c_i32_p), _p(nodes, c_double_p), _p(nv, c_u8_p), _p(pv, c_u8_p))
+    if rc != 0:
+        raise RuntimeError("orc_surface_script failed")
+    scale, npx, npy, sx, sy = (int(x) for x in info)
+    nn, npatch = (npx + 1) * (npy + 1), npx * npy
+    return dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
+                nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
+                patch_valid=pv[:npatch].copy())

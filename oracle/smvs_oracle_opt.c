@@ -1474,3 +1474,55 @@ orc_scale_planes(const uint8_t *bytes, int w, int h, int c, int scale,
         memcpy(hess3, v.hess, sizeof(float) * 3 * (size_t)w * h);
     oview_free(&v);
 }
+
+/* ---------------------------------------------------------------------- */
+/* Surface operations on their own (lib/surface.cc), for the CPU parity   */
+/* test of the host mirror's Surface class: create (from the bundle or    */
+/* an initial depth map) and then a script of                             */
+/*   1 expand, 2 subdivide_patches, 3 fill_patches_from_depth,            */
+/*   4 remove_isolated_patches, 5 delete every `delete_every`-th valid    */
+/*   patch + remove_nodes_without_patch.                                  */
+/* Outputs: info = { scale, npx, npy, start_x, start_y }, and the node /  */
+/* validity arrays (caller-sized for the finest scale the script reaches).*/
+/* ---------------------------------------------------------------------- */
+int
+orc_surface_script(const orc_view_input *main_in, const orc_bundle *bundle,
+    const float *init_depth, int init_scale, const int *ops, int n_ops,
+    int delete_every, int *info, double *nodes_out, uint8_t *node_valid_out,
+    uint8_t *patch_valid_out)
+{
+    OView mainv;
+    oview_init(&mainv, main_in, 0);
+    OSurf S;
+    surf_create(&S, bundle, &mainv, main_in->flen, init_scale, init_depth);
+    for (int k = 0; k < n_ops; ++k)
+        switch (ops[k])
+        {
+        case 1: surf_expand(&S); break;
+        case 2: surf_subdivide(&S); break;
+        case 3: surf_fill_patches_from_depth(&S); break;
+        case 4: surf_remove_isolated_patches(&S); break;
+        case 5:
+        {
+            int seen = 0;
+            for (int p = 0; p < S.s.npx * S.s.npy; ++p)
+                if (S.s.patch_valid[p] && (++seen % delete_every) == 0)
+                    S.s.patch_valid[p] = 0;
+            surf_remove_nodes_without_patch(&S);
+            break;
+        }
+        default:
+            oview_free(&mainv);
+            return -1;
+        }
+    int const nn = (S.s.npx + 1) * (S.s.npy + 1), np = S.s.npx * S.s.npy;
+    info[0] = S.s.scale; info[1] = S.s.npx; info[2] = S.s.npy;
+    info[3] = S.s.start_x; info[4] = S.s.start_y;
+    memcpy(nodes_out, S.s.nodes, sizeof(double) * 4 * (size_t)nn);
+    memcpy(node_valid_out, S.s.node_valid, (size_t)nn);
+    memcpy(patch_valid_out, S.s.patch_valid, (size_t)np);
+    surf_free_grid(&S);
+    free(S.depth);
+    oview_free(&mainv);
+    return 0;
+}

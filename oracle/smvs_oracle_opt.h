@@ -113,6 +113,16 @@ int orc_sgm_depth_for_view(const orc_view_input *main_view,
     int sgm_scale, float min_depth, float max_depth, int num_steps,
     int penalty1, int penalty2, int roundtrip, float *depth_out, int *out_w,
     int *out_h);
+/* lib/surface.cc on its own: Surface::create (from the bundle when init_depth
+ * is NULL) followed by a script of operations -- 1 expand, 2 subdivide_patches,
+ * 3 fill_patches_from_depth, 4 remove_isolated_patches, 5 delete every
+ * delete_every-th valid patch + remove_nodes_without_patch.  info = { scale,
+ * npx, npy, start_x, start_y }; the arrays are caller-sized. */
+int orc_surface_script(const orc_view_input *main_view, const orc_bundle *bundle,
+    const float *init_depth, int init_scale, const int *ops, int n_ops,
+    int delete_every, int *info, double *nodes_out, uint8_t *node_valid_out,
+    uint8_t *patch_valid_out);
+
 /* what ViewSelection reads of an mve::View (view_selection.cc:23-159) */
 typedef struct {
     int present;                   /* 0: a null entry of the scene's view list */

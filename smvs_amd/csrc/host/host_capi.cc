@@ -182,3 +182,56 @@ smvs_host_select_neighbors(const smvs_host_view *views_in, int n_views,
         return -1;
     }
 }
+
+extern "C" int
+smvs_host_surface_script(const smvs_host_view *main_in,
+    const smvs_host_bundle *bundle_in, const float *init_depth, int init_scale,
+    const int *ops, int n_ops, int delete_every, int *info, double *nodes_out,
+    uint8_t *node_valid_out, uint8_t *patch_valid_out)
+{
+    try {
+        if (main_in == nullptr || info == nullptr || nodes_out == nullptr
+            || node_valid_out == nullptr || patch_valid_out == nullptr
+            || (n_ops > 0 && ops == nullptr) || delete_every < 1)
+            throw std::invalid_argument("smvs_host_surface_script: bad argument");
+        StereoView::Ptr main_view = make_view(*main_in, false);
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        FloatImage::Ptr init;
+        if (init_depth != nullptr) {
+            init = FloatImage::create(main_in->width, main_in->height, 1);
+            std::memcpy(init->begin(), init_depth,
+                sizeof(float) * (size_t)main_in->width * main_in->height);
+        }
+        Surface::Ptr surface = Surface::create(bundle, main_view, init_scale, init);
+        for (int k = 0; k < n_ops; ++k)
+            switch (ops[k]) {
+            case 1: surface->expand(); break;
+            case 2: surface->subdivide_patches(); break;
+            case 3: surface->fill_patches_from_depth(); break;
+            case 4: surface->remove_isolated_patches(); break;
+            case 5: {
+                int seen = 0;
+                for (std::size_t p = 0; p < surface->patch_validity().size(); ++p)
+                    if (surface->patch_validity()[p] && (++seen % delete_every) == 0)
+                        surface->delete_patch(p);
+                surface->remove_nodes_without_patch();
+                break;
+            }
+            default:
+                throw std::invalid_argument("smvs_host_surface_script: unknown operation");
+            }
+        Surface const& s = *surface;
+        info[0] = s.get_scale();
+        info[1] = s.get_num_patches_x();
+        info[2] = s.get_num_patches_y();
+        info[3] = s.get_pixel_start_x();
+        info[4] = s.get_pixel_start_y();
+        std::copy(s.node_values().begin(), s.node_values().end(), nodes_out);
+        std::copy(s.node_validity().begin(), s.node_validity().end(), node_valid_out);
+        std::copy(s.patch_validity().begin(), s.patch_validity().end(), patch_valid_out);
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}

@@ -67,6 +67,18 @@ int smvs_host_sgm_depth(const smvs_host_view *main_view,
     int sgm_scale, float min_depth, float max_depth, int device,
     float *depth_out, int *out_w, int *out_h);
 
+/* smvs::Surface on its own (lib/surface.cc): Surface::create (from the bundle
+ * when init_depth is NULL, else from the W x H depth map) followed by a
+ * script of operations -- 1 expand, 2 subdivide_patches,
+ * 3 fill_patches_from_depth, 4 remove_isolated_patches, 5 delete every
+ * delete_every-th valid patch + remove_nodes_without_patch.  No device
+ * involved.  info = { scale, npx, npy, start_x, start_y }; the arrays are
+ * caller-sized (for the finest scale the script reaches). */
+int smvs_host_surface_script(const smvs_host_view *main_view,
+    const smvs_host_bundle *bundle, const float *init_depth, int init_scale,
+    const int *ops, int n_ops, int delete_every, int *info, double *nodes_out,
+    uint8_t *node_valid_out, uint8_t *patch_valid_out);
+
 /* smvs::ViewSelection(opts, views, bundle).get_neighbors_for_view(view)
  * (lib/view_selection.cc:14-161; bundle may be NULL: position-based).
  * A view whose `bytes` is NULL has no image in the embedding; width <= 0

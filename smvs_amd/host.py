@@ -179,3 +179,32 @@ def select_neighbors(scene, view, num_neighbors=6, use_bundle=True):
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
     return [int(x) for x in out[:n_out.value]]
+
+
+def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3):
+    """smvs_amd::Surface on its own (csrc/host/surface.cc, mirror of
+    lib/surface.cc): create + a script of operations (1 expand,
+    2 subdivide_patches, 3 fill_patches_from_depth, 4 remove_isolated_patches,
+    5 delete every delete_every-th valid patch + remove_nodes_without_patch).
+    No device involved."""
+    lib = load()
+    keep = []
+    main, _, _, bundle = _marshal(inputs, keep)
+    h, w = np.asarray(inputs["images"][0]).shape[:2]
+    cap_n, cap_p = (w + 2) * (h + 2), (w + 1) * (h + 1)
+    nodes = np.zeros(cap_n * 4); nv = np.zeros(cap_n, np.uint8); pv = np.zeros(cap_p, np.uint8)
+    info = np.zeros(5, np.int32)
+    ops_a = np.asarray(list(ops) + [0], dtype=np.int32)
+    depth = None if init_depth is None else np.ascontiguousarray(init_depth, dtype=np.float32)
+    rc = lib.smvs_host_surface_script(C.byref(main), C.byref(bundle),
+        depth.ctypes.data_as(_fp) if depth is not None else None, C.c_int(init_scale),
+        ops_a.ctypes.data_as(_i32p), C.c_int(len(ops)), C.c_int(delete_every),
+        info.ctypes.data_as(_i32p), nodes.ctypes.data_as(C.POINTER(C.c_double)),
+        nv.ctypes.data_as(_u8p), pv.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    scale, npx, npy, sx, sy = (int(x) for x in info)
+    nn, npatch = (npx + 1) * (npy + 1), npx * npy
+    return dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
+                nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
+                patch_valid=pv[:npatch].copy())

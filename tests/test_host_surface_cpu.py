@@ -1,0 +1,78 @@
+"""Host logic without a GPU: the C++ mirror of smvs::Surface
+(csrc/host/surface.cc; lib/surface.cc:19-130 create / depth from the bundle,
+:155-330 node initialisation from depth, :472-628 expand, :630-651 fill_holes,
+:887-955 isolated patches / nodes without patch, :983-1107 subdivide) against
+the oracle's restatement (oracle/smvs_oracle_opt.c) on the same inputs: grid
+geometry and validity identical; node values identical where they are copied
+or initialised from depth, and within 1e-12 where subdivide_patches evaluates
+the bicubic patch (the host evaluates it from the Hermite basis it shares with
+the device kernels, the oracle through the reference's coefficient form:
+a few ulps apart)."""
+import numpy as np
+import pytest
+
+from smvs_amd import synth
+
+
+@pytest.fixture(scope="module")
+def host():
+    from smvs_amd import host as h
+    h.load()
+    return h
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return synth.pipeline_inputs("sphere", 320, 240, 3, flen=1.2)
+
+
+def _exact(ops):
+    # bit-identical until a subdivision evaluates patches whose nodes went
+    # through another operation first (mixed derivative information)
+    return not (2 in ops and len(ops) > 1)
+
+
+def _same(a, b, exact=True):
+    for k in ("scale", "npx", "npy", "start_x", "start_y"):
+        assert a[k] == b[k], k
+    assert np.array_equal(a["patch_valid"], b["patch_valid"])
+    assert np.array_equal(a["node_valid"], b["node_valid"])
+    # invalid nodes may hold anything on either side
+    m = a["node_valid"].astype(bool)
+    if exact:
+        assert np.array_equal(a["nodes"][m], b["nodes"][m])
+    else:
+        assert np.allclose(a["nodes"][m], b["nodes"][m], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("init_scale", [5, 4, 3])
+def test_surface_create_from_bundle(host, oracle, scene, init_scale):
+    got = host.surface_script(scene, init_scale, [])
+    want = oracle.surface_script(scene, init_scale, [])
+    _same(got, want)
+    assert got["patch_valid"].sum() > 0
+
+
+@pytest.mark.parametrize("ops", [[1], [1, 1], [2], [1, 2], [5], [5, 4], [1, 5, 4, 1],
+                                 [2, 3], [1, 2, 5, 4, 1, 2, 3, 4]])
+def test_surface_operations_match_oracle(host, oracle, scene, ops):
+    got = host.surface_script(scene, 5, ops, delete_every=4)
+    want = oracle.surface_script(scene, 5, ops, delete_every=4)
+    _same(got, want, exact=_exact(ops))
+    assert got["scale"] == 5 - ops.count(2)
+
+
+def test_surface_from_an_initial_depth_map(host, oracle, scene):
+    """Surface::create with the SGM-style initial depth (surface.cc:46-50):
+    a depth map with holes and a discontinuity."""
+    h, w = scene["images"][0].shape[:2]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    depth = (4.0 + 0.002 * xx + 0.001 * yy).astype(np.float32)
+    depth[:, w // 2:] += 0.8                      # a step
+    depth[40:90, 60:140] = 0.0                    # a hole
+    depth[::7, ::5] = 0.0                         # scattered invalid pixels
+    for ops in ([], [1], [2], [1, 2, 3, 4]):
+        got = host.surface_script(scene, 4, ops, init_depth=depth)
+        want = oracle.surface_script(scene, 4, ops, init_depth=depth)
+        _same(got, want, exact=_exact(ops))
+    assert got["patch_valid"].sum() > 0
