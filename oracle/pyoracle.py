@@ -775,3 +775,24 @@ def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3):
     return dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
                 nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
                 patch_valid=pv[:npatch].copy())
+
+
+def sgm_image(inputs, view_index=0, halvings=1):
+    keep = []
+    v = _view_input(inputs["images"][view_index], inputs["cams"][view_index],
+                    inputs["view_ids"][view_index], keep)
+    out = np.zeros(v.width * v.height, np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    lib().orc_sgm_image(C.byref(v), C.c_int(halvings), _p(out, c_u8_p), C.byref(w), C.byref(h))
+    return out[:w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def view_reprojection(inputs, src, dst):
+    keep = []
+    a = _view_input(inputs["images"][src], inputs["cams"][src], inputs["view_ids"][src], keep)
+    b = _view_input(inputs["images"][dst], inputs["cams"][dst], inputs["view_ids"][dst], keep)
+    M = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+    f = lib().orc_view_reprojection
+    f.restype = None
+    f(C.byref(a), C.byref(b), _p(M, c_float_p), _p(t, c_float_p))
+    return M, t

@@ -526,3 +526,28 @@ orc_cut_depth_maps(int n_views, const orc_view_input *cams, const int *w,
     free(vps);
     return 0;
 }
+
+/* ---- pieces of the front end on their own (CPU parity tests of the host
+ * mirror): the SGM input image (stereo_view.cc:86-95 + sgm_stereo.cc:27-44)
+ * and the reprojection between two views at their image sizes
+ * (sgm_stereo.cc:56-62, 154-160) ---- */
+int
+orc_sgm_image(const orc_view_input *in, int halvings, uint8_t *out, int *ow,
+    int *oh)
+{
+    uint8_t *img = front_sgm_image(in, halvings, ow, oh);
+    memcpy(out, img, (size_t)*ow * *oh);
+    free(img);
+    return 0;
+}
+
+void
+orc_view_reprojection(const orc_view_input *src, const orc_view_input *dst,
+    float *M, float *t)
+{
+    float Ks[9], Ksi[9], Kd[9], Kdi[9];
+    front_calibration(src->flen, src->width, src->height, Ks, Ksi);
+    front_calibration(dst->flen, dst->width, dst->height, Kd, Kdi);
+    orc_fill_reprojection(Ksi, src->rot, src->trans, Kd, dst->rot, dst->trans,
+        M, t);
+}

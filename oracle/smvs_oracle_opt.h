@@ -113,6 +113,14 @@ int orc_sgm_depth_for_view(const orc_view_input *main_view,
     int sgm_scale, float min_depth, float max_depth, int num_steps,
     int penalty1, int penalty2, int roundtrip, float *depth_out, int *out_w,
     int *out_h);
+/* StereoView::get_byte_image + `halvings` rescale_half_size (the SGM input
+ * image); out is caller-sized */
+int orc_sgm_image(const orc_view_input *view, int halvings, uint8_t *out,
+    int *out_w, int *out_h);
+/* CameraInfo::fill_reprojection from src to dst at their image sizes */
+void orc_view_reprojection(const orc_view_input *src, const orc_view_input *dst,
+    float *M9, float *t3);
+
 /* lib/surface.cc on its own: Surface::create (from the bundle when init_depth
  * is NULL) followed by a script of operations -- 1 expand, 2 subdivide_patches,
  * 3 fill_patches_from_depth, 4 remove_isolated_patches, 5 delete every

@@ -235,3 +235,66 @@ smvs_host_surface_script(const smvs_host_view *main_in,
         return -1;
     }
 }
+
+extern "C" int
+smvs_host_depth_range(const smvs_host_view *view_in,
+    const smvs_host_bundle *bundle_in, float *range2)
+{
+    try {
+        if (view_in == nullptr || bundle_in == nullptr || range2 == nullptr)
+            throw std::invalid_argument("smvs_host_depth_range: bad argument");
+        StereoView::Ptr view = make_view(*view_in, false);
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        SGMStereo::fill_depth_range_for_view(bundle, view, range2);
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_reprojection(const smvs_host_view *source,
+    const smvs_host_view *destination, float *M9, float *t3)
+{
+    try {
+        if (source == nullptr || destination == nullptr || M9 == nullptr
+            || t3 == nullptr)
+            throw std::invalid_argument("smvs_host_reprojection: bad argument");
+        CameraInfo src, dst;
+        src.flen = source->flen;
+        std::copy(source->rot, source->rot + 9, src.rot);
+        std::copy(source->trans, source->trans + 3, src.trans);
+        dst.flen = destination->flen;
+        std::copy(destination->rot, destination->rot + 9, dst.rot);
+        std::copy(destination->trans, destination->trans + 3, dst.trans);
+        src.fill_reprojection(dst, (float)source->width, (float)source->height,
+            (float)destination->width, (float)destination->height, M9, t3);
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_sgm_image(const smvs_host_view *view_in, int halvings, uint8_t *out,
+    int *out_w, int *out_h)
+{
+    try {
+        if (view_in == nullptr || out == nullptr || out_w == nullptr
+            || out_h == nullptr || halvings < 0)
+            throw std::invalid_argument("smvs_host_sgm_image: bad argument");
+        StereoView::Ptr view = make_view(*view_in, false);
+        ByteImage::ConstPtr img = view->get_byte_image();
+        for (int i = 0; i < halvings; ++i)
+            img = imgtools::rescale_half_size(img);
+        *out_w = img->width();
+        *out_h = img->height();
+        std::memcpy(out, img->begin(), (size_t)img->width() * img->height());
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}

@@ -79,6 +79,21 @@ int smvs_host_surface_script(const smvs_host_view *main_view,
     const int *ops, int n_ops, int delete_every, int *info, double *nodes_out,
     uint8_t *node_valid_out, uint8_t *patch_valid_out);
 
+/* Host-only pieces of the SGM front end, for CPU tests (no device involved):
+ *   smvs_host_depth_range: SGMStereo::fill_depth_range_for_view
+ *     (lib/sgm_stereo.cc:669-720) -> range[2];
+ *   smvs_host_reprojection: CameraInfo::fill_reprojection from `source` to
+ *     `destination` at their image sizes -> M[9], t[3] (lib/sgm_stereo.cc:56-62);
+ *   smvs_host_sgm_image: StereoView::get_byte_image (desaturate<uint8_t>,
+ *     lib/stereo_view.cc:86-95) followed by `halvings` rescale_half_size
+ *     (lib/sgm_stereo.cc:31-39) -> out (caller-sized), *out_w, *out_h. */
+int smvs_host_depth_range(const smvs_host_view *view,
+    const smvs_host_bundle *bundle, float *range2);
+int smvs_host_reprojection(const smvs_host_view *source,
+    const smvs_host_view *destination, float *M9, float *t3);
+int smvs_host_sgm_image(const smvs_host_view *view, int halvings, uint8_t *out,
+    int *out_w, int *out_h);
+
 /* smvs::ViewSelection(opts, views, bundle).get_neighbors_for_view(view)
  * (lib/view_selection.cc:14-161; bundle may be NULL: position-based).
  * A view whose `bytes` is NULL has no image in the embedding; width <= 0

@@ -208,3 +208,43 @@ def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3):
     return dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
                 nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
                 patch_valid=pv[:npatch].copy())
+
+
+def depth_range(inputs, view_index=0):
+    """SGMStereo::fill_depth_range_for_view on the host mirror."""
+    lib = load()
+    keep = []
+    _, _, _, bundle = _marshal(inputs, keep)
+    v = _view(inputs["images"][view_index], inputs["cams"][view_index],
+              inputs["view_ids"][view_index], keep)
+    out = np.zeros(2, np.float32)
+    if lib.smvs_host_depth_range(C.byref(v), C.byref(bundle), out.ctypes.data_as(_fp)) != 0:
+        raise _capi.SmvsError(-1, lib.smvs_host_last_error().decode())
+    return out
+
+
+def view_reprojection(inputs, src, dst):
+    """CameraInfo::fill_reprojection between two views at their image sizes."""
+    lib = load()
+    keep = []
+    a = _view(inputs["images"][src], inputs["cams"][src], inputs["view_ids"][src], keep)
+    b = _view(inputs["images"][dst], inputs["cams"][dst], inputs["view_ids"][dst], keep)
+    M = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+    if lib.smvs_host_reprojection(C.byref(a), C.byref(b), M.ctypes.data_as(_fp),
+                                  t.ctypes.data_as(_fp)) != 0:
+        raise _capi.SmvsError(-1, lib.smvs_host_last_error().decode())
+    return M, t
+
+
+def sgm_image(inputs, view_index=0, halvings=1):
+    """StereoView::get_byte_image + rescale_half_size (the SGM input image)."""
+    lib = load()
+    keep = []
+    v = _view(inputs["images"][view_index], inputs["cams"][view_index],
+              inputs["view_ids"][view_index], keep)
+    out = np.zeros(v.width * v.height, np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    if lib.smvs_host_sgm_image(C.byref(v), C.c_int(halvings), out.ctypes.data_as(_u8p),
+                               C.byref(w), C.byref(h)) != 0:
+        raise _capi.SmvsError(-1, lib.smvs_host_last_error().decode())
+    return out[:w.value * h.value].reshape(h.value, w.value).copy()

@@ -76,3 +76,34 @@ def test_surface_from_an_initial_depth_map(host, oracle, scene):
         want = oracle.surface_script(scene, 4, ops, init_depth=depth)
         _same(got, want, exact=_exact(ops))
     assert got["patch_valid"].sum() > 0
+
+
+# ------------------------------------------------ host pieces of the SGM front end
+def test_depth_range_matches_oracle(host, oracle, scene):
+    """SGMStereo::fill_depth_range_for_view (lib/sgm_stereo.cc:669-720)."""
+    for i in range(len(scene["cams"])):
+        got = host.depth_range(scene, i)
+        want = oracle.sgm_depth_range(scene, i)
+        assert np.array_equal(got, want), i
+        assert 0 < got[0] < got[1]
+
+
+def test_reprojection_matches_oracle(host, oracle, scene):
+    """CameraInfo::fill_reprojection [MVE-unverified, README M14], float."""
+    for src, dst in ((0, 1), (1, 0), (2, 3), (3, 0)):
+        M, t = host.view_reprojection(scene, src, dst)
+        Mo, to = oracle.view_reprojection(scene, src, dst)
+        assert np.array_equal(M, Mo) and np.array_equal(t, to), (src, dst)
+
+
+@pytest.mark.parametrize("halvings", [0, 1, 2])
+def test_sgm_input_image_matches_oracle(host, oracle, halvings):
+    """get_byte_image (desaturate<uint8_t>) + rescale_half_size on an odd-sized
+    colour image: u8, bit-exact."""
+    inputs = synth.pipeline_inputs("sphere", 331, 247, 1, flen=1.2)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(247, 331, 3), dtype=np.uint8)
+    inputs["images"][0] = img
+    got = host.sgm_image(inputs, 0, halvings)
+    want = oracle.sgm_image(inputs, 0, halvings)
+    assert got.shape == want.shape and np.array_equal(got, want)
