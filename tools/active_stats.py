@@ -36,6 +36,7 @@ def main():
     ctx = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
     ctx.set_views(prob["views"])
     ctx.set_surface(surf)
+    ctx.save_nodes()
     bench.run_steps(ctx, prob, 10)
     stride = surf["npx"] + 1
     rows = surf["npy"] + 1
@@ -61,12 +62,11 @@ def main():
                           cg_iterations=st["linear_iterations"], wall_ms=1e3 * dt,
                           tiles_occupied=occ, tiles_total=tiles, tile_fill=fill,
                           kernels={kk: [round(v[0], 4), int(v[1])] for kk, v in prof.items()}))
-        print("step %2d: nodes %6d patches %6d cg %3d  tiles %4d/%4d fill %.2f  %.3f ms  patch %.0f us  "
-              "spmv %.1f us x %d  upd %.1f us" % (
+        print("step %2d: nodes %6d patches %6d cg %3d  tiles %4d/%4d fill %.2f  | HIP-event us: patch %.0f  "
+              "resident solve (assembly inside) %.0f  re-activation %.0f  loop begin + end of step %.0f" % (
                   k, n_before, st["active_patch_steps"], st["linear_iterations"], occ, tiles, fill,
-                  1e3 * dt, 1e3 * prof["patch"][0],
-                  1e3 * prof["cg_spmv"][0] / max(prof["cg_spmv"][1], 1), prof["cg_spmv"][1],
-                  1e3 * prof["cg_update"][0] / max(prof["cg_update"][1], 1)))
+                  1e3 * prof["patch"][0], 1e3 * prof["cg_resident"][0],
+                  1e3 * prof["reactivate"][0], 1e3 * prof["misc"][0]))
     res = dict(valid_nodes=n_init, valid_patches=int(surf["patch_valid"].sum()), steps=steps)
     if out_path:
         with open(out_path, "w") as f:

@@ -9,7 +9,7 @@ import bench, smvs_amd
 prob = bench.make_problem(0, False)
 surf = prob["surf"]
 ctx = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
-ctx.set_views(prob["views"]); ctx.set_surface(surf)
+ctx.set_views(prob["views"]); ctx.set_surface(surf); ctx.save_nodes()
 bench.run_steps(ctx, prob, 20)
 for rep in range(2):
     ctx.set_nodes(surf["nodes"]); ctx.set_active(None); ctx.synchronize()

@@ -13,7 +13,7 @@ for V in (1, 2, 3, 4):
     ctxs = []
     for v in range(V):
         c = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
-        c.set_views(prob["views"]); c.set_surface(surf)
+        c.set_views(prob["views"]); c.set_surface(surf); c.save_nodes()
         bench.run_steps(c, prob, 20); c.set_nodes(surf["nodes"])
         ctxs.append(c)
     res = [None] * V
