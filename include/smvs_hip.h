@@ -66,6 +66,30 @@ int smvs_ctx_create(int device, int width, int height, int n_subs,
 int smvs_ctx_destroy(smvs_ctx *ctx);
 int smvs_ctx_synchronize(smvs_ctx *ctx);
 
+/* Which implementation of ConjugateGradient::solve (conjugate_gradient.h:72-202)
+ * the context uses -- not in the reference, which has one.  All of them run
+ * the same preconditioned CG with the same termination rules (:136-198):
+ *   AUTO          the fastest one that applies: the chip-resident solver when
+ *                 the node grid fits the chip (<= 256 tiles of <= 512 nodes),
+ *                 with ONE grid-wide exchange per iteration (the scalars
+ *                 r.r, z.r, x.(b + r) follow by recurrence from six dot
+ *                 products taken before the step length is known); otherwise
+ *                 the streaming kernels
+ *   STREAMING     assembly kernel + two launches per iteration (csrc/cg.hip);
+ *                 any grid size
+ *   RESIDENT_REF  the chip-resident solver with the reference's operation
+ *                 order: d.Ad first, then r.r, z.r, x.(b + r) of the updated
+ *                 vectors (two exchanges per iteration); falls back to
+ *                 STREAMING when the grid does not fit
+ * A mode that cannot run (co-residency lost, grid too large) degrades to
+ * STREAMING; the choice never changes results beyond the summation order. */
+typedef enum {
+    SMVS_SOLVER_AUTO = 0,
+    SMVS_SOLVER_STREAMING = 1,
+    SMVS_SOLVER_RESIDENT_REF = 2
+} smvs_solver_mode;
+int smvs_ctx_set_solver(smvs_ctx *ctx, int mode);
+
 /* DepthOptimizer::prepare_correspondences, depth_optimizer.cc:679-699:
  * Mi[n_subs][9] row-major and ti[n_subs][3], already widened from the float
  * CameraInfo::fill_reprojection result; flen / inv_flen =

@@ -193,8 +193,10 @@ front_reconstruct(const orc_view_input *main_in, const orc_view_input *nbr_in,
     return d_main;
 }
 
-/* mve::image::depthmap_convert_conventions<float> [MVE-unverified]: multiply
- * (to_mve) or divide by |invproj (x + 0.5, y + 0.5, 1)| */
+/* mve::image::depthmap_convert_conventions<float> [MVE-unverified]: the ray
+ * length |invproj (x + 0.5, y + 0.5, 1)| is a float norm widened to double
+ * (`double len = px.norm()`), and the pixel is scaled in double and rounded
+ * once: dm *= (to_mve ? len : 1.0 / len) */
 static void
 front_convert_conventions(float *dm, int w, int h, const float *invproj,
     int to_mve)
@@ -208,8 +210,9 @@ front_convert_conventions(float *dm, int w, int h, const float *invproj,
                 v[r] = invproj[3 * r] * px + invproj[3 * r + 1] * py
                     + invproj[3 * r + 2];
             float const len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            double const len_d = (double)len;
             float *d = &dm[(size_t)y * w + x];
-            *d = to_mve ? *d * len : *d / len;
+            *d = (float)((double)*d * (to_mve ? len_d : 1.0 / len_d));
         }
 }
 

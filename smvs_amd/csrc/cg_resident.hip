@@ -1034,7 +1034,12 @@ resident_lds_bytes(int tw, int th)
 bool
 cg_resident_applies(smvs_ctx *ctx, int max_iterations)
 {
-    if (ctx->resident_disabled || max_iterations <= 1 || !ctx->has_surface)
+    if (ctx->resident_disabled || max_iterations <= 1 || !ctx->has_surface
+        || ctx->solver_mode == SMVS_SOLVER_STREAMING)
+        return false;
+    // the exchange tags carry the epoch (<= 2 per iteration + 1) in their low
+    // 16 bits beside the solve id: longer solves take the streaming kernels
+    if (2 * max_iterations + 1 > 0xFFFF)
         return false;
     static int const env_off = [] {
         const char *e = std::getenv("SMVS_CG_RESIDENT");

@@ -166,6 +166,7 @@ struct smvs_ctx {
     size_t res_zx_cap = 0;
     int resident_cus = 0, resident_lds = 0;
     bool resident_disabled = false;
+    int solver_mode = 0;            // smvs_solver_mode (smvs_ctx_set_solver)
     float *map_scratch = nullptr;   // depth / normal map output, W*H*3 floats
     double *light_partial = nullptr;  // per-block lighting sums (update.hip)
 

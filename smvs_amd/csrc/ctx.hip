@@ -157,7 +157,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     }
     (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
     (void)hipMemsetAsync(ctx->status, 0, sizeof(int) * I_NUM, ctx->stream);
-    (void)hipMemsetAsync(ctx->step_counter, 0, sizeof(unsigned long long), ctx->stream);
+    (void)hipMemsetAsync(ctx->step_counter, 0, 2 * sizeof(unsigned long long), ctx->stream);
     (void)hipMemsetAsync(ctx->zero_block, 0, 16 * sizeof(double), ctx->stream);
     for (int i = 0; i < 8; ++i)
         ctx->cg_progress[i] = 0;
@@ -235,6 +235,16 @@ smvs_ctx_synchronize(smvs_ctx *ctx)
     SMVS_REQUIRE(ctx != nullptr, "null context");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_set_solver(smvs_ctx *ctx, int mode)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    SMVS_REQUIRE(mode == SMVS_SOLVER_AUTO || mode == SMVS_SOLVER_STREAMING
+        || mode == SMVS_SOLVER_RESIDENT_REF, "unknown solver mode");
+    ctx->solver_mode = mode;
     return SMVS_OK;
 }
 
@@ -468,6 +478,9 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
     ctx->has_surface = true;
     ctx->has_system = false;
     ctx->cg_use_active = false;
+    // saved nodes belong to the surface they were saved from (same grid size
+    // does not mean same surface)
+    ctx->nodes_saved_count = 0;
     return SMVS_OK;
 }
 

@@ -175,6 +175,7 @@ DepthOptimizer::DepthOptimizer(StereoView::Ptr main_view,
     check(smvs_ctx_create(opts.device, main_view->get_width(),
         main_view->get_height(), (int)sub_views.size(), &this->ctx),
         "smvs_ctx_create");
+    check(smvs_ctx_set_solver(ctx, opts.solver), "smvs_ctx_set_solver");
     check(smvs_ctx_set_cameras(ctx, Mi.data(), ti.data(),
         main_view->get_flen(), main_view->get_inverse_flen()),
         "smvs_ctx_set_cameras");
@@ -303,7 +304,17 @@ DepthOptimizer::upload_surface(void)
     // Newton loop's result is downloaded into the host surface, so the
     // cut_boundaries / get_depth / get_normals that follow it find the
     // device copy current.
+    if (surface == nullptr)
+        throw std::logic_error("DepthOptimizer: no surface (call optimize() "
+            "first or use the constructor that takes one)");
     Surface const& s = *surface;
+    // (a surface handed to the constructor, or one that changed its grid, has
+    // no visibility masks yet: get_depth() / get_normals() before optimize(),
+    // lib/depth_optimizer.h:53-61)
+    if (subsurfaces.size() != (std::size_t)s.get_num_patches()) {
+        subsurfaces.assign(s.get_num_patches(), 0);
+        subs_rev += 1;
+    }
     if (uploaded_surface == surface.get() && uploaded_rev == s.revision()
         && uploaded_subs_rev == subs_rev)
         return;

@@ -31,6 +31,7 @@ public:
         bool full_optimization = false;
         std::string output_name = "smvs";
         int device = 0;  // HIP device (not in the reference)
+        int solver = 0;  // smvs_solver_mode of include/smvs_hip.h (not in the reference)
     };
 
     struct IterationLog

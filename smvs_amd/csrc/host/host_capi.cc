@@ -79,6 +79,7 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
         opts.use_sgm = o->use_sgm != 0;
         opts.full_optimization = o->full_optimization != 0;
         opts.device = o->device;
+        opts.solver = o->solver;
         DepthOptimizer optimizer(main_view, subs, bundle, opts);
         optimizer.optimize();
         size_t const npix = (size_t)main_in->width * main_in->height;
@@ -292,6 +293,43 @@ smvs_host_sgm_image(const smvs_host_view *view_in, int halvings, uint8_t *out,
         *out_w = img->width();
         *out_h = img->height();
         std::memcpy(out, img->begin(), (size_t)img->width() * img->height());
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_surface_maps(const smvs_host_view *main_in, const smvs_host_view *subs_in,
+    int n_subs, const smvs_host_bundle *bundle_in, const float *init_depth,
+    int init_scale, int device, float *depth_out, float *normals_out)
+{
+    try {
+        if (main_in == nullptr || subs_in == nullptr || n_subs < 1
+            || depth_out == nullptr || normals_out == nullptr)
+            throw std::invalid_argument("smvs_host_surface_maps: bad argument");
+        StereoView::Ptr main_view = make_view(*main_in, false);
+        std::vector<StereoView::Ptr> subs;
+        for (int j = 0; j < n_subs; ++j)
+            subs.push_back(make_view(subs_in[j], false));
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        FloatImage::Ptr init;
+        if (init_depth != nullptr) {
+            init = FloatImage::create(main_in->width, main_in->height, 1);
+            std::memcpy(init->begin(), init_depth,
+                sizeof(float) * (size_t)main_in->width * main_in->height);
+        }
+        Surface::Ptr surface = Surface::create(bundle, main_view, init_scale, init);
+        DepthOptimizer::Options opts;
+        opts.device = device;
+        // lib/depth_optimizer.h:53-61: the surface constructor, then the
+        // maps without a prior optimize()
+        DepthOptimizer optimizer(main_view, subs, surface, opts);
+        size_t const npix = (size_t)main_in->width * main_in->height;
+        std::memcpy(depth_out, optimizer.get_depth()->begin(), sizeof(float) * npix);
+        std::memcpy(normals_out, optimizer.get_normals()->begin(),
+            sizeof(float) * 3 * npix);
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();

@@ -34,6 +34,7 @@ typedef struct {                /* DepthOptimizer::Options */
     int use_sgm;
     int full_optimization;
     int device;
+    int solver;                 /* smvs_solver_mode of include/smvs_hip.h */
 } smvs_host_options;
 
 #define SMVS_HOST_LOG_MAX 256
@@ -78,6 +79,14 @@ int smvs_host_surface_script(const smvs_host_view *main_view,
     const smvs_host_bundle *bundle, const float *init_depth, int init_scale,
     const int *ops, int n_ops, int delete_every, int *info, double *nodes_out,
     uint8_t *node_valid_out, uint8_t *patch_valid_out);
+
+/* DepthOptimizer(main, subs, Surface::Ptr, opts) followed by get_depth() /
+ * get_normals() WITHOUT optimize() (lib/depth_optimizer.h:53-61): the maps of
+ * the surface Surface::create builds (from the bundle, or from init_depth). */
+int smvs_host_surface_maps(const smvs_host_view *main_view,
+    const smvs_host_view *subs, int n_subs, const smvs_host_bundle *bundle,
+    const float *init_depth, int init_scale, int device, float *depth_out,
+    float *normals_out);
 
 /* Host-only pieces of the SGM front end, for CPU tests (no device involved):
  *   smvs_host_depth_range: SGMStereo::fill_depth_range_for_view

@@ -151,8 +151,11 @@ depthmap_convert_conventions(FloatImage::Ptr dm, float const* invproj,
                 v[r] = invproj[3 * r] * px + invproj[3 * r + 1] * py
                     + invproj[3 * r + 2];
             float const len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-            dm->at(x, y, 0) = to_mve ? dm->at(x, y, 0) * len
-                : dm->at(x, y, 0) / len;
+            // `double len = px.norm(); dm *= (to_mve ? len : 1.0 / len)`
+            // [MVE-unverified, tests/golden/README.md M10]
+            double const len_d = (double)len;
+            dm->at(x, y, 0) = (float)((double)dm->at(x, y, 0)
+                * (to_mve ? len_d : 1.0 / len_d));
         }
 }
 

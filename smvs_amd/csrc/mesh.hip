@@ -124,7 +124,9 @@ mesh_prepare_kernel(const MeshViewDev *views, int i)
         v[r] = V.invproj[3 * r] * px + V.invproj[3 * r + 1] * py
             + V.invproj[3 * r + 2];
     float const len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    V.depth_z[p] = d / len;
+    // (depthmap_convert_conventions: `double len = px.norm(); dm *= 1.0 / len`,
+    // tests/golden/README.md M10)
+    V.depth_z[p] = (float)((double)d * (1.0 / (double)len));
 }
 
 // cut_depth_maps :61-150 for view i

@@ -254,6 +254,9 @@ struct FinishArgs {
     int *status;
     unsigned long long *counter;   // bits 0-23 list length, 24-47 active nodes,
                                    // 48-63 workgroups arrived: ONE atomic per workgroup
+                                   // (wide: [0] = list length | active nodes << 32,
+                                   // [1] = workgroups arrived)
+    int wide;              // surfaces of 2^24 nodes and more: two atomics per workgroup
     const double *scalars;
     int *host_words;       // pinned slot (STEP_SLOT_INTS ints): [0] sequence tag,
                            // [1] active nodes, [2] NaN, [3] active patches of the
@@ -325,6 +328,7 @@ finish_step_kernel(FinishArgs A)
     __shared__ int wave_cnt[WAVES];
     __shared__ int base;
     __shared__ unsigned long long seen;
+    __shared__ bool last_wide;
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long const ballot = __ballot(live);
     int const before = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -337,11 +341,29 @@ finish_step_kernel(FinishArgs A)
             total += wave_cnt[wv];
         // one device-scope atomic per workgroup (atomics on one address are
         // served one after the other): list slots, active nodes and arrival
-        unsigned long long const add = (unsigned long long)total
-            | ((unsigned long long)cnt_on << 24) | (1ull << 48);
-        unsigned long long const old = atomicAdd(A.counter, add);
-        base = (int)(old & 0xFFFFFFull);
-        seen = old + add;
+        if (!A.wide) {
+            unsigned long long const add = (unsigned long long)total
+                | ((unsigned long long)cnt_on << 24) | (1ull << 48);
+            unsigned long long const old = atomicAdd(A.counter, add);
+            base = (int)(old & 0xFFFFFFull);
+            seen = old + add;
+        } else {
+            // the counts no longer fit beside the arrivals: the counts first
+            // (the returned value orders it before the arrival), then the
+            // arrival; the last arriver reads the totals back
+            unsigned long long const add = (unsigned long long)total
+                | ((unsigned long long)cnt_on << 32);
+            unsigned long long const old = atomicAdd(A.counter, add);
+            base = (int)(old & 0xFFFFFFFFull);
+            unsigned long long const arrived = atomicAdd(A.counter + 1, 1ull) + 1ull;
+            unsigned long long totals = 0ull;
+            if (arrived == (unsigned long long)gridDim.x)
+                totals = atomicAdd(A.counter, 0ull);
+            // same layout as the packed word: length, active nodes, arrivals
+            // (the packed fields are only decoded below)
+            seen = arrived == (unsigned long long)gridDim.x ? totals : 0ull;
+            last_wide = arrived == (unsigned long long)gridDim.x;
+        }
     }
     __syncthreads();
     if (live) {
@@ -352,10 +374,15 @@ finish_step_kernel(FinishArgs A)
     }
     // the workgroup that arrives last publishes the step (no fences: the
     // counters travelled in the atomic itself)
-    if (threadIdx.x == 0 && (seen >> 48) == (unsigned long long)gridDim.x) {
-        int const next_live = (int)(seen & 0xFFFFFFull);
-        int const num_active = (int)((seen >> 24) & 0xFFFFFFull);
-        *A.counter = 0ull;   // (nobody else touches it any more) for the next launch
+    bool const last = A.wide ? last_wide
+        : (seen >> 48) == (unsigned long long)gridDim.x;
+    if (threadIdx.x == 0 && last) {
+        int const next_live = A.wide ? (int)(seen & 0xFFFFFFFFull)
+            : (int)(seen & 0xFFFFFFull);
+        int const num_active = A.wide ? (int)(seen >> 32)
+            : (int)((seen >> 24) & 0xFFFFFFull);
+        A.counter[0] = 0ull;   // (nobody else touches them any more) for the next launch
+        A.counter[1] = 0ull;
         if (begin) {
             A.status[I_NUM_INITIAL] = num_active;
             A.status[I_STEP_ABORT] = 0;
@@ -397,6 +424,8 @@ finish_step_kernel(FinishArgs A)
     }
 }
 
+int loop_test_mode(void);   // SMVS_LOOP_TEST, below
+
 static FinishArgs
 finish_args(smvs_ctx *ctx, int seq)
 {
@@ -416,6 +445,7 @@ finish_args(smvs_ctx *ctx, int seq)
     F.npy = ctx->npy;
     F.stride = ctx->node_stride;
     F.num_nodes = ctx->num_nodes;
+    F.wide = ctx->num_nodes >= (1 << 24) || loop_test_mode() == 4 ? 1 : 0;
     F.full_optimization = 0;
     F.seq = seq;
     F.check_stop = 0;
@@ -834,9 +864,11 @@ next_step_seq(smvs_ctx *ctx)
 // SMVS_LOOP_TEST (tests/test_gpu_parity.py, tools/cg_trace.py): "undersize"
 // sizes every launch-ahead step for half the list, "solver" makes the second
 // solve of a loop report that it gave up, "unpipelined" runs the fused steps
-// one at a time (the host waits for each solve: what SMVS_CG_TRACE needs).
-static int
-loop_test_mode(void)
+// one at a time (the host waits for each solve: what SMVS_CG_TRACE needs),
+// "wide" uses the end-of-step kernel's counters for surfaces of 2^24 nodes and
+// more on any surface.
+int
+smvs_hip::loop_test_mode(void)
 {
     static int const mode = [] {
         const char *e = std::getenv("SMVS_LOOP_TEST");
@@ -844,7 +876,8 @@ loop_test_mode(void)
             return 0;
         return std::strcmp(e, "undersize") == 0 ? 1
             : std::strcmp(e, "solver") == 0 ? 2
-            : std::strcmp(e, "unpipelined") == 0 ? 3 : 0;
+            : std::strcmp(e, "unpipelined") == 0 ? 3
+            : std::strcmp(e, "wide") == 0 ? 4 : 0;
     }();
     return mode;
 }
@@ -954,10 +987,15 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         }
         return r;
     };
-    if ((rc = enqueue()) != SMVS_OK) {
-        (void)drain();
-        return rc;
-    }
+    // An error exit must not release the device's barrier-kernel mutex while
+    // launches of this loop may still be in flight: wait for the stream (the
+    // result words may never come, so no drain()).
+    auto fail = [&](int r) -> int {
+        (void)hipStreamSynchronize(ctx->stream);
+        return r;
+    };
+    if ((rc = enqueue()) != SMVS_OK)
+        return fail(rc);
     // A step enqueued behind the end of the loop costs four empty launches
     // (~20 us); a step that was not enqueued ahead costs the host's turn-around
     // (~25 us) once its predecessor has ended.  So the next step is enqueued
@@ -978,14 +1016,12 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     for (;;) {
         if (enqueued < prm->max_newton_steps
             && (in_flight == 0 || (in_flight < 2 && likely_to_go_on())))
-            if ((rc = enqueue()) != SMVS_OK) {
-                (void)drain();
-                return rc;
-            }
+            if ((rc = enqueue()) != SMVS_OK)
+                return fail(rc);
         if (L.begin_seq != 0) {
             // (published long before the first step ends)
             if ((rc = read_loop_begin(ctx, L)) != SMVS_OK)
-                return rc;
+                return fail(rc);
             if (!loop_goes_on(prm, L)) {
                 // no active node: the steps in flight report themselves skipped
                 L.ended = true;
@@ -994,14 +1030,14 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         }
         const int *words = nullptr;
         if ((rc = wait_step_words(ctx, seqs[0], &words)) != SMVS_OK)
-            return rc;
+            return fail(rc);
         seqs[0] = seqs[1];
         in_flight -= 1;
         if (words[5] == 1 + ABORT_SOLVER || words[5] == 1 + ABORT_GRID) {
             // this step and the one behind it did nothing
             bool const solver = words[5] == 1 + ABORT_SOLVER;
             if ((rc = drain()) != SMVS_OK)
-                return rc;
+                return fail(rc);
             SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_STOP, 0,
                 2 * sizeof(int), ctx->stream));
             enqueued = L.newton_step;
@@ -1016,13 +1052,12 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             // the live list outgrew the launch: again, sized for the list
             // length that has come back in the meantime
             if ((rc = enqueue()) != SMVS_OK)
-                return rc;
+                return fail(rc);
             continue;
         }
         if (words[5] != 0) {
             set_error("smvs_gn_run_loop: a step was skipped before the loop ended");
-            (void)drain();
-            return SMVS_ERR_STATE;
+            return fail(SMVS_ERR_STATE);
         }
         ctx->last_cg_iterations = words[6];
         account_step(prm, stats, L, words, words[6]);
@@ -1035,8 +1070,7 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
         if (L.ended != (words[7] != 0)) {
             set_error("smvs_gn_run_loop: host and device disagree on the end "
                 "of the loop");
-            (void)drain();
-            return SMVS_ERR_STATE;
+            return fail(SMVS_ERR_STATE);
         }
         if (L.ended || L.newton_step >= prm->max_newton_steps)
             break;
@@ -1070,9 +1104,8 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     SMVS_REQUIRE(prm->cg_max_iterations >= 0 && prm->cg_max_iterations <= 0xFFFF,
         "cg_max_iterations out of range [0, 65535]");
     // (finish_step_kernel packs the list length and the active-node count
-    // into 24 bits each of one atomic)
-    SMVS_REQUIRE(ctx->num_nodes < (1 << 24),
-        "surface too large for the Newton loop (2^24 nodes)");
+    // into 24 bits each of one atomic; larger surfaces use two atomics per
+    // workgroup, FinishArgs::wide)
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     memset(stats, 0, sizeof(*stats));
     int rc;

@@ -57,6 +57,12 @@ class ViewContext:
         except Exception:
             pass
 
+    SOLVERS = dict(auto=0, streaming=1, resident_ref=2)
+
+    def set_solver(self, mode):
+        """smvs_ctx_set_solver: 'auto' | 'streaming' | 'resident_ref'."""
+        check(self.lib.smvs_ctx_set_solver(self.handle, self.SOLVERS[mode]))
+
     # ------------------------------------------------------------ uploads
     def set_views(self, views):
         """views: dict as produced by smvs_amd.synth.make_problem."""

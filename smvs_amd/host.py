@@ -32,7 +32,8 @@ class HostOptions(C.Structure):
                 ("light_surf_regularization", C.c_double),
                 ("num_iterations", C.c_int), ("min_scale", C.c_int),
                 ("use_shading", C.c_int), ("use_sgm", C.c_int),
-                ("full_optimization", C.c_int), ("device", C.c_int)]
+                ("full_optimization", C.c_int), ("device", C.c_int),
+                ("solver", C.c_int)]
 
 
 class HostLog(C.Structure):
@@ -89,13 +90,14 @@ def _marshal(inputs, keep):
 
 def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
              min_scale=2, use_shading=False, sgm_depth=None,
-             full_optimization=False, device=0):
+             full_optimization=False, device=0, solver="auto"):
     lib = load()
     keep = []
     main, subs, n_subs, b = _marshal(inputs, keep)
     o = HostOptions(regularization, light_reg, num_iterations, min_scale,
                     1 if use_shading else 0, 1 if sgm_depth is not None else 0,
-                    1 if full_optimization else 0, device)
+                    1 if full_optimization else 0, device,
+                    dict(auto=0, streaming=1, resident_ref=2)[solver])
     h, w = main.height, main.width
     depth = np.zeros((h, w), dtype=np.float32)
     normals = np.zeros((h, w, 3), dtype=np.float32)
@@ -208,6 +210,24 @@ def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3):
     return dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
                 nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
                 patch_valid=pv[:npatch].copy())
+
+
+def surface_maps(inputs, init_scale, init_depth=None, device=0):
+    """DepthOptimizer(main, subs, surface, opts).get_depth() / get_normals()
+    without optimize() (lib/depth_optimizer.h:53-61)."""
+    lib = load()
+    keep = []
+    main, subs, n_subs, b = _marshal(inputs, keep)
+    h, w = main.height, main.width
+    depth = np.zeros((h, w), dtype=np.float32)
+    normals = np.zeros((h, w, 3), dtype=np.float32)
+    init = None if init_depth is None else np.ascontiguousarray(init_depth, dtype=np.float32)
+    rc = lib.smvs_host_surface_maps(C.byref(main), subs, n_subs, C.byref(b),
+        init.ctypes.data_as(_fp) if init is not None else None, C.c_int(init_scale),
+        C.c_int(device), depth.ctypes.data_as(_fp), normals.ctypes.data_as(_fp))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return depth, normals
 
 
 def depth_range(inputs, view_index=0):

@@ -258,3 +258,52 @@ def test_config5_lighting_round_on_device_buffers(hip, oracle):
     assert _rel(H9, ref["H9"]) < 1e-9 and _rel(g, ref["g"]) < 1e-9
     for c in ctxs:
         c.close()
+
+
+def test_config5_whole_pipeline_round_robin(hip, oracle, oracle_threads):
+    """configs[4] as one rank runs it: four reference views round-robin, each
+    through the WHOLE per-view pipeline with -S (optimize(): scale loop, SH
+    lighting fit per view, shading residual) on one GPU, against the oracle's
+    optimize() of the same view: identical batch logs, same valid pixels,
+    depth within 1e-4, lighting within 1e-3 (ill-conditioned 16 x 16 system)."""
+    from smvs_amd import synth, host
+    rng = np.random.default_rng(4100)
+    for view in range(4):
+        lighting = np.zeros(16); lighting[0] = 0.85
+        lighting[1:4] = rng.uniform(-0.2, 0.2, 3)
+        inputs = synth.pipeline_inputs("sphere", 320 + 32 * view, 240, 3, flen=1.2,
+                                       lighting=lighting)
+        got = host.optimize(inputs, regularization=0.01, num_iterations=3, min_scale=2,
+                            use_shading=True)
+        want = oracle.optimize(inputs, regularization=0.01, num_iterations=3,
+                               min_scale=2, use_shading=True)
+        assert _same_control_flow(got["log"], want["log"]), (view, got["log"], want["log"])
+        assert got["lighting"] is not None and want["lighting"] is not None
+        assert _rel(got["lighting"], want["lighting"]) < 1e-3
+        assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+        assert _rel(got["depth"], want["depth"]) <= 1e-4, view
+
+
+def test_surface_constructor_maps_without_optimize(hip, oracle):
+    """DepthOptimizer(main, subs, Surface::Ptr, opts).get_depth() /
+    get_normals() before any optimize() (lib/depth_optimizer.h:53-61): the maps
+    of the surface as it was passed in."""
+    from smvs_amd import synth, host
+    inputs = synth.pipeline_inputs("plane", 320, 240, 2)
+    depth, normals = host.surface_maps(inputs, init_scale=4)
+    surf = oracle.surface_script(inputs, 4, [])
+    surf.update(width=320, height=240,
+                patch_vis=np.zeros(surf["npx"] * surf["npy"], np.uint32))
+    views = dict(M=np.eye(3).reshape(1, 9), t=np.zeros((1, 3)), flen=1.0,
+                 inv_flen=float(np.float32(1.0) / (np.float32(inputs["cams"][0].flen)
+                                                   * np.float32(320))),
+                 grad=np.zeros((240, 320, 2), np.float32),
+                 subs=[(np.zeros((240, 320, 2), np.float32),
+                        np.zeros((240, 320, 3), np.float32))])
+    orc = oracle.OracleProblem(surf, views)
+    want = orc.depth_map()
+    assert (want > 0).mean() > 0.3
+    assert np.array_equal(depth == 0, want == 0)
+    assert _rel(depth, want) < 1e-6
+    n_want = orc.normal_map()
+    assert np.max(np.abs(normals - n_want)) < 1e-5
