@@ -356,6 +356,15 @@ typedef struct {
 
 int smvs_cut_depth_maps(int device, smvs_mesh_view *views, int n_views);
 
+/* The context-free entry points above (smvs_sgm_run, smvs_sgm_depth_for_view,
+ * smvs_bilateral_upsample, smvs_cut_depth_maps) draw their device buffers,
+ * stream and pinned staging memory from a per-device pool of workspaces that
+ * is kept between calls (the reference allocates its volumes per SGMStereo
+ * object, lib/sgm_stereo.cc:192-225; a device allocation per call costs more
+ * than the kernels).  Concurrent callers get different workspaces.  This
+ * returns the pooled memory to the driver; -> number of workspaces freed. */
+int smvs_release_workspaces(void);
+
 /* ------------------------------------------------------------------ */
 /* measurement                                                        */
 /* ------------------------------------------------------------------ */

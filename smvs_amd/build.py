@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmvs_hip.so")
 SOURCES = ["ctx.hip", "gn_construct.hip", "cg.hip", "cg_resident.hip", "update.hip", "sgm.hip",
-           "scale.hip", "topology.hip", "mesh.hip"]
+           "scale.hip", "topology.hip", "mesh.hip", "pool.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 
@@ -24,7 +24,7 @@ def _stale():
 HOST_DIR = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libsmvs_host.so")
 HOST_SOURCES = ["camera.cc", "stereo_view.cc", "surface.cc", "sgm_stereo.cc",
-                "depth_optimizer.cc", "view_selection.cc", "host_capi.cc"]
+                "depth_optimizer.cc", "view_selection.cc", "view_queue.cc", "host_capi.cc"]
 
 
 def _host_stale():
@@ -43,7 +43,7 @@ def build_host(force=False, verbose=False):
     if not force and not _host_stale():
         return HOST_LIB
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-shared", "-o", HOST_LIB] \
+    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-pthread", "-shared", "-o", HOST_LIB] \
         + [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] \
         + ["-L" + CSRC, "-lsmvs_hip", "-Wl,-rpath,$ORIGIN/..",
            "-Wl,-rpath,/opt/rocm/lib"]

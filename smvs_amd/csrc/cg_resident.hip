@@ -57,9 +57,17 @@ struct ResState {           // mirrors CgState of cg.hip
 // 8-byte granules {tag = epoch, 32 data bits}: the data is its own flag
 // (cdna_hip_programming.md Guideline 16, form R2), so one sweep over the
 // granules of all workgroups is barrier and all-reduce at once.
-constexpr int RES_KINDS = 3;                 // doubles per all-reduce, at most
+constexpr int RES_KINDS = 8;                 // doubles per all-reduce, at most
+constexpr int RES_GROUP = 16;                                  // workgroups per first-level group
+constexpr int RES_MAX_GROUPS = RES_MAX_BLOCKS / RES_GROUP;
 struct ResExchange {
+    // flat all-reduce (two-exchange solver): every workgroup sweeps all of these
     unsigned long long gran[2][2 * RES_KINDS][RES_MAX_BLOCKS];   // [parity][..][wg]
+    // tree all-reduce (one-exchange solver): a double is the pair {lo, hi} of
+    // adjacent granules; the first workgroup of a group of RES_GROUP sums its
+    // group's partial sums into lvl2, every workgroup sums the groups
+    unsigned long long lvl1[2][RES_MAX_BLOCKS][RES_KINDS][2];    // [parity][wg][kind]
+    unsigned long long lvl2[2][RES_MAX_GROUPS][RES_KINDS][2];    // [parity][group][kind]
     unsigned timeout;
 };
 
@@ -181,6 +189,108 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
         double4_r const gv = *reinterpret_cast<const double4_r *>(
             pv[q] ? A.gp + (size_t)pidx[q] * 16 + 4 * ln : A.zeros);
         S.g[0] += gv.x; S.g[1] += gv.y; S.g[2] += gv.z; S.g[3] += gv.w;
+    }
+}
+
+// The diagonal block (upper triangle) and the gradient of node (ix, iy) alone,
+// with assemble_node's sums in assemble_node's order: what the one-exchange
+// solver needs of a HALO node to form that node's z = P r itself.
+__device__ __forceinline__ void
+assemble_diagonal(ResArgs const &A, int ix, int iy, double (&hd)[10], double (&g)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+        hd[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        g[i] = 0.0;
+    int const n = iy * A.stride + ix;
+    uint8_t const fself = A.active[n];
+    int pidx[4];
+    bool pv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int const pxq = ix - (1 - (q & 1));
+        int const pyq = iy - (1 - (q >> 1));
+        bool const inside = pxq >= 0 && pxq < A.npx && pyq >= 0 && pyq < A.npy;
+        pidx[q] = inside ? pyq * A.npx + pxq : 0;
+        uint8_t const f = A.patch_valid[pidx[q]];
+        pv[q] = inside && f != 0;
+    }
+    if (fself == 0)
+        return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int const ln = 3 - q;   // local index of the node in that patch
+        const double4_r *blk = reinterpret_cast<const double4_r *>(pv[q]
+            ? A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE + upper_block(ln, ln) * 16
+            : A.zeros);
+        double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
+        hd[0] += b0.x; hd[1] += b0.y; hd[2] += b0.z; hd[3] += b0.w;
+        hd[4] += b1.y; hd[5] += b1.z; hd[6] += b1.w;
+        hd[7] += b2.z; hd[8] += b2.w;
+        hd[9] += b3.w;
+        double4_r const gv = *reinterpret_cast<const double4_r *>(
+            pv[q] ? A.gp + (size_t)pidx[q] * 16 + 4 * ln : A.zeros);
+        g[0] += gv.x; g[1] += gv.y; g[2] += gv.z; g[3] += gv.w;
+    }
+}
+
+// The four upper blocks (slots 5..8) of node (ix, iy) alone, with
+// assemble_node's sums in assemble_node's order.
+__device__ __forceinline__ void
+assemble_upper(ResArgs const &A, int ix, int iy, bool on, double (&hu)[4][16])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            hu[k][i] = 0.0;
+    if (!on)
+        return;
+    int const n = iy * A.stride + ix;
+    int const rows = A.npy + 1;
+    bool act[2][3], pv[4];   // nodes (dx, dy) with dy in {0, 1}: the upper slots' ends
+#pragma unroll
+    for (int dy = 0; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            int const jx = ix + dx, jy = iy + dy;
+            bool const inside = jx >= 0 && jx < A.stride && jy >= 0 && jy < rows;
+            uint8_t const f = A.active[inside ? jy * A.stride + jx : n];
+            act[dy][dx + 1] = inside && f != 0;
+        }
+    int pidx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int const pxq = ix - (1 - (q & 1));
+        int const pyq = iy - (1 - (q >> 1));
+        bool const inside = pxq >= 0 && pxq < A.npx && pyq >= 0 && pyq < A.npy;
+        pidx[q] = inside ? pyq * A.npx + pxq : 0;
+        uint8_t const f = A.patch_valid[pidx[q]];
+        pv[q] = inside && f != 0;
+    }
+    if (!act[0][1])
+        return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int const ln = 3 - q;   // local index of the node in that patch
+        const double *Hl = A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE;
+#pragma unroll
+        for (int lm = 0; lm < 4; ++lm) {
+            if (lm <= ln)
+                continue;
+            int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
+            bool const use = pv[q] && act[dy][dx + 1];
+            const double4_r *blk = reinterpret_cast<const double4_r *>(
+                use ? Hl + upper_block(ln, lm) * 16 : A.zeros);
+            double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
+            int const k = (dy + 1) * 3 + dx + 1 - 5;
+            hu[k][0] += b0.x; hu[k][1] += b0.y; hu[k][2] += b0.z; hu[k][3] += b0.w;
+            hu[k][4] += b1.x; hu[k][5] += b1.y; hu[k][6] += b1.z; hu[k][7] += b1.w;
+            hu[k][8] += b2.x; hu[k][9] += b2.y; hu[k][10] += b2.z; hu[k][11] += b2.w;
+            hu[k][12] += b3.x; hu[k][13] += b3.y; hu[k][14] += b3.z; hu[k][15] += b3.w;
+        }
     }
 }
 
@@ -323,11 +433,12 @@ ld_agent(const double *p)
     return __longlong_as_double((long long)v);
 }
 
-// Sum K per-thread values over the workgroup in a fixed order; every thread
-// gets the result.
+// First half of a workgroup sum of K per-thread values: the per-wave sums go
+// to red[K][RES_WAVES]; after the barrier inside, the sum of kind k is
+// red[k][0] + ... + red[k][RES_WAVES - 1] in that order (block_total).
 template <int K>
 __device__ __forceinline__ void
-block_sum(double (&v)[K], double *red /*[K][RES_WAVES]*/)
+block_partials(double const (&v)[K], double *red /*[K][RES_WAVES]*/)
 {
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -340,52 +451,60 @@ block_sum(double (&v)[K], double *red /*[K][RES_WAVES]*/)
             red[k * RES_WAVES + wave] = s;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double s = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < RES_WAVES; ++wv)
-            s += red[k * RES_WAVES + wv];
-        v[k] = s;
-    }
-    // (no barrier: the partials are next written by the following block_sum,
-    // and every thread passes the caller's barrier behind the sweep first)
+    // (no second barrier: the partials are next written by the following
+    // block_partials, and every thread passes the caller's barrier behind the
+    // sweep first)
 }
+
+__device__ __forceinline__ double
+block_total(const double *red, int k)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < RES_WAVES; ++wv)
+        s += red[k * RES_WAVES + wv];
+    return s;
+}
+
+struct NoIdleWork {
+    __device__ __forceinline__ void operator()() const {}
+};
 
 // All-reduce of K doubles over the workgroups of the grid, and the grid-wide
 // synchronisation point of the phase: every workgroup publishes its K sums as
-// tagged granules AFTER its write-through stores of the phase have drained;
-// wave 0 of every workgroup sweeps the granules of all workgroups until every
-// tag carries this epoch, then all sum them in the same fixed order.  Seeing a
-// workgroup's granule implies seeing the z it stored before.  The slots are
+// tagged granules; K waves of every workgroup (kind k each, waves FIRST ..
+// FIRST + K - 1) sweep the granules of all workgroups until every tag carries
+// this epoch, then all sum them in the same fixed order.  The slots are
 // double-buffered by epoch parity: a workgroup can publish epoch e + 2 only
 // after everybody published e + 1, i.e. after everybody finished reading e.
-// Returns false after a bounded wait (a workgroup is not resident / gave up).
-template <int K>
+// The waves that do not sweep run `idle` meanwhile (the halo of the
+// one-exchange solver).  Returns false after a bounded wait (a workgroup is
+// not resident / gave up).
+template <int K, int FIRST, typename Idle>
 __device__ __forceinline__ bool
 grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
-    double (&v)[K], double *red, int *lds_flag)
+    double (&v)[K], double *red, int *lds_flag, Idle idle)
 {
+    static_assert(K <= RES_KINDS && FIRST + K <= RES_WAVES, "sweeping waves");
     // tags carry the solve id: granules of earlier solves never match, so the
     // exchange area needs no clearing between solves
     unsigned const tag = solve_tag | epoch;
-    double *res = red + 4 * RES_WAVES;   // [4] results, behind the partial sums
-    block_sum<K>(v, red);
+    double *res = red + RES_KINDS * RES_WAVES;   // [K] results, behind the partial sums
+    block_partials<K>(v, red);
     // (nothing to drain: everything that crosses workgroups is a granule, the
     // vectors of the solve live in registers and LDS)
     unsigned const par = epoch & 1u;
     if (threadIdx.x < 2 * K) {
+        // (only the publishing threads need the workgroup's sums)
         int const k = threadIdx.x >> 1, half = threadIdx.x & 1;
-        unsigned long long const bits = (unsigned long long)__double_as_longlong(v[k]);
+        unsigned long long const bits = (unsigned long long)__double_as_longlong(
+            block_total(red, k));
         unsigned const word = half ? (unsigned)(bits >> 32) : (unsigned)bits;
         __hip_atomic_store(&ex->gran[par][threadIdx.x][blockIdx.x],
             ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_AGENT);
     }
-    // Waves 3 .. 3 + K - 1 sweep (kind k each, side by side): they hold the
-    // middle rows of the tile and have next to no rim stores of their own in
-    // flight, which a wave's loads would have to wait behind (one counter).
-    int const wave = (int)(threadIdx.x >> 6) - 3;
+    int const wave = (int)(threadIdx.x >> 6) - FIRST;
     if (wave >= 0 && wave < K) {
         int const lane = threadIdx.x & 63;
         constexpr int PER_LANE = RES_MAX_BLOCKS / 64;
@@ -439,10 +558,12 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
                 ok = false;
             lds_flag[wave] = ok ? 1 : 0;
         }
+    } else {
+        idle();
     }
     __syncthreads();
     // The results live apart from the partial sums, so two workgroup barriers
-    // per all-reduce are enough (one inside block_sum, this one): results and
+    // per all-reduce are enough (one inside block_partials, this one): results and
     // flags are next written behind the next all-reduce's first barrier, which
     // every thread reaches only after it has read these.
     bool ok = true;
@@ -454,7 +575,336 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
     return ok;
 }
 
-template <bool FUSED>
+// One double as a pair of adjacent tagged granules: every lane of the wave
+// polls its own pair until all lanes see their tag (inactive lanes take no
+// part and get 0).  Wave-uniform result: false after a bounded wait.
+__device__ __forceinline__ bool
+poll_pairs(const unsigned long long *pair, bool active, unsigned tag,
+    ResExchange *ex, double *value)
+{
+    unsigned long long g0 = (unsigned long long)tag << 32, g1 = g0;
+    bool good = true;
+    for (unsigned spins = 0;; ++spins) {
+        if (active) {
+            g0 = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool const ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+        if (__all(ok))
+            break;
+        if (spins > (1u << 18)
+            || ((spins & 255u) == 255u
+                && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            good = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned long long const bits = (g1 << 32) | (g0 & 0xFFFFFFFFull);
+    *value = active ? __longlong_as_double((long long)bits) : 0.0;
+    return good;
+}
+
+// Sum over the 16 lanes of an aligned segment, fixed order, every lane gets it.
+__device__ __forceinline__ double
+segment16_sum(double v)
+{
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+// All-reduce of K doubles over the workgroups in two levels.  The flat sweep
+// above makes every workgroup read every workgroup's K sums: 256 x 256 x K
+// granule pairs per exchange, all aimed at the same few KB -- measured, its
+// time grows with K (4.4 us for one sum, 6.2 for three, 12 for seven).  Here
+// the first workgroup of every group of RES_GROUP sums its group (16 x K
+// pairs), publishes the group's sums, and every workgroup sums the <= 16
+// groups: 2 x 16 x K pairs per workgroup and exchange instead of 256 x K, two
+// hops instead of one.  Lane (kind, j) of the sweeping waves 1 .. (K + 3) / 4
+// handles member / group j of one kind; the other waves run `idle`.  Same
+// guarantees as the flat form: fixed summation order (a tree over the members
+// of a group, then a tree over the groups), bit-identical results in every
+// workgroup, slots double-buffered by epoch parity, bounded waits.
+template <int K, typename Idle>
+__device__ __forceinline__ bool
+grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
+    double (&v)[K], double *red, int *lds_flag, Idle idle)
+{
+    constexpr int SWEEPERS = (K + 3) / 4;
+    static_assert(K <= RES_KINDS && 1 + SWEEPERS <= RES_WAVES, "sweeping waves");
+    unsigned const tag = solve_tag | epoch;
+    double *res = red + RES_KINDS * RES_WAVES;
+    block_partials<K>(v, red);
+    unsigned const par = epoch & 1u;
+    int const b = (int)blockIdx.x;
+    if (threadIdx.x < 2 * K) {
+        int const k = threadIdx.x >> 1, half = threadIdx.x & 1;
+        unsigned long long const bits = (unsigned long long)__double_as_longlong(
+            block_total(red, k));
+        unsigned const word = half ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(&ex->lvl1[par][b][k][half],
+            ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int const wave = (int)(threadIdx.x >> 6) - 1;
+    if (wave >= 0 && wave < SWEEPERS) {
+        int const lane = threadIdx.x & 63;
+        int const kind = 4 * wave + (lane >> 4), j = lane & 15;
+        bool const kind_ok = kind < K;
+        bool ok = true;
+        if (b % RES_GROUP == 0) {
+            // this workgroup sums its group
+            int const member = b + j;
+            double part;
+            ok = poll_pairs(&ex->lvl1[par][member < nblocks ? member : b][kind][0],
+                kind_ok && member < nblocks, tag, ex, &part);
+            part = segment16_sum(part);
+            if (kind_ok && j == 0) {
+                unsigned long long const bits
+                    = (unsigned long long)__double_as_longlong(part);
+                unsigned long long *dst = &ex->lvl2[par][b / RES_GROUP][kind][0];
+                __hip_atomic_store(dst, ((unsigned long long)tag << 32)
+                    | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, ((unsigned long long)tag << 32)
+                    | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
+        double total;
+        bool const ok2 = poll_pairs(&ex->lvl2[par][j < ngroups ? j : 0][kind][0],
+            kind_ok && j < ngroups, tag, ex, &total);
+        total = segment16_sum(total);
+        if (kind_ok && j == 0)
+            res[kind] = total;
+        if (lane == 0) {
+            bool flag_ok = ok && ok2;
+            // (a halo wait that gave up raises the same flag)
+            if (wave == 0 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                flag_ok = false;
+            lds_flag[wave] = flag_ok ? 1 : 0;
+        }
+    } else {
+        idle();
+    }
+    __syncthreads();
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        v[k] = res[k];
+#pragma unroll
+    for (int w = 0; w < SWEEPERS; ++w)
+        ok = ok && lds_flag[w] != 0;
+    return ok;
+}
+
+// Position of a thread in its tile and the addressing that follows from it.
+struct TileGeom {
+    int tw, th, LW, lx, ly, li, lcore;
+    // index of the copy (in the tile's rim array) of the block that the lower
+    // neighbour of slot s = 0..3 <-> (dx, dy) = (-1,-1), (0,-1), (1,-1), (-1,0)
+    // stores towards this node
+    __device__ __forceinline__ int rim_index(int s) const
+    {
+        int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
+        if (ly + dy < 0)
+            return s * tw + lx;
+        if (lx + dx < 0)
+            return 3 * tw + (s == 0 ? 0 : th) + ly;
+        return 3 * tw + 2 * th + ly;
+    }
+};
+
+// acc = (H d)_node for the thread's node: its five stored blocks on the
+// direction tile (own rows), the transposed products of its four upper blocks
+// handed to the upper neighbours through `yl` one direction at a time (within
+// a direction every row receives exactly one contribution: no atomics, fixed
+// order), and the rows whose lower neighbour belongs to another tile from the
+// copies of that neighbour's blocks in `fb`.  dself = d of the node.  Four
+// workgroup barriers; the caller has synchronised the direction tile.
+__device__ __forceinline__ void
+tile_product(TileGeom const &G, const double *dtile, double *yl, const double *fb,
+    double const (&hd)[10], double const (&hu)[4][16], unsigned low, unsigned up,
+    bool mine, double (&acc)[4], double (&dself)[4])
+{
+    int const LW = G.LW, lcore = G.lcore;
+    const double4_r *dt = reinterpret_cast<const double4_r *>(dtile);
+    {
+        double4_r const ds = dt[lcore];
+        dself[0] = ds.x; dself[1] = ds.y; dself[2] = ds.z; dself[3] = ds.w;
+        {
+            // diagonal block from its upper triangle
+            double const *d4 = dself;
+            acc[0] = hd[0] * d4[0] + hd[1] * d4[1] + hd[2] * d4[2] + hd[3] * d4[3];
+            acc[1] = hd[1] * d4[0] + hd[4] * d4[1] + hd[5] * d4[2] + hd[6] * d4[3];
+            acc[2] = hd[2] * d4[0] + hd[5] * d4[1] + hd[7] * d4[2] + hd[8] * d4[3];
+            acc[3] = hd[3] * d4[0] + hd[6] * d4[1] + hd[8] * d4[2] + hd[9] * d4[3];
+        }
+#pragma unroll
+        for (int s = 5; s < 9; ++s) {
+            int const dx = s % 3 - 1, dy = s / 3 - 1;
+            double4_r const dm = dt[lcore + dy * LW + dx];
+            double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
+#pragma unroll
+            for (int row = 0; row < 4; ++row)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[row] = __builtin_fma(hu[s - 5][row * 4 + c], dv[c],
+                        acc[row]);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if ((up >> kk) & 1u) {
+            int const s = 5 + kk;
+            int const dx = s % 3 - 1, dy = s / 3 - 1;
+            int const target = (G.ly + dy) * G.tw + G.lx + dx;
+            double t[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int row = 0; row < 4; ++row)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    t[c] = __builtin_fma(hu[kk][row * 4 + c], dself[row],
+                        t[c]);
+            double4_r *dst = reinterpret_cast<double4_r *>(
+                yl + (size_t)target * 4);
+            double4_r const cur = *dst;
+            *dst = (double4_r){ cur.x + t[0], cur.y + t[1], cur.z + t[2],
+                cur.w + t[3] };
+        }
+        __syncthreads();
+    }
+    if (mine) {
+        {
+            double4_r const cv = *reinterpret_cast<const double4_r *>(
+                yl + (size_t)G.li * 4);
+            acc[0] += cv.x; acc[1] += cv.y; acc[2] += cv.z; acc[3] += cv.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            unsigned const kind = (low >> (2 * s)) & 3u;
+            if (kind == 2u) {
+                int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
+                double4_r const dm = dt[lcore + dy * LW + dx];
+                double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
+                const double4_r *blk = reinterpret_cast<const double4_r *>(
+                    fb + (size_t)G.rim_index(s) * 16);
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    double4_r const br = blk[row];
+                    acc[0] = __builtin_fma(br.x, dv[row], acc[0]);
+                    acc[1] = __builtin_fma(br.y, dv[row], acc[1]);
+                    acc[2] = __builtin_fma(br.z, dv[row], acc[2]);
+                    acc[3] = __builtin_fma(br.w, dv[row], acc[3]);
+                }
+            }
+        }
+    }
+}
+
+// z = P r with the reference's operation order (block_sparse_matrix.h:276-298
+// on a diagonal block: products added one by one, no contraction)
+__device__ __forceinline__ void
+precondition(double const (&P)[16], double const (&r)[4], double (&z)[4])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        double zi = 0.0;
+        zi += P[row * 4 + 0] * r[0];
+        zi += P[row * 4 + 1] * r[1];
+        zi += P[row * 4 + 2] * r[2];
+        zi += P[row * 4 + 3] * r[3];
+        z[row] = zi;
+    }
+}
+
+// Polls the eight granules of one node's exchanged vector until all carry
+// `want`; false after a bounded wait (the exchange's timeout flag is raised).
+__device__ __forceinline__ bool
+poll_node_granules(const unsigned long long *src, unsigned want, ResExchange *ex,
+    double (&out)[4])
+{
+    for (unsigned spins = 0;; ++spins) {
+        unsigned long long g[8];
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            g[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            ok &= (unsigned)(g[q] >> 32) == want;
+        }
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                out[q] = __longlong_as_double((long long)(
+                    (g[2 * q + 1] << 32) | (g[2 * q] & 0xFFFFFFFFull)));
+            return true;
+        }
+        if (spins > (1u << 18)) {
+            __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// LDS carve (doubles) of the two solver variants; the host sizes the launch
+// with the same function.
+struct ResLds {
+    size_t dtile, yl, Pl, fb, xl, bl, rh, Ph, qh, hinfo, red, total;
+};
+__host__ __device__ __forceinline__ ResLds
+resident_lds_layout(int tw, int th, bool one)
+{
+    size_t const tn = (size_t)tw * th;
+    size_t const ring = (size_t)2 * (tw + 2) + 2 * th;
+    ResLds L;
+    size_t o = 0;
+    L.dtile = o; o += (size_t)(tw + 2) * (th + 2) * 4;   // direction tile with halo
+    L.yl = o; o += tn * 4;                               // row sums from below
+    L.Pl = o; o += 4 * tn * 4;                           // P, four row planes
+    L.fb = o; o += (size_t)(3 * tw + 3 * th) * 16;       // rim blocks
+    L.xl = o; o += tn * 4;                               // x
+    L.bl = o; o += one ? 0 : tn * 4;                     // b (two-exchange solver only)
+    L.rh = o; o += one ? ring * 4 : 0;                   // r of the halo nodes
+    L.Ph = o; o += one ? ring * 16 : 0;                  // P of the halo nodes
+    L.qh = o; o += one ? ring * 4 : 0;                   // q of the halo nodes (one iteration)
+    L.hinfo = o; o += one ? (ring + 1) / 2 : 0;          // node id per halo slot (ints)
+    L.red = o; o += RES_KINDS * RES_WAVES + RES_KINDS;   // partial sums + results
+    o += (RES_KINDS + 1) / 2;                            // flags (ints)
+    L.total = o;
+    return L;
+}
+
+// ONE = false: the reference's operation order -- d.Ad is reduced first, then
+// r.r, x.(b + r), z.r of the updated vectors: two grid-wide exchanges per
+// iteration (conjugate_gradient.h:121-198 line by line).
+// ONE = true: one exchange per iteration.  Before the step length is known
+// the workgroups reduce six dot products of the CURRENT vectors,
+//   d.q, r.q, q.q, 2 w.r, w.q, d.r, r.r    (q = H d, w = P q),
+// from which alpha and the three scalars the reference tests follow exactly
+// (no approximation, only the association of the sums changes):
+//   r'.r'      = r.r - 2 alpha r.q + alpha^2 q.q          (r' = r - alpha q; r.r
+//                                                          taken directly each time)
+//   z'.r'      = z.r - 2 alpha w.r + alpha^2 w.q          (z' = P r' = z - alpha w;
+//                                                          z.q = w.r, P symmetric)
+//   x'.(b+r')  = x.(b+r) + 2 alpha d.r - alpha^2 d.q      (x' = x + alpha d,
+//                                                          b - r = H x)
+// The vectors themselves are updated with the reference's operations (z = P r
+// is recomputed, not taken from the recurrence).  The second grid-wide wait of
+// an iteration -- the z of the neighbouring tiles' rim nodes -- disappears as
+// well: a tile keeps r and P of its halo nodes and receives their q (published
+// BEFORE the all-reduce and collected by the wave that does not sweep, while
+// the sweep runs), so it forms the halo's z and d itself, bit-identical with
+// the owner's.
+template <bool FUSED, bool ONE>
 __global__ void __launch_bounds__(RES_THREADS, 2)
 cg_resident_kernel(ResArgs A)
 {
@@ -466,16 +916,19 @@ cg_resident_kernel(ResArgs A)
     int const tw = A.tw, th = A.th;
     int const LW = tw + 2, LH = th + 2;
     int const tile_nodes = tw * th;
-    // LDS carve (doubles): direction tile with halo, contributions of the
-    // four upper blocks, rim blocks, reduction scratch, flag
-    double *dtile = lds;                                  // [LH*LW][4]
-    double *yl = dtile + (size_t)LH * LW * 4;             // [tile_nodes][4] row sums from below
-    double *Pl = yl + (size_t)tile_nodes * 4;             // [4][tile_nodes][4] P, row-major planes
-    double *fb = Pl + (size_t)4 * tile_nodes * 4;         // [3*tw + 3*th][16]
-    double *xl = fb + (size_t)(3 * tw + 3 * th) * 16;     // [tile_nodes][4] x
-    double *bl = xl + (size_t)tile_nodes * 4;             // [tile_nodes][4] b
-    double *red = bl + (size_t)tile_nodes * 4;            // [4][RES_WAVES] partials + [4] results
-    int *flag = reinterpret_cast<int *>(red + 4 * RES_WAVES + 4);
+    ResLds const L = resident_lds_layout(tw, th, ONE);
+    double *dtile = lds + L.dtile;                        // [LH*LW][4]
+    double *yl = lds + L.yl;                              // [tile_nodes][4]
+    double *Pl = lds + L.Pl;                              // [4][tile_nodes][4]
+    double *fb = lds + L.fb;                              // [3*tw + 3*th][16]
+    double *xl = lds + L.xl;                              // [tile_nodes][4]
+    double *bl = lds + L.bl;                              // [tile_nodes][4] (!ONE)
+    double *rh = lds + L.rh;                              // [ring][4] (ONE)
+    double *Ph = lds + L.Ph;                              // [ring][16] (ONE)
+    double *qhl = lds + L.qh;                             // [ring][4] (ONE)
+    int *hnode = reinterpret_cast<int *>(lds + L.hinfo);  // [ring] (ONE)
+    double *red = lds + L.red;
+    int *flag = reinterpret_cast<int *>(red + RES_KINDS * RES_WAVES + RES_KINDS);
 
     int const tid = threadIdx.x;
     int const nblocks = (int)gridDim.x;
@@ -487,7 +940,8 @@ cg_resident_kernel(ResArgs A)
     int const n = mine ? gy * A.stride + gx : 0;
     int const lcore = (ly + 1) * LW + lx + 1;
     int const li = ly * tw + lx;             // index in the tile
-    // the z of a rim node is read by the neighbouring tiles
+    TileGeom const G = { tw, th, LW, lx, ly, li, lcore };
+    // the exchanged vector of a rim node is read by the neighbouring tiles
     bool const rim = mine && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
     size_t const N = (size_t)A.num_nodes;
 
@@ -504,11 +958,12 @@ cg_resident_kernel(ResArgs A)
     } else if (has_halo) {
         hx = LW - 1; hy = tid - 2 * LW - th + 1;
     }
-    int halo_node = -1;
+    int halo_node = -1, halo_ix = 0, halo_iy = 0;
     if (has_halo) {
-        int const ix = tx * tw + hx - 1, iy = ty * th + hy - 1;
-        if (ix >= 0 && ix < A.stride && iy >= 0 && iy < A.rows)
-            halo_node = iy * A.stride + ix;
+        halo_ix = tx * tw + hx - 1;
+        halo_iy = ty * th + hy - 1;
+        if (halo_ix >= 0 && halo_ix < A.stride && halo_iy >= 0 && halo_iy < A.rows)
+            halo_node = halo_iy * A.stride + halo_ix;
     }
     int const lhalo = hy * LW + hx;
 
@@ -516,12 +971,185 @@ cg_resident_kernel(ResArgs A)
         A.trace[0] = (long long)wall_clock64();
     if (A.trace != nullptr && tid == 0)
         A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 0] = (long long)wall_clock64();
+    // tag of the exchanged vectors: the solve id and the iteration that reads them
+    unsigned const ztag = (unsigned)A.solve_tag;
+    // block-Jacobi preconditioner (block_sparse_matrix.h:300-316): the
+    // inverted diagonal block, kept un-inverted on NaN / zero pivot (Q12)
+    auto invert_diagonal = [](double const (&d10)[10], double (&Pfull)[16]) {
+        double const full[16] = { d10[0], d10[1], d10[2], d10[3],
+            d10[1], d10[4], d10[5], d10[6], d10[2], d10[5], d10[7], d10[8],
+            d10[3], d10[6], d10[8], d10[9] };
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            Pfull[i] = full[i];
+        ldl_inverse4(Pfull);
+        bool nancheck = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            nancheck |= isnan(Pfull[i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            Pfull[i] = nancheck ? full[i] : Pfull[i];
+    };
     // ---- the matrix: five stored blocks in registers, the rim in LDS ----
     // (the diagonal block is symmetric, Q4: its upper triangle, 10 doubles)
     double hd[10];
     double hu[4][16];
     double gnode[4];          // gradient of the node
-    if (FUSED) {
+    double r[4], z[4];
+    double v0[2] = { 0.0, 0.0 };   // z.r and g.g of this thread's node
+    // x = 0, r = b = -g, z = P r of the thread's node (conjugate_gradient.h:86-118)
+    // from hd / gnode; P goes to LDS
+    auto init_own = [&]() {
+        if (mine) {
+            double const gg[4] = { gnode[0], gnode[1], gnode[2], gnode[3] };
+            double Pfull[16];
+            if (FUSED) {
+                invert_diagonal(hd, Pfull);
+            } else {
+                const double4_r *P = reinterpret_cast<const double4_r *>(
+                    A.Pinv + (size_t)n * 16);
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    double4_r const p = P[row];
+                    Pfull[row * 4 + 0] = p.x; Pfull[row * 4 + 1] = p.y;
+                    Pfull[row * 4 + 2] = p.z; Pfull[row * 4 + 3] = p.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = -gg[k];
+#pragma unroll
+            for (int row = 0; row < 4; ++row)
+                *reinterpret_cast<double4_r *>(Pl + ((size_t)row * tile_nodes + li) * 4)
+                    = (double4_r){ Pfull[row * 4 + 0], Pfull[row * 4 + 1],
+                        Pfull[row * 4 + 2], Pfull[row * 4 + 3] };
+            precondition(Pfull, r, z);
+            *reinterpret_cast<double4_r *>(xl + (size_t)li * 4)
+                = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
+            if (ONE) {
+                // b goes to HBM now (it is not needed again); d_1 = z_0
+                *reinterpret_cast<double4_r *>(A.b + (size_t)n * 4)
+                    = (double4_r){ r[0], r[1], r[2], r[3] };
+                reinterpret_cast<double4_r *>(dtile)[lcore]
+                    = (double4_r){ z[0], z[1], z[2], z[3] };
+                *reinterpret_cast<double4_r *>(yl + (size_t)li * 4)
+                    = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
+            } else {
+                *reinterpret_cast<double4_r *>(bl + (size_t)li * 4)
+                    = (double4_r){ r[0], r[1], r[2], r[3] };
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!ONE && rim)
+                    st_granules(A.zg + ((size_t)n * 4 + k) * 2, ztag + 1u, z[k]);
+                v0[0] += z[k] * r[k];
+                v0[1] += gg[k] * gg[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = z[k] = 0.0;
+        }
+    };
+    if constexpr (ONE) {
+        // Order of the one-exchange prologue: halo, own diagonal block and P,
+        // then the upper blocks -- the LDL^T inverses run before the 128
+        // registers of the upper blocks are occupied.
+        for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
+            dtile[i] = 0.0;   // (out-of-grid halo stays zero for the whole solve)
+        __syncthreads();
+        if (has_halo) {
+            hnode[tid] = halo_node;
+            // r and P of the halo node, with the operations of its owner
+            double Ph16[16], gh[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                Ph16[i] = 0.0;
+            if (halo_node >= 0) {
+                if (FUSED) {
+                    double hdh[10];
+                    assemble_diagonal(A, halo_ix, halo_iy, hdh, gh);
+                    invert_diagonal(hdh, Ph16);
+                } else {
+                    const double4_r *P = reinterpret_cast<const double4_r *>(
+                        A.Pinv + (size_t)halo_node * 16);
+#pragma unroll
+                    for (int row = 0; row < 4; ++row) {
+                        double4_r const p = P[row];
+                        Ph16[row * 4 + 0] = p.x; Ph16[row * 4 + 1] = p.y;
+                        Ph16[row * 4 + 2] = p.z; Ph16[row * 4 + 3] = p.w;
+                    }
+                    double4_r const gv = *reinterpret_cast<const double4_r *>(
+                        A.g + (size_t)halo_node * 4);
+                    gh[0] = gv.x; gh[1] = gv.y; gh[2] = gv.z; gh[3] = gv.w;
+                }
+            }
+            double rhv[4], zh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                rhv[k] = -gh[k];
+            precondition(Ph16, rhv, zh);
+            *reinterpret_cast<double4_r *>(rh + (size_t)tid * 4)
+                = (double4_r){ rhv[0], rhv[1], rhv[2], rhv[3] };
+#pragma unroll
+            for (int row = 0; row < 4; ++row)
+                *reinterpret_cast<double4_r *>(Ph + (size_t)tid * 16 + row * 4)
+                    = (double4_r){ Ph16[row * 4 + 0], Ph16[row * 4 + 1],
+                        Ph16[row * 4 + 2], Ph16[row * 4 + 3] };
+            if (halo_node >= 0)
+                reinterpret_cast<double4_r *>(dtile)[lhalo]
+                    = (double4_r){ zh[0], zh[1], zh[2], zh[3] };
+        }
+        if (FUSED) {
+            if (mine) {
+                assemble_diagonal(A, gx, gy, hd, gnode);
+                A.active_next[n] = 0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 10; ++i)
+                    hd[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    gnode[i] = 0.0;
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                A.status[I_ACTIVE_PATCHES] = A.status[I_LIVE_PATCHES];
+                A.status[I_NUM_ACTIVE] = 0;
+                A.scalars[S_SUMDIFF] = 0.0;
+                A.scalars[S_COUNT_DIFF] = 0.0;
+            }
+        } else {
+            const double4_r *src = reinterpret_cast<const double4_r *>(
+                A.H9 + (size_t)n * 16);
+            double4_r const zero4 = { 0, 0, 0, 0 };
+            double4_r const r0 = mine ? src[0] : zero4, r1 = mine ? src[1] : zero4,
+                r2 = mine ? src[2] : zero4, r3 = mine ? src[3] : zero4;
+            hd[0] = r0.x; hd[1] = r0.y; hd[2] = r0.z; hd[3] = r0.w;
+            hd[4] = r1.y; hd[5] = r1.z; hd[6] = r1.w;
+            hd[7] = r2.z; hd[8] = r2.w;
+            hd[9] = r3.w;
+            double4_r const gv = mine ? *reinterpret_cast<const double4_r *>(
+                A.g + (size_t)n * 4) : zero4;
+            gnode[0] = gv.x; gnode[1] = gv.y; gnode[2] = gv.z; gnode[3] = gv.w;
+        }
+        init_own();
+        if (FUSED) {
+            assemble_upper(A, gx, gy, mine, hu);
+        } else {
+#pragma unroll
+            for (int s = 1; s < 5; ++s) {
+                const double4_r *src = reinterpret_cast<const double4_r *>(
+                    A.H9 + ((size_t)s * N + (size_t)n) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double4_r const v = mine ? src[q] : (double4_r){ 0, 0, 0, 0 };
+                    hu[s - 1][4 * q + 0] = v.x; hu[s - 1][4 * q + 1] = v.y;
+                    hu[s - 1][4 * q + 2] = v.z; hu[s - 1][4 * q + 3] = v.w;
+                }
+            }
+        }
+    } else if (FUSED) {
         // assembled here from the per-patch systems: H, g and P never go to
         // HBM.  Also what the assembly kernel does for the step's node update.
         NodeSystem S;
@@ -572,26 +1200,15 @@ cg_resident_kernel(ResArgs A)
             A.g + (size_t)n * 4) : (double4_r){ 0, 0, 0, 0 };
         gnode[0] = gv.x; gnode[1] = gv.y; gnode[2] = gv.z; gnode[3] = gv.w;
     }
-    // lower slot s = 0..3 <-> (dx, dy) = (-1,-1), (0,-1), (1,-1), (-1,0).
-    // fb_idx[s]: -2 neighbour outside the grid, -1 neighbour inside the tile
-    // (its contribution arrives through `yl`), >= 0 index of the copy
-    // of the neighbour's block in the rim.
-    // `low` holds two bits per lower slot: 0 neighbour outside the grid,
-    // 1 neighbour inside the tile (its contribution arrives through
-    // `yl`), 2 the neighbour's block sits in the rim; `up` one bit per
-    // upper slot: the neighbour's row lives in this tile.
-    auto rim_index = [&](int s) -> int {
-        int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
-        if (ly + dy < 0)
-            return s * tw + lx;
-        if (lx + dx < 0)
-            return 3 * tw + (s == 0 ? 0 : th) + ly;
-        return 3 * tw + 2 * th + ly;
-    };
     if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
         A.trace[2] = (long long)wall_clock64();   // own blocks in registers
     if (A.trace != nullptr && tid == 0)
         A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 1] = (long long)wall_clock64();
+    // `low` holds two bits per lower slot s = 0..3 <-> (dx, dy) = (-1,-1),
+    // (0,-1), (1,-1), (-1,0): 0 neighbour outside the grid, 1 neighbour inside
+    // the tile (its contribution arrives through `yl`), 2 the neighbour's
+    // block sits in the rim; `up` one bit per upper slot: the neighbour's row
+    // lives in this tile.
     unsigned low = 0u, up = 0u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -603,7 +1220,7 @@ cg_resident_kernel(ResArgs A)
             low |= (in_tile ? 1u : 2u) << (2 * s);
             if (!in_tile) {
                 // block (row m, col n) is stored at m under its upper slot 8 - s
-                double *dst = fb + (size_t)rim_index(s) * 16;
+                double *dst = fb + (size_t)G.rim_index(s) * 16;
                 if (FUSED) {
                     // (assembled below, one thread per rim block)
                 } else {
@@ -659,320 +1276,318 @@ cg_resident_kernel(ResArgs A)
             && gx + dx < A.stride && gy + dy < A.rows;
         up |= (in_tile ? 1u : 0u) << k;
     }
-    // zero the direction tile (out-of-grid halo stays zero for the whole solve)
-    for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
-        dtile[i] = 0.0;
-
-    // tag of the z granules: the solve id and the iteration that reads them
-    unsigned const ztag = (unsigned)A.solve_tag;
-    // ---- x = 0, r = b = -g, z = P r  (conjugate_gradient.h:86-118) ----
-    double r[4], z[4];
     unsigned epoch = 1;
     bool alive = true;
     ResState st;
-    {
-        double v0[2] = { 0.0, 0.0 };
-        if (mine) {
-            double const gg[4] = { gnode[0], gnode[1], gnode[2], gnode[3] };
-            // block-Jacobi preconditioner (block_sparse_matrix.h:300-316): the
-            // inverted diagonal block, kept un-inverted on NaN / zero pivot (Q12)
-            double Pfull[16];
-            if (FUSED) {
-                double const full[16] = { hd[0], hd[1], hd[2], hd[3],
-                    hd[1], hd[4], hd[5], hd[6], hd[2], hd[5], hd[7], hd[8],
-                    hd[3], hd[6], hd[8], hd[9] };
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    Pfull[i] = full[i];
-                ldl_inverse4(Pfull);
-                bool nancheck = false;
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    nancheck |= isnan(Pfull[i]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    Pfull[i] = nancheck ? full[i] : Pfull[i];
-            } else {
-                const double4_r *P = reinterpret_cast<const double4_r *>(
-                    A.Pinv + (size_t)n * 16);
-#pragma unroll
-                for (int row = 0; row < 4; ++row) {
-                    double4_r const p = P[row];
-                    Pfull[row * 4 + 0] = p.x; Pfull[row * 4 + 1] = p.y;
-                    Pfull[row * 4 + 2] = p.z; Pfull[row * 4 + 3] = p.w;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                r[k] = -gg[k];
-#pragma unroll
-            for (int row = 0; row < 4; ++row) {
-#pragma clang fp contract(off)
-                double4_r const p = { Pfull[row * 4 + 0], Pfull[row * 4 + 1],
-                    Pfull[row * 4 + 2], Pfull[row * 4 + 3] };
-                *reinterpret_cast<double4_r *>(
-                    Pl + ((size_t)row * tile_nodes + li) * 4) = p;
-                double zi = 0.0;
-                zi += p.x * r[0];
-                zi += p.y * r[1];
-                zi += p.z * r[2];
-                zi += p.w * r[3];
-                z[row] = zi;
-            }
-            *reinterpret_cast<double4_r *>(bl + (size_t)li * 4)
-                = (double4_r){ r[0], r[1], r[2], r[3] };
-            *reinterpret_cast<double4_r *>(xl + (size_t)li * 4)
-                = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (rim)
-                    st_granules(A.zg + ((size_t)n * 4 + k) * 2, ztag + 1u, z[k]);
-                v0[0] += z[k] * r[k];
-                v0[1] += gg[k] * gg[k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                r[k] = z[k] = 0.0;
-        }
-        if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
-            A.trace[4] = (long long)wall_clock64();   // P, r, z done
-        if (A.trace != nullptr && tid == 0)
-            A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 3] = (long long)wall_clock64();
-        alive = grid_allreduce<2>(A.ex, ztag, epoch++, nblocks, v0, red, flag);
-        st.rr = v0[0];
-        st.q0 = -0.0;
-        st.gnorm = sqrt(v0[1]);
-        st.tol = A.fixed_tolerance < 0.0 ? st.gnorm * 0.01 : A.fixed_tolerance;
-        st.iter = 1;
-        st.done = 0;
-        st.info = SMVS_CG_MAX_ITERATIONS;
-        st.pad = 0;
+    if constexpr (!ONE) {
+        // zero the direction tile (out-of-grid halo stays zero for the whole solve)
+        for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
+            dtile[i] = 0.0;
+        init_own();
     }
+    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+        A.trace[4] = (long long)wall_clock64();   // P, r, z done
+    if (A.trace != nullptr && tid == 0)
+        A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 3] = (long long)wall_clock64();
+    st.q0 = -0.0;
+    st.iter = 1;
+    st.done = 0;
+    st.info = SMVS_CG_MAX_ITERATIONS;
+    st.pad = 0;
+    st.rr = st.tol = st.gnorm = 0.0;
 
     auto stamp = [&](int k, int point) {
         if (A.trace != nullptr && blockIdx.x == 0 && tid == 0 && k <= TRACE_ITERS)
             A.trace[k * TRACE_POINTS + point] = (long long)wall_clock64();
     };
-    stamp(0, 1);
-    // ---- iterations (conjugate_gradient.h:123-198) ----
-    double beta = 0.0;
-    for (int k = 1; alive && k < A.max_iterations; ++k) {
-        stamp(k, 0);
-        // d_k = z + beta d_{k-1}: own node and halo, in LDS
-        {
+    if constexpr (!ONE) {
+        alive = grid_allreduce<2, 3>(A.ex, ztag, epoch++, nblocks, v0, red, flag,
+            NoIdleWork());
+        st.rr = v0[0];
+        st.gnorm = sqrt(v0[1]);
+        st.tol = A.fixed_tolerance < 0.0 ? st.gnorm * 0.01 : A.fixed_tolerance;
+        stamp(0, 1);
+        // ---- iterations (conjugate_gradient.h:123-198) ----
+        double beta = 0.0;
+        for (int k = 1; alive && k < A.max_iterations; ++k) {
+            stamp(k, 0);
+            // d_k = z + beta d_{k-1}: own node and halo, in LDS
+            {
 #pragma clang fp contract(off)
-            double4_r *dt = reinterpret_cast<double4_r *>(dtile);
-            if (mine) {
-                double4_r const old = dt[lcore];
-                dt[lcore] = (double4_r){ z[0] + beta * old.x, z[1] + beta * old.y,
-                    z[2] + beta * old.z, z[3] + beta * old.w };
-                *reinterpret_cast<double4_r *>(yl + (size_t)li * 4)
-                    = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
+                double4_r *dt = reinterpret_cast<double4_r *>(dtile);
+                if (mine) {
+                    double4_r const old = dt[lcore];
+                    dt[lcore] = (double4_r){ z[0] + beta * old.x, z[1] + beta * old.y,
+                        z[2] + beta * old.z, z[3] + beta * old.w };
+                    *reinterpret_cast<double4_r *>(yl + (size_t)li * 4)
+                        = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
+                }
+                if (halo_node >= 0) {
+                    // the neighbour's z of the previous iteration: poll its eight
+                    // granules until all carry this iteration's tag
+                    double zh[4] = { 0.0, 0.0, 0.0, 0.0 };
+                    (void)poll_node_granules(A.zg + (size_t)halo_node * 8,
+                        ztag + (unsigned)k, A.ex, zh);
+                    double4_r const old = dt[lhalo];
+                    dt[lhalo] = (double4_r){ zh[0] + beta * old.x, zh[1] + beta * old.y,
+                        zh[2] + beta * old.z, zh[3] + beta * old.w };
+                }
             }
-            if (halo_node >= 0) {
-                // the neighbour's z of the previous iteration: poll its eight
-                // granules until all carry this iteration's tag
-                double zh[4] = { 0.0, 0.0, 0.0, 0.0 };
-                const unsigned long long *src = A.zg + (size_t)halo_node * 8;
-                unsigned const want = ztag + (unsigned)k;
-                for (unsigned spins = 0;; ++spins) {
-                    unsigned long long g[8];
-                    bool ok = true;
+            __syncthreads();
+            stamp(k, 1);
+            double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+            double dself[4];
+            tile_product(G, dtile, yl, fb, hd, hu, low, up, mine, acc, dself);
+            stamp(k, 2);
+            double dad[1] = { 0.0 };
+            if (mine)
+                dad[0] = dself[0] * acc[0] + dself[1] * acc[1]
+                    + dself[2] * acc[2] + dself[3] * acc[3];
+            stamp(k, 3);
+            if (!(alive = grid_allreduce<1, 3>(A.ex, ztag, epoch++, nblocks, dad, red,
+                      flag, NoIdleWork())))
+                break;
+            stamp(k, 4);
+            double const alpha = st.rr / dad[0];
+            // x += alpha d, r -= alpha Ad, z = P r: x, b and P in LDS; only the rim
+            // publishes its z (as granules: nothing to drain before the all-reduce)
+            double v3[3] = { 0.0, 0.0, 0.0 };
+            if (mine) {
+#pragma clang fp contract(off)
+                double4_r *xp = reinterpret_cast<double4_r *>(xl + (size_t)li * 4);
+                double4_r const xv = *xp;
+                double4_r const bv = *reinterpret_cast<const double4_r *>(
+                    bl + (size_t)li * 4);
+                double const xn[4] = { xv.x + alpha * dself[0], xv.y + alpha * dself[1],
+                    xv.z + alpha * dself[2], xv.w + alpha * dself[3] };
+                double const bo[4] = { bv.x, bv.y, bv.z, bv.w };
+                *xp = (double4_r){ xn[0], xn[1], xn[2], xn[3] };
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        g[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT);
-                        ok &= (unsigned)(g[q] >> 32) == want;
+                for (int q = 0; q < 4; ++q)
+                    r[q] = r[q] - alpha * acc[q];
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    double4_r const p = *reinterpret_cast<const double4_r *>(
+                        Pl + ((size_t)row * tile_nodes + li) * 4);
+                    double zi = 0.0;
+                    zi += p.x * r[0];
+                    zi += p.y * r[1];
+                    zi += p.z * r[2];
+                    zi += p.w * r[3];
+                    z[row] = zi;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (rim)
+                        st_granules(A.zg + ((size_t)n * 4 + q) * 2,
+                            ztag + (unsigned)k + 1u, z[q]);
+                    v3[0] += r[q] * r[q];
+                    v3[1] += xn[q] * (bo[q] + r[q]);
+                    v3[2] += z[q] * r[q];
+                }
+            }
+            stamp(k, 5);
+            if (!(alive = grid_allreduce<3, 3>(A.ex, ztag, epoch++, nblocks, v3, red,
+                      flag, NoIdleWork())))
+                break;
+            stamp(k, 6);
+            // termination tests of iteration k (conjugate_gradient.h:136-198)
+            double const new_rr = v3[0];
+            double const Q1 = -1.0 * v3[1];
+            int done = 0, info = SMVS_CG_MAX_ITERATIONS, iter_out = k + 1;
+            if (new_rr < st.tol) {
+                done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
+            } else {
+                double const zeta = k * (Q1 - st.q0) / Q1;
+                if (zeta < A.q_tolerance) {
+                    done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
+                } else if (k + 1 >= A.max_iterations) {
+                    done = 1;
+                }
+            }
+            beta = v3[2] / st.rr;
+            st.rr = v3[2];
+            st.q0 = Q1;
+            st.iter = iter_out;
+            st.done = done;
+            st.info = info;
+            if (done)
+                break;
+        }
+    } else {
+        // ---- one exchange per iteration ----
+        __syncthreads();          // d_1 (own and halo) in the tile
+        stamp(0, 1);
+        double zr = 0.0, xbr = 0.0;   // z.r and x.(b + r) of the current vectors
+        for (int k = 1; alive && k < A.max_iterations; ++k) {
+            stamp(k, 0);
+            double acc[4] = { 0.0, 0.0, 0.0, 0.0 };   // q = H d
+            double dself[4];
+            tile_product(G, dtile, yl, fb, hd, hu, low, up, mine, acc, dself);
+            stamp(k, 1);
+            // the rim's q for the neighbouring tiles, then the sums
+            // (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
+            double v7[7] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+            if (mine) {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    double4_r const p = *reinterpret_cast<const double4_r *>(
+                        Pl + ((size_t)row * tile_nodes + li) * 4);
+                    double wi = 0.0;
+                    wi += p.x * acc[0];
+                    wi += p.y * acc[1];
+                    wi += p.z * acc[2];
+                    wi += p.w * acc[3];
+                    v7[3] += 2.0 * (wi * r[row]);
+                    v7[4] += wi * acc[row];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (rim)
+                        st_granules(A.zg + ((size_t)n * 4 + q) * 2,
+                            ztag + (unsigned)k, acc[q]);
+                    v7[0] += dself[q] * acc[q];
+                    v7[1] += r[q] * acc[q];
+                    v7[2] += acc[q] * acc[q];
+                    v7[5] += dself[q] * r[q];
+                    v7[6] += r[q] * r[q];
+                }
+            }
+            stamp(k, 2);
+            // Waves 1 and 2 run the two-level all-reduce; wave 0 meanwhile collects
+            // the q of the halo nodes (published before the sums) into LDS.
+            alive = grid_allreduce_tree<7>(A.ex, ztag, epoch++, nblocks, v7, red, flag,
+                [&]() {
+                    for (int hs = tid; hs < ring; hs += 64) {
+                        int const node = hnode[hs];
+                        double qv[4] = { 0.0, 0.0, 0.0, 0.0 };
+                        if (node >= 0)
+                            (void)poll_node_granules(A.zg + (size_t)node * 8,
+                                ztag + (unsigned)k, A.ex, qv);
+                        *reinterpret_cast<double4_r *>(qhl + (size_t)hs * 4)
+                            = (double4_r){ qv[0], qv[1], qv[2], qv[3] };
                     }
-                    if (ok) {
+                });
+            if (!alive)
+                break;
+            stamp(k, 3);
+            double const dq = v7[0], rq = v7[1], qq = v7[2], s1 = v7[3], wq = v7[4],
+                dr = v7[5], rr = v7[6];
+            if (k == 1) {
+                // d_1 = z_0: d.r is z.r of the start; r_0 = -g
+                zr = dr;
+                st.gnorm = sqrt(rr);
+                st.tol = A.fixed_tolerance < 0.0 ? st.gnorm * 0.01 : A.fixed_tolerance;
+            }
+            double const alpha = zr / dq;
+            double const new_rr = __builtin_fma(alpha,
+                __builtin_fma(alpha, qq, -2.0 * rq), rr);
+            double const new_zr = __builtin_fma(alpha,
+                __builtin_fma(alpha, wq, -s1), zr);
+            double const new_xbr = __builtin_fma(alpha,
+                __builtin_fma(-alpha, dq, 2.0 * dr), xbr);
+            // termination tests of iteration k (conjugate_gradient.h:136-198)
+            double const Q1 = -1.0 * new_xbr;
+            int done = 0, info = SMVS_CG_MAX_ITERATIONS, iter_out = k + 1;
+            if (new_rr < st.tol) {
+                done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
+            } else {
+                double const zeta = k * (Q1 - st.q0) / Q1;
+                if (zeta < A.q_tolerance) {
+                    done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
+                } else if (k + 1 >= A.max_iterations) {
+                    done = 1;
+                }
+            }
+            double const beta = new_zr / zr;
+            // x += alpha d, r -= alpha q, z = P r, d = z + beta d: own node, and
+            // r, z, d of the halo with the same operations
+            {
+#pragma clang fp contract(off)
+                double4_r *dt = reinterpret_cast<double4_r *>(dtile);
+                if (mine) {
+                    double4_r *xp = reinterpret_cast<double4_r *>(xl + (size_t)li * 4);
+                    double4_r const xv = *xp;
+                    *xp = (double4_r){ xv.x + alpha * dself[0], xv.y + alpha * dself[1],
+                        xv.z + alpha * dself[2], xv.w + alpha * dself[3] };
+                    if (!done) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            zh[q] = __longlong_as_double((long long)(
-                                (g[2 * q + 1] << 32) | (g[2 * q] & 0xFFFFFFFFull)));
-                        break;
+                            r[q] = r[q] - alpha * acc[q];
+                        double zn[4];
+#pragma unroll
+                        for (int row = 0; row < 4; ++row) {
+                            double4_r const p = *reinterpret_cast<const double4_r *>(
+                                Pl + ((size_t)row * tile_nodes + li) * 4);
+                            double zi = 0.0;
+                            zi += p.x * r[0];
+                            zi += p.y * r[1];
+                            zi += p.z * r[2];
+                            zi += p.w * r[3];
+                            zn[row] = zi;
+                        }
+                        dt[lcore] = (double4_r){ zn[0] + beta * dself[0],
+                            zn[1] + beta * dself[1], zn[2] + beta * dself[2],
+                            zn[3] + beta * dself[3] };
+                        *reinterpret_cast<double4_r *>(yl + (size_t)li * 4)
+                            = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
                     }
-                    if (spins > (1u << 18)) {
-                        __hip_atomic_store(&A.ex->timeout, 1u, __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
                 }
-                double4_r const old = dt[lhalo];
-                dt[lhalo] = (double4_r){ zh[0] + beta * old.x, zh[1] + beta * old.y,
-                    zh[2] + beta * old.z, zh[3] + beta * old.w };
-            }
-        }
-        __syncthreads();
-        stamp(k, 1);
-        // own rows: five stored blocks; transposed products for the rows of
-        // the four upper neighbours
-        double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-        double dself[4];
-        {
-            const double4_r *dt = reinterpret_cast<const double4_r *>(dtile);
-            double4_r const ds = dt[lcore];
-            dself[0] = ds.x; dself[1] = ds.y; dself[2] = ds.z; dself[3] = ds.w;
-            {
-                // diagonal block from its upper triangle
-                double const *d4 = dself;
-                acc[0] = hd[0] * d4[0] + hd[1] * d4[1] + hd[2] * d4[2] + hd[3] * d4[3];
-                acc[1] = hd[1] * d4[0] + hd[4] * d4[1] + hd[5] * d4[2] + hd[6] * d4[3];
-                acc[2] = hd[2] * d4[0] + hd[5] * d4[1] + hd[7] * d4[2] + hd[8] * d4[3];
-                acc[3] = hd[3] * d4[0] + hd[6] * d4[1] + hd[8] * d4[2] + hd[9] * d4[3];
-            }
-#pragma unroll
-            for (int s = 5; s < 9; ++s) {
-                int const dx = s % 3 - 1, dy = s / 3 - 1;
-                double4_r const dm = dt[lcore + dy * LW + dx];
-                double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
-#pragma unroll
-                for (int row = 0; row < 4; ++row)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[row] = __builtin_fma(hu[s - 5][row * 4 + c], dv[c],
-                            acc[row]);
-            }
-        }
-        // transposed products for the rows of the four upper neighbours, one
-        // direction at a time: within a direction every row receives exactly
-        // one contribution, so the adds into yl need no atomics and the
-        // order of the sum is fixed
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if ((up >> kk) & 1u) {
-                int const s = 5 + kk;
-                int const dx = s % 3 - 1, dy = s / 3 - 1;
-                int const target = (ly + dy) * tw + lx + dx;
-                double t[4] = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                for (int row = 0; row < 4; ++row)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        t[c] = __builtin_fma(hu[kk][row * 4 + c], dself[row],
-                            t[c]);
-                double4_r *dst = reinterpret_cast<double4_r *>(
-                    yl + (size_t)target * 4);
-                double4_r const cur = *dst;
-                *dst = (double4_r){ cur.x + t[0], cur.y + t[1], cur.z + t[2],
-                    cur.w + t[3] };
-            }
-            if (kk < 3)
-                __syncthreads();
-        }
-        __syncthreads();
-        stamp(k, 2);
-        if (mine) {
-            const double4_r *dt = reinterpret_cast<const double4_r *>(dtile);
-            {
-                double4_r const cv = *reinterpret_cast<const double4_r *>(
-                    yl + (size_t)li * 4);
-                acc[0] += cv.x; acc[1] += cv.y; acc[2] += cv.z; acc[3] += cv.w;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                unsigned const kind = (low >> (2 * s)) & 3u;
-                if (kind == 2u) {
-                    int const dx = s == 3 ? -1 : s - 1, dy = s == 3 ? 0 : -1;
-                    double4_r const dm = dt[lcore + dy * LW + dx];
-                    double const dv[4] = { dm.x, dm.y, dm.z, dm.w };
-                    const double4_r *blk = reinterpret_cast<const double4_r *>(
-                        fb + (size_t)rim_index(s) * 16);
+                if (!done && halo_node >= 0) {
+                    double4_r *rp = reinterpret_cast<double4_r *>(rh + (size_t)tid * 4);
+                    double4_r const rv = *rp;
+                    double4_r const qv = *reinterpret_cast<const double4_r *>(
+                        qhl + (size_t)tid * 4);
+                    double const rn[4] = { rv.x - alpha * qv.x, rv.y - alpha * qv.y,
+                        rv.z - alpha * qv.z, rv.w - alpha * qv.w };
+                    *rp = (double4_r){ rn[0], rn[1], rn[2], rn[3] };
+                    double zh[4];
 #pragma unroll
                     for (int row = 0; row < 4; ++row) {
-                        double4_r const br = blk[row];
-                        acc[0] = __builtin_fma(br.x, dv[row], acc[0]);
-                        acc[1] = __builtin_fma(br.y, dv[row], acc[1]);
-                        acc[2] = __builtin_fma(br.z, dv[row], acc[2]);
-                        acc[3] = __builtin_fma(br.w, dv[row], acc[3]);
+                        double4_r const p = *reinterpret_cast<const double4_r *>(
+                            Ph + (size_t)tid * 16 + row * 4);
+                        double zi = 0.0;
+                        zi += p.x * rn[0];
+                        zi += p.y * rn[1];
+                        zi += p.z * rn[2];
+                        zi += p.w * rn[3];
+                        zh[row] = zi;
                     }
+                    double4_r const old = dt[lhalo];
+                    dt[lhalo] = (double4_r){ zh[0] + beta * old.x, zh[1] + beta * old.y,
+                        zh[2] + beta * old.z, zh[3] + beta * old.w };
                 }
             }
+            stamp(k, 4);
+            zr = new_zr;
+            xbr = new_xbr;
+            st.rr = new_zr;
+            st.q0 = Q1;
+            st.iter = iter_out;
+            st.done = done;
+            st.info = info;
+            if (done)
+                break;
+            __syncthreads();      // d_{k+1} in the tile
+            stamp(k, 5);
+            stamp(k, 6);
         }
-        double dad[1] = { 0.0 };
-        if (mine)
-            dad[0] = dself[0] * acc[0] + dself[1] * acc[1]
-                + dself[2] * acc[2] + dself[3] * acc[3];
-        stamp(k, 3);
-        if (!(alive = grid_allreduce<1>(A.ex, ztag, epoch++, nblocks, dad, red, flag)))
-            break;
-        stamp(k, 4);
-        double const alpha = st.rr / dad[0];
-        // x += alpha d, r -= alpha Ad, z = P r: x, b and P in LDS; only the rim
-        // publishes its z (as granules: nothing to drain before the all-reduce)
-        double v3[3] = { 0.0, 0.0, 0.0 };
-        if (mine) {
-#pragma clang fp contract(off)
-            double4_r *xp = reinterpret_cast<double4_r *>(xl + (size_t)li * 4);
-            double4_r const xv = *xp;
-            double4_r const bv = *reinterpret_cast<const double4_r *>(
-                bl + (size_t)li * 4);
-            double const xn[4] = { xv.x + alpha * dself[0], xv.y + alpha * dself[1],
-                xv.z + alpha * dself[2], xv.w + alpha * dself[3] };
-            double const bo[4] = { bv.x, bv.y, bv.z, bv.w };
-            *xp = (double4_r){ xn[0], xn[1], xn[2], xn[3] };
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                r[q] = r[q] - alpha * acc[q];
-#pragma unroll
-            for (int row = 0; row < 4; ++row) {
-                double4_r const p = *reinterpret_cast<const double4_r *>(
-                    Pl + ((size_t)row * tile_nodes + li) * 4);
-                double zi = 0.0;
-                zi += p.x * r[0];
-                zi += p.y * r[1];
-                zi += p.z * r[2];
-                zi += p.w * r[3];
-                z[row] = zi;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (rim)
-                    st_granules(A.zg + ((size_t)n * 4 + q) * 2,
-                        ztag + (unsigned)k + 1u, z[q]);
-                v3[0] += r[q] * r[q];
-                v3[1] += xn[q] * (bo[q] + r[q]);
-                v3[2] += z[q] * r[q];
-            }
-        }
-        stamp(k, 5);
-        if (!(alive = grid_allreduce<3>(A.ex, ztag, epoch++, nblocks, v3, red, flag)))
-            break;
-        stamp(k, 6);
-        // termination tests of iteration k (conjugate_gradient.h:136-198)
-        double const new_rr = v3[0];
-        double const Q1 = -1.0 * v3[1];
-        int done = 0, info = SMVS_CG_MAX_ITERATIONS, iter_out = k + 1;
-        if (new_rr < st.tol) {
-            done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
-        } else {
-            double const zeta = k * (Q1 - st.q0) / Q1;
-            if (zeta < A.q_tolerance) {
-                done = 1; info = SMVS_CG_CONVERGENCE; iter_out = k;
-            } else if (k + 1 >= A.max_iterations) {
-                done = 1;
-            }
-        }
-        beta = v3[2] / st.rr;
-        st.rr = v3[2];
-        st.q0 = Q1;
-        st.iter = iter_out;
-        st.done = done;
-        st.info = info;
-        if (done)
-            break;
     }
 
     // the solution (and b, which the streaming solver also leaves) go to HBM
     if (mine) {
         *reinterpret_cast<double4_r *>(A.x + (size_t)n * 4)
             = *reinterpret_cast<const double4_r *>(xl + (size_t)li * 4);
-        *reinterpret_cast<double4_r *>(A.b + (size_t)n * 4)
-            = *reinterpret_cast<const double4_r *>(bl + (size_t)li * 4);
+        if (!ONE)
+            *reinterpret_cast<double4_r *>(A.b + (size_t)n * 4)
+                = *reinterpret_cast<const double4_r *>(bl + (size_t)li * 4);
     }
     if (blockIdx.x == 0 && tid == 0) {
-        int const failed = alive && !(A.pipelined & 2) ? 0 : 1;   // (bit 1: test hook)
+        // (a halo wait of any workgroup that gave up raised the exchange's flag)
+        bool const late_timeout = __hip_atomic_load(&A.ex->timeout, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        int const failed = alive && !late_timeout && !(A.pipelined & 2) ? 0 : 1;   // (bit 1: test hook)
         if (!st.done && !failed) {
             // max_iterations <= 1 never reaches here (handled by the host)
             st.done = 1;
@@ -1022,11 +1637,16 @@ choose_tiling(int stride, int rows, int max_tiles, int *tw_out, int *th_out)
 }
 
 static size_t
-resident_lds_bytes(int tw, int th)
+resident_lds_bytes(int tw, int th, bool one)
 {
-    return ((size_t)(tw + 2) * (th + 2) * 4 + (size_t)tw * th * 4
-        + (size_t)4 * tw * th * 4 + (size_t)(3 * tw + 3 * th) * 16
-        + (size_t)2 * tw * th * 4 + 4 * RES_WAVES + 4 + 2) * sizeof(double);
+    return resident_lds_layout(tw, th, one).total * sizeof(double);
+}
+
+// Which of the two resident solvers a context runs (smvs_ctx_set_solver).
+static bool
+resident_one_exchange(const smvs_ctx *ctx)
+{
+    return ctx->solver_mode != SMVS_SOLVER_RESIDENT_REF;
 }
 
 // Does the resident solver take this system?  (grid fits the chip's CUs and
@@ -1060,7 +1680,7 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
     int tw = 0, th = 0;
     if (!choose_tiling(stride, rows, max_tiles, &tw, &th))
         return false;
-    if (resident_lds_bytes(tw, th) > (size_t)160 * 1024)
+    if (resident_lds_bytes(tw, th, resident_one_exchange(ctx)) > (size_t)160 * 1024)
         return false;
     if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32)
         return false;
@@ -1095,7 +1715,8 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     (void)choose_tiling(stride, rows, max_tiles, &tw, &th);
     int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
     int const num_tiles = tiles_x * tiles_y;
-    size_t const lds_bytes = resident_lds_bytes(tw, th);
+    bool const one = resident_one_exchange(ctx);
+    size_t const lds_bytes = resident_lds_bytes(tw, th, one);
 
     int rc;
     if (ctx->res_work == nullptr) {
@@ -1116,12 +1737,14 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     }
     static bool attr_set[16] = { false };
     if (ctx->device < 16 && !attr_set[ctx->device]) {
-        SMVS_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(cg_resident_kernel<false>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SMVS_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(cg_resident_kernel<true>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void *kernels[4] = {
+            reinterpret_cast<const void *>(cg_resident_kernel<false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<false, true>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true>) };
+        for (const void *k : kernels)
+            SMVS_HIP_CHECK(hipFuncSetAttribute(k,
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device] = true;
     }
 
@@ -1174,11 +1797,17 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     *num_tiles_out = num_tiles;
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
-        if (fused)
-            hipLaunchKernelGGL(cg_resident_kernel<true>, dim3(num_tiles),
+        if (fused && one)
+            hipLaunchKernelGGL((cg_resident_kernel<true, true>), dim3(num_tiles),
+                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+        else if (fused)
+            hipLaunchKernelGGL((cg_resident_kernel<true, false>), dim3(num_tiles),
+                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+        else if (one)
+            hipLaunchKernelGGL((cg_resident_kernel<false, true>), dim3(num_tiles),
                 dim3(RES_THREADS), lds_bytes, ctx->stream, A);
         else
-            hipLaunchKernelGGL(cg_resident_kernel<false>, dim3(num_tiles),
+            hipLaunchKernelGGL((cg_resident_kernel<false, false>), dim3(num_tiles),
                 dim3(RES_THREADS), lds_bytes, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
@@ -1255,8 +1884,9 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
             hipMemcpyDeviceToHost));
         (void)hipFree(trace_dev);
         if (FILE *f = std::fopen(trace_path, "a")) {
-            std::fprintf(f, "solve nodes=%d tiles=%d its=%d\n", ctx->num_nodes,
-                num_tiles, progress[3]);
+            std::fprintf(f, "solve nodes=%d tiles=%d its=%d exchanges=%d\n",
+                ctx->num_nodes, num_tiles, progress[3],
+                resident_one_exchange(ctx) ? 1 : 2);
             for (int k = 0; k <= TRACE_ITERS; ++k) {
                 for (int q = 0; q < TRACE_POINTS; ++q)
                     std::fprintf(f, "%lld ", tr[(size_t)k * TRACE_POINTS + q]);

@@ -160,6 +160,10 @@ struct smvs_ctx {
     double *lightAb = nullptr;      // [272] lighting normal equations
     float *stage = nullptr;         // upload staging (3-channel planes)
     size_t stage_cap = 0;
+    void *pin = nullptr;            // pinned host staging of the large transfers
+    size_t pin_cap = 0;
+    uint8_t *byte_stage = nullptr;  // device staging of smvs_ctx_upload_image
+    size_t byte_stage_cap = 0;
     // resident PCG (cg_resident.hip)
     double *res_work = nullptr;     // partial sums + barrier words
     double *res_zx = nullptr;       // [cap_nodes][4] z exchanged between workgroups
@@ -202,6 +206,11 @@ struct ScopedKernelTimer {
     ~ScopedKernelTimer();
 };
 int profile_collect(smvs_ctx *ctx);
+// Large host <-> device transfers of a context through its pinned staging
+// buffer (a pageable copy runs at a fraction of the link's rate); both return
+// when the caller's buffer may be reused / is filled.
+int ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 template <typename T>
 int device_alloc(T **ptr, size_t count)
@@ -220,6 +229,38 @@ int device_alloc(T **ptr, size_t count)
     }
     return SMVS_OK;
 }
+
+// A reusable device workspace of the context-free entry points (pool.hip): a
+// stream, named device buffers that only grow, pinned staging memory.
+struct Workspace {
+    enum { SLOTS = 24 };
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Buf dev[SLOTS];
+    void *pinned = nullptr;
+    size_t pinned_cap = 0, pinned_used = 0;
+    int ensure(int slot, size_t bytes, void **out);
+    template <typename T> int ensure(int slot, size_t count, T **out)
+    {
+        void *p = nullptr;
+        int const rc = ensure(slot, count * sizeof(T), &p);
+        *out = static_cast<T *>(p);
+        return rc;
+    }
+    int ensure_pinned(size_t bytes);
+    int upload(void *dst_dev, const void *src_host, size_t bytes);
+    int download(void *dst_host, const void *src_dev, size_t bytes);
+};
+Workspace *workspace_acquire(int device);   // nullptr: error text set
+void workspace_release(Workspace *w);
+struct WorkspaceLease {
+    Workspace *w;
+    explicit WorkspaceLease(int device) : w(workspace_acquire(device)) {}
+    ~WorkspaceLease() { workspace_release(w); }
+    WorkspaceLease(WorkspaceLease const &) = delete;
+    WorkspaceLease &operator=(WorkspaceLease const &) = delete;
+};
 
 // Maps the hardware block index to a logical block so that the blocks that
 // land on one XCD (blockIdx % 8, MI355X_MICROARCH.md "Workgroup dispatch")

@@ -75,6 +75,58 @@ expand_hessian_kernel(const float *__restrict__ src, float4 *__restrict__ dst,
 }
 
 static int
+ensure_pinned(smvs_ctx *ctx, size_t bytes)
+{
+    if (ctx->pin != nullptr && ctx->pin_cap >= bytes)
+        return SMVS_OK;
+    if (ctx->pin != nullptr) {
+        (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+    }
+    size_t const want = bytes < ((size_t)1 << 20) ? (size_t)1 << 20 : bytes;
+    hipError_t const e = hipHostMalloc(&ctx->pin, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+        ctx->pin = nullptr;
+        return SMVS_ERR_NOMEM;
+    }
+    ctx->pin_cap = want;
+    return SMVS_OK;
+}
+
+int
+ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0)
+        return SMVS_OK;
+    int const rc = ensure_pinned(ctx, bytes);
+    if (rc != SMVS_OK)
+        return rc;
+    memcpy(ctx->pin, src_host, bytes);
+    SMVS_HIP_CHECK(hipMemcpyAsync(dst_dev, ctx->pin, bytes, hipMemcpyHostToDevice,
+        ctx->stream));
+    // (one staging buffer: the next transfer may overwrite it)
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SMVS_OK;
+}
+
+int
+ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0)
+        return SMVS_OK;
+    int const rc = ensure_pinned(ctx, bytes);
+    if (rc != SMVS_OK)
+        return rc;
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->pin, src_dev, bytes, hipMemcpyDeviceToHost,
+        ctx->stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(dst_host, ctx->pin, bytes);
+    return SMVS_OK;
+}
+
+static int
 ensure_stage(smvs_ctx *ctx, size_t floats)
 {
     if (ctx->stage_cap >= floats)
@@ -183,7 +235,7 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
         ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list,
-        ctx->step_counter, ctx->nodes_saved, ctx->zero_block };
+        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -209,6 +261,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         if (ctx->subs[i].hess)
             (void)hipFree(ctx->subs[i].hess);
     }
+    if (ctx->pin)
+        (void)hipHostFree(ctx->pin);
     if (ctx->status_host)
         (void)hipHostFree(ctx->status_host);
     if (ctx->cg_progress)
@@ -463,8 +517,8 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
             tab.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->hermite_tab_ps = ps;
     }
-    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes, nodes, N * 4 * sizeof(double),
-        hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx_upload(ctx, ctx->nodes, nodes, N * 4 * sizeof(double))) != SMVS_OK)
+        return rc;
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->node_valid, node_valid, N,
         hipMemcpyHostToDevice, ctx->stream));
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->patch_valid, patch_valid, P,
@@ -541,11 +595,8 @@ smvs_get_nodes(smvs_ctx *ctx, double *nodes)
         return SMVS_ERR_STATE;
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
-    SMVS_HIP_CHECK(hipMemcpyAsync(nodes, ctx->nodes,
-        (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyDeviceToHost,
-        ctx->stream));
-    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return SMVS_OK;
+    return ctx_download(ctx, nodes, ctx->nodes,
+        (size_t)ctx->num_nodes * 4 * sizeof(double));
 }
 
 extern "C" int

@@ -9,6 +9,9 @@
 #include "depth_optimizer.h"
 #include "sgm_stereo.h"
 #include "view_selection.h"
+#include "view_queue.h"
+
+#include <chrono>
 
 using namespace smvs_amd;
 
@@ -330,6 +333,152 @@ smvs_host_surface_maps(const smvs_host_view *main_in, const smvs_host_view *subs
         std::memcpy(depth_out, optimizer.get_depth()->begin(), sizeof(float) * npix);
         std::memcpy(normals_out, optimizer.get_normals()->begin(),
             sizeof(float) * 3 * npix);
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+static void
+fill_log(DepthOptimizer const& optimizer, smvs_host_log *log)
+{
+    log->count = 0;
+    for (auto const& e : optimizer.get_log()) {
+        if (log->count >= SMVS_HOST_LOG_MAX)
+            break;
+        int const i = log->count++;
+        log->scale[i] = e.scale;
+        log->iter[i] = e.iter;
+        log->newton_steps[i] = e.newton_steps;
+        log->valid_patches[i] = e.valid_patches;
+        log->cg_iterations[i] = e.cg_iterations;
+    }
+    log->has_lighting = optimizer.has_lighting() ? 1 : 0;
+    std::copy(optimizer.get_lighting(), optimizer.get_lighting() + 16,
+        log->lighting);
+}
+
+extern "C" int
+smvs_host_optimize_views(const smvs_host_view *mains, const smvs_host_view *subs_in,
+    int n_jobs, int n_subs, const smvs_host_bundle *bundle_in,
+    const smvs_host_options *o, int sgm_scale, int first_device, int num_devices,
+    int views_in_flight, int keep_job, float *depth_out, float *normals_out,
+    double *job_seconds, double *total_seconds, smvs_host_log *logs)
+{
+    try {
+        if (mains == nullptr || subs_in == nullptr || o == nullptr || n_jobs < 1
+            || n_subs < 1 || num_devices < 1 || views_in_flight < 1)
+            throw std::invalid_argument("smvs_host_optimize_views: bad argument");
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        typedef std::chrono::steady_clock Clock;
+        std::vector<std::future<void>> done;
+        Clock::time_point const t_start = Clock::now();
+        {
+            ViewQueue queue(num_devices, views_in_flight);
+            for (int job = 0; job < n_jobs; ++job)
+                done.push_back(queue.add_task([=](ViewQueue::Slot const& slot) {
+                    // app/smvsrecon.cc:662-732
+                    Clock::time_point const t0 = Clock::now();
+                    StereoView::Ptr main_view = make_view(mains[job],
+                        o->use_shading != 0);
+                    std::vector<StereoView::Ptr> subs;
+                    for (int j = 0; j < n_subs; ++j)
+                        subs.push_back(make_view(subs_in[(size_t)job * n_subs + j],
+                            false));
+                    int const device = first_device + slot.device;
+                    bool const use_sgm = sgm_scale >= 0;
+                    if (use_sgm) {
+                        SGMStereo::Options sgm_opts;
+                        sgm_opts.scale = sgm_scale;
+                        sgm_opts.num_steps = 128;
+                        sgm_opts.device = device;
+                        (void)reconstruct_sgm_depth_for_view(sgm_opts, main_view, subs,
+                            bundle);
+                    }
+                    DepthOptimizer::Options opts;
+                    opts.regularization = o->regularization;
+                    opts.light_surf_regularization = o->light_surf_regularization;
+                    opts.num_iterations = o->num_iterations;
+                    opts.min_scale = o->min_scale;
+                    opts.use_shading = o->use_shading != 0;
+                    opts.use_sgm = use_sgm;
+                    opts.full_optimization = o->full_optimization != 0;
+                    opts.device = device;
+                    opts.solver = o->solver;
+                    DepthOptimizer optimizer(main_view, subs, bundle, opts);
+                    optimizer.optimize();
+                    FloatImage::Ptr depth = optimizer.get_depth();
+                    FloatImage::Ptr normals = optimizer.get_normals();
+                    if (job == keep_job) {
+                        size_t const npix = (size_t)mains[job].width * mains[job].height;
+                        if (depth_out != nullptr)
+                            std::memcpy(depth_out, depth->begin(), sizeof(float) * npix);
+                        if (normals_out != nullptr)
+                            std::memcpy(normals_out, normals->begin(),
+                                sizeof(float) * 3 * npix);
+                    }
+                    if (logs != nullptr)
+                        fill_log(optimizer, &logs[job]);
+                    if (job_seconds != nullptr)
+                        job_seconds[job] = std::chrono::duration<double>(
+                            Clock::now() - t0).count();
+                }));
+            queue.wait_idle();
+        }
+        if (total_seconds != nullptr)
+            *total_seconds = std::chrono::duration<double>(Clock::now() - t_start).count();
+        for (auto& f : done)
+            f.get();   // rethrows a task's exception
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_view_queue_selftest(int n_tasks, int num_devices, int views_in_flight,
+    int throwing_task, int *device_hist, int *worker_hist)
+{
+    try {
+        if (n_tasks < 0 || device_hist == nullptr || worker_hist == nullptr)
+            throw std::invalid_argument("smvs_host_view_queue_selftest: bad argument");
+        std::vector<int> ran(n_tasks, 0), on_device(n_tasks, -1), on_worker(n_tasks, -1);
+        std::vector<std::future<void>> done;
+        {
+            ViewQueue queue(num_devices, views_in_flight);
+            if (queue.num_workers() != num_devices * views_in_flight)
+                throw std::logic_error("ViewQueue: wrong number of workers");
+            for (int i = 0; i < n_tasks; ++i)
+                done.push_back(queue.add_task([&, i](ViewQueue::Slot const& slot) {
+                    ran[i] += 1;
+                    on_device[i] = slot.device;
+                    on_worker[i] = slot.worker;
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                    if (i == throwing_task)
+                        throw std::runtime_error("task failed on purpose");
+                }));
+            queue.wait_idle();
+        }
+        std::fill(device_hist, device_hist + num_devices, 0);
+        std::fill(worker_hist, worker_hist + num_devices * views_in_flight, 0);
+        for (int i = 0; i < n_tasks; ++i) {
+            bool threw = false;
+            try {
+                done[i].get();
+            } catch (std::runtime_error const&) {
+                threw = true;
+            }
+            if (threw != (i == throwing_task))
+                throw std::logic_error("ViewQueue: exception on the wrong future");
+            if (ran[i] != 1 || on_device[i] < 0 || on_device[i] >= num_devices)
+                throw std::logic_error("ViewQueue: a task did not run exactly once");
+            if (on_worker[i] % num_devices != on_device[i])
+                throw std::logic_error("ViewQueue: worker / device binding");
+            device_hist[on_device[i]] += 1;
+            worker_hist[on_worker[i]] += 1;
+        }
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();

@@ -80,6 +80,33 @@ int smvs_host_surface_script(const smvs_host_view *main_view,
     const int *ops, int n_ops, int delete_every, int *info, double *nodes_out,
     uint8_t *node_valid_out, uint8_t *patch_valid_out);
 
+/* The per-view tasks of smvsrecon (app/smvsrecon.cc:658-733) for n_jobs
+ * reference views on a smvs_amd::ViewQueue: per job StereoView::create for the
+ * main view and its neighbours, optionally reconstruct_sgm_depth_for_view
+ * (sgm_scale >= 0; a negative value skips the SGM front end and initialises
+ * from the bundle), DepthOptimizer(...).optimize(), depth + normal maps.
+ * Job i uses mains[i] and subs[i * n_subs .. (i + 1) * n_subs).  Worker w runs
+ * on device first_device + w % num_devices with views_in_flight workers per
+ * device.  Outputs (each may be NULL): depth_out / normals_out of job
+ * `keep_job` only (W * H and W * H * 3 floats of that job's main view),
+ * job_seconds[n_jobs] = wall time of each task, *total_seconds = wall time
+ * from the first task queued to the last finished, logs[n_jobs]. */
+int smvs_host_optimize_views(const smvs_host_view *mains,
+    const smvs_host_view *subs, int n_jobs, int n_subs,
+    const smvs_host_bundle *bundle, const smvs_host_options *opts, int sgm_scale,
+    int first_device, int num_devices, int views_in_flight, int keep_job,
+    float *depth_out, float *normals_out, double *job_seconds,
+    double *total_seconds, smvs_host_log *logs);
+
+/* smvs_amd::ViewQueue on its own (no device involved): n_tasks tasks that
+ * record the slot they ran on; task `throwing_task` (or -1) throws.
+ * device_hist[num_devices] and worker_hist[num_devices * views_in_flight]
+ * receive the number of tasks per device / worker.  Returns 0 when every task
+ * ran exactly once, the throwing task's exception arrived through its future
+ * and no other future carried one. */
+int smvs_host_view_queue_selftest(int n_tasks, int num_devices,
+    int views_in_flight, int throwing_task, int *device_hist, int *worker_hist);
+
 /* DepthOptimizer(main, subs, Surface::Ptr, opts) followed by get_depth() /
  * get_normals() WITHOUT optimize() (lib/depth_optimizer.h:53-61): the maps of
  * the surface Surface::create builds (from the bundle, or from init_depth). */

@@ -219,29 +219,34 @@ smvs_cut_depth_maps(int device, smvs_mesh_view *views, int n_views)
         SMVS_REQUIRE(views[i].width > 0 && views[i].height > 0
             && views[i].depth != nullptr && views[i].normals != nullptr
             && views[i].flen > 0.0f, "bad view");
-    int count = 0;
-    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
-    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
-    SMVS_HIP_CHECK(hipSetDevice(device));
-
-    struct Holder {
-        std::vector<void *> ptrs;
-        ~Holder() { for (void *p : ptrs) (void)hipFree(p); }
-        int alloc(void **p, size_t bytes)
-        {
-            hipError_t e = hipMalloc(p, bytes);
-            if (e != hipSuccess) {
-                set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-                return SMVS_ERR_NOMEM;
-            }
-            ptrs.push_back(*p);
-            return SMVS_OK;
-        }
-    } mem;
+    // one slab of a pooled workspace (pool.hip) holds every view's maps and
+    // the view table: no allocation per call
+    WorkspaceLease lease(device);
+    if (lease.w == nullptr)
+        return SMVS_ERR_HIP;
+    Workspace &ws = *lease.w;
+    size_t total = 0;
+    auto carve = [&](size_t bytes) {
+        size_t const at = total;
+        total += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    std::vector<size_t> offsets((size_t)n_views * 4);
+    for (int i = 0; i < n_views; ++i) {
+        size_t const npix = (size_t)views[i].width * views[i].height;
+        offsets[4 * i + 0] = carve(sizeof(float) * npix);       // depth_z
+        offsets[4 * i + 1] = carve(sizeof(float) * npix);       // depth_ray
+        offsets[4 * i + 2] = carve(sizeof(float) * npix);       // cut
+        offsets[4 * i + 3] = carve(sizeof(float) * 3 * npix);   // normals
+    }
+    size_t const table_at = carve(sizeof(MeshViewDev) * n_views);
+    char *slab = nullptr;
+    int rc;
+    if ((rc = ws.ensure(0, total, &slab)) != SMVS_OK)
+        return rc;
+    hipStream_t const stream = ws.stream;
 
     std::vector<MeshViewDev> table(n_views);
-    hipStream_t stream = nullptr;
-    int rc;
     for (int i = 0; i < n_views; ++i) {
         smvs_mesh_view const &in = views[i];
         MeshViewDev &V = table[i];
@@ -274,21 +279,17 @@ smvs_cut_depth_maps(int device, smvs_mesh_view *views, int n_views)
             V.t[r] = s;
         }
         size_t const npix = (size_t)in.width * in.height;
-        if ((rc = mem.alloc((void **)&V.depth_z, sizeof(float) * npix))
-            || (rc = mem.alloc((void **)&V.depth_ray, sizeof(float) * npix))
-            || (rc = mem.alloc((void **)&V.cut, sizeof(float) * npix))
-            || (rc = mem.alloc((void **)&V.normals, sizeof(float) * 3 * npix)))
+        V.depth_z = reinterpret_cast<float *>(slab + offsets[4 * i + 0]);
+        V.depth_ray = reinterpret_cast<float *>(slab + offsets[4 * i + 1]);
+        V.cut = reinterpret_cast<float *>(slab + offsets[4 * i + 2]);
+        V.normals = reinterpret_cast<float *>(slab + offsets[4 * i + 3]);
+        if ((rc = ws.upload(V.depth_ray, in.depth, sizeof(float) * npix))
+            || (rc = ws.upload(V.normals, in.normals, sizeof(float) * 3 * npix)))
             return rc;
-        SMVS_HIP_CHECK(hipMemcpyAsync(V.depth_ray, in.depth, sizeof(float) * npix,
-            hipMemcpyHostToDevice, stream));
-        SMVS_HIP_CHECK(hipMemcpyAsync(V.normals, in.normals,
-            sizeof(float) * 3 * npix, hipMemcpyHostToDevice, stream));
     }
-    MeshViewDev *d_table = nullptr;
-    if ((rc = mem.alloc((void **)&d_table, sizeof(MeshViewDev) * n_views)))
+    MeshViewDev *d_table = reinterpret_cast<MeshViewDev *>(slab + table_at);
+    if ((rc = ws.upload(d_table, table.data(), sizeof(MeshViewDev) * n_views)))
         return rc;
-    SMVS_HIP_CHECK(hipMemcpyAsync(d_table, table.data(),
-        sizeof(MeshViewDev) * n_views, hipMemcpyHostToDevice, stream));
     for (int i = 0; i < n_views; ++i)
         hipLaunchKernelGGL(mesh_prepare_kernel,
             dim3((table[i].w + 255) / 256, table[i].h), dim3(256), 0, stream,
@@ -303,11 +304,10 @@ smvs_cut_depth_maps(int device, smvs_mesh_view *views, int n_views)
     SMVS_HIP_CHECK(hipGetLastError());
     for (int i = 0; i < n_views; ++i) {
         size_t const npix = (size_t)table[i].w * table[i].h;
-        SMVS_HIP_CHECK(hipMemcpyAsync(views[i].depth, table[i].cut,
-            sizeof(float) * npix, hipMemcpyDeviceToHost, stream));
-        SMVS_HIP_CHECK(hipMemcpyAsync(views[i].normals, table[i].normals,
-            sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, stream));
+        if ((rc = ws.download(views[i].depth, table[i].cut, sizeof(float) * npix))
+            || (rc = ws.download(views[i].normals, table[i].normals,
+                    sizeof(float) * 3 * npix)))
+            return rc;
     }
-    SMVS_HIP_CHECK(hipStreamSynchronize(stream));
     return SMVS_OK;
 }

@@ -1,0 +1,204 @@
+// Reusable device workspaces for the context-free entry points (SGM front
+// end, bilateral upsample, cut_depth_maps).
+//
+// The reference allocates its cost volumes per SGMStereo object and frees them
+// when the object dies (lib/sgm_stereo.cc:192-225); on the device an
+// allocation is a driver call that synchronises the whole GPU and costs
+// hundreds of microseconds to milliseconds (the 270 MB of volumes of one
+// 960 x 540 x 128 run_sgm: ~20 ms to allocate and free, against 6 ms of
+// kernels).  A workspace -- its own HIP stream, named device buffers that only
+// grow, pinned staging memory -- is therefore checked out of a per-device free
+// list for the duration of one call and handed back afterwards; concurrent
+// callers (one host thread per reference view, host/view_queue.cc) get
+// different workspaces.  Nothing is returned to the driver before
+// smvs_release_workspaces() or process exit.
+#include "common.h"
+
+#include <mutex>
+
+namespace smvs_hip {
+
+namespace {
+constexpr int MAX_DEVICES = 16;
+std::mutex g_pool_mutex;
+std::vector<Workspace *> g_free[MAX_DEVICES];
+int g_created[MAX_DEVICES] = { 0 };
+}
+
+int
+Workspace::ensure(int slot, size_t bytes, void **out)
+{
+    Buf &b = dev[slot];
+    if (b.p == nullptr || b.cap < bytes) {
+        if (b.p != nullptr) {
+            // (work that still uses the old buffer is ordered on this stream)
+            SMVS_HIP_CHECK(hipStreamSynchronize(stream));
+            (void)hipFree(b.p);
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t const want = bytes ? bytes : 1;
+        hipError_t const e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu): %s", want, hipGetErrorString(e));
+            b.p = nullptr;
+            return SMVS_ERR_NOMEM;
+        }
+        b.cap = want;
+    }
+    *out = b.p;
+    return SMVS_OK;
+}
+
+int
+Workspace::ensure_pinned(size_t bytes)
+{
+    if (pinned != nullptr && pinned_cap >= bytes)
+        return SMVS_OK;
+    if (pinned != nullptr) {
+        SMVS_HIP_CHECK(hipStreamSynchronize(stream));
+        (void)hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_cap = 0;
+    }
+    hipError_t const e = hipHostMalloc(&pinned, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        pinned = nullptr;
+        return SMVS_ERR_NOMEM;
+    }
+    pinned_cap = bytes;
+    pinned_used = 0;
+    return SMVS_OK;
+}
+
+// Host -> device through the pinned staging area: the caller's (pageable)
+// buffer is free again when the call returns, the transfer itself is
+// asynchronous on the workspace's stream.
+int
+Workspace::upload(void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0)
+        return SMVS_OK;
+    size_t const aligned = (bytes + 255) & ~(size_t)255;
+    if (pinned == nullptr || pinned_cap < aligned) {
+        // grow geometrically: a view's uploads are a handful of images
+        size_t want = pinned_cap ? pinned_cap : (size_t)1 << 22;
+        while (want < aligned)
+            want *= 2;
+        int const rc = ensure_pinned(want);
+        if (rc != SMVS_OK)
+            return rc;
+    }
+    if (pinned_used + aligned > pinned_cap) {
+        // the staging area is full of transfers in flight: wait for them
+        SMVS_HIP_CHECK(hipStreamSynchronize(stream));
+        pinned_used = 0;
+    }
+    char *stage = static_cast<char *>(pinned) + pinned_used;
+    memcpy(stage, src_host, bytes);
+    pinned_used += aligned;
+    SMVS_HIP_CHECK(hipMemcpyAsync(dst_dev, stage, bytes, hipMemcpyHostToDevice,
+        stream));
+    return SMVS_OK;
+}
+
+// Device -> host through the staging area; returns when dst_host is filled.
+int
+Workspace::download(void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0)
+        return SMVS_OK;
+    // (everything uploaded so far has to be out of the staging area)
+    SMVS_HIP_CHECK(hipStreamSynchronize(stream));
+    pinned_used = 0;
+    if (pinned == nullptr || pinned_cap < bytes) {
+        int const rc = ensure_pinned(bytes);
+        if (rc != SMVS_OK)
+            return rc;
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(pinned, src_dev, bytes, hipMemcpyDeviceToHost,
+        stream));
+    SMVS_HIP_CHECK(hipStreamSynchronize(stream));
+    memcpy(dst_host, pinned, bytes);
+    return SMVS_OK;
+}
+
+Workspace *
+workspace_acquire(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count
+        || device >= MAX_DEVICES) {
+        set_error("workspace_acquire: no such HIP device (%d)", device);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> guard(g_pool_mutex);
+        if (!g_free[device].empty()) {
+            Workspace *w = g_free[device].back();
+            g_free[device].pop_back();
+            w->pinned_used = 0;
+            return w;
+        }
+        g_created[device] += 1;
+    }
+    Workspace *w = new Workspace();
+    w->device = device;
+    hipError_t const e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate: %s", hipGetErrorString(e));
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
+
+void
+workspace_release(Workspace *w)
+{
+    if (w == nullptr)
+        return;
+    std::lock_guard<std::mutex> guard(g_pool_mutex);
+    g_free[w->device].push_back(w);
+}
+
+static void
+workspace_destroy(Workspace *w)
+{
+    (void)hipSetDevice(w->device);
+    if (w->stream != nullptr)
+        (void)hipStreamSynchronize(w->stream);
+    for (auto &b : w->dev)
+        if (b.p != nullptr)
+            (void)hipFree(b.p);
+    if (w->pinned != nullptr)
+        (void)hipHostFree(w->pinned);
+    if (w->stream != nullptr)
+        (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_release_workspaces(void)
+{
+    std::vector<Workspace *> all;
+    {
+        std::lock_guard<std::mutex> guard(g_pool_mutex);
+        for (auto &list : g_free) {
+            all.insert(all.end(), list.begin(), list.end());
+            list.clear();
+        }
+    }
+    for (Workspace *w : all)
+        workspace_destroy(w);
+    return (int)all.size();
+}

@@ -160,19 +160,23 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
         vi.h = height;
         vi.c = channels;
     }
-    uint8_t *staging = nullptr;
-    if ((rc = device_alloc(&staging, n)) != SMVS_OK)
-        return rc;
-    hipError_t e = hipMemcpyAsync(staging, bytes, n, hipMemcpyHostToDevice,
-        ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
-            dim3(256), 0, ctx->stream, staging, vi.data, n);
-        e = hipGetLastError();
+    // (device staging owned by the context: no allocation per image; the
+    // bytes cross PCIe from pinned memory)
+    if (ctx->byte_stage_cap < n) {
+        if ((rc = device_alloc(&ctx->byte_stage, n)) != SMVS_OK) {
+            ctx->byte_stage_cap = 0;
+            return rc;
+        }
+        ctx->byte_stage_cap = n;
     }
+    uint8_t *staging = ctx->byte_stage;
+    if ((rc = ctx_upload(ctx, staging, bytes, n)) != SMVS_OK)
+        return rc;
+    hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+        dim3(256), 0, ctx->stream, staging, vi.data, n);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(staging);
     if (e != hipSuccess) {
         set_error("smvs_ctx_upload_image: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;

@@ -656,46 +656,36 @@ sgm_merge_kernel(float *__restrict__ d1, const float *__restrict__ d2, size_t n)
     d1[i] = a == 0.0f ? b : (a + b) * 0.5f;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        if (p != nullptr && cap >= bytes)
-            return SMVS_OK;
-        if (p != nullptr) {
-            (void)hipFree(p);
-            p = nullptr;
-            cap = 0;
-        }
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-        if (e != hipSuccess) {
-            set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-            p = nullptr;
-            return SMVS_ERR_NOMEM;
-        }
-        cap = bytes;
-        return SMVS_OK;
-    }
-    template <typename T> T *as() { return static_cast<T *>(p); }
+// Slots of a pooled workspace (pool.hip) used by this file.
+enum {
+    WS_DEPTHS = 0, WS_CENSUS, WS_WARPED, WS_COST, WS_SGM, WS_ARGMIN,   // one run_sgm
+    WS_MAIN, WS_NBR0, WS_NBR1, WS_FWD0, WS_FWD1, WS_BWD, WS_COST16,   // a view's front end
+    WS_BIL_DM, WS_BIL_CI, WS_BIL_OUT                                  // bilateral upsample
 };
 
-// Work buffers of one run_sgm; reused by the runs of a view (the runs are
-// ordered on one stream).  Every run has its own depth table.
+// Work buffers of one run_sgm inside a pooled workspace; reused by the runs of
+// a view (the runs are ordered on the workspace's stream).  Every run has its
+// own depth table.
 struct SgmWorkspace {
     static constexpr int MAX_RUNS = 4;
-    DevBuf depths, census, warped, cost, sgm, argmin;
+    Workspace *ws;
+    float *depths = nullptr;
+    unsigned long long *census = nullptr;
+    uint8_t *warped = nullptr, *cost = nullptr;
+    uint16_t *sgm = nullptr;
+    int32_t *argmin = nullptr;
     int runs = 0;
+    explicit SgmWorkspace(Workspace *w) : ws(w) {}
     int ensure(size_t npix, int num_steps)
     {
         size_t const vol = npix * (size_t)num_steps;
         int rc;
-        if ((rc = depths.alloc(sizeof(float) * 128 * MAX_RUNS))
-            || (rc = census.alloc(sizeof(unsigned long long) * npix))
-            || (rc = warped.alloc(vol)) || (rc = cost.alloc(vol))
-            || (rc = sgm.alloc(sizeof(uint16_t) * vol))
-            || (rc = argmin.alloc(sizeof(int32_t) * npix)))
+        if ((rc = ws->ensure(WS_DEPTHS, (size_t)128 * MAX_RUNS, &depths))
+            || (rc = ws->ensure(WS_CENSUS, npix, &census))
+            || (rc = ws->ensure(WS_WARPED, vol, &warped))
+            || (rc = ws->ensure(WS_COST, vol, &cost))
+            || (rc = ws->ensure(WS_SGM, vol, &sgm))
+            || (rc = ws->ensure(WS_ARGMIN, npix, &argmin)))
             return rc;
         return SMVS_OK;
     }
@@ -722,7 +712,7 @@ check_sgm_options(int num_steps, float min_depth, float max_depth,
 // SGMStereo::run_sgm (sgm_stereo.cc:98-124) on device images; the depth map
 // (and optionally argmin) stay on the device.  Asynchronous on `stream`.
 static int
-sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
+sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     int w, int h, const uint8_t *d_nbr, int nw, int nh, const float *M,
     const float *t, float min_depth, float max_depth, int num_steps,
     uint16_t penalty1, uint16_t penalty2, float *d_depth)
@@ -732,6 +722,7 @@ sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
     if (rc != SMVS_OK)
         return rc;
     SMVS_REQUIRE(B.runs < SgmWorkspace::MAX_RUNS, "too many runs on one workspace");
+    hipStream_t const stream = B.ws->stream;
     size_t const npix = (size_t)w * h;
     size_t const vol = npix * num_steps;
     if ((rc = B.ensure(npix, num_steps)) != SMVS_OK)
@@ -747,15 +738,13 @@ sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
             inv_depth += increment;
         }
     }
-    float *d_depths = B.depths.as<float>() + 128 * B.runs;
+    float *d_depths = B.depths + 128 * B.runs;
     B.runs += 1;
-    // (pageable source: the copy has returned from the host buffer when the
-    // call returns)
-    SMVS_HIP_CHECK(hipMemcpyAsync(d_depths, depths, sizeof(float) * num_steps,
-        hipMemcpyHostToDevice, stream));
+    if ((rc = B.ws->upload(d_depths, depths, sizeof(float) * num_steps)) != SMVS_OK)
+        return rc;
 
     hipLaunchKernelGGL(census_main_kernel, dim3((w + 255) / 256, h), dim3(256),
-        0, stream, d_main, w, h, B.census.as<unsigned long long>());
+        0, stream, d_main, w, h, B.census);
     WarpArgs W;
     W.neighbor = d_nbr;
     W.nw = nw;
@@ -766,15 +755,15 @@ sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
     W.D = num_steps;
     W.w = w;
     W.h = h;
-    W.warped = B.warped.as<uint8_t>();
+    W.warped = B.warped;
     unsigned const vblocks = (unsigned)((vol + 255) / 256);
     hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
     {
         int const tiles = ((w + CT_W - 1) / CT_W) * ((h + CT_H - 1) / CT_H);
         hipLaunchKernelGGL(cost_tiled_kernel,
             dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
-            B.warped.as<uint8_t>(), B.census.as<unsigned long long>(), w, h,
-            num_steps, B.cost.as<uint8_t>());
+            B.warped, B.census, w, h,
+            num_steps, B.cost);
     }
     SMVS_HIP_CHECK(hipGetLastError());
 
@@ -783,8 +772,8 @@ sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
     static const int dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 },
         { -1, 1 }, { 0, -1 }, { 1, -1 }, { -1, -1 } };
     PathArgs P;
-    P.cost = B.cost.as<uint8_t>();
-    P.sgm = B.sgm.as<uint16_t>();
+    P.cost = B.cost;
+    P.sgm = B.sgm;
     P.w = w;
     P.h = h;
     P.D = num_steps;
@@ -792,7 +781,7 @@ sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
     P.p2 = penalty2;
     P.last = 0;
     if ((num_steps % 2) == 0) {
-        SMVS_HIP_CHECK(hipMemsetAsync(B.sgm.p, 0, sizeof(uint16_t) * vol, stream));
+        SMVS_HIP_CHECK(hipMemsetAsync(B.sgm, 0, sizeof(uint16_t) * vol, stream));
         P.dx = P.dy = 0;
         P.first = 0;
         int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
@@ -812,19 +801,9 @@ sgm_run_device(hipStream_t stream, SgmWorkspace &B, const uint8_t *d_main,
     SMVS_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(wta_rows_kernel,
         dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
-        B.sgm.as<uint16_t>(), d_main, d_depths, npix, num_steps, d_depth,
-        B.argmin.as<int32_t>());
+        B.sgm, d_main, d_depths, npix, num_steps, d_depth,
+        B.argmin);
     SMVS_HIP_CHECK(hipGetLastError());
-    return SMVS_OK;
-}
-
-static int
-select_device(int device)
-{
-    int count = 0;
-    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
-    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
-    SMVS_HIP_CHECK(hipSetDevice(device));
     return SMVS_OK;
 }
 
@@ -843,43 +822,45 @@ smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
     SMVS_REQUIRE(w > 10 && h > 8 && nw > 1 && nh > 1, "image too small");
     int rc = check_sgm_options(num_steps, min_depth, max_depth, penalty1,
         penalty2);
-    if (rc != SMVS_OK || (rc = select_device(device)) != SMVS_OK)
+    if (rc != SMVS_OK)
         return rc;
+    WorkspaceLease lease(device);
+    if (lease.w == nullptr)
+        return SMVS_ERR_HIP;
+    Workspace &ws = *lease.w;
     size_t const npix = (size_t)w * h, nnpix = (size_t)nw * nh;
     size_t const vol = npix * num_steps;
-    SgmWorkspace B;
-    DevBuf d_main, d_nbr, d_depth, d_cost16;
-    if ((rc = d_main.alloc(npix)) || (rc = d_nbr.alloc(nnpix))
-        || (rc = d_depth.alloc(sizeof(float) * npix)))
+    SgmWorkspace B(&ws);
+    uint8_t *d_main = nullptr, *d_nbr = nullptr;
+    float *d_depth = nullptr;
+    if ((rc = ws.ensure(WS_MAIN, npix, &d_main)) || (rc = ws.ensure(WS_NBR0, nnpix, &d_nbr))
+        || (rc = ws.ensure(WS_FWD0, npix, &d_depth))
+        || (rc = ws.upload(d_main, main_img, npix))
+        || (rc = ws.upload(d_nbr, neighbor_img, nnpix)))
         return rc;
-    hipStream_t stream = nullptr;  // default stream: one-shot entry point
-    SMVS_HIP_CHECK(hipMemcpy(d_main.p, main_img, npix, hipMemcpyHostToDevice));
-    SMVS_HIP_CHECK(hipMemcpy(d_nbr.p, neighbor_img, nnpix, hipMemcpyHostToDevice));
-    if ((rc = sgm_run_device(stream, B, d_main.as<uint8_t>(), w, h,
-            d_nbr.as<uint8_t>(), nw, nh, M, t, min_depth, max_depth, num_steps,
-            penalty1, penalty2, d_depth.as<float>())) != SMVS_OK)
+    if ((rc = sgm_run_device(B, d_main, w, h, d_nbr, nw, nh, M, t, min_depth,
+            max_depth, num_steps, penalty1, penalty2, d_depth)) != SMVS_OK)
         return rc;
-    SMVS_HIP_CHECK(hipDeviceSynchronize());
-
-    if (depth != nullptr)
-        SMVS_HIP_CHECK(hipMemcpy(depth, d_depth.p, sizeof(float) * npix,
-            hipMemcpyDeviceToHost));
-    if (argmin != nullptr)
-        SMVS_HIP_CHECK(hipMemcpy(argmin, B.argmin.p, sizeof(int32_t) * npix,
-            hipMemcpyDeviceToHost));
-    if (sgm != nullptr)
-        SMVS_HIP_CHECK(hipMemcpy(sgm, B.sgm.p, sizeof(uint16_t) * vol,
-            hipMemcpyDeviceToHost));
+    if (depth != nullptr
+        && (rc = ws.download(depth, d_depth, sizeof(float) * npix)) != SMVS_OK)
+        return rc;
+    if (argmin != nullptr
+        && (rc = ws.download(argmin, B.argmin, sizeof(int32_t) * npix)) != SMVS_OK)
+        return rc;
+    if (sgm != nullptr
+        && (rc = ws.download(sgm, B.sgm, sizeof(uint16_t) * vol)) != SMVS_OK)
+        return rc;
     if (cost != nullptr) {
-        if ((rc = d_cost16.alloc(sizeof(uint16_t) * vol)))
+        uint16_t *d_cost16 = nullptr;
+        if ((rc = ws.ensure(WS_COST16, vol, &d_cost16)))
             return rc;
         hipLaunchKernelGGL(widen_u8_kernel, dim3((unsigned)((vol + 255) / 256)),
-            dim3(256), 0, stream, B.cost.as<uint8_t>(), d_cost16.as<uint16_t>(),
-            vol);
+            dim3(256), 0, ws.stream, B.cost, d_cost16, vol);
         SMVS_HIP_CHECK(hipGetLastError());
-        SMVS_HIP_CHECK(hipMemcpy(cost, d_cost16.p, sizeof(uint16_t) * vol,
-            hipMemcpyDeviceToHost));
+        if ((rc = ws.download(cost, d_cost16, sizeof(uint16_t) * vol)) != SMVS_OK)
+            return rc;
     }
+    SMVS_HIP_CHECK(hipStreamSynchronize(ws.stream));
     return SMVS_OK;
 }
 
@@ -896,40 +877,47 @@ smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
         SMVS_REQUIRE(neighbors[k].image && neighbors[k].width > 10
             && neighbors[k].height > 8, "bad neighbour image");
     int rc;
-    if ((rc = select_device(device)) != SMVS_OK)
-        return rc;
+    WorkspaceLease lease(device);
+    if (lease.w == nullptr)
+        return SMVS_ERR_HIP;
+    Workspace &ws = *lease.w;
+    hipStream_t const stream = ws.stream;
     size_t const npix = (size_t)w * h;
-    SgmWorkspace B;
-    DevBuf d_main, d_nbr[2], d_fwd[2], d_bwd;
-    if ((rc = d_main.alloc(npix)))
+    SgmWorkspace B(&ws);
+    uint8_t *d_main = nullptr, *d_nbr[2] = { nullptr, nullptr };
+    float *d_fwd[2] = { nullptr, nullptr }, *d_bwd = nullptr;
+    // (every buffer before the first launch: growing one waits for the stream)
+    size_t max_nnpix = 0;
+    for (int k = 0; k < n_neighbors; ++k) {
+        size_t const nnpix = (size_t)neighbors[k].width * neighbors[k].height;
+        max_nnpix = nnpix > max_nnpix ? nnpix : max_nnpix;
+        if ((rc = ws.ensure(k == 0 ? WS_NBR0 : WS_NBR1, nnpix, &d_nbr[k]))
+            || (rc = ws.ensure(k == 0 ? WS_FWD0 : WS_FWD1, npix, &d_fwd[k])))
+            return rc;
+    }
+    if ((rc = ws.ensure(WS_MAIN, npix, &d_main))
+        || (rc = ws.ensure(WS_BWD, max_nnpix, &d_bwd))
+        || (rc = B.ensure(npix > max_nnpix ? npix : max_nnpix, num_steps))
+        || (rc = ws.upload(d_main, main_img, npix)))
         return rc;
-    hipStream_t stream = nullptr;
-    SMVS_HIP_CHECK(hipMemcpyAsync(d_main.p, main_img, npix,
-        hipMemcpyHostToDevice, stream));
     for (int k = 0; k < n_neighbors; ++k) {
         smvs_sgm_neighbor const &N = neighbors[k];
         size_t const nnpix = (size_t)N.width * N.height;
-        if ((rc = d_nbr[k].alloc(nnpix))
-            || (rc = d_fwd[k].alloc(sizeof(float) * npix))
-            || (rc = d_bwd.alloc(sizeof(float) * nnpix)))
+        if ((rc = ws.upload(d_nbr[k], N.image, nnpix)))
             return rc;
-        SMVS_HIP_CHECK(hipMemcpyAsync(d_nbr[k].p, N.image, nnpix,
-            hipMemcpyHostToDevice, stream));
         // SGMStereo::reconstruct, sgm_stereo.cc:46-62: main -> neighbour,
         // then neighbour -> main with the neighbour's own depth range
-        if ((rc = sgm_run_device(stream, B, d_main.as<uint8_t>(), w, h,
-                d_nbr[k].as<uint8_t>(), N.width, N.height, N.M_fwd, N.t_fwd,
-                N.range_main[0], N.range_main[1], num_steps, penalty1, penalty2,
-                d_fwd[k].as<float>())) != SMVS_OK)
+        if ((rc = sgm_run_device(B, d_main, w, h, d_nbr[k], N.width, N.height,
+                N.M_fwd, N.t_fwd, N.range_main[0], N.range_main[1], num_steps,
+                penalty1, penalty2, d_fwd[k])) != SMVS_OK)
             return rc;
-        if ((rc = sgm_run_device(stream, B, d_nbr[k].as<uint8_t>(), N.width,
-                N.height, d_main.as<uint8_t>(), w, h, N.M_bwd, N.t_bwd,
-                N.range_neighbor[0], N.range_neighbor[1], num_steps, penalty1,
-                penalty2, d_bwd.as<float>())) != SMVS_OK)
+        if ((rc = sgm_run_device(B, d_nbr[k], N.width, N.height, d_main, w, h,
+                N.M_bwd, N.t_bwd, N.range_neighbor[0], N.range_neighbor[1],
+                num_steps, penalty1, penalty2, d_bwd)) != SMVS_OK)
             return rc;
         LrArgs L;
-        L.d_main = d_fwd[k].as<float>();
-        L.d_neig = d_bwd.as<float>();
+        L.d_main = d_fwd[k];
+        L.d_neig = d_bwd;
         L.w = w;
         L.h = h;
         L.nw = N.width;
@@ -945,14 +933,10 @@ smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
     }
     if (n_neighbors > 1) {
         hipLaunchKernelGGL(sgm_merge_kernel, dim3((unsigned)((npix + 255) / 256)),
-            dim3(256), 0, stream, d_fwd[0].as<float>(), d_fwd[1].as<float>(),
-            npix);
+            dim3(256), 0, stream, d_fwd[0], d_fwd[1], npix);
         SMVS_HIP_CHECK(hipGetLastError());
     }
-    SMVS_HIP_CHECK(hipMemcpyAsync(depth, d_fwd[0].p, sizeof(float) * npix,
-        hipMemcpyDeviceToHost, stream));
-    SMVS_HIP_CHECK(hipStreamSynchronize(stream));
-    return SMVS_OK;
+    return ws.download(depth, d_fwd[0], sizeof(float) * npix);
 }
 
 extern "C" int
@@ -963,25 +947,23 @@ smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     SMVS_REQUIRE(dm && ci && out, "null argument");
     SMVS_REQUIRE(dm_w > 0 && dm_h > 0 && w > 0 && h > 0 && channels > 0
         && kernel_size >= 0 && sigma > 0.f, "bad argument");
-    int count = 0;
-    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
-    SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
-    SMVS_HIP_CHECK(hipSetDevice(device));
-    DevBuf d_dm, d_ci, d_out;
+    WorkspaceLease lease(device);
+    if (lease.w == nullptr)
+        return SMVS_ERR_HIP;
+    Workspace &ws = *lease.w;
+    float *d_dm = nullptr, *d_ci = nullptr, *d_out = nullptr;
     int rc;
     size_t const n = (size_t)w * h;
-    if ((rc = d_dm.alloc(sizeof(float) * dm_w * dm_h))
-        || (rc = d_ci.alloc(sizeof(float) * n * channels))
-        || (rc = d_out.alloc(sizeof(float) * n)))
+    if ((rc = ws.ensure(WS_BIL_DM, (size_t)dm_w * dm_h, &d_dm))
+        || (rc = ws.ensure(WS_BIL_CI, n * channels, &d_ci))
+        || (rc = ws.ensure(WS_BIL_OUT, n, &d_out))
+        || (rc = ws.upload(d_dm, dm, sizeof(float) * dm_w * dm_h))
+        || (rc = ws.upload(d_ci, ci, sizeof(float) * n * channels)))
         return rc;
-    SMVS_HIP_CHECK(hipMemcpy(d_dm.p, dm, sizeof(float) * dm_w * dm_h,
-        hipMemcpyHostToDevice));
-    SMVS_HIP_CHECK(hipMemcpy(d_ci.p, ci, sizeof(float) * n * channels,
-        hipMemcpyHostToDevice));
     BilateralArgs A;
-    A.dm = d_dm.as<float>();
-    A.ci = d_ci.as<float>();
-    A.out = d_out.as<float>();
+    A.dm = d_dm;
+    A.ci = d_ci;
+    A.out = d_out;
     A.dm_w = dm_w;
     A.dm_h = dm_h;
     A.w = w;
@@ -990,9 +972,7 @@ smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     A.kernel_size = kernel_size;
     A.sigma = sigma;
     hipLaunchKernelGGL(bilateral_kernel, dim3((w + 255) / 256, h), dim3(256), 0,
-        nullptr, A);
+        ws.stream, A);
     SMVS_HIP_CHECK(hipGetLastError());
-    SMVS_HIP_CHECK(hipMemcpy(out, d_out.p, sizeof(float) * n,
-        hipMemcpyDeviceToHost));
-    return SMVS_OK;
+    return ws.download(out, d_out, sizeof(float) * n);
 }

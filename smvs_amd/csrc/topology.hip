@@ -549,8 +549,9 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         return rc;
     A.use_ncc = use_ncc ? 1 : 0;
     if (sgm_depth != nullptr) {
-        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->topo_sgm, sgm_depth,
-            npix * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = ctx_upload(ctx, ctx->topo_sgm, sgm_depth, npix * sizeof(float)))
+                != SMVS_OK)
+            return rc;
         A.sgm_depth = ctx->topo_sgm;
     }
     for (int s = 0; s < ctx->n_subs; ++s) {

@@ -1185,16 +1185,13 @@ smvs_get_depth_map(smvs_ctx *ctx, float *depth)
     hipError_t e = hipMemsetAsync(buf, 0, npix * sizeof(float), ctx->stream);
     if (e == hipSuccess)
         rc = launch_maps(ctx, buf, nullptr);
-    if (e == hipSuccess && rc == SMVS_OK)
-        e = hipMemcpyAsync(depth, buf, npix * sizeof(float),
-            hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         set_error("smvs_get_depth_map: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
     }
-    return rc;
+    if (rc != SMVS_OK)
+        return rc;
+    return ctx_download(ctx, depth, buf, npix * sizeof(float));
 }
 
 extern "C" int
@@ -1214,16 +1211,13 @@ smvs_get_normal_map(smvs_ctx *ctx, float *normals)
     hipError_t e = hipMemsetAsync(buf, 0, n * sizeof(float), ctx->stream);
     if (e == hipSuccess)
         rc = launch_maps(ctx, nullptr, buf);
-    if (e == hipSuccess && rc == SMVS_OK)
-        e = hipMemcpyAsync(normals, buf, n * sizeof(float),
-            hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         set_error("smvs_get_normal_map: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
     }
-    return rc;
+    if (rc != SMVS_OK)
+        return rc;
+    return ctx_download(ctx, normals, buf, n * sizeof(float));
 }
 
 extern "C" int

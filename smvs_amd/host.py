@@ -122,6 +122,59 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
                 lighting=np.array(log.lighting[:]) if log.has_lighting else None)
 
 
+def optimize_views(inputs, n_jobs, regularization=0.01, light_reg=0.0,
+                   num_iterations=5, min_scale=2, use_shading=False, sgm_scale=None,
+                   first_device=0, num_devices=1, views_in_flight=1, solver="auto",
+                   keep_job=0):
+    """n_jobs reference views (each job the same scene: main + neighbours of
+    `inputs`) through smvs_amd::ViewQueue -- the per-view tasks of smvsrecon
+    (app/smvsrecon.cc:658-733): StereoViews, SGM front end (sgm_scale is not
+    None), DepthOptimizer::optimize, depth + normal maps.  Returns the maps of
+    job `keep_job`, the per-job logs and wall times."""
+    lib = load()
+    keep = []
+    main, subs, n_subs, b = _marshal(inputs, keep)
+    mains = (HostView * n_jobs)(*([main] * n_jobs))
+    all_subs = (HostView * (n_jobs * n_subs))()
+    for j in range(n_jobs):
+        for k in range(n_subs):
+            all_subs[j * n_subs + k] = subs[k]
+    o = HostOptions(regularization, light_reg, num_iterations, min_scale,
+                    1 if use_shading else 0, 1 if sgm_scale is not None else 0,
+                    0, first_device, dict(auto=0, streaming=1, resident_ref=2)[solver])
+    h, w = main.height, main.width
+    depth = np.zeros((h, w), dtype=np.float32)
+    normals = np.zeros((h, w, 3), dtype=np.float32)
+    secs = np.zeros(n_jobs)
+    total = C.c_double(0.0)
+    logs = (HostLog * n_jobs)()
+    rc = lib.smvs_host_optimize_views(mains, all_subs, C.c_int(n_jobs), C.c_int(n_subs),
+        C.byref(b), C.byref(o), C.c_int(-1 if sgm_scale is None else sgm_scale),
+        C.c_int(first_device), C.c_int(num_devices), C.c_int(views_in_flight),
+        C.c_int(keep_job), depth.ctypes.data_as(_fp), normals.ctypes.data_as(_fp),
+        secs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(total), logs)
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    out_logs = [[dict(scale=l.scale[i], iter=l.iter[i], newton_steps=l.newton_steps[i],
+                      valid_patches=l.valid_patches[i], cg_iterations=l.cg_iterations[i])
+                 for i in range(l.count)] for l in logs]
+    return dict(depth=depth, normals=normals, logs=out_logs, job_seconds=secs,
+                total_seconds=total.value, views_per_s=n_jobs / total.value)
+
+
+def view_queue_selftest(n_tasks, num_devices, views_in_flight, throwing_task=-1):
+    """smvs_amd::ViewQueue without a device: -> (tasks per device, per worker)."""
+    lib = load()
+    dev = np.zeros(num_devices, np.int32)
+    wrk = np.zeros(num_devices * views_in_flight, np.int32)
+    rc = lib.smvs_host_view_queue_selftest(C.c_int(n_tasks), C.c_int(num_devices),
+        C.c_int(views_in_flight), C.c_int(throwing_task), dev.ctypes.data_as(_i32p),
+        wrk.ctypes.data_as(_i32p))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return dev, wrk
+
+
 def sgm_depth(inputs, sgm_scale=1, min_depth=0.0, max_depth=0.0, device=0):
     lib = load()
     keep = []

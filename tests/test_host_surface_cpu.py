@@ -107,3 +107,21 @@ def test_sgm_input_image_matches_oracle(host, oracle, halvings):
     got = host.sgm_image(inputs, 0, halvings)
     want = oracle.sgm_image(inputs, 0, halvings)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_view_queue_runs_every_task_once_and_binds_workers_to_devices():
+    """smvs_amd::ViewQueue (the reference's one-task-per-view ThreadPool,
+    lib/thread_pool.h, app/smvsrecon.cc:658-733, cut for GPUs): every task runs
+    exactly once, worker w drives device w % num_devices, all devices get
+    work, a task's exception arrives through its own future only."""
+    from smvs_amd import host
+    dev, wrk = host.view_queue_selftest(64, 8, 2, throwing_task=17)
+    assert dev.sum() == 64 and wrk.sum() == 64
+    assert (dev > 0).all()          # views spread over the 8 GPUs
+    assert (wrk > 0).sum() >= 8
+    dev, wrk = host.view_queue_selftest(5, 1, 3)
+    assert dev.tolist() == [5]
+    dev, wrk = host.view_queue_selftest(0, 2, 1)
+    assert dev.sum() == 0
+    with pytest.raises(Exception):
+        host.view_queue_selftest(4, 0, 1)

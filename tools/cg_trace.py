@@ -18,7 +18,8 @@ ctx = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
 ctx.set_views(prob["views"]); ctx.set_surface(surf)
 ctx.run_loop(bench.REG, max_newton_steps=3, reset_active=True)
 ctx.close()
-names = ["start", "d+halo", "spmv", "lower", "allreduce A", "update", "allreduce B"]
+names2 = ["start", "d+halo", "spmv", "lower", "allreduce A", "update", "allreduce B"]
+names1 = ["start", "product", "P q + sums", "allreduce (+ halo q)", "update", "barrier", "-"]
 for block in open(path).read().split("solve")[1:]:
     lines = block.strip().split("\n")
     blocks = np.array([[int(x) for x in l.split()[1:]] for l in lines if l.startswith("block")],
@@ -36,12 +37,14 @@ for block in open(path).read().split("solve")[1:]:
         print("    a workgroup's own prologue (start -> before all-reduce): median %.2f, max %.2f us"
               % (np.median(own), own.max()))
     print("solve", lines[0])
+    names = names1 if "exchanges=1" in lines[0] else names2
     rows = np.array([[int(x) for x in l.split()] for l in lines[1:]], dtype=np.int64)
     t0 = rows[0, 0]
     print("  kernel start -> first iteration: %.2f us" % ((rows[1, 0] - t0) / 100.0 if rows[1, 0] else -1))
     p = rows[0]
     if p[2] and p[3] and p[4]:
-        print("  prologue: own blocks %.2f  rim blocks %.2f  P/r/z %.2f  first all-reduce %.2f us"
+        print("  prologue: own blocks (one exchange: halo, diagonal, P, upper blocks) %.2f  "
+              "rim blocks %.2f  P/r/z %.2f  first all-reduce (one exchange: barrier) %.2f us"
               % ((p[2] - p[0]) / 100.0, (p[3] - p[2]) / 100.0, (p[4] - p[3]) / 100.0,
                  (p[1] - p[4]) / 100.0))
     for k in range(1, min(len(rows), 9)):
