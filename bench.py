@@ -57,6 +57,13 @@ FP64_PEAK_TFLOPS = 78.6
 FLOP_PER_PATCH = 0.114e6
 FLOP_PER_PATCH_SURVEY = 0.50e6
 BYTES_PER_PATCH = 4.2e3
+# The resident PCG reads its input once per solve (1,280 + 128 B per live patch,
+# 64 B per node for x and b) and then exchanges per iteration: one two-level
+# all-reduce whose floor is two dependent cross-CU hand-offs at the idle price
+# of MI355X_MICROARCH.md's handoff-1to1 row (0.8-1.1 us each).
+RESIDENT_BYTES_PER_PATCH = 1280 + 128
+RESIDENT_BYTES_PER_NODE = 64
+EXCHANGE_FLOOR_S = 2 * 1.1e-6
 CG_BYTES = {"cg_spmv": 5 * 128 + 2 * 32 + 2 * 32,      # H upper half; z, d_old; Ad, d_new
             "cg_update": 5 * 32 + 128 + 3 * 32 + 2}    # x d r Ad b; P; x r z; mask
 
@@ -238,7 +245,7 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     patch_steps = sum(p for _, p, _ in per_step)
     cg_its = sum(c for _, _, c in per_step)
     traffic = None
-    for tf in ("traffic_r2.json", "traffic_r1.json"):
+    for tf in ("traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
         tfile = os.path.join(ROOT, "profiles", tf)
         if os.path.exists(tfile):
             with open(tfile) as f:
@@ -253,25 +260,39 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     beta = HBM_PEAK_GBPS * 1e9
     pi = FP64_PEAK_TFLOPS * 1e12
     cg_bytes_node = CG_BYTES["cg_spmv"] + CG_BYTES["cg_update"]
-    t_min = t_min_survey = 0.0
+    t_min = t_min_survey = t_min_resident = 0.0
     for nodes_act, patches, its in per_step:
         b_construct = patches * BYTES_PER_PATCH / beta
         t_cg = its * cg_bytes_node * nodes_act / beta
-        t_min += max(patches * FLOP_PER_PATCH / pi, b_construct) + t_cg
+        t_construct = max(patches * FLOP_PER_PATCH / pi, b_construct)
+        t_min += t_construct + t_cg
         t_min_survey += max(patches * FLOP_PER_PATCH_SURVEY / pi, b_construct) + t_cg
+        # the design that is built: H in registers, one pass over its input,
+        # one exchange per iteration at its latency floor
+        t_min_resident += t_construct + (RESIDENT_BYTES_PER_PATCH * patches
+                                         + RESIDENT_BYTES_PER_NODE * n_nodes) / beta \
+            + its * EXCHANGE_FLOOR_S
     t_meas = ms_per_step * 1e-3 * steps
     out = dict(kernel=name, traffic=traffic, kernels=kernels,
-               step_frac=round(t_min / t_meas, 4),
-               step_t_min_us=round(1e6 * t_min / steps, 1),
+               step_frac=round(t_min_resident / t_meas, 4),
+               step_t_min_us=round(1e6 * t_min_resident / steps, 1),
+               step_frac_streaming_model=round(t_min / t_meas, 4),
+               step_t_min_streaming_model_us=round(1e6 * t_min / steps, 1),
                step_frac_with_survey_flops=round(t_min_survey / t_meas, 4),
-               step_note="step_frac = T_min / T per SURVEY.md 8(d) with the measured "
-                         "per-step active patches / nodes / CG iterations, %.3f MFLOP per "
-                         "patch (executed by the factored construction), %d B per active "
-                         "node and CG iteration, peaks %.0f GB/s and %.1f TFLOP/s; the "
-                         "survey's 0.50 MFLOP (unfactored rows) is not a lower bound and "
-                         "gives step_frac_with_survey_flops"
-                         % (FLOP_PER_PATCH / 1e6, cg_bytes_node, HBM_PEAK_GBPS,
-                            FP64_PEAK_TFLOPS),
+               step_note="step_frac = T_min / T with the measured per-step active "
+                         "patches / nodes / CG iterations: construction %.3f MFLOP per "
+                         "patch (executed by the factored kernel) at %.1f TFLOP/s, the "
+                         "resident solver's one pass over its input (%d B per live patch + "
+                         "%d B per node) at %.0f GB/s and %.1f us per CG iteration for "
+                         "its one two-hop exchange (two idle cross-CU hand-offs, "
+                         "MI355X_MICROARCH.md); step_frac_streaming_model is SURVEY.md "
+                         "8(d)'s formula (%d B per active node and CG iteration streamed "
+                         "from HBM), which the resident design no longer moves; the survey's "
+                         "0.50 MFLOP per patch (unfactored rows) gives "
+                         "step_frac_with_survey_flops"
+                         % (FLOP_PER_PATCH / 1e6, FP64_PEAK_TFLOPS, RESIDENT_BYTES_PER_PATCH,
+                            RESIDENT_BYTES_PER_NODE, HBM_PEAK_GBPS, 1e6 * EXCHANGE_FLOOR_S,
+                            cg_bytes_node),
                peaks_assumed=dict(hbm_GBps=HBM_PEAK_GBPS, fp64_TFLOPs=FP64_PEAK_TFLOPS),
                peaks_measured=measured_peaks() if with_peaks else None)
     def cg_resident_line():
@@ -293,9 +314,9 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
                     bytes_per_launch=int(bytes_per_launch), avg_us=round(avg_s * 1e6, 2),
                     note="whole PCG solve in one launch (%.1f iterations on average, "
                          "system assembled in the kernel: %s): after the one pass over "
-                         "its input the kernel is bound by the latency of its two "
-                         "grid-wide exchanges per iteration (~15 us per iteration), "
-                         "not by HBM" % (cg_its / max(cnt_k, 1), "yes" if fused else "no"))
+                         "its input the kernel is bound by the latency of its one "
+                         "grid-wide exchange per iteration, not by HBM"
+                         % (cg_its / max(cnt_k, 1), "yes" if fused else "no"))
 
     def patch_line():
         # gn_patch_kernel: FP64 arithmetic.  The vector FMA and v_mfma_f64 share
@@ -339,6 +360,91 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     return out
 
 
+
+# ----------------------------------------------------------------- secondary
+def secondary_workloads(args):
+    """Beside the headline: (1) BASELINE.md's own timed region -- all Newton
+    loops of all scales of ONE DepthOptimizer::optimize (lib/depth_optimizer.cc:
+    53-162) through the C++ host mirror: sum of active patch-steps / sum of
+    in-loop seconds; (2) whole reference views per second through the C++
+    ViewQueue (the per-view task of app/smvsrecon.cc:658-733: StereoViews,
+    optional SGM front end, optimize, maps), one and several views in flight;
+    (3) per-kernel times of the SGM front end with their HBM rooflines."""
+    import ctypes as C
+    from smvs_amd import synth, host, _capi
+    w, h = (480, 270) if args.small else (W, H)
+    inp = synth.pipeline_inputs("sphere", w, h, NSUBS, flen=1.2)
+    out = {}
+    # (1) one optimize(), warm (the first call pays library / pool start-up)
+    host.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+    t = time.perf_counter()
+    r = host.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+    wall = time.perf_counter() - t
+    aps = sum(e["active_patch_steps"] for e in r["log"])
+    loop_s = sum(e["loop_seconds"] for e in r["log"])
+    by_scale = {}
+    for e in r["log"]:
+        d = by_scale.setdefault(str(e["scale"]), dict(active_patch_steps=0, loop_ms=0.0,
+                                                      newton_steps=0, cg_iterations=0))
+        d["active_patch_steps"] += e["active_patch_steps"]
+        d["loop_ms"] = round(d["loop_ms"] + 1e3 * e["loop_seconds"], 3)
+        d["newton_steps"] += e["newton_steps"]
+        d["cg_iterations"] += e["cg_iterations"]
+    out["optimize"] = dict(
+        value=aps / loop_s, unit="active-patch-steps/s",
+        active_patch_steps=aps, newton_loop_ms=round(1e3 * loop_s, 3),
+        optimize_wall_ms=round(1e3 * wall, 1), batches=len(r["log"]), by_scale=by_scale,
+        note="all Newton loops of all scales (init .. %d) of one optimize() of the "
+             "%dx%d / %d-neighbour sphere scene, --no-sgm: sum of active patch-steps over "
+             "the sum of the loops' wall time (BASELINE.md's timed region)" % (SCALE, w, h, NSUBS))
+    # (2) views per second, whole per-view pipeline
+    views = {}
+    for label, sgm_scale in (("no_sgm", None), ("sgm", 1)):
+        host.optimize_views(inp, 2, regularization=REG, min_scale=SCALE, sgm_scale=sgm_scale)
+        for in_flight in (1, 3):
+            v = host.optimize_views(inp, 4 * in_flight, regularization=REG, min_scale=SCALE,
+                                    sgm_scale=sgm_scale, views_in_flight=in_flight)
+            views["%s_in_flight_%d" % (label, in_flight)] = dict(
+                views_per_s=round(v["views_per_s"], 2), views=4 * in_flight,
+                mean_task_ms=round(1e3 * float(np.mean(v["job_seconds"])), 1))
+    out["views_per_s"] = dict(per_gpu=views,
+        note="whole per-view tasks (9 x StereoView::create, [SGM front end,] optimize() of "
+             "all scales, depth + normal maps) through smvs_amd::ViewQueue on one GPU, "
+             "%dx%d, %d neighbours" % (w, h, NSUBS))
+    # (3) SGM front end kernels
+    lib = _capi.load()
+    host.sgm_depth(inp, sgm_scale=1)
+    lib.smvs_sgm_profile(1, None, None)
+    host.sgm_depth(inp, sgm_scale=1)
+    ms = (C.c_double * 8)(); cnt = (C.c_longlong * 8)()
+    lib.smvs_sgm_profile(0, ms, cnt)
+    sw, sh = (w + 1) // 2, (h + 1) // 2
+    cells = sw * sh * 128
+    names = ["census", "warp", "cost", "paths", "wta", "lr_check", "merge", "bilateral"]
+    # algorithmic HBM bytes per launch (one run_sgm at sw x sh x 128):
+    bytes_per = dict(paths=cells * (8 * 1 + 8 * 8),   # 8 cost reads + 8 u32 read-modify-writes of S
+                     cost=cells * 2,                   # warped plane in, cost out
+                     warp=cells * 1,                   # warped plane out (neighbour image cached)
+                     wta=cells * 2)                    # S in
+    sgm = {}
+    for i, nme in enumerate(names):
+        if cnt[i] == 0:
+            continue
+        avg_s = 1e-3 * ms[i] / cnt[i]
+        line = dict(avg_us=round(1e6 * avg_s, 1), launches=int(cnt[i]))
+        if nme in bytes_per:
+            ach = bytes_per[nme] / avg_s / 1e9
+            line.update(bound="hbm", bytes_per_launch=int(bytes_per[nme]),
+                        achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBPS, 4))
+        sgm[nme] = line
+    out["sgm_front_end"] = dict(kernels=sgm, size=[sw, sh, 128],
+        note="HIP-event times of one reconstruct_sgm_depth_for_view (4 x run_sgm); "
+             "algorithmic bytes per launch: paths 8 cost reads + 8 read-modify-writes of "
+             "the u16 S volume through u32 atomics per cell, cost 1 B in + 1 B out, warp "
+             "1 B out, wta 2 B in per cell")
+    return out
+
 # ----------------------------------------------------------------------- main
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a torch.distributed environment:
@@ -361,7 +467,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=30,
+    ap.add_argument("--repeats", type=int, default=100,
                     help="how often the K-step region is measured (median reported)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 5),
                     help="1: BASELINE configs[1] (headline); 5: configs[4], views sharded "
@@ -373,6 +479,12 @@ def main():
                          "reference's behaviour)")
     ap.add_argument("--small", action="store_true", help="480x270 debug size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="print the CPU baseline JSON and exit (how the main run obtains it: "
+                         "in a child process, after the GPU phase)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (whole optimize(), views per second, "
+                         "SGM kernels)")
     ap.add_argument("--no-peaks", action="store_true",
                     help="skip the peak microbenchmarks (profiling runs)")
     ap.add_argument("--views-in-flight", type=int, default=1,
@@ -389,11 +501,9 @@ def main():
 
     shading = args.config == 5
     prob = make_problem(rank, args.small, shading=shading)
-    # The CPU baseline forks one oracle process per view: run it before the
-    # HIP runtime (and its threads) exists in this process.
-    cpu = None
-    if rank == 0 and world == 1 and args.config == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(prob)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(prob)))
+        return
 
     import torch  # device plumbing + torch.distributed only
     import smvs_amd
@@ -502,6 +612,25 @@ def main():
         roof = roofline(ctx, prob, args.steps, 1e3 * secs / args.steps, lighting,
                         with_peaks=not args.no_peaks)
 
+    # The GPU phase comes first (what the driver's samplers watch at the start
+    # of the run); the CPU baseline forks one oracle process per view, so it
+    # runs afterwards in a child process that never loads the HIP runtime.
+    secondary = cpu = None
+    if rank == 0 and world == 1 and args.config == 1:
+        if not args.no_secondary:
+            try:
+                secondary = secondary_workloads(args)
+            except Exception as e:   # a report, never a reason to lose the headline
+                secondary = dict(error=repr(e))
+        if not args.no_cpu_baseline:
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
+            if args.small:
+                cmd.append("--small")
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            try:
+                cpu = json.loads(res.stdout.strip().splitlines()[-1])
+            except Exception:
+                cpu = dict(error=(res.stderr or res.stdout)[-500:])
     if rank == 0:
         views_in_flight = max(args.views_in_flight, 1) if args.config == 1 else 1
         workload = ("configs[1]: %dx%d synthetic textured sphere, 1 ref + %d neighbours, -o2 "
@@ -531,7 +660,7 @@ def main():
                        "value_min": repeats[0][0], "value_max": repeats[-1][0],
                        "ms_per_step_min": 1e3 * repeats[-1][1] / args.steps,
                        "ms_per_step_max": 1e3 * repeats[0][1] / args.steps},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
     for c in ctxs:

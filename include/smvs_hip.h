@@ -63,6 +63,10 @@ int smvs_device_count(void);
  * depth_optimizer.h:48-51).  width/height = main view size. */
 int smvs_ctx_create(int device, int width, int height, int n_subs,
     smvs_ctx **out);
+/* Parks the context (its device buffers and stream stay allocated) for the
+ * next smvs_ctx_create of the same device / size / neighbour count: a view's
+ * few hundred MB are not returned to the driver between views.
+ * smvs_release_workspaces() frees the parked contexts. */
 int smvs_ctx_destroy(smvs_ctx *ctx);
 int smvs_ctx_synchronize(smvs_ctx *ctx);
 
@@ -362,7 +366,8 @@ int smvs_cut_depth_maps(int device, smvs_mesh_view *views, int n_views);
  * is kept between calls (the reference allocates its volumes per SGMStereo
  * object, lib/sgm_stereo.cc:192-225; a device allocation per call costs more
  * than the kernels).  Concurrent callers get different workspaces.  This
- * returns the pooled memory to the driver; -> number of workspaces freed. */
+ * returns the pooled memory (workspaces and parked contexts) to the driver;
+ * -> number of objects freed. */
 int smvs_release_workspaces(void);
 
 /* ------------------------------------------------------------------ */
@@ -381,6 +386,24 @@ enum {
     SMVS_K_CG_RESIDENT,   /* whole PCG solve in one launch, H in registers */
     SMVS_K_COUNT
 };
+/* Kernel classes of the context-free front end (SGM, bilateral upsample),
+ * timed with HIP events on the call's workspace stream while enabled.
+ * smvs_sgm_profile returns the accumulated ms / launches (either may be NULL)
+ * and then, if enable >= 0, switches the timing on (1) or off (0) and clears
+ * the accumulators; enable < 0 only reads. */
+enum {
+    SMVS_SGM_K_CENSUS = 0,   /* census of the main image (K11) */
+    SMVS_SGM_K_WARP,         /* plane-sweep warp (K12) */
+    SMVS_SGM_K_COST,         /* census of the warped planes + Hamming cost (K11, K13) */
+    SMVS_SGM_K_PATHS,        /* 8-path aggregation (K14) */
+    SMVS_SGM_K_WTA,          /* argmin + depth (K15) */
+    SMVS_SGM_K_LR_CHECK,     /* left / right consistency (K16) */
+    SMVS_SGM_K_MERGE,        /* two-neighbour merge (K16) */
+    SMVS_SGM_K_BILATERAL,    /* joint bilateral upsample (K17) */
+    SMVS_SGM_K_COUNT
+};
+int smvs_sgm_profile(int enable, double *ms, long long *launches);
+
 int smvs_profile_enable(smvs_ctx *ctx, int on);
 int smvs_profile_reset(smvs_ctx *ctx);
 /* ms[SMVS_K_COUNT] accumulated kernel time, launches[SMVS_K_COUNT] */

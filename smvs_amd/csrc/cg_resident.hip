@@ -98,6 +98,7 @@ struct ResArgs {
     double *scalars;
     int npx, npy;
     const double *zeros;     // 16 doubles of +0.0 (a block that does not contribute)
+    int tune;                // experiment switches of the one-exchange solver (SMVS_RES_TUNE)
 };
 
 // GaussNewtonStep::construct's scatter (gauss_newton_step.cc:88-142) in gather
@@ -575,22 +576,76 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
     return ok;
 }
 
-// One double as a pair of adjacent tagged granules: every lane of the wave
-// polls its own pair until all lanes see their tag (inactive lanes take no
-// part and get 0).  Wave-uniform result: false after a bounded wait.
+// A double as ONE 16-byte write-through store / ONE 16-byte L1-bypassing load
+// of its two adjacent granules {data lo, tag}, {data hi, tag}.  Both halves
+// carry the tag, so nothing depends on the 16 bytes arriving together; what
+// the wide access buys is half the number of fabric transactions of the
+// exchange (an 8-byte sc1 store is one fabric write per lane:
+// MI355X_MICROARCH.md, "stores of each flavour").
+typedef unsigned int uint4_r __attribute__((ext_vector_type(4)));
+constexpr int AUX_SC1 = 16;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t
+pair_buffer(void *base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void
+st_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double v)
+{
+    unsigned long long const bits = (unsigned long long)__double_as_longlong(v);
+    uint4_r const w = { (unsigned)bits, tag, (unsigned)(bits >> 32), tag };
+    __builtin_amdgcn_raw_buffer_store_b128(w, buf, (int)byte_offset, 0, AUX_SC1);
+}
+
 __device__ __forceinline__ bool
-poll_pairs(const unsigned long long *pair, bool active, unsigned tag,
+ld_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double *v)
+{
+    uint4_r const w = __builtin_amdgcn_raw_buffer_load_b128(buf, (int)byte_offset, 0,
+        AUX_SC1);
+    *v = __longlong_as_double((long long)(((unsigned long long)w.z << 32) | w.x));
+    return w.y == tag && w.w == tag;
+}
+
+// The four doubles of one node's exchanged vector (64 bytes): four 16-byte
+// loads per poll until all carry `want`; false after a bounded wait.
+__device__ __forceinline__ bool
+poll_node_pairs(__amdgpu_buffer_rsrc_t buf, unsigned node, unsigned want,
+    ResExchange *ex, double (&out)[4])
+{
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ok &= ld_pair16(buf, (node * 4u + (unsigned)q) * 16u, want, &out[q]);
+        if (ok)
+            return true;
+        if (spins > (1u << 18)) {
+            __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");   // (the loads are re-issued every round)
+    }
+}
+
+// One double as a pair of adjacent tagged granules: every lane of the wave
+// polls its own pair (one 16-byte load) until all lanes see their tag
+// (inactive lanes take no part and get 0).  Wave-uniform result: false after a
+// bounded wait.
+__device__ __forceinline__ bool
+poll_pairs(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, bool active, unsigned tag,
     ResExchange *ex, double *value)
 {
-    unsigned long long g0 = (unsigned long long)tag << 32, g1 = g0;
+    double got = 0.0;
+    bool mine_ok = !active;
     bool good = true;
     for (unsigned spins = 0;; ++spins) {
-        if (active) {
-            g0 = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = __hip_atomic_load(pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        bool const ok = (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
-        if (__all(ok))
+        if (!mine_ok)
+            mine_ok = ld_pair16(buf, byte_offset, tag, &got);
+        if (__all(mine_ok))
             break;
         if (spins > (1u << 18)
             || ((spins & 255u) == 255u
@@ -602,9 +657,9 @@ poll_pairs(const unsigned long long *pair, bool active, unsigned tag,
             break;
         }
         __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
     }
-    unsigned long long const bits = (g1 << 32) | (g0 & 0xFFFFFFFFull);
-    *value = active ? __longlong_as_double((long long)bits) : 0.0;
+    *value = active ? got : 0.0;
     return good;
 }
 
@@ -630,10 +685,11 @@ segment16_sum(double v)
 // guarantees as the flat form: fixed summation order (a tree over the members
 // of a group, then a tree over the groups), bit-identical results in every
 // workgroup, slots double-buffered by epoch parity, bounded waits.
-template <int K, typename Idle>
+template <int K, typename Idle, typename AfterPublish, typename Mark>
 __device__ __forceinline__ bool
 grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
-    double (&v)[K], double *red, int *lds_flag, Idle idle)
+    double (&v)[K], double *red, int *lds_flag, Idle idle, AfterPublish after_publish,
+    Mark mark)
 {
     constexpr int SWEEPERS = (K + 3) / 4;
     static_assert(K <= RES_KINDS && 1 + SWEEPERS <= RES_WAVES, "sweeping waves");
@@ -642,15 +698,18 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
     block_partials<K>(v, red);
     unsigned const par = epoch & 1u;
     int const b = (int)blockIdx.x;
-    if (threadIdx.x < 2 * K) {
-        int const k = threadIdx.x >> 1, half = threadIdx.x & 1;
-        unsigned long long const bits = (unsigned long long)__double_as_longlong(
-            block_total(red, k));
-        unsigned const word = half ? (unsigned)(bits >> 32) : (unsigned)bits;
-        __hip_atomic_store(&ex->lvl1[par][b][k][half],
-            ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __amdgpu_buffer_rsrc_t const xbuf = pair_buffer(ex, sizeof(ResExchange));
+    auto lvl1_at = [&](int wg, int kind) {
+        return (unsigned)(offsetof(ResExchange, lvl1)
+            + ((((size_t)par * RES_MAX_BLOCKS + (size_t)wg) * RES_KINDS + (size_t)kind) * 16));
+    };
+    auto lvl2_at = [&](int group, int kind) {
+        return (unsigned)(offsetof(ResExchange, lvl2)
+            + ((((size_t)par * RES_MAX_GROUPS + (size_t)group) * RES_KINDS + (size_t)kind) * 16));
+    };
+    if (threadIdx.x < K)
+        st_pair16(xbuf, lvl1_at(b, (int)threadIdx.x), tag, block_total(red, (int)threadIdx.x));
+    after_publish();
     int const wave = (int)(threadIdx.x >> 6) - 1;
     if (wave >= 0 && wave < SWEEPERS) {
         int const lane = threadIdx.x & 63;
@@ -661,24 +720,19 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
             // this workgroup sums its group
             int const member = b + j;
             double part;
-            ok = poll_pairs(&ex->lvl1[par][member < nblocks ? member : b][kind][0],
+            ok = poll_pairs(xbuf, lvl1_at(member < nblocks ? member : b, kind_ok ? kind : 0),
                 kind_ok && member < nblocks, tag, ex, &part);
             part = segment16_sum(part);
-            if (kind_ok && j == 0) {
-                unsigned long long const bits
-                    = (unsigned long long)__double_as_longlong(part);
-                unsigned long long *dst = &ex->lvl2[par][b / RES_GROUP][kind][0];
-                __hip_atomic_store(dst, ((unsigned long long)tag << 32)
-                    | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((unsigned long long)tag << 32)
-                    | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            mark(5);
+            if (kind_ok && j == 0)
+                st_pair16(xbuf, lvl2_at(b / RES_GROUP, kind), tag, part);
         }
         int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
         double total;
-        bool const ok2 = poll_pairs(&ex->lvl2[par][j < ngroups ? j : 0][kind][0],
+        bool const ok2 = poll_pairs(xbuf, lvl2_at(j < ngroups ? j : 0, kind_ok ? kind : 0),
             kind_ok && j < ngroups, tag, ex, &total);
         total = segment16_sum(total);
+        mark(6);
         if (kind_ok && j == 0)
             res[kind] = total;
         if (lane == 0) {
@@ -1419,15 +1473,25 @@ cg_resident_kernel(ResArgs A)
         __syncthreads();          // d_1 (own and halo) in the tile
         stamp(0, 1);
         double zr = 0.0, xbr = 0.0;   // z.r and x.(b + r) of the current vectors
+        __amdgpu_buffer_rsrc_t const zbuf = pair_buffer(A.zg, (size_t)A.num_nodes * 64);
         for (int k = 1; alive && k < A.max_iterations; ++k) {
             stamp(k, 0);
             double acc[4] = { 0.0, 0.0, 0.0, 0.0 };   // q = H d
             double dself[4];
             tile_product(G, dtile, yl, fb, hd, hu, low, up, mine, acc, dself);
             stamp(k, 1);
-            // the rim's q for the neighbouring tiles, then the sums
-            // (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
+            // the sums (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
             double v7[7] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+            // the rim's q for the neighbouring tiles' halo (tune bit 0: behind
+            // the partial sums, which the all-reduce is waiting for)
+            auto publish_rim = [&]() {
+                if (rim) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        st_pair16(zbuf, ((unsigned)n * 4u + (unsigned)q) * 16u,
+                            ztag + (unsigned)k, acc[q]);
+                }
+            };
             if (mine) {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -1444,9 +1508,6 @@ cg_resident_kernel(ResArgs A)
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (rim)
-                        st_granules(A.zg + ((size_t)n * 4 + q) * 2,
-                            ztag + (unsigned)k, acc[q]);
                     v7[0] += dself[q] * acc[q];
                     v7[1] += r[q] * acc[q];
                     v7[2] += acc[q] * acc[q];
@@ -1454,21 +1515,43 @@ cg_resident_kernel(ResArgs A)
                     v7[6] += r[q] * r[q];
                 }
             }
+            if (!(A.tune & 1))
+                publish_rim();
             stamp(k, 2);
             // Waves 1 and 2 run the two-level all-reduce; wave 0 meanwhile collects
-            // the q of the halo nodes (published before the sums) into LDS.
+            // the q of the halo nodes into LDS.
+            auto fetch_halo = [&](int first, int step) {
+                for (int hs = first; hs < ring; hs += step) {
+                    int const node = hnode[hs];
+                    double qv[4] = { 0.0, 0.0, 0.0, 0.0 };
+                    if (node >= 0)
+                        (void)poll_node_pairs(zbuf, (unsigned)node, ztag + (unsigned)k,
+                            A.ex, qv);
+                    *reinterpret_cast<double4_r *>(qhl + (size_t)hs * 4)
+                        = (double4_r){ qv[0], qv[1], qv[2], qv[3] };
+                }
+            };
             alive = grid_allreduce_tree<7>(A.ex, ztag, epoch++, nblocks, v7, red, flag,
                 [&]() {
-                    for (int hs = tid; hs < ring; hs += 64) {
-                        int const node = hnode[hs];
-                        double qv[4] = { 0.0, 0.0, 0.0, 0.0 };
-                        if (node >= 0)
-                            (void)poll_node_granules(A.zg + (size_t)node * 8,
-                                ztag + (unsigned)k, A.ex, qv);
-                        *reinterpret_cast<double4_r *>(qhl + (size_t)hs * 4)
-                            = (double4_r){ qv[0], qv[1], qv[2], qv[3] };
+                    if (!(A.tune & 2) && tid < 64) {
+                        fetch_halo(tid, 64);
+                        stamp(k, 7);
                     }
+                },
+                [&]() {
+                    if (A.tune & 1)
+                        publish_rim();
+                },
+                [&](int point) {
+                    if (A.trace != nullptr && blockIdx.x == 0 && tid == 64
+                        && k <= TRACE_ITERS)
+                        A.trace[k * TRACE_POINTS + point] = (long long)wall_clock64();
                 });
+            if (A.tune & 2) {
+                if (tid < ring)
+                    fetch_halo(tid, RES_THREADS);
+                __syncthreads();
+            }
             if (!alive)
                 break;
             stamp(k, 3);
@@ -1570,8 +1653,6 @@ cg_resident_kernel(ResArgs A)
             if (done)
                 break;
             __syncthreads();      // d_{k+1} in the tile
-            stamp(k, 5);
-            stamp(k, 6);
         }
     }
 
@@ -1791,6 +1872,11 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.npx = ctx->npx;
     A.npy = ctx->npy;
     A.zeros = ctx->zero_block;
+    static int const tune = [] {
+        const char *e = std::getenv("SMVS_RES_TUNE");
+        return e != nullptr ? std::atoi(e) : 0;
+    }();
+    A.tune = tune;
     A.trace = trace_dev;
     A.pipelined = pipelined ? (test_give_up ? 3 : 1) : 0;
     *solve_tag_out = A.solve_tag;

@@ -101,6 +101,10 @@ struct smvs_ctx {
     int width = 0, height = 0, n_subs = 0;
     hipStream_t stream = nullptr;
     float flen = 0.f, inv_flen = 0.f;
+    // which views hold an uploaded image / which neighbours hold planes: the
+    // buffers themselves outlive a pooled context's previous use (ctx.hip)
+    uint32_t image_ok = 0, planes_ok = 0;
+    float *blur_kernel = nullptr;   // Gaussian taps of smvs_ctx_set_scale (64 floats)
     bool has_cameras = false, has_surface = false, has_system = false;
     bool has_shading = false;
     bool update_prepared = false;   // active_next / counters cleared for the next update
@@ -206,6 +210,7 @@ struct ScopedKernelTimer {
     ~ScopedKernelTimer();
 };
 int profile_collect(smvs_ctx *ctx);
+int ctx_pool_release(void);   // frees the parked contexts (ctx.hip) -> how many
 // Large host <-> device transfers of a context through its pinned staging
 // buffer (a pageable copy runs at a fraction of the link's rate); both return
 // when the caller's buffer may be reused / is filled.

@@ -157,9 +157,60 @@ smvs_device_count(void)
     return n;
 }
 
+// A context is a few hundred MB of device buffers (the per-patch systems, H,
+// the neighbours' planes) behind ~40 allocations.  The reference creates its
+// per-view state inside the view's task and drops it afterwards
+// (app/smvsrecon.cc:662-732); doing the same with device memory costs every
+// view tens of milliseconds, and every hipFree waits for the whole device --
+// for the views in flight on the other streams too.  smvs_ctx_destroy
+// therefore parks the context, smvs_ctx_create takes a parked context of the
+// same geometry and resets its state; smvs_release_workspaces() really frees.
+namespace {
+std::mutex g_ctx_pool_mutex;
+std::vector<smvs_ctx *> g_ctx_pool;
+constexpr size_t CTX_POOL_MAX = 32;
+
+void
+ctx_reset_for_reuse(smvs_ctx *ctx)
+{
+    ctx->image_ok = ctx->planes_ok = 0;
+    ctx->has_cameras = ctx->has_surface = ctx->has_system = false;
+    ctx->has_shading = false;
+    ctx->update_prepared = false;
+    ctx->cg_use_active = false;
+    ctx->last_cg_iterations = 0;
+    ctx->last_loop_steps = 1 << 30;
+    ctx->nodes_saved_count = 0;
+    ctx->solver_mode = 0;
+    ctx->resident_disabled = false;   // (a new view tries the resident solver again)
+    ctx->num_nodes = ctx->num_patches = 0;
+    (void)profile_collect(ctx);
+    ctx->prof.enabled = false;
+    for (int i = 0; i < SMVS_K_COUNT; ++i) {
+        ctx->prof.ms[i] = 0.0;
+        ctx->prof.launches[i] = 0;
+    }
+}
+}
+
+static int ctx_free(smvs_ctx *ctx);
+
 extern "C" int
 smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
 {
+    if (out != nullptr && width > 4 && height > 4 && n_subs >= 1
+        && n_subs <= SMVS_MAX_SUBS) {
+        std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
+        for (size_t i = 0; i < g_ctx_pool.size(); ++i) {
+            smvs_ctx *c = g_ctx_pool[i];
+            if (c->device == device && c->width == width && c->height == height
+                && c->n_subs == n_subs) {
+                g_ctx_pool.erase(g_ctx_pool.begin() + (long)i);
+                *out = c;
+                return SMVS_OK;
+            }
+        }
+    }
     SMVS_REQUIRE(out != nullptr, "out must not be null");
     SMVS_REQUIRE(width > 4 && height > 4, "image too small");
     SMVS_REQUIRE(n_subs >= 1 && n_subs <= SMVS_MAX_SUBS,
@@ -193,7 +244,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || (rc = device_alloc(&ctx->step_counter, 2)) != SMVS_OK
         || (rc = device_alloc(&ctx->zero_block, 16)) != SMVS_OK
         || (rc = device_alloc(reinterpret_cast<char **>(&ctx->cg_state), 256)) != SMVS_OK) {
-        smvs_ctx_destroy(ctx);
+        ctx_free(ctx);
         return rc;
     }
     // coherent (fine-grained) pinned memory: the CG kernels publish their
@@ -204,7 +255,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || hipHostMalloc((void **)&ctx->status_host, sizeof(int) * I_NUM, host_flags) != hipSuccess
         || hipHostMalloc((void **)&ctx->scalars_host, sizeof(double) * S_NUM, host_flags) != hipSuccess) {
         set_error("hipHostMalloc failed");
-        smvs_ctx_destroy(ctx);
+        ctx_free(ctx);
         return SMVS_ERR_NOMEM;
     }
     (void)hipMemsetAsync(ctx->scalars, 0, sizeof(double) * S_NUM, ctx->stream);
@@ -224,6 +275,37 @@ smvs_ctx_destroy(smvs_ctx *ctx)
 {
     if (ctx == nullptr)
         return SMVS_OK;
+    // park it for the next view of this geometry
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream != nullptr && hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        ctx_reset_for_reuse(ctx);
+        std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
+        if (g_ctx_pool.size() < CTX_POOL_MAX) {
+            g_ctx_pool.push_back(ctx);
+            return SMVS_OK;
+        }
+    }
+    return ctx_free(ctx);
+}
+
+int
+smvs_hip::ctx_pool_release(void)
+{
+    std::vector<smvs_ctx *> all;
+    {
+        std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
+        all.swap(g_ctx_pool);
+    }
+    for (smvs_ctx *c : all)
+        (void)ctx_free(c);
+    return (int)all.size();
+}
+
+static int
+ctx_free(smvs_ctx *ctx)
+{
+    if (ctx == nullptr)
+        return SMVS_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
@@ -235,7 +317,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
         ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list,
-        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage };
+        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage,
+        ctx->blur_kernel };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -396,6 +479,7 @@ smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->subs_dev, ctx->subs,
         sizeof(SubPlanes) * SMVS_MAX_SUBS, hipMemcpyHostToDevice, ctx->stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->planes_ok |= 1u << sub;
     return SMVS_OK;
 }
 

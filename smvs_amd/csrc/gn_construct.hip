@@ -1057,7 +1057,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     // Shared by smvs_gn_construct and smvs_gn_run_loop: the patch kernel
     // dereferences every neighbour's planes and the main gradient.
     for (int j = 0; j < ctx->n_subs; ++j)
-        if (ctx->subs[j].grad == nullptr || ctx->subs[j].hess == nullptr) {
+        if (!((ctx->planes_ok >> j) & 1u)) {
             set_error("gn_construct: sub view %d has no gradient / Hessian "
                 "planes (smvs_ctx_upload_sub or smvs_ctx_set_scale first)", j);
             return SMVS_ERR_STATE;

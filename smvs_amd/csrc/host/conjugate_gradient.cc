@@ -1,0 +1,95 @@
+#include "conjugate_gradient.h"
+
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/smvs_hip.h"
+
+namespace smvs_amd {
+
+std::size_t
+BlockStencilMatrix::num_non_zero(void) const
+{
+    std::size_t count = 0;
+    for (std::size_t b = 0; b + 16 <= blocks.size(); b += 16) {
+        bool any = false;
+        for (int i = 0; i < 16; ++i)
+            any = any || blocks[b + i] != 0.0;
+        count += any ? 16 : 0;
+    }
+    return count;
+}
+
+ConjugateGradient::ConjugateGradient(Options const& options, int device)
+    : opts(options), device(device)
+{
+}
+
+ConjugateGradient::~ConjugateGradient(void)
+{
+    if (ctx != nullptr)
+        smvs_ctx_destroy(ctx);
+}
+
+ConjugateGradient::Status
+ConjugateGradient::solve(Functor const& A_in, Vector const& b, Vector* x,
+    Functor const* P_in)
+{
+    // lib/conjugate_gradient.h:72-84
+    if (x == nullptr || A_in.output_size() != b.size())
+        throw std::invalid_argument("ConjugateGradient: dimension mismatch");
+    BlockStencilMatrix const* A = dynamic_cast<BlockStencilMatrix const*>(&A_in);
+    BlockStencilMatrix const* P = P_in == nullptr ? nullptr
+        : dynamic_cast<BlockStencilMatrix const*>(P_in);
+    if (A == nullptr || (P_in != nullptr && P == nullptr))
+        throw std::invalid_argument("ConjugateGradient: the device solver takes "
+            "BlockStencilMatrix systems (GaussNewtonStep::construct) only");
+    std::size_t const N = A->num_nodes, stride = A->node_stride;
+    if (N == 0 || stride < 2 || N % stride != 0 || N / stride < 2
+        || A->blocks.size() != N * 9 * 16
+        || (P != nullptr && (P->num_nodes != N || P->blocks.size() != N * 9 * 16)))
+        throw std::invalid_argument("ConjugateGradient: malformed block stencil");
+
+    auto check = [](int rc, char const* what) {
+        if (rc != SMVS_OK)
+            throw std::runtime_error(std::string(what) + ": " + smvs_last_error());
+    };
+    // a solver-only context with a surface of this node grid (scale 0: one
+    // pixel per patch; no images are needed to solve)
+    if (ctx == nullptr || ctx_nodes != N || ctx_stride != stride) {
+        if (ctx != nullptr)
+            smvs_ctx_destroy(ctx);
+        ctx = nullptr;
+        int const npx = (int)stride - 1, npy = (int)(N / stride) - 1;
+        check(smvs_ctx_create(device, npx + 8, npy + 8, 1, &ctx), "smvs_ctx_create");
+        std::vector<double> nodes(4 * N, 0.0);
+        std::vector<uint8_t> node_valid(N, 1), patch_valid((std::size_t)npx * npy, 1);
+        std::vector<uint32_t> vis((std::size_t)npx * npy, 1u);
+        check(smvs_ctx_set_surface(ctx, 0, npx, npy, 0, 0, nodes.data(),
+            node_valid.data(), patch_valid.data(), vis.data()), "smvs_ctx_set_surface");
+        ctx_nodes = N;
+        ctx_stride = stride;
+    }
+    // the device solves H x = -g with the block-Jacobi preconditioner it is
+    // given: g = -b; no preconditioner = identity blocks (z = r, :100-104)
+    std::vector<double> g(4 * N), Pdiag(N * 16, 0.0);
+    for (std::size_t i = 0; i < 4 * N; ++i)
+        g[i] = -b[i];
+    for (std::size_t n = 0; n < N; ++n)
+        for (int i = 0; i < 16; ++i)
+            Pdiag[n * 16 + i] = P != nullptr ? P->blocks[(n * 9 + 4) * 16 + i]
+                : (i % 5 == 0 ? 1.0 : 0.0);
+    check(smvs_gn_upload(ctx, A->blocks.data(), g.data(), Pdiag.data()),
+        "smvs_gn_upload");
+    int iterations = 0, info = 0;
+    check(smvs_cg_solve(ctx, opts.max_iterations, opts.error_tolerance,
+        opts.q_tolerance, &iterations, &info), "smvs_cg_solve");
+    x->assign(4 * N, 0.0);
+    check(smvs_cg_download_x(ctx, x->data()), "smvs_cg_download_x");
+    status.num_iterations = iterations;
+    status.info = info == SMVS_CG_CONVERGENCE ? CG_CONVERGENCE
+        : (info == SMVS_CG_MAX_ITERATIONS ? CG_MAX_ITERATIONS : CG_INVALID_INPUT);
+    return status;
+}
+
+} // namespace smvs_amd

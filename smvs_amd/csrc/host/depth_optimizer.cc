@@ -436,9 +436,13 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         std::copy(lighting, lighting + 16, prm.lighting);
         prm.reset_active = 1;
         smvs_gn_loop_stats stats;
+        double loop_seconds = 0.0;
         {
             ScopedHostTimer timer("device Newton loop");
+            auto const t0 = std::chrono::steady_clock::now();
             check(smvs_gn_run_loop(ctx, &prm, &stats), "smvs_gn_run_loop");
+            loop_seconds = std::chrono::duration<double>(
+                std::chrono::steady_clock::now() - t0).count();
             check(smvs_get_nodes(ctx, surface->node_values().data()),
                 "smvs_get_nodes");
             // host and device nodes are the same again
@@ -446,7 +450,8 @@ DepthOptimizer::run_newton_iterations(int num_iters)
                 uploaded_rev = surface->revision();
         }
         log.push_back({ surface->get_scale(), iter, stats.newton_steps,
-            num_valid_patches, stats.linear_iterations });
+            num_valid_patches, stats.linear_iterations, stats.active_patch_steps,
+            loop_seconds });
         this->dump_state(iter, "newton");
 
         if (finished)

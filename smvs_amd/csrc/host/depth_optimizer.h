@@ -37,6 +37,8 @@ public:
     struct IterationLog
     {
         int scale, iter, newton_steps, valid_patches, cg_iterations;
+        long long active_patch_steps;   // sum over the steps of active patches
+        double loop_seconds;            // wall time of the device Newton loop
     };
 
 public:

@@ -10,6 +10,10 @@
 #include "sgm_stereo.h"
 #include "view_selection.h"
 #include "view_queue.h"
+#include "gauss_newton_step.h"
+#include "conjugate_gradient.h"
+
+#include <cmath>
 
 #include <chrono>
 
@@ -22,6 +26,8 @@ smvs_host_last_error(void)
 {
     return g_host_error.c_str();
 }
+
+static void fill_log(DepthOptimizer const& optimizer, smvs_host_log *log);
 
 static StereoView::Ptr
 make_view(smvs_host_view const& v, bool linear)
@@ -92,22 +98,8 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
         if (normals_out != nullptr)
             std::memcpy(normals_out, optimizer.get_normals()->begin(),
                 sizeof(float) * 3 * npix);
-        if (log != nullptr) {
-            log->count = 0;
-            for (auto const& e : optimizer.get_log()) {
-                if (log->count >= SMVS_HOST_LOG_MAX)
-                    break;
-                int const i = log->count++;
-                log->scale[i] = e.scale;
-                log->iter[i] = e.iter;
-                log->newton_steps[i] = e.newton_steps;
-                log->valid_patches[i] = e.valid_patches;
-                log->cg_iterations[i] = e.cg_iterations;
-            }
-            log->has_lighting = optimizer.has_lighting() ? 1 : 0;
-            std::copy(optimizer.get_lighting(), optimizer.get_lighting() + 16,
-                log->lighting);
-        }
+        if (log != nullptr)
+            fill_log(optimizer, log);
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();
@@ -353,6 +345,8 @@ fill_log(DepthOptimizer const& optimizer, smvs_host_log *log)
         log->newton_steps[i] = e.newton_steps;
         log->valid_patches[i] = e.valid_patches;
         log->cg_iterations[i] = e.cg_iterations;
+        log->active_patch_steps[i] = e.active_patch_steps;
+        log->loop_seconds[i] = e.loop_seconds;
     }
     log->has_lighting = optimizer.has_lighting() ? 1 : 0;
     std::copy(optimizer.get_lighting(), optimizer.get_lighting() + 16,
@@ -478,6 +472,115 @@ smvs_host_view_queue_selftest(int n_tasks, int num_devices, int views_in_flight,
                 throw std::logic_error("ViewQueue: worker / device binding");
             device_hist[on_device[i]] += 1;
             worker_hist[on_worker[i]] += 1;
+        }
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_gn_solve_step(const smvs_host_view *main_in, const smvs_host_view *subs_in,
+    int n_subs, const smvs_host_bundle *bundle_in, int init_scale,
+    double regularization, int device, float *main_grad, float *sub_grad,
+    float *sub_hess, double *Mi_out, double *ti_out, float *flen2, double *g_out,
+    double *x_out, double *H9_out, double *P_out, int *cg_out)
+{
+    try {
+        if (main_in == nullptr || subs_in == nullptr || n_subs < 1)
+            throw std::invalid_argument("smvs_host_gn_solve_step: bad argument");
+        StereoView::Ptr main_view = make_view(*main_in, false);
+        std::vector<StereoView::Ptr> subs;
+        for (int j = 0; j < n_subs; ++j)
+            subs.push_back(make_view(subs_in[j], false));
+        Bundle::Ptr bundle = make_bundle(bundle_in);
+        Surface::Ptr surface = Surface::create(bundle, main_view, init_scale);
+        // lib/depth_optimizer.cc:63-66
+        main_view->set_scale(surface->get_scale());
+        for (auto& v : subs)
+            v->set_scale(surface->get_scale());
+        // lib/depth_optimizer.cc:679-699
+        std::vector<Matrix3d> Mi(n_subs);
+        std::vector<Vec3d> ti(n_subs);
+        for (int j = 0; j < n_subs; ++j) {
+            float M[9], t[3];
+            main_view->get_camera().fill_reprojection(subs[j]->get_camera(),
+                (float)main_view->get_width(), (float)main_view->get_height(),
+                (float)subs[j]->get_width(), (float)subs[j]->get_height(), M, t);
+            for (int k = 0; k < 9; ++k)
+                Mi[j].m[k] = M[k];
+            for (int k = 0; k < 3; ++k)
+                ti[j].v[k] = t[k];
+        }
+        std::size_t const N = surface->get_num_nodes(), Pn = surface->get_num_patches();
+        std::vector<std::vector<std::size_t>> subsurfaces(Pn);
+        for (std::size_t p = 0; p < Pn; ++p)
+            if (surface->patch_validity()[p])
+                for (int j = 0; j < n_subs; ++j)
+                    subsurfaces[p].push_back((std::size_t)j);
+        std::vector<char> active(N);
+        for (std::size_t n = 0; n < N; ++n)
+            active[n] = surface->node_validity()[n] ? 1 : 0;
+
+        GaussNewtonStep::Options gn_opts;
+        gn_opts.regularization = regularization;
+        gn_opts.device = device;
+        GaussNewtonStep gauss_newton_step(gn_opts, main_view, subs, Mi, ti);
+        GaussNewtonStep::SparseMatrix hessian, precond;
+        GaussNewtonStep::DenseVector gradient;
+        gauss_newton_step.construct(surface, subsurfaces, active, nullptr,
+            &hessian, &gradient, &precond);
+        // lib/depth_optimizer.cc:245-254
+        double norm = 0.0;
+        for (double v : gradient)
+            norm += v * v;
+        ConjugateGradient::Options cg_opts;
+        cg_opts.error_tolerance = std::sqrt(norm) * 0.01;
+        cg_opts.max_iterations = 200;
+        ConjugateGradient cg(cg_opts, device);
+        ConjugateGradient::Vector b(gradient.size()), delta;
+        for (std::size_t i = 0; i < b.size(); ++i)
+            b[i] = -gradient[i];
+        ConjugateGradient::Status const status = cg.solve(hessian, b, &delta, &precond);
+
+        std::size_t const npix = (size_t)main_in->width * main_in->height;
+        if (main_grad != nullptr)
+            std::memcpy(main_grad, main_view->get_image_gradients()->begin(),
+                sizeof(float) * 2 * npix);
+        for (int j = 0; j < n_subs; ++j) {
+            std::size_t const sp = (size_t)subs[j]->get_width() * subs[j]->get_height();
+            if (sp != npix)
+                throw std::invalid_argument("smvs_host_gn_solve_step: the planes "
+                    "are returned for neighbours of the main view's size");
+            if (sub_grad != nullptr)
+                std::memcpy(sub_grad + 2 * npix * j,
+                    subs[j]->get_image_gradients()->begin(), sizeof(float) * 2 * npix);
+            if (sub_hess != nullptr)
+                std::memcpy(sub_hess + 3 * npix * j,
+                    subs[j]->get_image_hessian()->begin(), sizeof(float) * 3 * npix);
+            if (Mi_out != nullptr)
+                std::copy(Mi[j].m, Mi[j].m + 9, Mi_out + 9 * j);
+            if (ti_out != nullptr)
+                std::copy(ti[j].v, ti[j].v + 3, ti_out + 3 * j);
+        }
+        if (flen2 != nullptr) {
+            flen2[0] = main_view->get_flen();
+            flen2[1] = main_view->get_inverse_flen();
+        }
+        if (g_out != nullptr)
+            std::copy(gradient.begin(), gradient.end(), g_out);
+        if (x_out != nullptr)
+            std::copy(delta.begin(), delta.end(), x_out);
+        if (H9_out != nullptr)
+            std::copy(hessian.blocks.begin(), hessian.blocks.end(), H9_out);
+        if (P_out != nullptr)
+            for (std::size_t n = 0; n < N; ++n)
+                std::copy(precond.blocks.begin() + (n * 9 + 4) * 16,
+                    precond.blocks.begin() + (n * 9 + 5) * 16, P_out + n * 16);
+        if (cg_out != nullptr) {
+            cg_out[0] = status.num_iterations;
+            cg_out[1] = (int)status.info;
         }
         return 0;
     } catch (std::exception const& e) {

@@ -45,6 +45,8 @@ typedef struct {
     int newton_steps[SMVS_HOST_LOG_MAX];
     int valid_patches[SMVS_HOST_LOG_MAX];
     int cg_iterations[SMVS_HOST_LOG_MAX];
+    long long active_patch_steps[SMVS_HOST_LOG_MAX];   /* sum over the steps */
+    double loop_seconds[SMVS_HOST_LOG_MAX];            /* device Newton loop */
     int has_lighting;
     double lighting[16];
 } smvs_host_log;
@@ -97,6 +99,22 @@ int smvs_host_optimize_views(const smvs_host_view *mains,
     int first_device, int num_devices, int views_in_flight, int keep_job,
     float *depth_out, float *normals_out, double *job_seconds,
     double *total_seconds, smvs_host_log *logs);
+
+/* The reference's own Newton-step calls through the compatibility classes
+ * (lib/depth_optimizer.cc:225-262): Surface::create(bundle, main, init_scale),
+ * StereoView::set_scale(scale of the surface) on every view (host planes),
+ * GaussNewtonStep(opts, main, subs, Mi, ti).construct(surface, subsurfaces =
+ * every neighbour for every patch, active = every node, lighting = NULL, &H,
+ * &g, &P), then ConjugateGradient({200, 0.01 |g|, 1e-3}).solve(H, -g, &x, &P).
+ * Outputs (caller-sized, each may be NULL): the planes the step used --
+ * main_grad[W*H*2], sub_grad[n_subs][W*H*2], sub_hess[n_subs][W*H*3] -- the
+ * reprojections Mi[n_subs*9], ti[n_subs*3], flen2 = { flen, inverse flen }, and
+ * g[4N], x[4N], H9[N*9*16], P[N*16], cg = { iterations, info }. */
+int smvs_host_gn_solve_step(const smvs_host_view *main_view,
+    const smvs_host_view *subs, int n_subs, const smvs_host_bundle *bundle,
+    int init_scale, double regularization, int device, float *main_grad,
+    float *sub_grad, float *sub_hess, double *Mi, double *ti, float *flen2,
+    double *g, double *x, double *H9, double *P, int *cg);
 
 /* smvs_amd::ViewQueue on its own (no device involved): n_tasks tasks that
  * record the slot they ran on; task `throwing_task` (or -1) throws.

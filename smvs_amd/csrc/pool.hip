@@ -200,5 +200,5 @@ smvs_release_workspaces(void)
     }
     for (Workspace *w : all)
         workspace_destroy(w);
-    return (int)all.size();
+    return (int)all.size() + ctx_pool_release();
 }

@@ -160,6 +160,7 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
         vi.h = height;
         vi.c = channels;
     }
+    ctx->image_ok &= ~(1u << (view + 1));
     // (device staging owned by the context: no allocation per image; the
     // bytes cross PCIe from pinned memory)
     if (ctx->byte_stage_cap < n) {
@@ -181,6 +182,7 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
         set_error("smvs_ctx_upload_image: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
     }
+    ctx->image_ok |= 1u << (view + 1);
     return SMVS_OK;
 }
 
@@ -190,7 +192,7 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
     SMVS_REQUIRE(ctx != nullptr, "null context");
     SMVS_REQUIRE(scale >= 0 && scale <= 10, "scale out of range");
     for (int v = 0; v <= ctx->n_subs; ++v)
-        if (ctx->images[v].data == nullptr) {
+        if (!((ctx->image_ok >> v) & 1u)) {
             set_error("smvs_ctx_set_scale: view %d has no image", v - 1);
             return SMVS_ERR_STATE;
         }
@@ -202,10 +204,13 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
     std::vector<float> kernel(ks + 1);
     for (int i = 0; i <= ks; ++i)
         kernel[i] = std::exp(-((float)i * (float)i) / (2.0f * sigma * sigma));
-    float *kernel_dev = nullptr;
-    int rc = device_alloc(&kernel_dev, kernel.size());
-    if (rc != SMVS_OK)
+    // (taps in a buffer the context keeps: no allocation per scale)
+    SMVS_REQUIRE(kernel.size() <= 64, "blur kernel too wide");
+    int rc;
+    if (ctx->blur_kernel == nullptr
+        && (rc = device_alloc(&ctx->blur_kernel, 64)) != SMVS_OK)
         return rc;
+    float *kernel_dev = ctx->blur_kernel;
     hipError_t e = hipMemcpyAsync(kernel_dev, kernel.data(),
         kernel.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     FitMatrix const fit = quadratic_fit_matrix();
@@ -216,10 +221,8 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
         size_t const n = (size_t)vi.w * vi.h * vi.c;
         if (n > ctx->blur_cap) {
             if ((rc = device_alloc(&ctx->blur_tmp[0], n)) != SMVS_OK
-                || (rc = device_alloc(&ctx->blur_tmp[1], n)) != SMVS_OK) {
-                (void)hipFree(kernel_dev);
+                || (rc = device_alloc(&ctx->blur_tmp[1], n)) != SMVS_OK)
                 return rc;
-            }
             ctx->blur_cap = n;
         }
         const float *src = vi.data;
@@ -249,7 +252,6 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
                     || (rc = device_alloc(&sp.hess, npix)) != SMVS_OK) {
                     (void)device_alloc(&sp.grad, 0);
                     (void)device_alloc(&sp.hess, 0);
-                    (void)hipFree(kernel_dev);
                     return rc;
                 }
                 sp.width = vi.w;
@@ -257,6 +259,7 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
             }
             grad = sp.grad;
             hess = sp.hess;
+            ctx->planes_ok |= 1u << (v - 1);
         }
         {
             ScopedKernelTimer timer(ctx, SMVS_K_MISC);
@@ -270,7 +273,6 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
             sizeof(SubPlanes) * SMVS_MAX_SUBS, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(kernel_dev);
     if (e != hipSuccess) {
         set_error("smvs_ctx_set_scale: %s", hipGetErrorString(e));
         return SMVS_ERR_HIP;
@@ -293,7 +295,7 @@ smvs_ctx_download_planes(smvs_ctx *ctx, int view, float *grad2, float *hess3)
         return SMVS_OK;
     }
     SubPlanes const &sp = ctx->subs[view];
-    if (sp.grad == nullptr) {
+    if (!((ctx->planes_ok >> view) & 1u)) {
         set_error("smvs_ctx_download_planes: view %d has no planes", view);
         return SMVS_ERR_STATE;
     }

@@ -656,6 +656,64 @@ sgm_merge_kernel(float *__restrict__ d1, const float *__restrict__ d2, size_t n)
     d1[i] = a == 0.0f ? b : (a + b) * 0.5f;
 }
 
+// Optional per-kernel timing of the front end (smvs_sgm_profile): HIP events
+// on the workspace's stream around every launch of a call, read back when the
+// call has synchronised.  Off by default: no events, no overhead.
+static std::mutex g_sgm_prof_mutex;
+static bool g_sgm_prof_on = false;
+static double g_sgm_prof_ms[SMVS_SGM_K_COUNT] = { 0 };
+static long long g_sgm_prof_launches[SMVS_SGM_K_COUNT] = { 0 };
+
+struct SgmProfile {
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    bool on;
+    SgmProfile()
+    {
+        std::lock_guard<std::mutex> guard(g_sgm_prof_mutex);
+        on = g_sgm_prof_on;
+    }
+    // (called when the stream is idle)
+    ~SgmProfile()
+    {
+        if (pending.empty())
+            return;
+        std::lock_guard<std::mutex> guard(g_sgm_prof_mutex);
+        for (auto &p : pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.b) == hipSuccess
+                && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                g_sgm_prof_ms[p.cls] += ms;
+                g_sgm_prof_launches[p.cls] += 1;
+            }
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+    }
+};
+
+struct SgmKernelTimer {
+    SgmProfile *prof;
+    hipStream_t stream;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    SgmKernelTimer(SgmProfile *p, hipStream_t s, int c) : prof(p), stream(s), cls(c)
+    {
+        if (prof == nullptr || !prof->on)
+            return;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, stream);
+    }
+    ~SgmKernelTimer()
+    {
+        if (a == nullptr)
+            return;
+        (void)hipEventRecord(b, stream);
+        prof->pending.push_back({ cls, a, b });
+    }
+};
+
 // Slots of a pooled workspace (pool.hip) used by this file.
 enum {
     WS_DEPTHS = 0, WS_CENSUS, WS_WARPED, WS_COST, WS_SGM, WS_ARGMIN,   // one run_sgm
@@ -669,6 +727,7 @@ enum {
 struct SgmWorkspace {
     static constexpr int MAX_RUNS = 4;
     Workspace *ws;
+    SgmProfile *prof = nullptr;
     float *depths = nullptr;
     unsigned long long *census = nullptr;
     uint8_t *warped = nullptr, *cost = nullptr;
@@ -743,8 +802,11 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     if ((rc = B.ws->upload(d_depths, depths, sizeof(float) * num_steps)) != SMVS_OK)
         return rc;
 
-    hipLaunchKernelGGL(census_main_kernel, dim3((w + 255) / 256, h), dim3(256),
-        0, stream, d_main, w, h, B.census);
+    {
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_CENSUS);
+        hipLaunchKernelGGL(census_main_kernel, dim3((w + 255) / 256, h), dim3(256),
+            0, stream, d_main, w, h, B.census);
+    }
     WarpArgs W;
     W.neighbor = d_nbr;
     W.nw = nw;
@@ -757,8 +819,12 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     W.h = h;
     W.warped = B.warped;
     unsigned const vblocks = (unsigned)((vol + 255) / 256);
-    hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
     {
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_WARP);
+        hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
+    }
+    {
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_COST);
         int const tiles = ((w + CT_W - 1) / CT_W) * ((h + CT_H - 1) / CT_H);
         hipLaunchKernelGGL(cost_tiled_kernel,
             dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
@@ -785,9 +851,11 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
         P.dx = P.dy = 0;
         P.first = 0;
         int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_PATHS);
         hipLaunchKernelGGL((sgm_all_paths_kernel<16>), dim3(lines), dim3(64), 0,
             stream, P);
     } else {
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_PATHS);
         // odd plane counts: one launch per direction, scalar accesses
         for (int k = 0; k < 8; ++k) {
             P.dx = dirs[k][0];
@@ -799,10 +867,13 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
         }
     }
     SMVS_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(wta_rows_kernel,
-        dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
-        B.sgm, d_main, d_depths, npix, num_steps, d_depth,
-        B.argmin);
+    {
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_WTA);
+        hipLaunchKernelGGL(wta_rows_kernel,
+            dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
+            B.sgm, d_main, d_depths, npix, num_steps, d_depth,
+            B.argmin);
+    }
     SMVS_HIP_CHECK(hipGetLastError());
     return SMVS_OK;
 }
@@ -830,7 +901,9 @@ smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
     Workspace &ws = *lease.w;
     size_t const npix = (size_t)w * h, nnpix = (size_t)nw * nh;
     size_t const vol = npix * num_steps;
+    SgmProfile prof;
     SgmWorkspace B(&ws);
+    B.prof = &prof;
     uint8_t *d_main = nullptr, *d_nbr = nullptr;
     float *d_depth = nullptr;
     if ((rc = ws.ensure(WS_MAIN, npix, &d_main)) || (rc = ws.ensure(WS_NBR0, nnpix, &d_nbr))
@@ -883,7 +956,9 @@ smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
     Workspace &ws = *lease.w;
     hipStream_t const stream = ws.stream;
     size_t const npix = (size_t)w * h;
+    SgmProfile prof;
     SgmWorkspace B(&ws);
+    B.prof = &prof;
     uint8_t *d_main = nullptr, *d_nbr[2] = { nullptr, nullptr };
     float *d_fwd[2] = { nullptr, nullptr }, *d_bwd = nullptr;
     // (every buffer before the first launch: growing one waits for the stream)
@@ -927,11 +1002,15 @@ smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
             L.M[i] = (double)N.M_fwd[i];
         for (int i = 0; i < 3; ++i)
             L.t[i] = (double)N.t_fwd[i];
-        hipLaunchKernelGGL(sgm_lr_check_kernel, dim3((w + 255) / 256, h),
-            dim3(256), 0, stream, L);
+        {
+            SgmKernelTimer timer(&prof, stream, SMVS_SGM_K_LR_CHECK);
+            hipLaunchKernelGGL(sgm_lr_check_kernel, dim3((w + 255) / 256, h),
+                dim3(256), 0, stream, L);
+        }
         SMVS_HIP_CHECK(hipGetLastError());
     }
     if (n_neighbors > 1) {
+        SgmKernelTimer timer(&prof, stream, SMVS_SGM_K_MERGE);
         hipLaunchKernelGGL(sgm_merge_kernel, dim3((unsigned)((npix + 255) / 256)),
             dim3(256), 0, stream, d_fwd[0], d_fwd[1], npix);
         SMVS_HIP_CHECK(hipGetLastError());
@@ -971,8 +1050,33 @@ smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     A.channels = channels;
     A.kernel_size = kernel_size;
     A.sigma = sigma;
-    hipLaunchKernelGGL(bilateral_kernel, dim3((w + 255) / 256, h), dim3(256), 0,
-        ws.stream, A);
+    SgmProfile prof;
+    {
+        SgmKernelTimer timer(&prof, ws.stream, SMVS_SGM_K_BILATERAL);
+        hipLaunchKernelGGL(bilateral_kernel, dim3((w + 255) / 256, h), dim3(256), 0,
+            ws.stream, A);
+    }
     SMVS_HIP_CHECK(hipGetLastError());
     return ws.download(out, d_out, sizeof(float) * n);
+}
+
+extern "C" int
+smvs_sgm_profile(int enable, double *ms, long long *launches)
+{
+    std::lock_guard<std::mutex> guard(g_sgm_prof_mutex);
+    for (int i = 0; i < SMVS_SGM_K_COUNT; ++i) {
+        if (ms != nullptr)
+            ms[i] = g_sgm_prof_ms[i];
+        if (launches != nullptr)
+            launches[i] = g_sgm_prof_launches[i];
+    }
+    if (enable >= 0) {
+        // (switching it on or off starts a new measurement)
+        g_sgm_prof_on = enable != 0;
+        for (int i = 0; i < SMVS_SGM_K_COUNT; ++i) {
+            g_sgm_prof_ms[i] = 0.0;
+            g_sgm_prof_launches[i] = 0;
+        }
+    }
+    return SMVS_OK;
 }

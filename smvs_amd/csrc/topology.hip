@@ -450,7 +450,7 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
         return SMVS_ERR_STATE;
     }
     for (int v = 0; v <= ctx->n_subs; ++v)
-        if (ctx->images[v].data == nullptr) {
+        if (!((ctx->image_ok >> v) & 1u)) {
             set_error("%s: view %d has no image (smvs_ctx_upload_image)", who,
                 v - 1);
             return SMVS_ERR_STATE;
@@ -505,7 +505,7 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
 {
     SMVS_REQUIRE(ctx && patch_vis_out, "null argument");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->images[0].data != nullptr
+    if ((ctx->image_ok & 1u) != 0u
         && (ctx->images[0].w != ctx->width || ctx->images[0].h != ctx->height)) {
         set_error("smvs_topology_subviews: main image size differs from the context");
         return SMVS_ERR_INVALID;
@@ -586,7 +586,7 @@ launch_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
         return SMVS_ERR_STATE;
     }
     for (int j = 0; j < ctx->n_subs; ++j)
-        if (ctx->subs[j].grad == nullptr) {
+        if (!((ctx->planes_ok >> j) & 1u)) {
             set_error("%s: sub view %d has no planes", who, j);
             return SMVS_ERR_STATE;
         }

@@ -40,6 +40,8 @@ class HostLog(C.Structure):
     _fields_ = [("count", C.c_int), ("scale", C.c_int * 256),
                 ("iter", C.c_int * 256), ("newton_steps", C.c_int * 256),
                 ("valid_patches", C.c_int * 256), ("cg_iterations", C.c_int * 256),
+                ("active_patch_steps", C.c_longlong * 256),
+                ("loop_seconds", C.c_double * 256),
                 ("has_lighting", C.c_int), ("lighting", C.c_double * 16)]
 
 
@@ -117,7 +119,9 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
     steps = [dict(scale=log.scale[i], iter=log.iter[i],
                   newton_steps=log.newton_steps[i],
                   valid_patches=log.valid_patches[i],
-                  cg_iterations=log.cg_iterations[i]) for i in range(log.count)]
+                  cg_iterations=log.cg_iterations[i],
+                  active_patch_steps=log.active_patch_steps[i],
+                  loop_seconds=log.loop_seconds[i]) for i in range(log.count)]
     return dict(depth=depth, normals=normals, log=steps, sgm_roundtrip=rt,
                 lighting=np.array(log.lighting[:]) if log.has_lighting else None)
 
@@ -156,10 +160,49 @@ def optimize_views(inputs, n_jobs, regularization=0.01, light_reg=0.0,
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
     out_logs = [[dict(scale=l.scale[i], iter=l.iter[i], newton_steps=l.newton_steps[i],
-                      valid_patches=l.valid_patches[i], cg_iterations=l.cg_iterations[i])
+                      valid_patches=l.valid_patches[i], cg_iterations=l.cg_iterations[i],
+                      active_patch_steps=l.active_patch_steps[i],
+                      loop_seconds=l.loop_seconds[i])
                  for i in range(l.count)] for l in logs]
     return dict(depth=depth, normals=normals, logs=out_logs, job_seconds=secs,
                 total_seconds=total.value, views_per_s=n_jobs / total.value)
+
+
+def gn_solve_step(inputs, init_scale, regularization=0.01, device=0):
+    """One construct + solve through the compatibility classes
+    smvs_amd::GaussNewtonStep / ConjugateGradient (reference signatures,
+    lib/gauss_newton_step.h:40-50, lib/conjugate_gradient.h:55-56) on the
+    surface Surface::create builds at init_scale.  Returns the planes and
+    reprojections the step used (to feed the oracle the same inputs), the
+    surface, g, x, H9, P and the solver's status."""
+    lib = load()
+    keep = []
+    main, subs, n_subs, b = _marshal(inputs, keep)
+    surf = surface_script(inputs, init_scale, [])
+    h, w = main.height, main.width
+    N = (surf["npx"] + 1) * (surf["npy"] + 1)
+    mg = np.zeros((h, w, 2), np.float32)
+    sg = np.zeros((n_subs, h, w, 2), np.float32)
+    sh = np.zeros((n_subs, h, w, 3), np.float32)
+    M = np.zeros((n_subs, 9)); t = np.zeros((n_subs, 3)); fl = np.zeros(2, np.float32)
+    g = np.zeros(4 * N); x = np.zeros(4 * N); H9 = np.zeros((N, 9, 16)); P = np.zeros((N, 16))
+    cg = np.zeros(2, np.int32)
+    dp = C.POINTER(C.c_double)
+    rc = lib.smvs_host_gn_solve_step(C.byref(main), subs, C.c_int(n_subs), C.byref(b),
+        C.c_int(init_scale), C.c_double(regularization), C.c_int(device),
+        mg.ctypes.data_as(_fp), sg.ctypes.data_as(_fp), sh.ctypes.data_as(_fp),
+        M.ctypes.data_as(dp), t.ctypes.data_as(dp), fl.ctypes.data_as(_fp),
+        g.ctypes.data_as(dp), x.ctypes.data_as(dp), H9.ctypes.data_as(dp),
+        P.ctypes.data_as(dp), cg.ctypes.data_as(_i32p))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    surf.update(width=w, height=h,
+                patch_vis=np.where(surf["patch_valid"] != 0, (1 << n_subs) - 1, 0).astype(np.uint32))
+    views = dict(flen=float(fl[0]), inv_flen=float(fl[1]), grad=mg,
+                 subs=[(sg[j], sh[j]) for j in range(n_subs)], M=M, t=t,
+                 shading=None, shading_grad=None)
+    return dict(surf=surf, views=views, g=g, x=x, H9=H9, P=P,
+                iterations=int(cg[0]), info=int(cg[1]))
 
 
 def view_queue_selftest(n_tasks, num_devices, views_in_flight, throwing_task=-1):

@@ -35,3 +35,28 @@ def test_integration_stub_compiles_and_links(tmp_path):
                               text=True).stdout
     for sym in wanted:
         assert re.search(r"\b%s\b" % sym, exported), sym
+
+
+def test_reference_signature_classes_compile_and_link(tmp_path):
+    """INTEGRATION.md section 1b is real code as well: GaussNewtonStep /
+    ConjugateGradient with the reference's signatures, compiled against the
+    host mirror's headers and linked with libsmvs_host.so."""
+    from smvs_amd import build as hip_build
+    lib = hip_build.build()
+    host_dir = os.path.join(os.path.dirname(lib), "host")
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(// newton_step_with_reference_calls\.cc.*?)```", text, flags=re.S)
+    assert len(blocks) == 1
+    src = tmp_path / "newton_step_with_reference_calls.cc"
+    src.write_text(blocks[0])
+    out = tmp_path / "libstep.so"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I", host_dir,
+           str(src), "-o", str(out), "-L", host_dir, "-lsmvs_host",
+           "-L", os.path.dirname(lib), "-lsmvs_hip",
+           "-Wl,-rpath," + host_dir, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--no-undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", "-D", "-C", "--undefined-only", str(out)], capture_output=True,
+                        text=True).stdout
+    assert "smvs_amd::GaussNewtonStep::construct(" in nm
+    assert "smvs_amd::ConjugateGradient::solve(" in nm

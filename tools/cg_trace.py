@@ -19,7 +19,7 @@ ctx.set_views(prob["views"]); ctx.set_surface(surf)
 ctx.run_loop(bench.REG, max_newton_steps=3, reset_active=True)
 ctx.close()
 names2 = ["start", "d+halo", "spmv", "lower", "allreduce A", "update", "allreduce B"]
-names1 = ["start", "product", "P q + sums", "allreduce (+ halo q)", "update", "barrier", "-"]
+names1 = ["start", "product", "P q + sums", "allreduce (+ halo q)", "update"]
 for block in open(path).read().split("solve")[1:]:
     lines = block.strip().split("\n")
     blocks = np.array([[int(x) for x in l.split()[1:]] for l in lines if l.startswith("block")],
@@ -49,6 +49,16 @@ for block in open(path).read().split("solve")[1:]:
                  (p[1] - p[4]) / 100.0))
     for k in range(1, min(len(rows), 9)):
         r = rows[k]
+        if "exchanges=1" in lines[0]:
+            if r[4] == 0:
+                break
+            d = np.diff(r[:5])
+            extra = "  [after the sums: group sum %.2f, total %.2f, halo %.2f]" % (
+                (r[5] - r[2]) / 100.0 if r[5] else -1, (r[6] - r[2]) / 100.0 if r[6] else -1,
+                (r[7] - r[2]) / 100.0 if r[7] else -1)
+            print("  it %2d: " % k + "  ".join("%s %.2f" % (n, v / 100.0) for n, v in zip(names[1:], d))
+                  + "  | total %.2f us" % ((r[4] - r[0]) / 100.0) + extra)
+            continue
         if r[6] == 0:
             break
         d = np.diff(r[:7])
