@@ -422,7 +422,7 @@ def secondary_workloads(args):
     cells = sw * sh * 128
     names = ["census", "warp", "cost", "paths", "wta", "lr_check", "merge", "bilateral"]
     # algorithmic HBM bytes per launch (one run_sgm at sw x sh x 128):
-    bytes_per = dict(paths=cells * (8 * 1 + 8 * 8),   # 8 cost reads + 8 u32 read-modify-writes of S
+    bytes_per = dict(paths=cells * (8 * 1 + 8 * 4),   # 8 cost reads + 8 x (2 B read + 2 B write) of S
                      cost=cells * 2,                   # warped plane in, cost out
                      warp=cells * 1,                   # warped plane out (neighbour image cached)
                      wta=cells * 2)                    # S in
@@ -441,7 +441,7 @@ def secondary_workloads(args):
     out["sgm_front_end"] = dict(kernels=sgm, size=[sw, sh, 128],
         note="HIP-event times of one reconstruct_sgm_depth_for_view (4 x run_sgm); "
              "algorithmic bytes per launch: paths 8 cost reads + 8 read-modify-writes of "
-             "the u16 S volume through u32 atomics per cell, cost 1 B in + 1 B out, warp "
+             "the u16 S entry (through u32 atomics on packed pairs) per cell, cost 1 B in + 1 B out, warp "
              "1 B out, wta 2 B in per cell")
     return out
 
@@ -548,11 +548,17 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # --shared-lighting: the one collective of the configuration, natively over
+    # RCCL (include/smvs_rccl.h); torch.distributed only hands out the id
+    native = shard.NativeComm(local_rank, dist) if (args.config == 5
+                                                    and args.shared_lighting) else None
+
     def fit_lighting(round_ctxs):
         """light_optimizer.cc:22-55 for the views of one lock-step round."""
-        ptrs = [c.light_accumulate_dev() for c in round_ctxs]
-        if args.shared_lighting:
-            shard.allreduce_lighting_device(ptrs, dist, device)
+        for c in round_ctxs:
+            c.light_accumulate_dev()
+        if native is not None:
+            native.allreduce_lighting(round_ctxs)
         return [shard.solve_lighting(*c.light_download()) for c in round_ctxs]
 
     def run_all(steps):
@@ -663,6 +669,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
+    if native is not None:
+        native.close()
     for c in ctxs:
         c.close()
     if dist is not None:

@@ -44,7 +44,7 @@ def build_host(force=False, verbose=False):
     if not force and not _host_stale():
         return HOST_LIB
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-pthread", "-shared", "-o", HOST_LIB] \
+    cmd = [cxx, "-std=c++17", "-O3", "-fPIC", "-Wall", "-pthread", "-shared", "-o", HOST_LIB] \
         + [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] \
         + ["-L" + CSRC, "-lsmvs_hip", "-Wl,-rpath,$ORIGIN/..",
            "-Wl,-rpath,/opt/rocm/lib"]
@@ -54,9 +54,32 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+RCCL_LIB = os.path.join(CSRC, "libsmvs_rccl.so")
+
+
+def build_rccl(force=False, verbose=False):
+    """libsmvs_rccl.so: the lighting all-reduce over RCCL (include/smvs_rccl.h);
+    links libsmvs_hip.so and librccl."""
+    src = os.path.join(CSRC, "rccl_light.hip")
+    deps = [src, LIB, os.path.join(CSRC, "common.h"),
+            os.path.join(HERE, "..", "include", "smvs_rccl.h")]
+    if not force and os.path.exists(RCCL_LIB) \
+            and all(os.path.getmtime(d) <= os.path.getmtime(RCCL_LIB) for d in deps):
+        return RCCL_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-shared", "-o", RCCL_LIB, src, "-L" + CSRC, "-lsmvs_hip",
+                             "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN",
+                             "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return RCCL_LIB
+
+
 def build(force=False, verbose=False):
     lib = _build_hip(force, verbose)
     build_host(force, verbose)
+    build_rccl(force, verbose)
     return lib
 
 

@@ -98,7 +98,6 @@ struct ResArgs {
     double *scalars;
     int npx, npy;
     const double *zeros;     // 16 doubles of +0.0 (a block that does not contribute)
-    int tune;                // experiment switches of the one-exchange solver (SMVS_RES_TUNE)
 };
 
 // GaussNewtonStep::construct's scatter (gauss_newton_step.cc:88-142) in gather
@@ -720,6 +719,7 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
             // this workgroup sums its group
             int const member = b + j;
             double part;
+
             ok = poll_pairs(xbuf, lvl1_at(member < nblocks ? member : b, kind_ok ? kind : 0),
                 kind_ok && member < nblocks, tag, ex, &part);
             part = segment16_sum(part);
@@ -728,6 +728,13 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
                 st_pair16(xbuf, lvl2_at(b / RES_GROUP, kind), tag, part);
         }
         int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
+        if (b % RES_GROUP != 0) {
+            // the group sums cannot be there yet (they are a hop behind): stay
+            // off the fabric for ~1.5 us instead of polling (measured: -0.2 us
+            // per exchange)
+            for (int i = 0; i < 6; ++i)
+                __builtin_amdgcn_s_sleep(8);
+        }
         double total;
         bool const ok2 = poll_pairs(xbuf, lvl2_at(j < ngroups ? j : 0, kind_ok ? kind : 0),
             kind_ok && j < ngroups, tag, ex, &total);
@@ -1482,8 +1489,11 @@ cg_resident_kernel(ResArgs A)
             stamp(k, 1);
             // the sums (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
             double v7[7] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-            // the rim's q for the neighbouring tiles' halo (tune bit 0: behind
-            // the partial sums, which the all-reduce is waiting for)
+            // the rim's q for the neighbouring tiles' halo.  It goes out BEFORE
+            // the partial sums although the all-reduce waits for those: a
+            // write-through store takes ~3 us to become visible to a poll on a
+            // busy chip, and issuing the rim later made every exchange later
+            // (measured: 11.5 instead of 9.3 us per iteration)
             auto publish_rim = [&]() {
                 if (rim) {
 #pragma unroll
@@ -1515,8 +1525,7 @@ cg_resident_kernel(ResArgs A)
                     v7[6] += r[q] * r[q];
                 }
             }
-            if (!(A.tune & 1))
-                publish_rim();
+            publish_rim();
             stamp(k, 2);
             // Waves 1 and 2 run the two-level all-reduce; wave 0 meanwhile collects
             // the q of the halo nodes into LDS.
@@ -1533,25 +1542,17 @@ cg_resident_kernel(ResArgs A)
             };
             alive = grid_allreduce_tree<7>(A.ex, ztag, epoch++, nblocks, v7, red, flag,
                 [&]() {
-                    if (!(A.tune & 2) && tid < 64) {
+                    if (tid < 64) {
                         fetch_halo(tid, 64);
                         stamp(k, 7);
                     }
                 },
-                [&]() {
-                    if (A.tune & 1)
-                        publish_rim();
-                },
+                [&]() {},
                 [&](int point) {
                     if (A.trace != nullptr && blockIdx.x == 0 && tid == 64
                         && k <= TRACE_ITERS)
                         A.trace[k * TRACE_POINTS + point] = (long long)wall_clock64();
                 });
-            if (A.tune & 2) {
-                if (tid < ring)
-                    fetch_halo(tid, RES_THREADS);
-                __syncthreads();
-            }
             if (!alive)
                 break;
             stamp(k, 3);
@@ -1872,11 +1873,6 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.npx = ctx->npx;
     A.npy = ctx->npy;
     A.zeros = ctx->zero_block;
-    static int const tune = [] {
-        const char *e = std::getenv("SMVS_RES_TUNE");
-        return e != nullptr ? std::atoi(e) : 0;
-    }();
-    A.tune = tune;
     A.trace = trace_dev;
     A.pipelined = pipelined ? (test_give_up ? 3 : 1) : 0;
     *solve_tag_out = A.solve_tag;

@@ -16,6 +16,9 @@
 #include <cmath>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 
 using namespace smvs_amd;
 
@@ -366,20 +369,33 @@ smvs_host_optimize_views(const smvs_host_view *mains, const smvs_host_view *subs
             throw std::invalid_argument("smvs_host_optimize_views: bad argument");
         Bundle::Ptr bundle = make_bundle(bundle_in);
         typedef std::chrono::steady_clock Clock;
+        // per-phase wall time over all tasks (stderr with SMVS_HOST_TIMING)
+        static const char *const phase_names[5] = { "StereoView::create x (1 + subs)",
+            "SGM front end", "DepthOptimizer ctor", "optimize()", "maps for the caller (one job)" };
+        std::mutex phase_lock;
+        double phase_s[5] = { 0, 0, 0, 0, 0 };
+        auto lap = [&](Clock::time_point& from, int phase) {
+            Clock::time_point const now = Clock::now();
+            std::lock_guard<std::mutex> guard(phase_lock);
+            phase_s[phase] += std::chrono::duration<double>(now - from).count();
+            from = now;
+        };
         std::vector<std::future<void>> done;
         Clock::time_point const t_start = Clock::now();
         {
             ViewQueue queue(num_devices, views_in_flight);
             for (int job = 0; job < n_jobs; ++job)
-                done.push_back(queue.add_task([=](ViewQueue::Slot const& slot) {
+                done.push_back(queue.add_task([=, &lap](ViewQueue::Slot const& slot) {
                     // app/smvsrecon.cc:662-732
                     Clock::time_point const t0 = Clock::now();
+                    Clock::time_point tp = t0;
                     StereoView::Ptr main_view = make_view(mains[job],
                         o->use_shading != 0);
                     std::vector<StereoView::Ptr> subs;
                     for (int j = 0; j < n_subs; ++j)
                         subs.push_back(make_view(subs_in[(size_t)job * n_subs + j],
                             false));
+                    lap(tp, 0);
                     int const device = first_device + slot.device;
                     bool const use_sgm = sgm_scale >= 0;
                     if (use_sgm) {
@@ -400,11 +416,17 @@ smvs_host_optimize_views(const smvs_host_view *mains, const smvs_host_view *subs
                     opts.full_optimization = o->full_optimization != 0;
                     opts.device = device;
                     opts.solver = o->solver;
+                    lap(tp, 1);
                     DepthOptimizer optimizer(main_view, subs, bundle, opts);
+                    lap(tp, 2);
                     optimizer.optimize();
-                    FloatImage::Ptr depth = optimizer.get_depth();
-                    FloatImage::Ptr normals = optimizer.get_normals();
+                    lap(tp, 3);
+                    // (optimize() has written the depth / normal embeddings,
+                    // lib/depth_optimizer.cc:158-161; the maps are fetched once
+                    // more only for the job whose result the caller wants)
                     if (job == keep_job) {
+                        FloatImage::Ptr depth = optimizer.get_depth();
+                        FloatImage::Ptr normals = optimizer.get_normals();
                         size_t const npix = (size_t)mains[job].width * mains[job].height;
                         if (depth_out != nullptr)
                             std::memcpy(depth_out, depth->begin(), sizeof(float) * npix);
@@ -412,6 +434,7 @@ smvs_host_optimize_views(const smvs_host_view *mains, const smvs_host_view *subs
                             std::memcpy(normals_out, normals->begin(),
                                 sizeof(float) * 3 * npix);
                     }
+                    lap(tp, 4);
                     if (logs != nullptr)
                         fill_log(optimizer, &logs[job]);
                     if (job_seconds != nullptr)
@@ -422,6 +445,10 @@ smvs_host_optimize_views(const smvs_host_view *mains, const smvs_host_view *subs
         }
         if (total_seconds != nullptr)
             *total_seconds = std::chrono::duration<double>(Clock::now() - t_start).count();
+        if (std::getenv("SMVS_HOST_TIMING") != nullptr)
+            for (int i = 0; i < 5; ++i)
+                std::fprintf(stderr, "[smvs views] %-34s %8.2f ms per view\n",
+                    phase_names[i], 1e3 * phase_s[i] / n_jobs);
         for (auto& f : done)
             f.get();   // rethrows a task's exception
         return 0;

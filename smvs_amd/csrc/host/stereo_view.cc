@@ -169,15 +169,25 @@ StereoView::create(int view_id, ByteImage::ConstPtr bytes,
     sv->view_id = view_id;
     sv->camera = camera;
     sv->bytes = bytes;
-    FloatImage::Ptr img = FloatImage::create(bytes->width(), bytes->height(),
-        bytes->channels());
-    int64_t const n = (int64_t)bytes->get_pixel_amount() * bytes->channels();
-    for (int64_t i = 0; i < n; ++i)
-        img->at(i) = (float)bytes->at(i) / 255.0f;
-    sv->image = img;
     if (initialize_linear)
         sv->initialize_linear(gamma_correction);
     return sv;
+}
+
+FloatImage::ConstPtr
+StereoView::get_image(void) const
+{
+    std::call_once(image_once, [this]() {
+        FloatImage::Ptr img = FloatImage::create(bytes->width(), bytes->height(),
+            bytes->channels());
+        int64_t const n = (int64_t)bytes->get_pixel_amount() * bytes->channels();
+        uint8_t const* src = bytes->begin();
+        float* dst = img->begin();
+        for (int64_t i = 0; i < n; ++i)
+            dst[i] = (float)src[i] / 255.0f;
+        image = img;
+    });
+    return image;
 }
 
 void
@@ -185,7 +195,7 @@ StereoView::set_scale(int scale, bool)
 {
     // lib/stereo_view.cc:24-46
     double const sigma = 0.12 * std::pow(2.0, scale) + 0.2;
-    this->scaleimage = imgtools::blur_gaussian(this->image, (float)sigma);
+    this->scaleimage = imgtools::blur_gaussian(this->get_image(), (float)sigma);
     FloatImage::ConstPtr grey = this->scaleimage->channels() > 1
         ? FloatImage::ConstPtr(imgtools::desaturate(this->scaleimage))
         : FloatImage::ConstPtr(this->scaleimage);
@@ -205,7 +215,7 @@ void
 StereoView::initialize_linear(bool gamma_correction)
 {
     // lib/stereo_view.cc:64-84
-    this->linear_image = this->image->duplicate();
+    this->linear_image = this->get_image()->duplicate();
     if (gamma_correction) {
         int64_t const n = (int64_t)linear_image->get_pixel_amount()
             * linear_image->channels();

@@ -14,6 +14,8 @@
 // mirror compiles too).  The z-buffer minimum is order independent:
 // (float)min(d) == min((float)d) because rounding is monotone.
 #include "common.h"
+
+#include <algorithm>
 #include "host/topo_math.h"
 
 #include <vector>
@@ -38,7 +40,8 @@ struct TopoArgs {
     TopoView views[1 + SMVS_MAX_SUBS];   // [0] main, [1 + j] neighbour j
     const float2 *main_grad;
     const SubPlanes *subs;
-    float *zbuf[SMVS_MAX_SUBS];     // [(h + 1)][(w + 1)]
+    float *zbuf[SMVS_MAX_SUBS];     // [(h + 1)][(w + 1)] z-buffer (3 x 3 splats)
+    float *zraw[SMVS_MAX_SUBS];     // same shape: nearest depth per centre cell
     const float *sgm_depth;         // [H][W] or nullptr
     const NccSample *ncc;           // 32 concatenated templates
     int ncc_off[33];
@@ -115,12 +118,40 @@ topo_splat_kernel(TopoArgs A)
             float const df = (float)wp.d;
             if (!(df == df))
                 continue;
-            for (int dx = -1; dx < 2; ++dx)
-                for (int dy = -1; dy < 2; ++dy)
-                    atomic_min_float(A.zbuf[s] + (size_t)(cy + dy) * (sw + 1)
-                        + (cx + dx), df);
+            // The reference writes df into the 3 x 3 cells around (cx, cy)
+            // (:455-462).  min is exact and order free, so the same buffer is
+            // the 3 x 3 minimum filter of the per-centre minima: one atomic per
+            // (pixel, neighbour) here instead of nine, topo_dilate_kernel does
+            // the rest.
+            atomic_min_float(A.zraw[s] + (size_t)cy * (sw + 1) + cx, df);
         }
     }
+}
+
+// zbuf = 3 x 3 minimum filter of zraw (cells outside the buffer do not exist)
+__global__ void __launch_bounds__(256)
+topo_dilate_kernel(TopoArgs A)
+{
+    int const s = blockIdx.z;
+    int const zw = A.views[1 + s].w + 1, zh = A.views[1 + s].h + 1;
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= zw || y >= zh)
+        return;
+    const float *raw = A.zraw[s];
+    float m = 10000.0f;
+    for (int dy = -1; dy < 2; ++dy) {
+        int const yy = y + dy;
+        if (yy < 0 || yy >= zh)
+            continue;
+        for (int dx = -1; dx < 2; ++dx) {
+            int const xx = x + dx;
+            if (xx < 0 || xx >= zw)
+                continue;
+            m = fminf(m, raw[(size_t)yy * zw + xx]);
+        }
+    }
+    A.zbuf[s][(size_t)y * zw + x] = m;
 }
 
 // A group of G = min(64, ps^2) consecutive lanes works on one (patch,
@@ -469,8 +500,12 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     }
     A->main_grad = ctx->main_grad;
     A->subs = ctx->subs_dev;
-    for (int s = 0; s < SMVS_MAX_SUBS; ++s)
+    for (int s = 0; s < SMVS_MAX_SUBS; ++s) {
         A->zbuf[s] = ctx->topo_zbuf[s];
+        A->zraw[s] = ctx->topo_zbuf[s] == nullptr ? nullptr
+            : ctx->topo_zbuf[s] + (size_t)(ctx->images[1 + s].w + 1)
+                * (ctx->images[1 + s].h + 1);
+    }
     A->sgm_depth = nullptr;
     A->ncc = ctx->topo_ncc;
     for (int i = 0; i < 33; ++i)
@@ -533,7 +568,8 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         size_t const n = (size_t)(ctx->images[1 + s].w + 1)
             * (ctx->images[1 + s].h + 1);
         if (n > ctx->topo_zbuf_cap[s]) {
-            if ((rc = device_alloc(&ctx->topo_zbuf[s], n)) != SMVS_OK)
+            // (the z-buffer and, behind it, the per-centre minima)
+            if ((rc = device_alloc(&ctx->topo_zbuf[s], 2 * n)) != SMVS_OK)
                 return rc;
             ctx->topo_zbuf_cap[s] = n;
         }
@@ -558,13 +594,22 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         size_t const n = (size_t)(ctx->images[1 + s].w + 1)
             * (ctx->images[1 + s].h + 1);
         // 10000.0f
-        SMVS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)ctx->topo_zbuf[s],
+        SMVS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(ctx->topo_zbuf[s] + n),
             0x461C4000, n, ctx->stream));
     }
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->patch_vis, 0,
         sizeof(uint32_t) * ctx->num_patches, ctx->stream));
     hipLaunchKernelGGL(topo_splat_kernel, dim3((ctx->width + 255) / 256,
         ctx->height), dim3(256), 0, ctx->stream, A);
+    {
+        int zw = 0, zh = 0;
+        for (int s = 0; s < ctx->n_subs; ++s) {
+            zw = std::max(zw, ctx->images[1 + s].w + 1);
+            zh = std::max(zh, ctx->images[1 + s].h + 1);
+        }
+        hipLaunchKernelGGL(topo_dilate_kernel, dim3((zw + 255) / 256, zh, ctx->n_subs),
+            dim3(256), 0, ctx->stream, A);
+    }
     int const pp = ctx->patchsize * ctx->patchsize;
     long long const group = pp >= 64 ? 64 : pp;
     long long const items = (long long)ctx->num_patches * ctx->n_subs * group;

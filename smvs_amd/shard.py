@@ -86,6 +86,51 @@ def allreduce_lighting_device(ptrs, dist=None, device=None):
     torch.cuda.synchronize(device)
 
 
+class NativeComm:
+    """RCCL communicator of this rank behind include/smvs_rccl.h
+    (csrc/libsmvs_rccl.so): the lighting all-reduce without PyTorch in the data
+    path.  `dist` (torch.distributed, any backend) is used ONCE, to hand rank
+    0's 128-byte unique id to the other ranks."""
+
+    def __init__(self, device_index, dist=None):
+        import ctypes as C
+        import os
+        from . import _capi
+        _capi.load()
+        path = os.path.join(_capi.HERE, "csrc", "libsmvs_rccl.so")
+        if not os.path.exists(path):
+            raise _capi.SmvsError(-2, "RCCL library %s is missing" % path)
+        self.lib = C.CDLL(path)
+        rank, world = 0, 1
+        if dist is not None and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            _capi.check(self.lib.smvs_comm_unique_id(ident))
+        if world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        self.handle = C.c_void_p()
+        _capi.check(self.lib.smvs_comm_create(device_index, rank, world, ident,
+                                              C.byref(self.handle)))
+        self.rank, self.world = rank, world
+
+    def allreduce_lighting(self, ctxs):
+        """Sum the device-resident normal equations (smvs_light_accumulate_dev)
+        of the ViewContexts `ctxs` and over the ranks, in place."""
+        import ctypes as C
+        from . import _capi
+        arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+        _capi.check(self.lib.smvs_light_allreduce(self.handle, arr, len(ctxs)))
+
+    def close(self):
+        if self.handle:
+            self.lib.smvs_comm_destroy(self.handle)
+            import ctypes as C
+            self.handle = C.c_void_p()
+
+
 def solve_lighting(A, b):
     """params = pinv(A) b (light_optimizer.cc:50-52), singular values below
     1e-12 of the largest dropped."""

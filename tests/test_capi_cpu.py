@@ -22,6 +22,25 @@ def test_exports_every_declared_symbol(lib):
     assert not missing, missing
 
 
+def test_rccl_library_exports_its_header():
+    """include/smvs_rccl.h <-> csrc/libsmvs_rccl.so (the lighting all-reduce
+    over RCCL): every declared entry point is exported; no call without a GPU."""
+    import os, re
+    from smvs_amd import build as hip_build, _capi
+    path = hip_build.build_rccl()
+    text = open(os.path.join(_capi.HERE, "..", "include", "smvs_rccl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(smvs_[a-z_0-9]+)\s*\(", text)))
+    assert syms == ["smvs_comm_create", "smvs_comm_destroy", "smvs_comm_unique_id",
+                    "smvs_light_allreduce"]
+    lib = C.CDLL(path)
+    assert not [s for s in syms if not hasattr(lib, s)]
+    # argument errors are status codes
+    assert lib.smvs_comm_unique_id(None) == -1
+    assert lib.smvs_light_allreduce(None, None, 0) == -1
+    assert lib.smvs_comm_destroy(None) == 0
+
+
 def test_product_package_does_not_import_oracle():
     import os, re
     root = os.path.join(os.path.dirname(__file__), "..", "smvs_amd")

@@ -363,3 +363,36 @@ def test_reference_signature_classes_match_oracle(hip, oracle):
                                   0.01 * np.linalg.norm(ref["g"]), 1e-3)
     assert (got["iterations"], got["info"]) == (itr, infor)
     assert _rel(got["x"], xr) < 1e-7
+
+
+def test_native_rccl_lighting_allreduce_world_1(hip, oracle):
+    """include/smvs_rccl.h: one-rank communicator (ncclCommInitRank), the
+    normal equations of three views of a lock-step round summed on the device
+    and written back to every context -- against the oracle's sums.  (The
+    cross-rank step is ncclAllReduce on the same buffer; the driver's
+    multi-GPU run is what exercises it.)"""
+    from smvs_amd import synth, shard
+    prob = synth.make_problem(224, 160, 3, 2, shading=True, noise=0.003)
+    rng = np.random.default_rng(12)
+    ctxs, refs = [], []
+    for v in range(3):
+        s = dict(prob["surf"])
+        nodes = prob["surf"]["nodes"].copy()
+        nodes[:, 0] *= 1.0 + 0.002 * v * rng.standard_normal(nodes.shape[0])
+        s["nodes"] = nodes
+        c = hip.ViewContext(224, 160, 3)
+        c.set_views(prob["views"]); c.set_surface(s)
+        c.light_accumulate_dev()
+        ctxs.append(c)
+        orc = oracle.OracleProblem(s, prob["views"])
+        refs.append(oracle.light_accumulate(orc.normal_map(), prob["views"]["shading"]))
+    comm = shard.NativeComm(0, None)
+    assert (comm.rank, comm.world) == (0, 1)
+    comm.allreduce_lighting(ctxs)
+    A_sum = sum(r[0] for r in refs); b_sum = sum(r[1] for r in refs)
+    for c in ctxs:
+        A, b = c.light_download()
+        assert _rel(A, A_sum) < 1e-10 and _rel(b, b_sum) < 1e-10
+    comm.close()
+    for c in ctxs:
+        c.close()
