@@ -706,7 +706,8 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
         return (unsigned)(offsetof(ResExchange, lvl2)
             + ((((size_t)par * RES_MAX_GROUPS + (size_t)group) * RES_KINDS + (size_t)kind) * 16));
     };
-    if (threadIdx.x < K)
+    int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
+    if (nblocks > 1 && threadIdx.x < K)
         st_pair16(xbuf, lvl1_at(b, (int)threadIdx.x), tag, block_total(red, (int)threadIdx.x));
     after_publish();
     int const wave = (int)(threadIdx.x >> 6) - 1;
@@ -714,31 +715,39 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
         int const lane = threadIdx.x & 63;
         int const kind = 4 * wave + (lane >> 4), j = lane & 15;
         bool const kind_ok = kind < K;
-        bool ok = true;
-        if (b % RES_GROUP == 0) {
-            // this workgroup sums its group
-            int const member = b + j;
-            double part;
-
-            ok = poll_pairs(xbuf, lvl1_at(member < nblocks ? member : b, kind_ok ? kind : 0),
-                kind_ok && member < nblocks, tag, ex, &part);
-            part = segment16_sum(part);
-            mark(5);
-            if (kind_ok && j == 0)
-                st_pair16(xbuf, lvl2_at(b / RES_GROUP, kind), tag, part);
-        }
-        int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
-        if (b % RES_GROUP != 0) {
-            // the group sums cannot be there yet (they are a hop behind): stay
-            // off the fabric for ~1.5 us instead of polling (measured: -0.2 us
-            // per exchange)
-            for (int i = 0; i < 6; ++i)
-                __builtin_amdgcn_s_sleep(8);
-        }
+        bool ok = true, ok2 = true;
         double total;
-        bool const ok2 = poll_pairs(xbuf, lvl2_at(j < ngroups ? j : 0, kind_ok ? kind : 0),
-            kind_ok && j < ngroups, tag, ex, &total);
-        total = segment16_sum(total);
+        if (nblocks == 1) {
+            // a grid of one tile (the coarse scales): nothing to exchange
+            total = kind_ok ? block_total(red, kind) : 0.0;
+        } else if (ngroups == 1) {
+            // a single group: every workgroup sums its <= 16 members itself,
+            // one hop instead of two
+            ok = poll_pairs(xbuf, lvl1_at(j < nblocks ? j : 0, kind_ok ? kind : 0),
+                kind_ok && j < nblocks, tag, ex, &total);
+            total = segment16_sum(total);
+        } else {
+            if (b % RES_GROUP == 0) {
+                // this workgroup sums its group
+                int const member = b + j;
+                double part;
+                ok = poll_pairs(xbuf, lvl1_at(member < nblocks ? member : b,
+                        kind_ok ? kind : 0), kind_ok && member < nblocks, tag, ex, &part);
+                part = segment16_sum(part);
+                mark(5);
+                if (kind_ok && j == 0)
+                    st_pair16(xbuf, lvl2_at(b / RES_GROUP, kind), tag, part);
+            } else {
+                // the group sums cannot be there yet (they are a hop behind):
+                // stay off the fabric for ~1.5 us instead of polling (measured:
+                // -0.2 us per exchange)
+                for (int i = 0; i < 6; ++i)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            ok2 = poll_pairs(xbuf, lvl2_at(j < ngroups ? j : 0, kind_ok ? kind : 0),
+                kind_ok && j < ngroups, tag, ex, &total);
+            total = segment16_sum(total);
+        }
         mark(6);
         if (kind_ok && j == 0)
             res[kind] = total;
@@ -1691,9 +1700,16 @@ cg_resident_kernel(ResArgs A)
     }
 }
 
-// Tile shape: tw * th <= 512 nodes, at most max_tiles tiles, smallest rim.
+static size_t
+resident_lds_bytes(int tw, int th, bool one)
+{
+    return resident_lds_layout(tw, th, one).total * sizeof(double);
+}
+
+// Tile shape: tw * th <= 512 nodes, at most max_tiles tiles, fits the LDS of
+// the solver variant, smallest rim.
 static bool
-choose_tiling(int stride, int rows, int max_tiles, int *tw_out, int *th_out)
+choose_tiling(int stride, int rows, int max_tiles, bool one, int *tw_out, int *th_out)
 {
     long best = -1;
     for (int tw = 4; tw <= 128 && tw <= RES_THREADS; ++tw) {
@@ -1704,6 +1720,10 @@ choose_tiling(int stride, int rows, int max_tiles, int *tw_out, int *th_out)
             long const tiles = (long)((stride + tw - 1) / tw)
                 * ((rows + t2 - 1) / t2);
             if (tiles > max_tiles)
+                continue;
+            // (long thin tiles have a long rim: the one-exchange solver keeps
+            // r, P and q of the halo in LDS)
+            if (resident_lds_bytes(tw, t2, one) > (size_t)160 * 1024)
                 continue;
             // prefer few idle threads, then a short rim
             long const waste = tiles * (long)(tw * t2) - (long)stride * rows;
@@ -1716,12 +1736,6 @@ choose_tiling(int stride, int rows, int max_tiles, int *tw_out, int *th_out)
         }
     }
     return best >= 0;
-}
-
-static size_t
-resident_lds_bytes(int tw, int th, bool one)
-{
-    return resident_lds_layout(tw, th, one).total * sizeof(double);
 }
 
 // Which of the two resident solvers a context runs (smvs_ctx_set_solver).
@@ -1760,9 +1774,7 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
     int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
         ? ctx->resident_cus : RES_MAX_BLOCKS;
     int tw = 0, th = 0;
-    if (!choose_tiling(stride, rows, max_tiles, &tw, &th))
-        return false;
-    if (resident_lds_bytes(tw, th, resident_one_exchange(ctx)) > (size_t)160 * 1024)
+    if (!choose_tiling(stride, rows, max_tiles, resident_one_exchange(ctx), &tw, &th))
         return false;
     if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32)
         return false;
@@ -1794,7 +1806,7 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
         ? ctx->resident_cus : RES_MAX_BLOCKS;
     int tw = 0, th = 0;
-    (void)choose_tiling(stride, rows, max_tiles, &tw, &th);
+    (void)choose_tiling(stride, rows, max_tiles, resident_one_exchange(ctx), &tw, &th);
     int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
     int const num_tiles = tiles_x * tiles_y;
     bool const one = resident_one_exchange(ctx);

@@ -10,6 +10,7 @@
 #include "sgm_stereo.h"
 #include "view_selection.h"
 #include "view_queue.h"
+#include "scene_io.h"
 #include "gauss_newton_step.h"
 #include "conjugate_gradient.h"
 
@@ -609,6 +610,111 @@ smvs_host_gn_solve_step(const smvs_host_view *main_in, const smvs_host_view *sub
             cg_out[0] = status.num_iterations;
             cg_out[1] = (int)status.info;
         }
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_reconstruct_scene(const char *scene_dir,
+    const smvs_host_recon_settings *o, const int *view_ids, int n_view_ids,
+    int *reconstructed_out, int *n_reconstructed, int *n_skipped, double *seconds)
+{
+    try {
+        if (scene_dir == nullptr || o == nullptr)
+            throw std::invalid_argument("smvs_host_reconstruct_scene: bad argument");
+        ReconSettings conf;
+        if (o->image_embedding != nullptr)
+            conf.image_embedding = o->image_embedding;
+        conf.regularization = o->regularization;
+        conf.output_scale = o->output_scale;
+        conf.use_shading = o->use_shading != 0;
+        conf.use_sgm = o->use_sgm != 0;
+        conf.force_recon = o->force_recon != 0;
+        conf.force_sgm = o->force_sgm != 0;
+        conf.full_optimization = o->full_optimization != 0;
+        conf.sgm_min = o->sgm_min;
+        conf.sgm_max = o->sgm_max;
+        conf.sgm_scale = o->sgm_scale;
+        conf.num_neighbors = (std::size_t)o->num_neighbors;
+        conf.min_neighbors = (std::size_t)o->min_neighbors;
+        conf.first_device = o->first_device;
+        conf.num_devices = o->num_devices;
+        conf.views_in_flight = o->views_in_flight;
+        if (view_ids != nullptr)
+            conf.view_ids.assign(view_ids, view_ids + n_view_ids);
+        ReconReport const report = reconstruct_scene(scene_dir, conf);
+        if (reconstructed_out != nullptr)
+            std::copy(report.reconstructed.begin(), report.reconstructed.end(),
+                reconstructed_out);
+        if (n_reconstructed != nullptr)
+            *n_reconstructed = (int)report.reconstructed.size();
+        if (n_skipped != nullptr)
+            *n_skipped = (int)(report.skipped_few_neighbors.size()
+                + report.already_done.size());
+        if (seconds != nullptr)
+            *seconds = report.seconds;
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_scene_info(const char *scene_dir, const char *image_embedding,
+    int max_views, int *n_views, int *present, float *flen, float *rot9,
+    float *trans3, int *width, int *height, int *n_features)
+{
+    try {
+        if (scene_dir == nullptr || image_embedding == nullptr || n_views == nullptr)
+            throw std::invalid_argument("smvs_host_scene_info: bad argument");
+        Scene::Ptr scene = Scene::create(scene_dir);
+        std::vector<SceneView> const& views = scene->get_views();
+        *n_views = (int)views.size();
+        if ((int)views.size() > max_views)
+            throw std::invalid_argument("smvs_host_scene_info: more views than room");
+        for (std::size_t i = 0; i < views.size(); ++i) {
+            SceneView const& v = views[i];
+            present[i] = v.present ? 1 : 0;
+            flen[i] = v.camera.flen;
+            std::copy(v.camera.rot, v.camera.rot + 9, rot9 + 9 * i);
+            std::copy(v.camera.trans, v.camera.trans + 3, trans3 + 3 * i);
+            int whct[4] = { 0, 0, 0, 0 };
+            if (v.present)
+                (void)mvei_header(v.image_path(image_embedding), whct);
+            width[i] = whct[0];
+            height[i] = whct[1];
+        }
+        if (n_features != nullptr) {
+            try {
+                *n_features = (int)scene->get_bundle()->features.size();
+            } catch (std::exception const&) {
+                *n_features = -1;
+            }
+        }
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_mvei_roundtrip(const char *in_path, const char *out_path)
+{
+    try {
+        if (in_path == nullptr || out_path == nullptr)
+            throw std::invalid_argument("smvs_host_mvei_roundtrip: bad argument");
+        int whct[4];
+        if (!mvei_header(in_path, whct))
+            throw std::runtime_error(std::string("not an .mvei file: ") + in_path);
+        if (whct[3] == 1)
+            save_mvei(out_path, ByteImage::ConstPtr(load_mvei_u8(in_path)));
+        else
+            save_mvei(out_path, FloatImage::ConstPtr(load_mvei_float(in_path)));
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();

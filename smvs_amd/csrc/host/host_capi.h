@@ -116,6 +116,35 @@ int smvs_host_gn_solve_step(const smvs_host_view *main_view,
     float *sub_grad, float *sub_hess, double *Mi, double *ti, float *flen2,
     double *g, double *x, double *H9, double *P, int *cg);
 
+/* smvsrecon's scene-level run (app/smvsrecon.cc:400-745) on an MVE scene
+ * directory whose input embedding exists as <image_embedding>.mvei: view list,
+ * ViewSelection, one ViewQueue task per reference view, result embeddings
+ * written into the view directories.  view_ids may be NULL (every view).
+ * reconstructed_out: room for the scene's view count; *n_reconstructed. */
+typedef struct {
+    const char *image_embedding;    /* "undistorted" */
+    float regularization;           /* alpha, 1.0 */
+    int output_scale;               /* -o */
+    int use_shading, use_sgm, force_recon, force_sgm, full_optimization;
+    float sgm_min, sgm_max;
+    int sgm_scale;
+    int num_neighbors, min_neighbors;
+    int first_device, num_devices, views_in_flight;
+} smvs_host_recon_settings;
+int smvs_host_reconstruct_scene(const char *scene_dir,
+    const smvs_host_recon_settings *settings, const int *view_ids, int n_view_ids,
+    int *reconstructed_out, int *n_reconstructed, int *n_skipped, double *seconds);
+
+/* MVE scene I/O without a device: parses the scene (views/*.mve/meta.ini,
+ * synth_0.out) -> number of list entries, and per entry (caller-sized arrays of
+ * at least max_views): present, flen, rot[9], trans[3], and the size of the
+ * image embedding (0 x 0 when missing); *n_features of the bundle (-1: none).
+ * mvei_roundtrip: loads in_path (u8 or float .mvei) and saves it to out_path. */
+int smvs_host_scene_info(const char *scene_dir, const char *image_embedding,
+    int max_views, int *n_views, int *present, float *flen, float *rot9,
+    float *trans3, int *width, int *height, int *n_features);
+int smvs_host_mvei_roundtrip(const char *in_path, const char *out_path);
+
 /* smvs_amd::ViewQueue on its own (no device involved): n_tasks tasks that
  * record the slot they ran on; task `throwing_task` (or -1) throws.
  * device_hist[num_devices] and worker_hist[num_devices * views_in_flight]

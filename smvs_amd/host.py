@@ -205,6 +205,65 @@ def gn_solve_step(inputs, init_scale, regularization=0.01, device=0):
                 iterations=int(cg[0]), info=int(cg[1]))
 
 
+class ReconSettings(C.Structure):
+    _fields_ = [("image_embedding", C.c_char_p), ("regularization", C.c_float),
+                ("output_scale", C.c_int), ("use_shading", C.c_int), ("use_sgm", C.c_int),
+                ("force_recon", C.c_int), ("force_sgm", C.c_int),
+                ("full_optimization", C.c_int), ("sgm_min", C.c_float),
+                ("sgm_max", C.c_float), ("sgm_scale", C.c_int), ("num_neighbors", C.c_int),
+                ("min_neighbors", C.c_int), ("first_device", C.c_int),
+                ("num_devices", C.c_int), ("views_in_flight", C.c_int)]
+
+
+def reconstruct_scene(scene_dir, view_ids=None, image_embedding="undistorted",
+                      regularization=1.0, output_scale=2, use_shading=False, use_sgm=True,
+                      force_recon=False, force_sgm=False, sgm_range=(0.0, 0.0), sgm_scale=1,
+                      num_neighbors=6, min_neighbors=3, first_device=0, num_devices=1,
+                      views_in_flight=2):
+    """smvsrecon's scene-level run (app/smvsrecon.cc:400-745) through
+    smvs_amd::reconstruct_scene: returns (reconstructed ids, skipped, seconds)."""
+    lib = load()
+    st = ReconSettings(image_embedding.encode(), regularization, output_scale,
+                       1 if use_shading else 0, 1 if use_sgm else 0,
+                       1 if force_recon else 0, 1 if force_sgm else 0, 0,
+                       sgm_range[0], sgm_range[1], sgm_scale, num_neighbors, min_neighbors,
+                       first_device, num_devices, views_in_flight)
+    ids = None if view_ids is None else np.asarray(view_ids, dtype=np.int32)
+    out = np.zeros(4096, np.int32)
+    n = C.c_int(0); sk = C.c_int(0); secs = C.c_double(0.0)
+    rc = lib.smvs_host_reconstruct_scene(scene_dir.encode(), C.byref(st),
+        ids.ctypes.data_as(_i32p) if ids is not None else None,
+        C.c_int(0 if ids is None else ids.size), out.ctypes.data_as(_i32p),
+        C.byref(n), C.byref(sk), C.byref(secs))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return [int(x) for x in out[:n.value]], sk.value, secs.value
+
+
+def scene_info(scene_dir, image_embedding="undistorted", max_views=4096):
+    """Scene::create + bundle of csrc/host/scene_io.cc (no device)."""
+    lib = load()
+    n = C.c_int(0); nf = C.c_int(0)
+    present = np.zeros(max_views, np.int32); flen = np.zeros(max_views, np.float32)
+    rot = np.zeros((max_views, 9), np.float32); trans = np.zeros((max_views, 3), np.float32)
+    w = np.zeros(max_views, np.int32); h = np.zeros(max_views, np.int32)
+    rc = lib.smvs_host_scene_info(scene_dir.encode(), image_embedding.encode(),
+        C.c_int(max_views), C.byref(n), present.ctypes.data_as(_i32p),
+        flen.ctypes.data_as(_fp), rot.ctypes.data_as(_fp), trans.ctypes.data_as(_fp),
+        w.ctypes.data_as(_i32p), h.ctypes.data_as(_i32p), C.byref(nf))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    k = n.value
+    return dict(present=present[:k], flen=flen[:k], rot=rot[:k], trans=trans[:k],
+                width=w[:k], height=h[:k], n_features=nf.value)
+
+
+def mvei_roundtrip(in_path, out_path):
+    lib = load()
+    if lib.smvs_host_mvei_roundtrip(in_path.encode(), out_path.encode()) != 0:
+        raise _capi.SmvsError(-1, lib.smvs_host_last_error().decode())
+
+
 def view_queue_selftest(n_tasks, num_devices, views_in_flight, throwing_task=-1):
     """smvs_amd::ViewQueue without a device: -> (tasks per device, per worker)."""
     lib = load()

@@ -396,3 +396,51 @@ def test_native_rccl_lighting_allreduce_world_1(hip, oracle):
     comm.close()
     for c in ctxs:
         c.close()
+
+
+def test_reconstruct_scene_end_to_end(hip, oracle, oracle_threads, tmp_path):
+    """an MVE scene directory (meta.ini, synth_0.out, .mvei
+    images) through smvs_amd::reconstruct_scene -- smvsrecon's main between
+    scene loading and mesh generation (app/smvsrecon.cc:400-745): view
+    selection, one ViewQueue task per view (SGM front end + optimize), result
+    embeddings written as .mvei.  The reference view's depth embedding is what
+    the oracle's pipeline computes for the neighbours ViewSelection chose."""
+    from smvs_amd import synth, host, mve_scene
+    inputs = synth.pipeline_inputs("sphere", 384, 256, 3, flen=1.2)
+    d = str(tmp_path)
+    mve_scene.write_scene(d, inputs)
+    done, skipped, secs = host.reconstruct_scene(d, view_ids=[0], num_neighbors=3,
+                                                 min_neighbors=2, output_scale=2)
+    assert done == [0] and skipped == 0 and secs > 0
+    vdir = os.path.join(d, "views", "view_0000.mve")
+    depth_mve = mve_scene.load_mvei(os.path.join(vdir, "smvs-B0.mvei"))
+    normals = mve_scene.load_mvei(os.path.join(vdir, "smvs-B0N.mvei"))
+    sgm = mve_scene.load_mvei(os.path.join(vdir, "smvs-sgm.mvei"))
+    assert depth_mve.shape == (256, 384) and normals.shape == (256, 384, 3)
+    assert sgm.shape == (128, 192)
+    # the neighbours the scene run used: ViewSelection on the same scene
+    scene = dict(views=[dict(id=i, flen=c.flen, rot=c.R, trans=c.t, width=384, height=256)
+                        for i, c in enumerate(inputs["cams"])],
+                 features=inputs["features"],
+                 refs=[list(range(4))] * len(inputs["features"]))
+    nb = host.select_neighbors(scene, 0, num_neighbors=3)
+    assert sorted(nb) == [1, 2, 3]
+    order = [0] + nb
+    sel = dict(inputs, cams=[inputs["cams"][i] for i in order],
+               images=[inputs["images"][i] for i in order], view_ids=order)
+    sgm_o = oracle.sgm_depth_for_view(sel, sgm_scale=1, roundtrip=True)
+    want = oracle.optimize(sel, regularization=0.01, num_iterations=5, min_scale=2,
+                           sgm_depth=sgm_o)
+    # the embedding is stored in MVE's ray-length convention (stereo_view.h:100-119)
+    xs, ys = np.meshgrid(np.arange(384, dtype=np.float32) + np.float32(0.5),
+                         np.arange(256, dtype=np.float32) + np.float32(0.5))
+    f = np.float32(inputs["cams"][0].flen) * np.float32(384)
+    vx = (xs - np.float32(192)) / f; vy = (ys - np.float32(128)) / f
+    ray = np.sqrt(vx * vx + vy * vy + np.float32(1)).astype(np.float64)
+    z = depth_mve.astype(np.float64) / ray
+    assert np.array_equal(z > 0, want["depth"] > 0)
+    assert _rel(z, want["depth"]) <= 1e-4
+    # a second run finds the view reconstructed (smvsrecon.cc:544-555)
+    done2, skipped2, _ = host.reconstruct_scene(d, view_ids=[0], num_neighbors=3,
+                                                min_neighbors=2, output_scale=2)
+    assert done2 == [] and skipped2 == 1
