@@ -36,9 +36,15 @@
 // solve reports failure and the caller falls back to the streaming kernels.
 #include "common.h"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <mutex>
+#include <string>
 
 namespace smvs_hip {
 
@@ -1781,14 +1787,53 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
     return true;
 }
 
-static std::mutex g_resident_mutex[16];   // one barrier kernel per device at a time
+static DeviceBarrierLock g_resident_mutex[16];   // one barrier kernel per device at a time
 
-// one barrier kernel at a time per device: two of them started together
-// could each hold half of the CUs and wait for the other half for ever
-std::mutex &
+void
+DeviceBarrierLock::bind(int device)
+{
+    std::lock_guard<std::mutex> guard(mutex);
+    if (bound)
+        return;
+    bound = true;
+    // the same GPU may have different indices in different processes
+    // (HIP_VISIBLE_DEVICES): name the file after the PCI bus id
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess)
+        std::snprintf(bus, sizeof(bus), "index%d", device);
+    for (char *c = bus; *c != 0; ++c)
+        if (*c == ':' || *c == '/')
+            *c = '_';
+    const char *dir = std::getenv("SMVS_LOCK_DIR");
+    std::string const path = std::string(dir != nullptr ? dir : "/tmp") + "/smvs_hip_barrier_"
+        + bus + ".lock";
+    fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    // (no file: the lock protects this process only, as before)
+}
+
+void
+DeviceBarrierLock::lock(void)
+{
+    mutex.lock();
+    if (fd >= 0)
+        while (::flock(fd, LOCK_EX) != 0 && errno == EINTR) {
+        }
+}
+
+void
+DeviceBarrierLock::unlock(void)
+{
+    if (fd >= 0)
+        (void)::flock(fd, LOCK_UN);
+    mutex.unlock();
+}
+
+DeviceBarrierLock &
 cg_resident_mutex(int device)
 {
-    return g_resident_mutex[device & 15];
+    DeviceBarrierLock &l = g_resident_mutex[device & 15];
+    l.bind(device);
+    return l;
 }
 
 // Launches the solver (the caller holds cg_resident_mutex and has checked
@@ -1942,7 +1987,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         SMVS_HIP_CHECK(hipMemsetAsync(trace_dev, 0, trace_n * sizeof(long long),
             ctx->stream));
     }
-    std::lock_guard<std::mutex> guard(cg_resident_mutex(ctx->device));
+    std::lock_guard<DeviceBarrierLock> guard(cg_resident_mutex(ctx->device));
     int solve_tag = 0, num_tiles = 0;
     int const rc = resident_enqueue(ctx, max_iterations, error_tolerance,
         q_tolerance, fused, false, trace_dev, &solve_tag, &num_tiles);

@@ -388,7 +388,22 @@ int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
 bool cg_resident_applies(smvs_ctx *ctx, int max_iterations);
 // The launch-ahead Newton loop (update.hip): holds cg_resident_mutex for the
 // whole loop and enqueues fused solves without waiting for them.
-std::mutex &cg_resident_mutex(int device);
+// One barrier kernel per DEVICE at a time -- across the threads of this process
+// (a mutex) and across processes that share the GPU (an advisory lock on a
+// file named after the device's PCI bus id): two such kernels started together
+// could each hold half of the CUs and wait for the other half for ever.
+// BasicLockable, for std::lock_guard.
+class DeviceBarrierLock {
+public:
+    void lock(void);
+    void unlock(void);
+    void bind(int device);   // opens the lock file once
+private:
+    std::mutex mutex;
+    int fd = -1;
+    bool bound = false;
+};
+DeviceBarrierLock &cg_resident_mutex(int device);
 int cg_resident_enqueue(smvs_ctx *ctx, int max_iterations, double q_tolerance,
     bool test_give_up = false);
 size_t cg_resident_exchange_bytes(void);   // size of ctx->res_work

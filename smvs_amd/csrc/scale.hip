@@ -25,35 +25,54 @@ byte_to_float_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
         out[i] = (float)in[i] / 255.0f;
 }
 
-// one separable pass; axis 0: along x, axis 1: along y.  Accum<float>:
+// one separable pass; AXIS 0: along x, AXIS 1: along y.  Accum<float>:
 // v += value * weight; w += weight; result v / w, borders clamped.
+// One thread per element of a row (grid y = image row): no 64-bit index
+// arithmetic, the channel count is a compile-time constant, and the taps of a
+// wave are contiguous in memory in both passes.  Same operations in the same
+// order per element as the reference's loop (bit-exact against the oracle).
+template <int C, int AXIS>
 __global__ void __launch_bounds__(256)
 blur_pass_kernel(const float *__restrict__ in, float *__restrict__ out, int w,
-    int h, int c, int ks, const float *__restrict__ kernel, int axis)
+    int h, int ks, const float *__restrict__ kernel)
 {
 #pragma clang fp contract(off)
-    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t const n = (size_t)w * h * c;
-    if (i >= n)
+    int const e = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // element of the row
+    int const y = (int)blockIdx.y;
+    if (e >= w * C)
         return;
-    int const cc = (int)(i % c);
-    size_t const p = i / c;
-    int const x = (int)(p % w), y = (int)(p / w);
+    int const x = e / C, cc = e - x * C;
+    const float *row = in + (size_t)y * w * C;
     float av = 0.0f, aw = 0.0f;
     for (int k = -ks; k <= ks; ++k) {
         float const kw = kernel[k < 0 ? -k : k];
         float v;
-        if (axis == 0) {
+        if (AXIS == 0) {
             int const xx = min(max(x + k, 0), w - 1);
-            v = in[((size_t)y * w + xx) * c + cc];
+            v = row[xx * C + cc];
         } else {
             int const yy = min(max(y + k, 0), h - 1);
-            v = in[((size_t)yy * w + x) * c + cc];
+            v = in[(size_t)yy * w * C + e];
         }
         av += v * kw;
         aw += kw;
     }
-    out[i] = av / aw;
+    out[(size_t)y * w * C + e] = av / aw;
+}
+
+static void
+launch_blur_pass(hipStream_t stream, const float *in, float *out, int w, int h, int c,
+    int ks, const float *kernel, int axis)
+{
+    dim3 const grid((unsigned)((w * c + 255) / 256), (unsigned)h);
+    if (c == 1 && axis == 0)
+        hipLaunchKernelGGL((blur_pass_kernel<1, 0>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
+    else if (c == 1)
+        hipLaunchKernelGGL((blur_pass_kernel<1, 1>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
+    else if (axis == 0)
+        hipLaunchKernelGGL((blur_pass_kernel<3, 0>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
+    else
+        hipLaunchKernelGGL((blur_pass_kernel<3, 1>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
 }
 
 // luminance (0.21, 0.72, 0.07) + quadratic fit on the 3x3 window, double
@@ -227,13 +246,10 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
         }
         const float *src = vi.data;
         if (blur) {
-            unsigned const blocks = (unsigned)((n + 255) / 256);
             ScopedKernelTimer timer(ctx, SMVS_K_MISC);
-            hipLaunchKernelGGL(blur_pass_kernel, dim3(blocks), dim3(256), 0,
-                ctx->stream, vi.data, ctx->blur_tmp[0], vi.w, vi.h, vi.c, ks,
-                kernel_dev, 0);
-            hipLaunchKernelGGL(blur_pass_kernel, dim3(blocks), dim3(256), 0,
-                ctx->stream, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w, vi.h,
+            launch_blur_pass(ctx->stream, vi.data, ctx->blur_tmp[0], vi.w, vi.h, vi.c,
+                ks, kernel_dev, 0);
+            launch_blur_pass(ctx->stream, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w, vi.h,
                 vi.c, ks, kernel_dev, 1);
             src = ctx->blur_tmp[1];
         }

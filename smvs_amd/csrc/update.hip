@@ -932,7 +932,7 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     smvs_gn_loop_stats *stats, LoopState &L)
 {
     // barrier kernels of two loops must not interleave on one device
-    std::lock_guard<std::mutex> guard(cg_resident_mutex(ctx->device));
+    std::lock_guard<DeviceBarrierLock> guard(cg_resident_mutex(ctx->device));
     static_assert(I_STEP_ABORT == I_STOP + 1, "cleared together");
     int const test_mode = loop_test_mode();
     int rc;

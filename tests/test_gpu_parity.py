@@ -1012,3 +1012,55 @@ def test_fuzz_outliers_keep_the_control_flow(hip, oracle, case, solver):
         assert abs(stats["final_active_nodes"] - n_act) <= 0.05 * n_init
         assert ed <= 1e-3
     ctx.close()
+
+
+_SHARED_GPU_PROBE = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime, see conftest.py)
+sys.path.insert(0, sys.argv[1])
+import smvs_amd
+from smvs_amd import synth
+prob = synth.make_problem(512, 384, 4, 2, noise=0.01)
+ctx = smvs_amd.ViewContext(512, 384, 4)
+ctx.set_views(prob["views"])
+ctx.set_surface(prob["surf"])
+ctx.save_nodes()
+ctx.profile(True)
+stats = []
+for rep in range(30):
+    ctx.restore_nodes()
+    stats.append(ctx.run_loop(0.01, max_newton_steps=4))
+launches = {k: int(v[1]) for k, v in ctx.profile_get().items()}
+np.save(sys.argv[2], ctx.get_nodes())
+print(json.dumps(dict(steps=[int(s["newton_steps"]) for s in stats], launches=launches)))
+"""
+
+
+def test_two_processes_share_one_gpu_without_losing_the_resident_solver(hip, tmp_path):
+    """The resident PCG needs every workgroup of its launch co-resident; two
+    such kernels started together by two PROCESSES on one GPU could each hold
+    half of the CUs.  The per-device lock is therefore also a file lock
+    (DeviceBarrierLock): both processes keep the resident solver (no give-up
+    into the streaming kernels) and compute the same nodes as a process alone."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMVS_LOCK_DIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", _SHARED_GPU_PROBE, root,
+                               str(tmp_path / ("nodes%d.npy" % i))], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for i in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    replies = []
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        replies.append(json.loads(out.strip().splitlines()[-1]))
+    if replies[0]["launches"]["cg_resident"] == 0:
+        pytest.skip("the resident solver does not apply on this device")
+    for r in replies:
+        assert r["launches"]["cg_spmv"] == 0, r["launches"]      # never fell back
+        assert r["launches"]["cg_resident"] >= sum(r["steps"])
+        assert r["steps"] == replies[0]["steps"]
+    assert np.array_equal(np.load(str(tmp_path / "nodes0.npy")),
+                          np.load(str(tmp_path / "nodes1.npy")))
+    assert any(f.startswith("smvs_hip_barrier_") for f in os.listdir(str(tmp_path)))
