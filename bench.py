@@ -401,11 +401,12 @@ def secondary_workloads(args):
     views = {}
     for label, sgm_scale in (("no_sgm", None), ("sgm", 1)):
         host.optimize_views(inp, 2, regularization=REG, min_scale=SCALE, sgm_scale=sgm_scale)
-        for in_flight in (1, 3):
-            v = host.optimize_views(inp, 4 * in_flight, regularization=REG, min_scale=SCALE,
+        for in_flight in (1, 4, 8):
+            jobs = 4 if in_flight == 1 else 3 * in_flight
+            v = host.optimize_views(inp, jobs, regularization=REG, min_scale=SCALE,
                                     sgm_scale=sgm_scale, views_in_flight=in_flight)
             views["%s_in_flight_%d" % (label, in_flight)] = dict(
-                views_per_s=round(v["views_per_s"], 2), views=4 * in_flight,
+                views_per_s=round(v["views_per_s"], 2), views=jobs,
                 mean_task_ms=round(1e3 * float(np.mean(v["job_seconds"])), 1))
     out["views_per_s"] = dict(per_gpu=views,
         note="whole per-view tasks (9 x StereoView::create, [SGM front end,] optimize() of "

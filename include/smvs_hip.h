@@ -294,6 +294,19 @@ int smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
     const smvs_sgm_neighbor *neighbors, int n_neighbors, int num_steps,
     uint16_t penalty1, uint16_t penalty2, float *depth);
 
+/* The same with SGMStereo's constructor (sgm_stereo.cc:27-39) on the device as
+ * well: the images are the views' FULL-resolution u8 embeddings (interleaved,
+ * `channels` / neighbor_channels[k] = 1 or 3); StereoView::get_byte_image
+ * (desaturate<uint8_t>, stereo_view.cc:86-95) and `halvings` x
+ * mve::image::rescale_half_size run on the device.  w, h and the neighbours'
+ * width / height are the full-resolution sizes; the reprojections, the depth
+ * ranges and the output map refer to the SGM-scale sizes ((s + 1) >> 1 per
+ * halving). */
+int smvs_sgm_depth_for_view_raw(int device, const uint8_t *main_img, int w, int h,
+    int channels, const smvs_sgm_neighbor *neighbors, const int *neighbor_channels,
+    int n_neighbors, int halvings, int num_steps, uint16_t penalty1,
+    uint16_t penalty2, float *depth);
+
 /* DepthOptimizer::depthmap_bilateral_filter, depth_optimizer.cc:957-1004 */
 int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     const float *ci, int w, int h, int channels, float sigma,

@@ -135,7 +135,7 @@ int smvs_host_reconstruct_scene(const char *scene_dir,
     const smvs_host_recon_settings *settings, const int *view_ids, int n_view_ids,
     int *reconstructed_out, int *n_reconstructed, int *n_skipped, double *seconds);
 
-/* MVE scene I/O without a device: parses the scene (views/*.mve/meta.ini,
+/* MVE scene I/O without a device: parses the scene (views/<x>.mve/meta.ini,
  * synth_0.out) -> number of list entries, and per entry (caller-sized arrays of
  * at least max_views): present, flen, rot[9], trans[3], and the size of the
  * image embedding (0 x 0 when missing); *n_features of the bundle (-1: none).

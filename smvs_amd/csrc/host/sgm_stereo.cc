@@ -83,36 +83,40 @@ SGMStereo::fill_depth_range_for_view(Bundle::ConstPtr bundle,
 
 namespace {
 
-// One (main, neighbour) pair as the device entry wants it: SGM-scale images
-// (SGMStereo's constructor), both reprojections and both depth ranges
-// (lib/sgm_stereo.cc:46-62).
+// One (main, neighbour) pair as the device entry wants it: the neighbour's raw
+// bytes (the device desaturates and halves them: SGMStereo's constructor,
+// lib/sgm_stereo.cc:27-39), both reprojections at the SGM-scale sizes and both
+// depth ranges (lib/sgm_stereo.cc:46-62).
 struct PairInputs {
-    ByteImage::ConstPtr main_image, neighbor_image;
+    ByteImage::ConstPtr neighbor_bytes;
+    int channels;
     smvs_sgm_neighbor dev;
 };
 
-ByteImage::ConstPtr
-sgm_scale_image(StereoView::Ptr view, int scale)
+void
+sgm_scale_size(int scale, int* w, int* h)
 {
-    ByteImage::ConstPtr img = view->get_byte_image();
-    for (int i = 0; i < scale; ++i)
-        img = imgtools::rescale_half_size(img);
-    return img;
+    for (int i = 0; i < scale; ++i) {
+        *w = (*w + 1) >> 1;
+        *h = (*h + 1) >> 1;
+    }
 }
 
 void
 prepare_pair(SGMStereo::Options const& o, StereoView::Ptr main_view,
-    StereoView::Ptr neighbor, Bundle::ConstPtr bundle,
-    ByteImage::ConstPtr main_image, PairInputs* out)
+    StereoView::Ptr neighbor, Bundle::ConstPtr bundle, PairInputs* out)
 {
-    out->main_image = main_image;
-    out->neighbor_image = sgm_scale_image(neighbor, o.scale);
+    out->neighbor_bytes = neighbor->get_raw_bytes();
+    out->channels = out->neighbor_bytes->channels();
     smvs_sgm_neighbor& d = out->dev;
-    d.image = out->neighbor_image->begin();
-    d.width = out->neighbor_image->width();
-    d.height = out->neighbor_image->height();
-    float const mw = (float)main_image->width(), mh = (float)main_image->height();
-    float const nw = (float)d.width, nh = (float)d.height;
+    d.image = out->neighbor_bytes->begin();
+    d.width = out->neighbor_bytes->width();      // full resolution
+    d.height = out->neighbor_bytes->height();
+    int mwi = main_view->get_width(), mhi = main_view->get_height();
+    int nwi = d.width, nhi = d.height;
+    sgm_scale_size(o.scale, &mwi, &mhi);
+    sgm_scale_size(o.scale, &nwi, &nhi);
+    float const mw = (float)mwi, mh = (float)mhi, nw = (float)nwi, nh = (float)nhi;
     main_view->get_camera().fill_reprojection(neighbor->get_camera(), mw, mh,
         nw, nh, d.M_fwd, d.t_fwd);
     neighbor->get_camera().fill_reprojection(main_view->get_camera(), nw, nh,
@@ -126,19 +130,26 @@ prepare_pair(SGMStereo::Options const& o, StereoView::Ptr main_view,
 }
 
 FloatImage::Ptr
-run_pairs(SGMStereo::Options const& o, ByteImage::ConstPtr main_image,
+run_pairs(SGMStereo::Options const& o, StereoView::Ptr main_view,
     std::vector<PairInputs> const& pairs)
 {
     std::vector<smvs_sgm_neighbor> dev;
-    for (auto const& p : pairs)
+    std::vector<int> channels;
+    for (auto const& p : pairs) {
         dev.push_back(p.dev);
-    FloatImage::Ptr depth = FloatImage::create(main_image->width(),
-        main_image->height(), 1);
-    int const rc = smvs_sgm_depth_for_view(o.device, main_image->begin(),
-        main_image->width(), main_image->height(), dev.data(), (int)dev.size(),
-        o.num_steps, o.penalty1, o.penalty2, depth->begin());
+        channels.push_back(p.channels);
+    }
+    ByteImage::ConstPtr main_bytes = main_view->get_raw_bytes();
+    int w = main_bytes->width(), h = main_bytes->height();
+    sgm_scale_size(o.scale, &w, &h);
+    FloatImage::Ptr depth = FloatImage::create(w, h, 1);
+    // desaturate + half-size on the device, then 4 x run_sgm, L/R check, merge
+    int const rc = smvs_sgm_depth_for_view_raw(o.device, main_bytes->begin(),
+        main_bytes->width(), main_bytes->height(), main_bytes->channels(), dev.data(),
+        channels.data(), (int)dev.size(), o.scale, o.num_steps, o.penalty1, o.penalty2,
+        depth->begin());
     if (rc != SMVS_OK)
-        throw std::runtime_error(std::string("smvs_sgm_depth_for_view: ")
+        throw std::runtime_error(std::string("smvs_sgm_depth_for_view_raw: ")
             + smvs_last_error());
     return depth;
 }
@@ -151,10 +162,9 @@ SGMStereo::reconstruct(Options sgm_opts, StereoView::Ptr main_view,
 {
     // lib/sgm_stereo.cc:46-96: both run_sgm calls and the left / right
     // consistency check on the device
-    ByteImage::ConstPtr main_image = sgm_scale_image(main_view, sgm_opts.scale);
     std::vector<PairInputs> pairs(1);
-    prepare_pair(sgm_opts, main_view, neighbor, bundle, main_image, &pairs[0]);
-    return run_pairs(sgm_opts, main_image, pairs);
+    prepare_pair(sgm_opts, main_view, neighbor, bundle, &pairs[0]);
+    return run_pairs(sgm_opts, main_view, pairs);
 }
 
 FloatImage::Ptr
@@ -166,11 +176,10 @@ reconstruct_sgm_depth_for_view(SGMStereo::Options opts,
     // neighbours and the merge of the two checked maps, in one device call
     if (neighbors.empty())
         throw std::invalid_argument("reconstruct_sgm_depth_for_view: no neighbour");
-    ByteImage::ConstPtr main_image = sgm_scale_image(main_view, opts.scale);
     std::vector<PairInputs> pairs(std::min<std::size_t>(neighbors.size(), 2));
     for (std::size_t k = 0; k < pairs.size(); ++k)
-        prepare_pair(opts, main_view, neighbors[k], bundle, main_image, &pairs[k]);
-    FloatImage::Ptr d1 = run_pairs(opts, main_image, pairs);
+        prepare_pair(opts, main_view, neighbors[k], bundle, &pairs[k]);
+    FloatImage::Ptr d1 = run_pairs(opts, main_view, pairs);
     main_view->write_depth_to_view(d1, "smvs-sgm");
     return d1;
 }

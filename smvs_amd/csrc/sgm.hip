@@ -718,6 +718,7 @@ struct SgmKernelTimer {
 enum {
     WS_DEPTHS = 0, WS_CENSUS, WS_WARPED, WS_COST, WS_SGM, WS_ARGMIN,   // one run_sgm
     WS_MAIN, WS_NBR0, WS_NBR1, WS_FWD0, WS_FWD1, WS_BWD, WS_COST16,   // a view's front end
+    WS_RAW, WS_RAW0, WS_RAW1,                                         // raw u8 images + scratch
     WS_BIL_DM, WS_BIL_CI, WS_BIL_OUT                                  // bilateral upsample
 };
 
@@ -937,74 +938,169 @@ smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
     return SMVS_OK;
 }
 
-extern "C" int
-smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
-    const smvs_sgm_neighbor *neighbors, int n_neighbors, int num_steps,
+// StereoView::get_byte_image (desaturate<uint8_t>, stereo_view.cc:86-95
+// [MVE-unverified]: 0.21 r + 0.72 g + 0.07 b + 0.5, truncated) on the device
+__global__ void __launch_bounds__(256)
+sgm_desaturate_kernel(const uint8_t *__restrict__ in, size_t npix, int channels,
+    uint8_t *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    size_t const p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix)
+        return;
+    if (channels < 3) {
+        out[p] = in[p * channels];
+        return;
+    }
+    float const v = (float)in[p * channels] * 0.21f + (float)in[p * channels + 1] * 0.72f
+        + (float)in[p * channels + 2] * 0.07f + 0.5f;
+    out[p] = (uint8_t)v;
+}
+
+// mve::image::rescale_half_size<uint8_t> (sgm_stereo.cc:31-39 [MVE-unverified]):
+// mean of the 2 x 2 block (odd sizes repeat the last row / column), + 0.5, truncated
+__global__ void __launch_bounds__(256)
+sgm_half_size_kernel(const uint8_t *__restrict__ in, int w, int h,
+    uint8_t *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    int const ow = (w + 1) >> 1, oh = (h + 1) >> 1;
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= ow || y >= oh)
+        return;
+    int const x0 = 2 * x, x1 = min(2 * x + 1, w - 1);
+    int const y0 = 2 * y, y1 = min(2 * y + 1, h - 1);
+    float const v = (float)in[(size_t)y0 * w + x0] * 0.25f
+        + (float)in[(size_t)y0 * w + x1] * 0.25f
+        + (float)in[(size_t)y1 * w + x0] * 0.25f
+        + (float)in[(size_t)y1 * w + x1] * 0.25f;
+    out[(size_t)y * ow + x] = (uint8_t)(v + 0.5f);
+}
+
+// One view's SGM input image on the device: upload (raw: interleaved u8 of
+// `channels`; otherwise already at SGM scale, one channel), desaturate and
+// `halvings` half-size steps.  *out (slot `slot_out`) receives the image,
+// *ow / *oh its size.
+static int
+sgm_prepare_image(Workspace &ws, const uint8_t *host, int w, int h, int channels,
+    int halvings, int slot_out, int slot_tmp, uint8_t **out, int *ow, int *oh)
+{
+    int rc;
+    size_t const npix = (size_t)w * h;
+    uint8_t *a = nullptr, *b = nullptr;
+    if (channels == 1 && halvings == 0) {
+        if ((rc = ws.ensure(slot_out, npix, &a)) || (rc = ws.upload(a, host, npix)))
+            return rc;
+        *out = a;
+        *ow = w;
+        *oh = h;
+        return SMVS_OK;
+    }
+    // raw bytes into the scratch slot, results ping-pong between the two
+    if ((rc = ws.ensure(slot_tmp, npix * (size_t)channels + npix, &b))
+        || (rc = ws.ensure(slot_out, npix, &a))
+        || (rc = ws.upload(b, host, npix * (size_t)channels)))
+        return rc;
+    uint8_t *grey = b + npix * (size_t)channels;   // behind the raw bytes
+    hipLaunchKernelGGL(sgm_desaturate_kernel, dim3((unsigned)((npix + 255) / 256)),
+        dim3(256), 0, ws.stream, b, npix, channels, halvings % 2 == 0 ? a : grey);
+    uint8_t *cur = halvings % 2 == 0 ? a : grey;
+    uint8_t *other = halvings % 2 == 0 ? grey : a;
+    int cw = w, ch = h;
+    for (int i = 0; i < halvings; ++i) {
+        int const nw = (cw + 1) >> 1, nh = (ch + 1) >> 1;
+        hipLaunchKernelGGL(sgm_half_size_kernel, dim3((nw + 255) / 256, nh), dim3(256), 0,
+            ws.stream, cur, cw, ch, other);
+        uint8_t *t = cur; cur = other; other = t;
+        cw = nw;
+        ch = nh;
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    // (an even number of swaps ends in `a` when it started there, an odd one
+    // when it started in `grey`: cur == a by construction)
+    *out = cur;
+    *ow = cw;
+    *oh = ch;
+    return SMVS_OK;
+}
+
+// reconstruct_sgm_depth_for_view on prepared device images
+static int
+sgm_depth_for_view_impl(int device, const uint8_t *main_img, int w, int h,
+    int main_channels, const smvs_sgm_neighbor *neighbors,
+    const int *neighbor_channels, int n_neighbors, int halvings, int num_steps,
     uint16_t penalty1, uint16_t penalty2, float *depth)
 {
     SMVS_REQUIRE(main_img && neighbors && depth, "null argument");
     SMVS_REQUIRE(n_neighbors >= 1 && n_neighbors <= 2,
         "one or two neighbours (app/smvsrecon.cc:360-365)");
-    SMVS_REQUIRE(w > 10 && h > 8, "image too small");
+    SMVS_REQUIRE(halvings >= 0 && halvings <= 8, "halvings out of range");
+    SMVS_REQUIRE((w >> halvings) > 10 && (h >> halvings) > 8, "image too small");
     for (int k = 0; k < n_neighbors; ++k)
-        SMVS_REQUIRE(neighbors[k].image && neighbors[k].width > 10
-            && neighbors[k].height > 8, "bad neighbour image");
+        SMVS_REQUIRE(neighbors[k].image && (neighbors[k].width >> halvings) > 10
+            && (neighbors[k].height >> halvings) > 8, "bad neighbour image");
     int rc;
     WorkspaceLease lease(device);
     if (lease.w == nullptr)
         return SMVS_ERR_HIP;
     Workspace &ws = *lease.w;
     hipStream_t const stream = ws.stream;
-    size_t const npix = (size_t)w * h;
     SgmProfile prof;
     SgmWorkspace B(&ws);
     B.prof = &prof;
+    // the SGM-scale images (every buffer before the first SGM launch: growing
+    // one waits for the stream)
     uint8_t *d_main = nullptr, *d_nbr[2] = { nullptr, nullptr };
+    int mw = 0, mh = 0, nw[2] = { 0, 0 }, nh[2] = { 0, 0 };
+    if ((rc = sgm_prepare_image(ws, main_img, w, h, main_channels, halvings, WS_MAIN,
+             WS_RAW, &d_main, &mw, &mh)) != SMVS_OK)
+        return rc;
+    for (int k = 0; k < n_neighbors; ++k)
+        if ((rc = sgm_prepare_image(ws, neighbors[k].image, neighbors[k].width,
+                 neighbors[k].height, neighbor_channels != nullptr ? neighbor_channels[k] : 1,
+                 halvings, k == 0 ? WS_NBR0 : WS_NBR1, k == 0 ? WS_RAW0 : WS_RAW1,
+                 &d_nbr[k], &nw[k], &nh[k])) != SMVS_OK)
+            return rc;
+    size_t const npix = (size_t)mw * mh;
     float *d_fwd[2] = { nullptr, nullptr }, *d_bwd = nullptr;
-    // (every buffer before the first launch: growing one waits for the stream)
     size_t max_nnpix = 0;
     for (int k = 0; k < n_neighbors; ++k) {
-        size_t const nnpix = (size_t)neighbors[k].width * neighbors[k].height;
+        size_t const nnpix = (size_t)nw[k] * nh[k];
         max_nnpix = nnpix > max_nnpix ? nnpix : max_nnpix;
-        if ((rc = ws.ensure(k == 0 ? WS_NBR0 : WS_NBR1, nnpix, &d_nbr[k]))
-            || (rc = ws.ensure(k == 0 ? WS_FWD0 : WS_FWD1, npix, &d_fwd[k])))
+        if ((rc = ws.ensure(k == 0 ? WS_FWD0 : WS_FWD1, npix, &d_fwd[k])))
             return rc;
     }
-    if ((rc = ws.ensure(WS_MAIN, npix, &d_main))
-        || (rc = ws.ensure(WS_BWD, max_nnpix, &d_bwd))
-        || (rc = B.ensure(npix > max_nnpix ? npix : max_nnpix, num_steps))
-        || (rc = ws.upload(d_main, main_img, npix)))
+    if ((rc = ws.ensure(WS_BWD, max_nnpix, &d_bwd))
+        || (rc = B.ensure(npix > max_nnpix ? npix : max_nnpix, num_steps)))
         return rc;
     for (int k = 0; k < n_neighbors; ++k) {
         smvs_sgm_neighbor const &N = neighbors[k];
-        size_t const nnpix = (size_t)N.width * N.height;
-        if ((rc = ws.upload(d_nbr[k], N.image, nnpix)))
-            return rc;
         // SGMStereo::reconstruct, sgm_stereo.cc:46-62: main -> neighbour,
         // then neighbour -> main with the neighbour's own depth range
-        if ((rc = sgm_run_device(B, d_main, w, h, d_nbr[k], N.width, N.height,
+        if ((rc = sgm_run_device(B, d_main, mw, mh, d_nbr[k], nw[k], nh[k],
                 N.M_fwd, N.t_fwd, N.range_main[0], N.range_main[1], num_steps,
                 penalty1, penalty2, d_fwd[k])) != SMVS_OK)
             return rc;
-        if ((rc = sgm_run_device(B, d_nbr[k], N.width, N.height, d_main, w, h,
+        if ((rc = sgm_run_device(B, d_nbr[k], nw[k], nh[k], d_main, mw, mh,
                 N.M_bwd, N.t_bwd, N.range_neighbor[0], N.range_neighbor[1],
                 num_steps, penalty1, penalty2, d_bwd)) != SMVS_OK)
             return rc;
         LrArgs L;
         L.d_main = d_fwd[k];
         L.d_neig = d_bwd;
-        L.w = w;
-        L.h = h;
-        L.nw = N.width;
-        L.nh = N.height;
-        L.cut = (int)(0.03 * (double)(N.width > N.height ? N.width : N.height));
+        L.w = mw;
+        L.h = mh;
+        L.nw = nw[k];
+        L.nh = nh[k];
+        L.cut = (int)(0.03 * (double)(nw[k] > nh[k] ? nw[k] : nh[k]));
         for (int i = 0; i < 9; ++i)
             L.M[i] = (double)N.M_fwd[i];
         for (int i = 0; i < 3; ++i)
             L.t[i] = (double)N.t_fwd[i];
         {
             SgmKernelTimer timer(&prof, stream, SMVS_SGM_K_LR_CHECK);
-            hipLaunchKernelGGL(sgm_lr_check_kernel, dim3((w + 255) / 256, h),
+            hipLaunchKernelGGL(sgm_lr_check_kernel, dim3((mw + 255) / 256, mh),
                 dim3(256), 0, stream, L);
         }
         SMVS_HIP_CHECK(hipGetLastError());
@@ -1016,6 +1112,30 @@ smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
         SMVS_HIP_CHECK(hipGetLastError());
     }
     return ws.download(depth, d_fwd[0], sizeof(float) * npix);
+}
+
+extern "C" int
+smvs_sgm_depth_for_view(int device, const uint8_t *main_img, int w, int h,
+    const smvs_sgm_neighbor *neighbors, int n_neighbors, int num_steps,
+    uint16_t penalty1, uint16_t penalty2, float *depth)
+{
+    return sgm_depth_for_view_impl(device, main_img, w, h, 1, neighbors, nullptr,
+        n_neighbors, 0, num_steps, penalty1, penalty2, depth);
+}
+
+extern "C" int
+smvs_sgm_depth_for_view_raw(int device, const uint8_t *main_img, int w, int h,
+    int channels, const smvs_sgm_neighbor *neighbors, const int *neighbor_channels,
+    int n_neighbors, int halvings, int num_steps, uint16_t penalty1,
+    uint16_t penalty2, float *depth)
+{
+    SMVS_REQUIRE(channels == 1 || channels == 3, "1 or 3 channels");
+    SMVS_REQUIRE(neighbor_channels != nullptr, "null argument");
+    for (int k = 0; k < n_neighbors && k < 2; ++k)
+        SMVS_REQUIRE(neighbor_channels[k] == 1 || neighbor_channels[k] == 3,
+            "1 or 3 channels");
+    return sgm_depth_for_view_impl(device, main_img, w, h, channels, neighbors,
+        neighbor_channels, n_neighbors, halvings, num_steps, penalty1, penalty2, depth);
 }
 
 extern "C" int

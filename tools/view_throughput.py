@@ -27,8 +27,8 @@ print("inputs rendered in %.1f s" % (time.perf_counter() - t), flush=True)
 kw = dict(min_scale=2, use_shading=shading, sgm_scale=1 if use_sgm else None)
 host.optimize_views(inp, 2, views_in_flight=1, **kw)   # warm-up: library, pools
 out = {}
-for in_flight in (1, 2, 3, 4):
-    jobs = 4 * in_flight
+for in_flight in (1, 2, 4, 6, 8):
+    jobs = 3 * in_flight if in_flight > 4 else 4 * in_flight
     r = host.optimize_views(inp, jobs, views_in_flight=in_flight, **kw)
     out[in_flight] = dict(views=jobs, seconds=round(r["total_seconds"], 3),
                           views_per_s=round(r["views_per_s"], 2),
