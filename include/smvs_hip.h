@@ -312,6 +312,17 @@ int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     const float *ci, int w, int h, int channels, float sigma,
     int kernel_size, float *out);
 
+/* The same filter inside a view's context (DepthOptimizer::create_initial_surface,
+ * depth_optimizer.cc:35-51: init = depthmap_bilateral_filter(sgm_depth,
+ * main_view->get_image())): guided by the main image smvs_ctx_upload_image
+ * left on the device (SMVS_ERR_STATE without one), result written to
+ * out[W*H] (may be NULL) AND kept in the context as the SGM depth map the
+ * visibility tests of smvs_topology_subviews compare with -- the reference
+ * hands the same filtered map to both (:41-45, :463-466).  dm == NULL forgets
+ * the resident map. */
+int smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
+    float sigma, int kernel_size, float *out);
+
 /* ------------------------------------------------------------------ */
 /* topology tests between Newton batches              */
 /* ------------------------------------------------------------------ */
@@ -319,8 +330,9 @@ int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
 /* The per-(patch, neighbour) part of DepthOptimizer::create_subview_surfaces,
  * depth_optimizer.cc:433-590, for the surface of smvs_ctx_set_surface and the
  * images of smvs_ctx_upload_image: z-buffer of the surface depth map (and of
- * sgm_depth[W*H], may be NULL; the reference splats it when use_sgm is set,
- * :463-466) in every neighbour, then border / occlusion test (:505-530),
+ * sgm_depth[W*H]; NULL: the map smvs_ctx_sgm_init_depth left in the context,
+ * if any, else none; the reference splats it when use_sgm is set, :463-466)
+ * in every neighbour, then border / occlusion test (:505-530),
  * warp anisotropy <= 8 (:532-575) and, if use_ncc (the reference's !use_sgm,
  * :577-580), ncc_for_patch >= 0 (:792-912).
  * patch_vis_out[num_patches]: bit j = patch visible in neighbour j; 0 for

@@ -104,7 +104,6 @@ struct smvs_ctx {
     // which views hold an uploaded image / which neighbours hold planes: the
     // buffers themselves outlive a pooled context's previous use (ctx.hip)
     uint32_t image_ok = 0, planes_ok = 0;
-    float *blur_kernel = nullptr;   // Gaussian taps of smvs_ctx_set_scale (64 floats)
     bool has_cameras = false, has_surface = false, has_system = false;
     bool has_shading = false;
     bool update_prepared = false;   // active_next / counters cleared for the next update
@@ -190,6 +189,9 @@ struct smvs_ctx {
     size_t topo_zbuf_cap[SMVS_MAX_SUBS] = { 0 };
     float *topo_sgm = nullptr;
     size_t topo_sgm_cap = 0;
+    bool sgm_resident = false;   // topo_sgm holds smvs_ctx_sgm_init_depth's result
+    float *sgm_lowres = nullptr; // its input, SGM resolution
+    size_t sgm_lowres_cap = 0;
     smvs_topo::NccSample *topo_ncc = nullptr;
     int topo_ncc_off[33] = { 0 };
     int topo_ncc_ps = 0;

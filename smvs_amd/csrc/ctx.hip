@@ -174,6 +174,7 @@ void
 ctx_reset_for_reuse(smvs_ctx *ctx)
 {
     ctx->image_ok = ctx->planes_ok = 0;
+    ctx->sgm_resident = false;
     ctx->has_cameras = ctx->has_surface = ctx->has_system = false;
     ctx->has_shading = false;
     ctx->update_prepared = false;
@@ -317,8 +318,7 @@ ctx_free(smvs_ctx *ctx)
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
         ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list,
-        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage,
-        ctx->blur_kernel };
+        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -330,6 +330,8 @@ ctx_free(smvs_ctx *ctx)
             (void)hipFree(ctx->topo_zbuf[i]);
     if (ctx->topo_sgm)
         (void)hipFree(ctx->topo_sgm);
+    if (ctx->sgm_lowres)
+        (void)hipFree(ctx->sgm_lowres);
     if (ctx->topo_ncc)
         (void)hipFree(ctx->topo_ncc);
     if (ctx->topo_mse)

@@ -135,9 +135,8 @@ sym6(int a, int b)
                   : b * 6 - (b * (b - 1)) / 2 + (a - b);
 }
 
-// Derivative of the six normal-divergence entries with respect to the six
-// pixel-space surface quantities, evaluated along `p`
-// (surface_derivative.cc:128-188 with the dn row replaced by p).
+// Per-pixel quantities of the normal divergence (surface_derivative.cc:69-107)
+// shared by its value and its derivatives.
 struct DivState {
     double x, y, f, f2inv;
     double w, wx, wy, wxy, wxx, wyy;
@@ -145,41 +144,112 @@ struct DivState {
     double inv_n, inv_t, inv_t2, inv_t2f, inv_f;
 };
 
-__device__ __forceinline__ void
-div_along(DivState const &s, double const p[6], double out[6])
+// The 6 x 6 Jacobian E[v][a] = d div[v] / d (w, w_x, w_y, w_xy, w_xx, w_yy):
+// surface_derivative.cc:128-188 with the basis-table row replaced by the six
+// unit directions, each written out.  (A generic directional derivative
+// called with unit vectors costs 1.8x the instructions: strict IEEE
+// arithmetic cannot drop a product with a literal zero, 0 * x being NaN for
+// an infinite x.)  The x-divergences (v = 0, 1, 2) do not
+// depend on w_yy, the y-divergences (v = 3, 4, 5) not on w_xx.
+__device__ __forceinline__ constexpr bool
+div_depends_on(int v, int a)
 {
-    double const wp = p[0], dxp = p[1], dyp = p[2], dxyp = p[3],
-        dxxp = p[4], dyyp = p[5];
-    double const ap = wp + s.x * dxp + s.y * dyp;
-    double const axp = 2.0 * dxp + s.x * dxxp + s.y * dxyp;
-    double const ayp = 2.0 * dyp + s.y * dyyp + s.x * dxyp;
-    double const t2p = s.wx * dxp + s.wy * dyp + s.f2inv * s.a * ap;
-    double const np = t2p * s.inv_n;
-    double const bp = (dxp * s.wxx + s.wx * dxxp) + (dyp * s.wxy + s.wy * dxyp)
-        + s.f2inv * (ap * s.ax + s.a * axp);
-    double const cp = (dxp * s.wxy + s.wx * dxyp) + (dyp * s.wyy + s.wy * dyyp)
-        + s.f2inv * (ap * s.ay + s.a * ayp);
-    double const nxp = (bp * s.n - s.b * np) * s.inv_t;
-    double const nyp = (cp * s.n - s.c * np) * s.inv_t;
-    double const two_t2p = 2.0 * t2p;
-    double const xxp = ((dxxp * s.n + s.wxx * np - dxp * s.nx - s.wx * nxp) * s.t
-        - (s.wxx * s.n - s.wx * s.nx) * two_t2p) * s.inv_t2;
-    double const yyp = ((dyyp * s.n + s.wyy * np - dyp * s.ny - s.wy * nyp) * s.t
-        - (s.wyy * s.n - s.wy * s.ny) * two_t2p) * s.inv_t2;
-    double const xyp = ((dxyp * s.n + s.wxy * np - dxp * s.ny - s.wx * nyp) * s.t
-        - (s.wxy * s.n - s.wx * s.ny) * two_t2p) * s.inv_t2;
-    double const yxp = ((dxyp * s.n + s.wxy * np - dyp * s.nx - s.wy * nxp) * s.t
-        - (s.wxy * s.n - s.wy * s.nx) * two_t2p) * s.inv_t2;
-    double const zxp = ((axp * s.n + s.ax * np - ap * s.nx - s.a * nxp) * s.t
-        - (s.ax * s.n - s.a * s.nx) * two_t2p) * s.inv_t2f;
-    double const zyp = ((ayp * s.n + s.ay * np - ap * s.ny - s.a * nyp) * s.t
-        - (s.ay * s.n - s.a * s.ny) * two_t2p) * s.inv_t2f;
-    out[0] = xxp;
-    out[1] = -yxp;
-    out[2] = zxp;
-    out[3] = xyp;
-    out[4] = -yyp;
-    out[5] = zyp;
+    return v < 3 ? a != 5 : a != 4;
+}
+
+__device__ __forceinline__ void
+div_jacobian(DivState const &s, double E[6][6])
+{
+    double const n = s.n, t = s.t, F = s.f2inv;
+    double const it = s.inv_t, it2 = s.inv_t2, it2f = s.inv_t2f;
+    // the numerators of the six divergence entries
+    double const Kxx = s.wxx * n - s.wx * s.nx, Kyx = s.wxy * n - s.wy * s.nx;
+    double const Kzx = s.ax * n - s.a * s.nx, Kxy = s.wxy * n - s.wx * s.ny;
+    double const Kyy = s.wyy * n - s.wy * s.ny, Kzy = s.ay * n - s.a * s.ny;
+    double const Fa = F * s.a;
+
+    // ---- along w: ap = 1 ----
+    {
+        double const t2p = Fa;
+        double const np = t2p * s.inv_n;
+        double const bp = F * s.ax, cp = F * s.ay;
+        double const nxp = (bp * n - s.b * np) * it;
+        double const nyp = (cp * n - s.c * np) * it;
+        double const tt = 2.0 * t2p;
+        E[0][0] = ((s.wxx * np - s.wx * nxp) * t - Kxx * tt) * it2;
+        E[1][0] = -(((s.wxy * np - s.wy * nxp) * t - Kyx * tt) * it2);
+        E[2][0] = ((s.ax * np - s.nx - s.a * nxp) * t - Kzx * tt) * it2f;
+        E[3][0] = ((s.wxy * np - s.wx * nyp) * t - Kxy * tt) * it2;
+        E[4][0] = -(((s.wyy * np - s.wy * nyp) * t - Kyy * tt) * it2);
+        E[5][0] = ((s.ay * np - s.ny - s.a * nyp) * t - Kzy * tt) * it2f;
+    }
+    // ---- along w_x: ap = x, axp = 2 ----
+    {
+        double const t2p = s.wx + Fa * s.x;
+        double const np = t2p * s.inv_n;
+        double const bp = s.wxx + F * (s.x * s.ax + s.a * 2.0);
+        double const cp = s.wxy + F * (s.x * s.ay);
+        double const nxp = (bp * n - s.b * np) * it;
+        double const nyp = (cp * n - s.c * np) * it;
+        double const tt = 2.0 * t2p;
+        E[0][1] = ((s.wxx * np - s.nx - s.wx * nxp) * t - Kxx * tt) * it2;
+        E[1][1] = -(((s.wxy * np - s.wy * nxp) * t - Kyx * tt) * it2);
+        E[2][1] = ((2.0 * n + s.ax * np - s.x * s.nx - s.a * nxp) * t - Kzx * tt) * it2f;
+        E[3][1] = ((s.wxy * np - s.ny - s.wx * nyp) * t - Kxy * tt) * it2;
+        E[4][1] = -(((s.wyy * np - s.wy * nyp) * t - Kyy * tt) * it2);
+        E[5][1] = ((s.ay * np - s.x * s.ny - s.a * nyp) * t - Kzy * tt) * it2f;
+    }
+    // ---- along w_y: ap = y, ayp = 2 ----
+    {
+        double const t2p = s.wy + Fa * s.y;
+        double const np = t2p * s.inv_n;
+        double const bp = s.wxy + F * (s.y * s.ax);
+        double const cp = s.wyy + F * (s.y * s.ay + s.a * 2.0);
+        double const nxp = (bp * n - s.b * np) * it;
+        double const nyp = (cp * n - s.c * np) * it;
+        double const tt = 2.0 * t2p;
+        E[0][2] = ((s.wxx * np - s.wx * nxp) * t - Kxx * tt) * it2;
+        E[1][2] = -(((s.wxy * np - s.nx - s.wy * nxp) * t - Kyx * tt) * it2);
+        E[2][2] = ((s.ax * np - s.y * s.nx - s.a * nxp) * t - Kzx * tt) * it2f;
+        E[3][2] = ((s.wxy * np - s.wx * nyp) * t - Kxy * tt) * it2;
+        E[4][2] = -(((s.wyy * np - s.ny - s.wy * nyp) * t - Kyy * tt) * it2);
+        E[5][2] = ((2.0 * n + s.ay * np - s.y * s.ny - s.a * nyp) * t - Kzy * tt) * it2f;
+    }
+    // ---- along w_xy: axp = y, ayp = x; the length of the normal does not move ----
+    {
+        double const bp = s.wy + Fa * s.y;
+        double const cp = s.wx + Fa * s.x;
+        double const nxp = (bp * n) * it;
+        double const nyp = (cp * n) * it;
+        E[0][3] = ((-s.wx * nxp) * t) * it2;
+        E[1][3] = -(((n - s.wy * nxp) * t) * it2);
+        E[2][3] = ((s.y * n - s.a * nxp) * t) * it2f;
+        E[3][3] = ((n - s.wx * nyp) * t) * it2;
+        E[4][3] = -(((-s.wy * nyp) * t) * it2);
+        E[5][3] = ((s.x * n - s.a * nyp) * t) * it2f;
+    }
+    // ---- along w_xx: axp = x ----
+    {
+        double const bp = s.wx + Fa * s.x;
+        double const nxp = (bp * n) * it;
+        E[0][4] = ((n - s.wx * nxp) * t) * it2;
+        E[1][4] = -(((-s.wy * nxp) * t) * it2);
+        E[2][4] = ((s.x * n - s.a * nxp) * t) * it2f;
+        E[3][4] = 0.0;
+        E[4][4] = 0.0;
+        E[5][4] = 0.0;
+    }
+    // ---- along w_yy: ayp = y ----
+    {
+        double const cp = s.wy + Fa * s.y;
+        double const nyp = (cp * n) * it;
+        E[0][5] = 0.0;
+        E[1][5] = 0.0;
+        E[2][5] = 0.0;
+        E[3][5] = ((-s.wx * nyp) * t) * it2;
+        E[4][5] = -(((n - s.wy * nyp) * t) * it2);
+        E[5][5] = ((s.y * n - s.a * nyp) * t) * it2f;
+    }
 }
 
 // surface_derivative.cc:42-63 along p (only w, w_x, w_y matter)
@@ -535,16 +605,7 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
 
     // E[v][a] = d div[v] / d (surface quantity a)
     double E[6][6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        double unit[6] = { 0, 0, 0, 0, 0, 0 };
-        unit[a] = 1.0;
-        double out[6];
-        div_along(s, unit, out);
-#pragma unroll
-        for (int v = 0; v < 6; ++v)
-            E[v][a] = out[v];
-    }
+    div_jacobian(s, E);
 
     bool const lit = A.use_lighting != 0;
     if (!lit || A.light_reg > 0.0) {
@@ -557,11 +618,14 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
                 * fast_rcp(R_FACTOR + fabs(div[v]));
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
+                if (!div_depends_on(v, a))
+                    continue;
                 double const wa = wgt * E[v][a];
                 v6[a] += wa * div[v];
 #pragma unroll
                 for (int b = a; b < 6; ++b)
-                    M6[sym6(a, b)] += wa * E[v][b];
+                    if (div_depends_on(v, b))
+                        M6[sym6(a, b)] += wa * E[v][b];
             }
         }
     }

@@ -219,7 +219,7 @@ FloatImage::Ptr
 DepthOptimizer::depthmap_bilateral_filter(FloatImage::ConstPtr dm,
     FloatImage::ConstPtr ci, float sigma, int kernel_size)
 {
-    FloatImage::Ptr out = FloatImage::create(ci->width(), ci->height(), 1);
+    FloatImage::Ptr out = FloatImage::create_for_overwrite(ci->width(), ci->height(), 1);
     check(smvs_bilateral_upsample(opts.device, dm->begin(), dm->width(),
         dm->height(), ci->begin(), ci->width(), ci->height(), ci->channels(),
         sigma, kernel_size, out->begin()), "smvs_bilateral_upsample");
@@ -236,7 +236,15 @@ DepthOptimizer::create_initial_surface(void)
         FloatImage::Ptr init = main_view->get_sgm_depth();
         if (init == nullptr)
             throw std::invalid_argument("use_sgm without an smvs-sgm embedding");
-        init = depthmap_bilateral_filter(init, main_view->get_image());
+        // depthmap_bilateral_filter(init, main_view->get_image()) guided by
+        // the main image on the device; the filtered map also stays there for
+        // create_subview_surfaces (:463-466 splats the same map)
+        this->upload_images();
+        FloatImage::Ptr full = FloatImage::create_for_overwrite(main_view->get_width(),
+            main_view->get_height(), 1);
+        check(smvs_ctx_sgm_init_depth(ctx, init->begin(), init->width(),
+            init->height(), 5.0f, 5, full->begin()), "smvs_ctx_sgm_init_depth");
+        init = full;
         this->surface = Surface::create(bundle, main_view, init_scale, init);
         this->sgm_depth = init;
     } else {
@@ -253,6 +261,16 @@ DepthOptimizer::set_scale_everywhere(int scale)
     // StereoView::set_scale for the main view and every neighbour
     // (lib/depth_optimizer.cc:63-66, 99-103) on the device.
     ScopedHostTimer timer("set_scale (device)");
+    this->upload_images();
+    check(smvs_ctx_set_scale(ctx, scale), "smvs_ctx_set_scale");
+    // The planes stay on the device: every consumer (Newton loop, patch MSE,
+    // NCC) runs there.  StereoView::get_image_gradients() of the views keeps
+    // what the caller last set; download_scale_planes() fetches them.
+}
+
+void
+DepthOptimizer::upload_images(void)
+{
     if (!images_uploaded) {
         ByteImage::ConstPtr mb = main_view->get_raw_bytes();
         check(smvs_ctx_upload_image(ctx, -1, mb->width(), mb->height(),
@@ -269,26 +287,22 @@ DepthOptimizer::set_scale_everywhere(int scale)
                 "smvs_ctx_upload_shading");
         images_uploaded = true;
     }
-    check(smvs_ctx_set_scale(ctx, scale), "smvs_ctx_set_scale");
-    // The planes stay on the device: every consumer (Newton loop, patch MSE,
-    // NCC) runs there.  StereoView::get_image_gradients() of the views keeps
-    // what the caller last set; download_scale_planes() fetches them.
 }
 
 void
 DepthOptimizer::download_scale_planes(void)
 {
     {
-        FloatImage::Ptr g = FloatImage::create(main_view->get_width(),
+        FloatImage::Ptr g = FloatImage::create_for_overwrite(main_view->get_width(),
             main_view->get_height(), 2);
         check(smvs_ctx_download_planes(ctx, -1, g->begin(), nullptr),
             "smvs_ctx_download_planes");
         main_view->set_scale_planes(g, nullptr);
     }
     for (std::size_t j = 0; j < sub_views.size(); ++j) {
-        FloatImage::Ptr g = FloatImage::create(sub_views[j]->get_width(),
+        FloatImage::Ptr g = FloatImage::create_for_overwrite(sub_views[j]->get_width(),
             sub_views[j]->get_height(), 2);
-        FloatImage::Ptr hs = FloatImage::create(sub_views[j]->get_width(),
+        FloatImage::Ptr hs = FloatImage::create_for_overwrite(sub_views[j]->get_width(),
             sub_views[j]->get_height(), 3);
         check(smvs_ctx_download_planes(ctx, (int)j, g->begin(), hs->begin()),
             "smvs_ctx_download_planes");
@@ -385,7 +399,7 @@ DepthOptimizer::get_depth(void)
 {
     // Surface::get_depth_map (lib/surface.cc:155-168) on the device
     this->upload_surface();
-    FloatImage::Ptr dm = FloatImage::create(main_view->get_width(),
+    FloatImage::Ptr dm = FloatImage::create_for_overwrite(main_view->get_width(),
         main_view->get_height(), 1);
     check(smvs_get_depth_map(ctx, dm->begin()), "smvs_get_depth_map");
     return dm;
@@ -396,7 +410,7 @@ DepthOptimizer::get_normals(void)
 {
     // Surface::get_normal_map (lib/surface.cc:170-183) on the device
     this->upload_surface();
-    FloatImage::Ptr nm = FloatImage::create(main_view->get_width(),
+    FloatImage::Ptr nm = FloatImage::create_for_overwrite(main_view->get_width(),
         main_view->get_height(), 3);
     check(smvs_get_normal_map(ctx, nm->begin()), "smvs_get_normal_map");
     return nm;
@@ -521,8 +535,8 @@ DepthOptimizer::create_subview_surfaces(void)
     subsurfaces.assign(num_patches, 0);
     subs_rev += 1;
     this->upload_surface();
-    check(smvs_topology_subviews(ctx,
-        opts.use_sgm ? sgm_depth->begin() : nullptr, opts.use_sgm ? 0 : 1,
+    // (use_sgm: the filtered SGM map is resident, create_initial_surface)
+    check(smvs_topology_subviews(ctx, nullptr, opts.use_sgm ? 0 : 1,
         subsurfaces.data()), "smvs_topology_subviews");
     subs_rev += 1;   // (the device still holds the masks that were uploaded)
 

@@ -83,6 +83,7 @@ private:
     void fit_lighting(void);
 
     void set_scale_everywhere(int scale);
+    void upload_images(void);
     void upload_surface(void);
     void check(int status, char const* what) const;
     void dump_state(int iter, char const* tag) const;

@@ -36,7 +36,7 @@ static void fill_log(DepthOptimizer const& optimizer, smvs_host_log *log);
 static StereoView::Ptr
 make_view(smvs_host_view const& v, bool linear)
 {
-    ByteImage::Ptr img = ByteImage::create(v.width, v.height, v.channels);
+    ByteImage::Ptr img = ByteImage::create_for_overwrite(v.width, v.height, v.channels);
     std::memcpy(img->begin(), v.bytes, (size_t)v.width * v.height * v.channels);
     CameraInfo cam;
     cam.flen = v.flen;
@@ -74,7 +74,7 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
             subs.push_back(make_view(subs_in[j], false));
         Bundle::Ptr bundle = make_bundle(bundle_in);
         if (sgm_depth != nullptr) {
-            FloatImage::Ptr d = FloatImage::create(sgm_w, sgm_h, 1);
+            FloatImage::Ptr d = FloatImage::create_for_overwrite(sgm_w, sgm_h, 1);
             std::memcpy(d->begin(), sgm_depth, sizeof(float) * sgm_w * sgm_h);
             main_view->write_depth_to_view(d, "smvs-sgm");
             if (sgm_roundtrip != nullptr) {
@@ -198,7 +198,7 @@ smvs_host_surface_script(const smvs_host_view *main_in,
         Bundle::Ptr bundle = make_bundle(bundle_in);
         FloatImage::Ptr init;
         if (init_depth != nullptr) {
-            init = FloatImage::create(main_in->width, main_in->height, 1);
+            init = FloatImage::create_for_overwrite(main_in->width, main_in->height, 1);
             std::memcpy(init->begin(), init_depth,
                 sizeof(float) * (size_t)main_in->width * main_in->height);
         }
@@ -315,7 +315,7 @@ smvs_host_surface_maps(const smvs_host_view *main_in, const smvs_host_view *subs
         Bundle::Ptr bundle = make_bundle(bundle_in);
         FloatImage::Ptr init;
         if (init_depth != nullptr) {
-            init = FloatImage::create(main_in->width, main_in->height, 1);
+            init = FloatImage::create_for_overwrite(main_in->width, main_in->height, 1);
             std::memcpy(init->begin(), init_depth,
                 sizeof(float) * (size_t)main_in->width * main_in->height);
         }

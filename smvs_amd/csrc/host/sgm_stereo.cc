@@ -142,7 +142,7 @@ run_pairs(SGMStereo::Options const& o, StereoView::Ptr main_view,
     ByteImage::ConstPtr main_bytes = main_view->get_raw_bytes();
     int w = main_bytes->width(), h = main_bytes->height();
     sgm_scale_size(o.scale, &w, &h);
-    FloatImage::Ptr depth = FloatImage::create(w, h, 1);
+    FloatImage::Ptr depth = FloatImage::create_for_overwrite(w, h, 1);
     // desaturate + half-size on the device, then 4 x run_sgm, L/R check, merge
     int const rc = smvs_sgm_depth_for_view_raw(o.device, main_bytes->begin(),
         main_bytes->width(), main_bytes->height(), main_bytes->channels(), dev.data(),

@@ -178,7 +178,7 @@ FloatImage::ConstPtr
 StereoView::get_image(void) const
 {
     std::call_once(image_once, [this]() {
-        FloatImage::Ptr img = FloatImage::create(bytes->width(), bytes->height(),
+        FloatImage::Ptr img = FloatImage::create_for_overwrite(bytes->width(), bytes->height(),
             bytes->channels());
         int64_t const n = (int64_t)bytes->get_pixel_amount() * bytes->channels();
         uint8_t const* src = bytes->begin();

@@ -50,14 +50,19 @@ Surface::create(Bundle::ConstPtr bundle, StereoView::Ptr main_view, int scale,
     s->nodes.assign(s->node_valid.size() * 4, 0.0);
     s->start_x = (width - s->npx * s->patchsize) / 2;
     s->start_y = (height - s->npy * s->patchsize) / 2;
-    s->depth = FloatImage::create(width, height, 1);
-    if (init_depth == nullptr)
+    if (init_depth == nullptr) {
+        s->depth = FloatImage::create(width, height, 1);
         s->initialize_depth_from_bundle(bundle, main_view->get_camera(),
             main_view->get_view_id());
-    else
-        for (int p = 0; p < s->depth->get_pixel_amount(); ++p)
-            if (init_depth->at(p) > 0.0)
-                s->depth->at(p) = init_depth->at(p);
+    } else {
+        // lib/surface.cc:74-79: the positive depths, zero elsewhere
+        s->depth = FloatImage::create_for_overwrite(width, height, 1);
+        float const* src = init_depth->begin();
+        float* dst = s->depth->begin();
+        int64_t const n = s->depth->get_pixel_amount();
+        for (int64_t p = 0; p < n; ++p)
+            dst[p] = src[p] > 0.0f ? src[p] : 0.0f;
+    }
     s->fill_patches_from_depth();
     return s;
 }

@@ -25,54 +25,158 @@ byte_to_float_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
         out[i] = (float)in[i] / 255.0f;
 }
 
-// one separable pass; AXIS 0: along x, AXIS 1: along y.  Accum<float>:
-// v += value * weight; w += weight; result v / w, borders clamped.
-// One thread per element of a row (grid y = image row): no 64-bit index
-// arithmetic, the channel count is a compile-time constant, and the taps of a
-// wave are contiguous in memory in both passes.  Same operations in the same
-// order per element as the reference's loop (bit-exact against the oracle).
-template <int C, int AXIS>
+// The Gaussian taps of one scale, handed to the kernels by value: the tap
+// index is uniform across a wave, so the weights come out of the kernel
+// arguments with scalar loads.  wsum is Accum<float>'s weight total: the
+// reference adds every tap's weight in tap order for every element, clamped
+// or not, so it is one number per scale, summed here in that order.
+struct BlurTaps {
+    float k[64];
+    float wsum;
+    int ks;
+};
+
+// Separable pass along x: v += value * weight per tap in ascending tap order,
+// result v / wsum, borders clamped -- the same operations in the same order
+// per element as the reference's loop (bit-exact against the oracle).  One
+// thread per element of a row (grid y = image row): the taps of a wave are
+// contiguous in memory; workgroups whose taps stay inside the row (all but
+// the first and the last of a row) skip the clamps.
+// KS > 0: the half width is a compile-time constant (the scales 0 .. 6 of
+// stereo_view.cc:29-31 give 1, 2, 2, 4, 7, 12, 23): the tap loops unroll, the
+// weights sit in scalar registers and the loads of a thread are all in
+// flight at once.  KS == 0: any half width, taps.ks at run time.
+template <int C, int KS>
 __global__ void __launch_bounds__(256)
-blur_pass_kernel(const float *__restrict__ in, float *__restrict__ out, int w,
-    int h, int ks, const float *__restrict__ kernel)
+blur_x_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h,
+    BlurTaps taps)
 {
 #pragma clang fp contract(off)
-    int const e = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // element of the row
+    int const e0 = (int)(blockIdx.x * blockDim.x);
+    int const e = e0 + (int)threadIdx.x;       // element of the row
     int const y = (int)blockIdx.y;
+    int const ks = KS > 0 ? KS : taps.ks;
+    const float *row = in + (size_t)y * w * C;
+    bool const interior = e0 / C - ks >= 0 && (e0 + 255) / C + ks <= w - 1;
     if (e >= w * C)
         return;
-    int const x = e / C, cc = e - x * C;
-    const float *row = in + (size_t)y * w * C;
-    float av = 0.0f, aw = 0.0f;
-    for (int k = -ks; k <= ks; ++k) {
-        float const kw = kernel[k < 0 ? -k : k];
-        float v;
-        if (AXIS == 0) {
-            int const xx = min(max(x + k, 0), w - 1);
-            v = row[xx * C + cc];
+    float av = 0.0f;
+    if (interior) {
+        const float *p = row + e;
+        if (KS > 0) {
+            float v[2 * KS + 1];
+#pragma unroll
+            for (int k = -KS; k <= KS; ++k)
+                v[k + KS] = p[k * C];
+#pragma unroll
+            for (int k = -KS; k <= KS; ++k)
+                av += v[k + KS] * taps.k[k < 0 ? -k : k];
         } else {
-            int const yy = min(max(y + k, 0), h - 1);
-            v = in[(size_t)yy * w * C + e];
+            for (int k = -ks; k <= ks; ++k)
+                av += p[k * C] * taps.k[k < 0 ? -k : k];
         }
-        av += v * kw;
-        aw += kw;
+    } else {
+        int const x = e / C, cc = e - x * C;
+        for (int k = -ks; k <= ks; ++k) {
+            int const xx = min(max(x + k, 0), w - 1);
+            av += row[xx * C + cc] * taps.k[k < 0 ? -k : k];
+        }
     }
-    out[(size_t)y * w * C + e] = av / aw;
+    out[(size_t)y * w * C + e] = av / taps.wsum;
+}
+
+// Separable pass along y, BLUR_ROWS output rows per thread: a loaded value
+// feeds the (up to) BLUR_ROWS outputs it is a tap of, each of which still
+// sees its taps in ascending order.
+#define BLUR_ROWS 4
+template <int KS>
+__global__ void __launch_bounds__(256)
+blur_y_kernel(const float *__restrict__ in, float *__restrict__ out, int row_len,
+    int h, BlurTaps taps)
+{
+#pragma clang fp contract(off)
+    int const e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int const y0 = (int)blockIdx.y * BLUR_ROWS;
+    int const ks = KS > 0 ? KS : taps.ks;
+    if (e >= row_len)
+        return;
+    float av[BLUR_ROWS];
+#pragma unroll
+    for (int j = 0; j < BLUR_ROWS; ++j)
+        av[j] = 0.0f;
+    if (KS > 0) {
+        constexpr int N = 2 * KS + BLUR_ROWS;
+        // (in groups: every load of a group is issued before its values are used)
+        constexpr int GROUP = 16;
+#pragma unroll
+        for (int g = 0; g < N; g += GROUP) {
+            float v[GROUP];
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i)
+                if (g + i < N) {
+                    int const yy = min(max(y0 + g + i - KS, 0), h - 1);
+                    v[i] = in[(size_t)yy * row_len + e];
+                }
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i)
+                if (g + i < N) {
+                    int const t = g + i - KS;
+#pragma unroll
+                    for (int j = 0; j < BLUR_ROWS; ++j) {
+                        int const k = t - j;     // tap of output row y0 + j
+                        if (k >= -KS && k <= KS)
+                            av[j] += v[i] * taps.k[k < 0 ? -k : k];
+                    }
+                }
+        }
+    } else {
+        for (int t = -ks; t <= ks + BLUR_ROWS - 1; ++t) {
+            int const yy = min(max(y0 + t, 0), h - 1);
+            float const v = in[(size_t)yy * row_len + e];
+#pragma unroll
+            for (int j = 0; j < BLUR_ROWS; ++j) {
+                int const k = t - j;
+                if (k >= -ks && k <= ks)
+                    av[j] += v * taps.k[k < 0 ? -k : k];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BLUR_ROWS; ++j)
+        if (y0 + j < h)
+            out[(size_t)(y0 + j) * row_len + e] = av[j] / taps.wsum;
+}
+
+template <int KS>
+static void
+launch_blur_ks(hipStream_t stream, const float *in, float *tmp, float *out, int w, int h,
+    int c, BlurTaps const &taps)
+{
+    unsigned const bx = (unsigned)((w * c + 255) / 256);
+    if (c == 1)
+        hipLaunchKernelGGL((blur_x_kernel<1, KS>), dim3(bx, (unsigned)h), dim3(256), 0,
+            stream, in, tmp, w, h, taps);
+    else
+        hipLaunchKernelGGL((blur_x_kernel<3, KS>), dim3(bx, (unsigned)h), dim3(256), 0,
+            stream, in, tmp, w, h, taps);
+    hipLaunchKernelGGL(blur_y_kernel<KS>,
+        dim3(bx, (unsigned)((h + BLUR_ROWS - 1) / BLUR_ROWS)), dim3(256), 0, stream, tmp,
+        out, w * c, h, taps);
 }
 
 static void
-launch_blur_pass(hipStream_t stream, const float *in, float *out, int w, int h, int c,
-    int ks, const float *kernel, int axis)
+launch_blur(hipStream_t stream, const float *in, float *tmp, float *out, int w, int h,
+    int c, BlurTaps const &taps)
 {
-    dim3 const grid((unsigned)((w * c + 255) / 256), (unsigned)h);
-    if (c == 1 && axis == 0)
-        hipLaunchKernelGGL((blur_pass_kernel<1, 0>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
-    else if (c == 1)
-        hipLaunchKernelGGL((blur_pass_kernel<1, 1>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
-    else if (axis == 0)
-        hipLaunchKernelGGL((blur_pass_kernel<3, 0>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
-    else
-        hipLaunchKernelGGL((blur_pass_kernel<3, 1>), grid, dim3(256), 0, stream, in, out, w, h, ks, kernel);
+    switch (taps.ks) {
+    case 1: launch_blur_ks<1>(stream, in, tmp, out, w, h, c, taps); break;
+    case 2: launch_blur_ks<2>(stream, in, tmp, out, w, h, c, taps); break;
+    case 4: launch_blur_ks<4>(stream, in, tmp, out, w, h, c, taps); break;
+    case 7: launch_blur_ks<7>(stream, in, tmp, out, w, h, c, taps); break;
+    case 12: launch_blur_ks<12>(stream, in, tmp, out, w, h, c, taps); break;
+    case 23: launch_blur_ks<23>(stream, in, tmp, out, w, h, c, taps); break;
+    default: launch_blur_ks<0>(stream, in, tmp, out, w, h, c, taps); break;
+    }
 }
 
 // luminance (0.21, 0.72, 0.07) + quadratic fit on the 3x3 window, double
@@ -220,18 +324,21 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
     double const sigma_d = 0.12 * std::pow(2.0, scale) + 0.2;
     float const sigma = (float)sigma_d;
     int const ks = (int)std::ceil(sigma * 2.884f);
-    std::vector<float> kernel(ks + 1);
+    SMVS_REQUIRE(ks + 1 <= 64, "blur kernel too wide");
+    BlurTaps taps = {};
+    taps.ks = ks;
     for (int i = 0; i <= ks; ++i)
-        kernel[i] = std::exp(-((float)i * (float)i) / (2.0f * sigma * sigma));
-    // (taps in a buffer the context keeps: no allocation per scale)
-    SMVS_REQUIRE(kernel.size() <= 64, "blur kernel too wide");
+        taps.k[i] = std::exp(-((float)i * (float)i) / (2.0f * sigma * sigma));
+    {
+        // (volatile: the sum must be rounded to float after every addition,
+        // like Accum<float>)
+        volatile float wsum = 0.0f;
+        for (int i = -ks; i <= ks; ++i)
+            wsum = wsum + taps.k[i < 0 ? -i : i];
+        taps.wsum = wsum;
+    }
     int rc;
-    if (ctx->blur_kernel == nullptr
-        && (rc = device_alloc(&ctx->blur_kernel, 64)) != SMVS_OK)
-        return rc;
-    float *kernel_dev = ctx->blur_kernel;
-    hipError_t e = hipMemcpyAsync(kernel_dev, kernel.data(),
-        kernel.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
     FitMatrix const fit = quadratic_fit_matrix();
     bool const blur = !(std::fabs(sigma) < 0.1f);
 
@@ -247,10 +354,8 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
         const float *src = vi.data;
         if (blur) {
             ScopedKernelTimer timer(ctx, SMVS_K_MISC);
-            launch_blur_pass(ctx->stream, vi.data, ctx->blur_tmp[0], vi.w, vi.h, vi.c,
-                ks, kernel_dev, 0);
-            launch_blur_pass(ctx->stream, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w, vi.h,
-                vi.c, ks, kernel_dev, 1);
+            launch_blur(ctx->stream, vi.data, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w,
+                vi.h, vi.c, taps);
             src = ctx->blur_tmp[1];
         }
         float2 *grad;

@@ -1180,6 +1180,76 @@ smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
     return ws.download(out, d_out, sizeof(float) * n);
 }
 
+// The same filter for a view whose context already holds the main image
+// (smvs_ctx_upload_image): guided by that image, and the full-size result
+// stays on the device as the depth map the visibility tests of
+// smvs_topology_subviews compare with (lib/depth_optimizer.cc:35-51 hands the
+// filtered map to both).  Saves the upload of the float image (25 MB at
+// 1920 x 1080 x 3) and of the result, once per topology pass.
+extern "C" int
+smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
+    float sigma, int kernel_size, float *out)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null argument");
+    if (dm == nullptr) {   // forget the resident map
+        ctx->sgm_resident = false;
+        return SMVS_OK;
+    }
+    SMVS_REQUIRE(dm_w > 0 && dm_h > 0 && kernel_size >= 0 && sigma > 0.f,
+        "bad argument");
+    if ((ctx->image_ok & 1u) == 0u) {
+        set_error("smvs_ctx_sgm_init_depth: no main image (smvs_ctx_upload_image)");
+        return SMVS_ERR_STATE;
+    }
+    if (ctx->images[0].w != ctx->width || ctx->images[0].h != ctx->height) {
+        set_error("smvs_ctx_sgm_init_depth: main image size differs from the context");
+        return SMVS_ERR_INVALID;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc;
+    size_t const n = (size_t)ctx->width * ctx->height;
+    size_t const n_low = (size_t)dm_w * dm_h;
+    if (ctx->sgm_lowres_cap < n_low) {
+        if ((rc = device_alloc(&ctx->sgm_lowres, n_low)) != SMVS_OK)
+            return rc;
+        ctx->sgm_lowres_cap = n_low;
+    }
+    if (ctx->topo_sgm_cap < n) {
+        if ((rc = device_alloc(&ctx->topo_sgm, n)) != SMVS_OK)
+            return rc;
+        ctx->topo_sgm_cap = n;
+    }
+    ctx->sgm_resident = false;
+    if ((rc = ctx_upload(ctx, ctx->sgm_lowres, dm, sizeof(float) * n_low)) != SMVS_OK)
+        return rc;
+    BilateralArgs A;
+    A.dm = ctx->sgm_lowres;
+    A.ci = ctx->images[0].data;
+    A.out = ctx->topo_sgm;
+    A.dm_w = dm_w;
+    A.dm_h = dm_h;
+    A.w = ctx->width;
+    A.h = ctx->height;
+    A.channels = ctx->images[0].c;
+    A.kernel_size = kernel_size;
+    A.sigma = sigma;
+    SgmProfile prof;
+    {
+        SgmKernelTimer timer(&prof, ctx->stream, SMVS_SGM_K_BILATERAL);
+        hipLaunchKernelGGL(bilateral_kernel, dim3((ctx->width + 255) / 256, ctx->height),
+            dim3(256), 0, ctx->stream, A);
+    }
+    SMVS_HIP_CHECK(hipGetLastError());
+    if (out != nullptr) {
+        if ((rc = ctx_download(ctx, out, ctx->topo_sgm, sizeof(float) * n)) != SMVS_OK)
+            return rc;
+    } else {
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->sgm_resident = true;
+    return SMVS_OK;
+}
+
 extern "C" int
 smvs_sgm_profile(int enable, double *ms, long long *launches)
 {

@@ -588,6 +588,10 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         if ((rc = ctx_upload(ctx, ctx->topo_sgm, sgm_depth, npix * sizeof(float)))
                 != SMVS_OK)
             return rc;
+        ctx->sgm_resident = false;   // (overwritten by the caller's map)
+        A.sgm_depth = ctx->topo_sgm;
+    } else if (ctx->sgm_resident) {
+        // the map smvs_ctx_sgm_init_depth left on the device
         A.sgm_depth = ctx->topo_sgm;
     }
     for (int s = 0; s < ctx->n_subs; ++s) {

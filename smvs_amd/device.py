@@ -93,6 +93,19 @@ class ViewContext:
             self._image_shapes = {}
         self._image_shapes[view] = (h, w)
 
+    def sgm_init_depth(self, dm, sigma=5.0, kernel_size=5):
+        """depthmap_bilateral_filter(dm, main image) guided by the uploaded main
+        image; the result also stays in the context for topology_subviews()."""
+        if dm is None:
+            check(self.lib.smvs_ctx_sgm_init_depth(self.handle, None, 0, 0,
+                  C.c_float(sigma), kernel_size, None))
+            return None
+        d = _f32(dm)
+        out = np.zeros((self.height, self.width), dtype=np.float32)
+        check(self.lib.smvs_ctx_sgm_init_depth(self.handle, _p(d, _fp), d.shape[1],
+              d.shape[0], C.c_float(sigma), kernel_size, _p(out, _fp)))
+        return out
+
     def set_scale(self, scale):
         check(self.lib.smvs_ctx_set_scale(self.handle, scale))
 
@@ -262,7 +275,8 @@ class ViewContext:
 
     # ------------------------------------------------------------ topology
     def topology_subviews(self, sgm_depth=None, use_ncc=True):
-        """create_subview_surfaces' per-(patch, neighbour) tests -> bit masks."""
+        """create_subview_surfaces' per-(patch, neighbour) tests -> bit masks.
+        sgm_depth None: the map sgm_init_depth() left in the context, if any."""
         sd = _f32(sgm_depth) if sgm_depth is not None else None
         if sd is not None:
             assert sd.shape == (self.height, self.width)

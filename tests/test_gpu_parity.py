@@ -616,6 +616,46 @@ def test_topology_subviews_with_sgm_depth(hip, oracle):
     ctx.close()
 
 
+def test_context_sgm_init_depth_is_the_bilateral_filter_and_stays_resident(hip, oracle):
+    """smvs_ctx_sgm_init_depth: depthmap_bilateral_filter guided by the main
+    image the context already holds (depth_optimizer.cc:35-51) -- bit-identical
+    to the stand-alone entry point with the float image, equal to the oracle --
+    and the filtered map stays on the device for create_subview_surfaces:
+    smvs_topology_subviews(NULL) then gives what it gives for the explicit map."""
+    from smvs_amd import synth
+    W, H = 320, 256
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, W, H, 3, 2, 0.0)
+    xs, ys = np.meshgrid(np.arange(0, W, 2, dtype=float) + 0.5, np.arange(0, H, 2, dtype=float) + 0.5)
+    low = synth.depth_at(prob["scene"], prob["main"], xs, ys).astype(np.float32)
+    low[::9, ::4] = 0.0
+    low[40:60, 70:100] *= 0.8
+    ci = prob["images"][0].astype(np.float32) / np.float32(255.0)
+    ctx.set_surface(surf)
+    # before anything is resident: NULL means no SGM splat
+    vis_none = ctx.topology_subviews(None, use_ncc=False)
+    full = ctx.sgm_init_depth(low)
+    assert np.array_equal(full, hip.bilateral_upsample(low, ci))
+    assert np.array_equal(full, oracle.bilateral_upsample(low, ci))
+    vis_resident = ctx.topology_subviews(None, use_ncc=False)
+    assert np.array_equal(vis_resident, tp.subviews(full))
+    assert not np.array_equal(vis_resident, vis_none)   # the wrong blob occludes
+    # an explicit map replaces the resident one ...
+    other = full.copy(); other[:] = 0.0
+    assert np.array_equal(ctx.topology_subviews(other, use_ncc=False), vis_none)
+    # ... and NULL does not silently fall back to stale data afterwards
+    assert np.array_equal(ctx.topology_subviews(None, use_ncc=False), vis_none)
+    ctx.sgm_init_depth(low)
+    ctx.sgm_init_depth(None)
+    assert np.array_equal(ctx.topology_subviews(None, use_ncc=False), vis_none)
+    # no main image: a state error, not a crash
+    from smvs_amd._capi import SmvsError
+    ctx2 = hip.ViewContext(W, H, 3)
+    with pytest.raises(SmvsError):
+        ctx2.sgm_init_depth(low)
+    ctx2.close()
+    ctx.close()
+
+
 def test_full_size_shading_step_matches_oracle(hip, oracle):
     """configs[3]: the shading-aware step at 1920x1080 with 8 neighbours --
     SH lighting fit (light_optimizer.cc:22-55) and the construct with the

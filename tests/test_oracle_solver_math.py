@@ -1,0 +1,172 @@
+"""Mathematical pins of the oracle's assembly and PCG (no GPU, no reference
+build exists for either): the restatement of gauss_newton_step.cc:33-143 and
+conjugate_gradient.h:96-172 is checked against independent linear algebra.
+
+ * the assembled block-stencil matrix is the sum over the live patches of
+   their 16 x 16 systems scattered to the patches' four nodes, restricted to
+   the active nodes -- built here a second time as a scipy sparse matrix from
+   gn_patch() alone;
+ * orc_block_spmv is that matrix times a vector;
+ * the preconditioner blocks are the inverses of the diagonal blocks;
+ * orc_cg_solve, run to convergence, solves H x = b (sparse direct solve);
+ * with the reference's termination rule (zeta = i (Q1 - Q0) / Q1 < q_tol,
+   Q = -x.(b + r)) it stops where a textbook PCG written with numpy / scipy
+   stops, with the same x.
+"""
+import numpy as np
+import pytest
+
+sp = pytest.importorskip("scipy.sparse")
+spla = pytest.importorskip("scipy.sparse.linalg")
+
+
+def _patch_nodes(surf, p):
+    stride = surf["npx"] + 1
+    px, py = p % surf["npx"], p // surf["npx"]
+    n00 = py * stride + px
+    return [n00, n00 + 1, n00 + stride, n00 + stride + 1]
+
+
+def _system(oracle, active_fraction, seed):
+    from smvs_amd import synth
+    prob = synth.make_problem(128, 96, 3, scale=2, noise=0.004, seed=seed)
+    surf = prob["surf"]
+    orc = oracle.OracleProblem(surf, prob["views"])
+    rng = np.random.default_rng(seed)
+    active = np.array(surf["node_valid"], dtype=np.uint8)
+    if active_fraction < 1.0:
+        active &= (rng.random(active.size) < active_fraction).astype(np.uint8)
+    sys9 = orc.gn_construct(active, 0.01)
+    return prob, orc, active, sys9
+
+
+def _independent_matrix(oracle, prob, orc, active):
+    """sum_p S_p^T H_p S_p and sum_p S_p^T g_p over the live patches, rows and
+    columns of inactive nodes dropped (gauss_newton_step.cc:89-121)."""
+    surf = prob["surf"]
+    N = (surf["npx"] + 1) * (surf["npy"] + 1)
+    # the oracle's own node order of a patch, read off a one-hot probe: the
+    # test must not assume it
+    rows, cols, vals = [], [], []
+    g = np.zeros(4 * N)
+    live = 0
+    for p in range(surf["npx"] * surf["npy"]):
+        if not surf["patch_valid"][p]:
+            continue
+        nodes = _patch_nodes(surf, p)
+        if not any(active[n] for n in nodes):
+            continue
+        live += 1
+        gp, Hp = orc.gn_patch(p, 0.01)
+        Hp = np.triu(Hp) + np.triu(Hp, 1).T          # the reference fills the upper triangle
+        idx = np.array([4 * nodes[k // 4] + k % 4 for k in range(16)])
+        keep = np.array([bool(active[nodes[k // 4]]) for k in range(16)])
+        g[idx[keep]] += gp[keep]
+        ii, jj = np.meshgrid(idx, idx, indexing="ij")
+        m = keep[:, None] & keep[None, :]
+        rows.append(ii[m]); cols.append(jj[m]); vals.append(Hp[m])
+    H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(4 * N, 4 * N)).tocsr()
+    return H, g, live
+
+
+def _stencil_to_sparse(surf, H9, present):
+    stride = surf["npx"] + 1
+    N = H9.shape[0]
+    rows, cols, vals = [], [], []
+    for r in range(N):
+        ry, rx = divmod(r, stride)
+        for s in range(9):
+            if not present[r, s]:
+                continue
+            c = (ry + s // 3 - 1) * stride + (rx + s % 3 - 1)
+            blk = H9[r, s].reshape(4, 4)
+            for br in range(4):
+                for bc in range(4):
+                    rows.append(4 * r + br); cols.append(4 * c + bc); vals.append(blk[br, bc])
+    return sp.coo_matrix((vals, (rows, cols)), shape=(4 * N, 4 * N)).tocsr()
+
+
+@pytest.mark.parametrize("active_fraction", [1.0, 0.4])
+def test_assembly_is_the_sum_of_the_patch_systems(oracle, active_fraction):
+    prob, orc, active, sys9 = _system(oracle, active_fraction, seed=5)
+    H_ind, g_ind, live = _independent_matrix(oracle, prob, orc, active)
+    assert live == sys9["active_patches"] and live > 50
+    H_orc = _stencil_to_sparse(prob["surf"], sys9["H9"], sys9["present"])
+    scale = abs(H_ind).max()
+    assert abs(H_orc - H_ind).max() <= 1e-13 * scale
+    assert np.abs(sys9["g"] - g_ind).max() <= 1e-13 * np.abs(g_ind).max()
+    # symmetric, and the product is the sparse product
+    assert abs(H_orc - H_orc.T).max() <= 1e-13 * scale
+    x = np.random.default_rng(3).standard_normal(H_orc.shape[0])
+    y = orc.spmv(sys9["H9"], sys9["present"], x)
+    assert np.abs(y - H_ind @ x).max() <= 1e-12 * np.abs(y).max()
+    # the preconditioner inverts the diagonal blocks
+    worst = 0.0
+    for n in np.flatnonzero(sys9["present"][:, 4])[::7]:
+        D = sys9["H9"][n, 4].reshape(4, 4)
+        worst = max(worst, np.abs(sys9["P"][n].reshape(4, 4) @ D - np.eye(4)).max())
+    assert worst < 1e-8, worst
+
+
+def _textbook_pcg(H, Pinv, b, max_iterations, error_tolerance, q_tolerance):
+    """Preconditioned CG as in any textbook, with the reference's two stopping
+    rules (conjugate_gradient.h:136-153)."""
+    x = np.zeros_like(b)
+    r = b.copy()
+    z = Pinv @ r
+    rho = z @ r
+    d = z.copy()
+    Q0 = -(x @ (b + r))
+    it = 1
+    while it < max_iterations:
+        q = H @ d
+        alpha = rho / (d @ q)
+        x += alpha * d
+        r -= alpha * q
+        if r @ r < error_tolerance:
+            break
+        Q1 = -(x @ (b + r))
+        if it * (Q1 - Q0) / Q1 < q_tolerance:
+            break
+        Q0 = Q1
+        z = Pinv @ r
+        rho_new = z @ r
+        d = z + (rho_new / rho) * d
+        rho = rho_new
+        it += 1
+    return x, it
+
+
+@pytest.mark.parametrize("active_fraction", [1.0, 0.4])
+def test_pcg_solves_the_system_and_stops_like_a_textbook_pcg(oracle, active_fraction):
+    prob, orc, active, sys9 = _system(oracle, active_fraction, seed=9)
+    H = _stencil_to_sparse(prob["surf"], sys9["H9"], sys9["present"])
+    b = -sys9["g"]
+    rows = np.flatnonzero(np.repeat(sys9["present"][:, 4], 4))
+    # block-diagonal preconditioner as a sparse matrix
+    N = sys9["P"].shape[0]
+    blocks = [sys9["P"][n].reshape(4, 4) if sys9["present"][n, 4] else np.zeros((4, 4))
+              for n in range(N)]
+    Pinv = sp.block_diag(blocks, format="csr")
+
+    # (1) run to convergence: the solution of the linear system
+    x_full, it_full, info = orc.cg_solve(sys9["H9"], sys9["present"], sys9["P"], b,
+                                         max_iterations=5000, error_tolerance=1e-28,
+                                         q_tolerance=-1.0)
+    assert info == 0
+    Hs = H[rows][:, rows].tocsc()
+    x_direct = np.zeros_like(b)
+    x_direct[rows] = spla.spsolve(Hs, b[rows])
+    assert np.linalg.norm(x_full - x_direct) <= 1e-8 * np.linalg.norm(x_direct)
+    assert np.abs(x_full[np.setdiff1d(np.arange(b.size), rows)]).max(initial=0.0) == 0.0
+
+    # (2) the reference's settings (200 iterations, 1e-20, q 1e-3): the same
+    # iteration count and iterate as the textbook recurrence
+    x_ref, it_ref, info = orc.cg_solve(sys9["H9"], sys9["present"], sys9["P"], b)
+    x_tb, it_tb = _textbook_pcg(H, Pinv, b, 200, 1e-20, 1e-3)
+    assert info == 0 and 3 < it_ref < 200
+    assert it_ref == it_tb
+    assert np.linalg.norm(x_ref - x_tb) <= 1e-10 * np.linalg.norm(x_tb)
+    # and it is a useful step: most of the way to the solution
+    assert np.linalg.norm(x_ref - x_direct) < 0.2 * np.linalg.norm(x_direct)
