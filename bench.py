@@ -51,10 +51,10 @@ FP64_PEAK_TFLOPS = 78.6
 # Per-unit algorithmic work:
 #  * per active patch, FP64 flops the factored construction executes at S = 8
 #    neighbours, P = 16 samples (SQ instruction counters,
-#    profiles/r2_patch_kernel_counters.txt);
+#    profiles/r3_patch_kernel_counters.txt: 1.081e5 executed);
 #    SURVEY.md 8(d) prices the reference's unfactored rows at 0.50 MFLOP
 #  * per node and CG iteration, bytes of the upper-half block stencil + vectors
-FLOP_PER_PATCH = 0.114e6
+FLOP_PER_PATCH = 0.1081e6
 FLOP_PER_PATCH_SURVEY = 0.50e6
 BYTES_PER_PATCH = 4.2e3
 # The resident PCG reads its input once per solve (1,280 + 128 B per live patch,
