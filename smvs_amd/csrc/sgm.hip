@@ -62,18 +62,24 @@ struct WarpArgs {
     uint8_t *warped;   // [h][w][D]
 };
 
-// sgm_stereo.cc:150-190, one thread per (pixel, plane)
-__global__ void __launch_bounds__(256)
+// sgm_stereo.cc:150-190, one thread per (pixel, plane): a wave is 64 planes
+// of one pixel, a workgroup 4 pixels of a row; grid x = plane chunks x pixel
+// groups, grid y = image row (no per-thread division: the 64-bit quotients of
+// a flat index cost more than the sample itself).
+constexpr int WARP_PIXELS = 4;
+
+__global__ void __launch_bounds__(64 * WARP_PIXELS)
 warp_kernel(WarpArgs A)
 {
 #pragma clang fp contract(off)
-    size_t const gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t const total = (size_t)A.w * A.h * A.D;
-    if (gid >= total)
+    int const chunks = (A.D + 63) >> 6;
+    int const group = (int)blockIdx.x / chunks;
+    int const d = ((int)blockIdx.x - group * chunks) * 64 + (int)threadIdx.x;
+    int const x = group * WARP_PIXELS + (int)threadIdx.y;
+    int const y = (int)blockIdx.y;
+    if (d >= A.D || x >= A.w)
         return;
-    int const d = (int)(gid % A.D);
-    size_t const p = gid / A.D;
-    int const x = (int)(p % A.w), y = (int)(p / A.w);
+    size_t const gid = ((size_t)y * A.w + x) * A.D + d;
     float const px = 0.5f + (float)x, py = 0.5f + (float)y;
     float tp[3];
 #pragma unroll
@@ -819,10 +825,12 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     W.w = w;
     W.h = h;
     W.warped = B.warped;
-    unsigned const vblocks = (unsigned)((vol + 255) / 256);
     {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_WARP);
-        hipLaunchKernelGGL(warp_kernel, dim3(vblocks), dim3(256), 0, stream, W);
+        unsigned const chunks = (unsigned)((num_steps + 63) / 64);
+        unsigned const groups = (unsigned)((w + WARP_PIXELS - 1) / WARP_PIXELS);
+        hipLaunchKernelGGL(warp_kernel, dim3(chunks * groups, (unsigned)h),
+            dim3(64, WARP_PIXELS), 0, stream, W);
     }
     {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_COST);
