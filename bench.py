@@ -446,6 +446,43 @@ def secondary_workloads(args):
              "1 B out, wta 2 B in per cell")
     return out
 
+def optimize_workload(args):
+    """--workload optimize: a "step" is one whole DepthOptimizer::optimize of one
+    reference view (all scales, init .. 2) through the C++ host mirror; value =
+    sum of active patch-steps over the sum of the Newton loops' wall time
+    (BASELINE.md's timed region), ms_per_step = wall time of one optimize()."""
+    from smvs_amd import synth, host
+    import smvs_amd
+    if smvs_amd.device_count() < 1:
+        raise RuntimeError("bench.py needs a GPU")
+    w, h = (480, 270) if args.small else (W, H)
+    inp = synth.pipeline_inputs("sphere", w, h, NSUBS, flen=1.2)
+    for _ in range(max(args.warmup, 1)):
+        host.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+    aps = 0
+    loop_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = host.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+        aps += sum(e["active_patch_steps"] for e in r["log"])
+        loop_s += sum(e["loop_seconds"] for e in r["log"])
+    wall = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "Gauss-Newton iters/sec x active patches over all Newton loops of optimize(), "
+                  "1920x1080 ref view, 8 neighbours",
+        "value": aps / loop_s, "unit": "active-patch-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1], whole optimize(): %dx%d synthetic textured sphere, "
+                               "1 ref + %d neighbours, --no-sgm, scales init .. %d, 5 iterations "
+                               "per scale; a step = one optimize()" % (w, h, NSUBS, SCALE),
+                   "regularization": REG,
+                   "newton_loop_ms_per_optimize": 1e3 * loop_s / args.steps,
+                   "active_patch_steps_per_optimize": aps / args.steps},
+        "roofline": None, "cpu_baseline": None}))
+
+
 # ----------------------------------------------------------------------- main
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a torch.distributed environment:
@@ -488,6 +525,11 @@ def main():
                          "SGM kernels)")
     ap.add_argument("--no-peaks", action="store_true",
                     help="skip the peak microbenchmarks (profiling runs)")
+    ap.add_argument("--workload", default="newton_steps", choices=("newton_steps", "optimize"),
+                    help="newton_steps (default, the headline): Newton steps of configs[1] at "
+                         "scale 2; optimize: BASELINE.md's timed region literally -- all "
+                         "Newton loops of all scales of --steps whole optimize() calls of the "
+                         "same scene (also reported as secondary.optimize of the default run)")
     ap.add_argument("--views-in-flight", type=int, default=1,
                     help="reference views processed concurrently per GPU (own context, "
                          "stream and host thread each); the headline number uses 1")
@@ -499,6 +541,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if args.workload == "optimize":
+        return optimize_workload(args)
 
     shading = args.config == 5
     prob = make_problem(rank, args.small, shading=shading)
