@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): everything the round's profiles/ hold.
+# Usage: final_round.sh [round]
+R=${1:-r3}
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.txt 2>&1
+tail -3 gpurun_out/${R}_pytest_gpu.txt
+timeout 600 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
+python - <<PY
+import json
+d = json.load(open("gpurun_out/${R}_bench_default.json"))
+print("bench", d["value"], d["ms_per_step"], d["roofline"]["step_frac"], d["cpu_baseline"])
+print({k: v for k, v in d["secondary"]["views_per_s"]["per_gpu"].items()} if "views_per_s" in d.get("secondary", {}) else d.get("secondary"))
+PY
+timeout 300 python bench.py --workload optimize > gpurun_out/${R}_bench_optimize.json 2>> gpurun_out/${R}_bench_default.err
+cat gpurun_out/${R}_bench_optimize.json | cut -c1-300
+timeout 900 bash tools/collect_profiles.sh $R > gpurun_out/${R}_collect.log 2>&1
+tail -3 gpurun_out/${R}_collect.log
+(timeout 600 python tools/fuzz_parity.py 150 0; timeout 900 python tools/fuzz_parity.py 40 1 1) > gpurun_out/${R}_fuzz_parity.txt 2>&1
+grep "^cases\|^worst\|Error\|assert" gpurun_out/${R}_fuzz_parity.txt | tail -8

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (not part of the test suite): random image sizes,
 neighbour counts, scales, shading on / off, partially active sets; one Newton
-step on the GPU against the oracle."""
+step and one whole Newton loop on the GPU against the oracle.
+Usage: fuzz_parity.py [cases [seed [big]]] -- big = 1: grids of 5 k .. 60 k
+nodes (scales 1-3, images 300 .. 900 px wide), i.e. 10 .. 120 tiles of the
+resident solver with its grid-wide exchange; default: single-tile grids."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,11 +17,16 @@ def rel(a, b):
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+big = len(sys.argv) > 3 and sys.argv[3] == "1"
+oracle.lib().orc_set_threads(max(1, (os.cpu_count() or 2) // 2))
 worst = dict(H=0, g=0, P=0, x=0)
 for case in range(n_cases):
-    scale = int(rng.integers(1, 6))
+    scale = int(rng.integers(1, 4 if big else 6))
     ps = 1 << scale
-    w = int(rng.integers(6 * ps + 8, 14 * ps + 40)); h = int(rng.integers(5 * ps + 8, 10 * ps + 40))
+    if big:
+        w = int(rng.integers(300, 900)); h = int(rng.integers(200, 700))
+    else:
+        w = int(rng.integers(6 * ps + 8, 14 * ps + 40)); h = int(rng.integers(5 * ps + 8, 10 * ps + 40))
     n_subs = int(rng.integers(1, 9))
     shading = bool(rng.integers(0, 2))
     light_reg = float(rng.choice([0.0, 0.5])) if shading else 0.0
