@@ -75,10 +75,11 @@ int smvs_ctx_synchronize(smvs_ctx *ctx);
  * the same preconditioned CG with the same termination rules (:136-198):
  *   AUTO          the fastest one that applies: the chip-resident solver when
  *                 the node grid fits the chip (<= 256 tiles of <= 512 nodes),
- *                 with ONE grid-wide exchange per iteration (the scalars
- *                 r.r, z.r, x.(b + r) follow by recurrence from six dot
- *                 products taken before the step length is known); otherwise
- *                 the streaming kernels
+ *                 with ONE grid-wide exchange per iteration (eight dot
+ *                 products of the current vectors are reduced before the
+ *                 step length is known; r.r, z.r, x.(b + r) of the updated
+ *                 vectors follow from them one step ahead); otherwise the
+ *                 streaming kernels
  *   STREAMING     assembly kernel + two launches per iteration (csrc/cg.hip);
  *                 any grid size
  *   RESIDENT_REF  the chip-resident solver with the reference's operation

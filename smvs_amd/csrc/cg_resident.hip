@@ -963,16 +963,19 @@ resident_lds_layout(int tw, int th, bool one)
 // r.r, x.(b + r), z.r of the updated vectors: two grid-wide exchanges per
 // iteration (conjugate_gradient.h:121-198 line by line).
 // ONE = true: one exchange per iteration.  Before the step length is known
-// the workgroups reduce six dot products of the CURRENT vectors,
-//   d.q, r.q, q.q, 2 w.r, w.q, d.r, r.r    (q = H d, w = P q),
+// the workgroups reduce eight dot products of the CURRENT vectors,
+//   d.q, r.q, q.q, 2 w.r, w.q, d.r, r.r, z.r    (q = H d, w = P q),
 // from which alpha and the three scalars the reference tests follow exactly
 // (no approximation, only the association of the sums changes):
-//   r'.r'      = r.r - 2 alpha r.q + alpha^2 q.q          (r' = r - alpha q; r.r
-//                                                          taken directly each time)
+//   r'.r'      = r.r - 2 alpha r.q + alpha^2 q.q          (r' = r - alpha q)
 //   z'.r'      = z.r - 2 alpha w.r + alpha^2 w.q          (z' = P r' = z - alpha w;
 //                                                          z.q = w.r, P symmetric)
 //   x'.(b+r')  = x.(b+r) + 2 alpha d.r - alpha^2 d.q      (x' = x + alpha d,
 //                                                          b - r = H x)
+// r.r and z.r are summed directly in every iteration and only extrapolated
+// ONE step (carried by recurrence over a whole solve, z.r kept the absolute
+// rounding errors of its large early values while it shrank by orders of
+// magnitude: iteration counts on ill-conditioned systems moved by up to 10 %).
 // The vectors themselves are updated with the reference's operations (z = P r
 // is recomputed, not taken from the recurrence).  The second grid-wide wait of
 // an iteration -- the z of the neighbouring tiles' rim nodes -- disappears as
@@ -1494,7 +1497,8 @@ cg_resident_kernel(ResArgs A)
         // ---- one exchange per iteration ----
         __syncthreads();          // d_1 (own and halo) in the tile
         stamp(0, 1);
-        double zr = 0.0, xbr = 0.0;   // z.r and x.(b + r) of the current vectors
+        double xbr = 0.0;       // x.(b + r) of the current vectors
+        double zr_part = 0.0;   // this node's z.r, formed where z is (end of the last iteration)
         __amdgpu_buffer_rsrc_t const zbuf = pair_buffer(A.zg, (size_t)A.num_nodes * 64);
         for (int k = 1; alive && k < A.max_iterations; ++k) {
             stamp(k, 0);
@@ -1503,7 +1507,7 @@ cg_resident_kernel(ResArgs A)
             tile_product(G, dtile, yl, fb, hd, hu, low, up, mine, acc, dself);
             stamp(k, 1);
             // the sums (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
-            double v7[7] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+            double v8[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
             // the rim's q for the neighbouring tiles' halo.  It goes out BEFORE
             // the partial sums although the all-reduce waits for those: a
             // write-through store takes ~3 us to become visible to a poll on a
@@ -1528,17 +1532,18 @@ cg_resident_kernel(ResArgs A)
                     wi += p.y * acc[1];
                     wi += p.z * acc[2];
                     wi += p.w * acc[3];
-                    v7[3] += 2.0 * (wi * r[row]);
-                    v7[4] += wi * acc[row];
+                    v8[3] += 2.0 * (wi * r[row]);
+                    v8[4] += wi * acc[row];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    v7[0] += dself[q] * acc[q];
-                    v7[1] += r[q] * acc[q];
-                    v7[2] += acc[q] * acc[q];
-                    v7[5] += dself[q] * r[q];
-                    v7[6] += r[q] * r[q];
+                    v8[0] += dself[q] * acc[q];
+                    v8[1] += r[q] * acc[q];
+                    v8[2] += acc[q] * acc[q];
+                    v8[5] += dself[q] * r[q];
+                    v8[6] += r[q] * r[q];
                 }
+                v8[7] = zr_part;
             }
             publish_rim();
             stamp(k, 2);
@@ -1555,7 +1560,7 @@ cg_resident_kernel(ResArgs A)
                         = (double4_r){ qv[0], qv[1], qv[2], qv[3] };
                 }
             };
-            alive = grid_allreduce_tree<7>(A.ex, ztag, epoch++, nblocks, v7, red, flag,
+            alive = grid_allreduce_tree<8>(A.ex, ztag, epoch++, nblocks, v8, red, flag,
                 [&]() {
                     if (tid < 64) {
                         fetch_halo(tid, 64);
@@ -1571,11 +1576,15 @@ cg_resident_kernel(ResArgs A)
             if (!alive)
                 break;
             stamp(k, 3);
-            double const dq = v7[0], rq = v7[1], qq = v7[2], s1 = v7[3], wq = v7[4],
-                dr = v7[5], rr = v7[6];
+            double const dq = v8[0], rq = v8[1], qq = v8[2], s1 = v8[3], wq = v8[4],
+                dr = v8[5], rr = v8[6];
+            // z.r of the current vectors, summed directly like r.r (d_1 = z_0:
+            // in the first iteration it is d.r); only the values one step ahead
+            // come from the recurrences, so no rounding error is carried from
+            // iteration to iteration
+            double const zr = k == 1 ? dr : v8[7];
             if (k == 1) {
-                // d_1 = z_0: d.r is z.r of the start; r_0 = -g
-                zr = dr;
+                // r_0 = -g
                 st.gnorm = sqrt(rr);
                 st.tol = A.fixed_tolerance < 0.0 ? st.gnorm * 0.01 : A.fixed_tolerance;
             }
@@ -1626,6 +1635,14 @@ cg_resident_kernel(ResArgs A)
                             zi += p.w * r[3];
                             zn[row] = zi;
                         }
+                        {
+                            double t = 0.0;
+                            t += zn[0] * r[0];
+                            t += zn[1] * r[1];
+                            t += zn[2] * r[2];
+                            t += zn[3] * r[3];
+                            zr_part = t;
+                        }
                         dt[lcore] = (double4_r){ zn[0] + beta * dself[0],
                             zn[1] + beta * dself[1], zn[2] + beta * dself[2],
                             zn[3] + beta * dself[3] };
@@ -1659,7 +1676,6 @@ cg_resident_kernel(ResArgs A)
                 }
             }
             stamp(k, 4);
-            zr = new_zr;
             xbr = new_xbr;
             st.rr = new_zr;
             st.q0 = Q1;
