@@ -64,6 +64,8 @@ def test_argument_errors_are_status_codes(lib):
     assert lib.smvs_ctx_destroy(None) == 0
     assert lib.smvs_gn_construct(None, C.c_double(0.1), C.c_double(0.0), None, None) == -1
     assert lib.smvs_cg_solve(None, 200, C.c_double(-1), C.c_double(1e-3), None, None) == -1
+    assert lib.smvs_ctx_sgm_init_depth(None, None, 0, 0, C.c_float(5.0), 5, None) == -1
+    assert lib.smvs_topology_subviews(None, None, 0, None) == -1
 
 
 def test_no_gpu_fails_loudly(lib):
