@@ -423,10 +423,10 @@ def secondary_workloads(args):
     cells = sw * sh * 128
     names = ["census", "warp", "cost", "paths", "wta", "lr_check", "merge", "bilateral"]
     # algorithmic HBM bytes per launch (one run_sgm at sw x sh x 128):
-    bytes_per = dict(paths=cells * (8 * 1 + 8 * 4),   # 8 cost reads + 8 x (2 B read + 2 B write) of S
+    bytes_per = dict(paths=cells * (8 * 1 + 8 * 1),   # per direction: cost in, path byte (L - C) out
                      cost=cells * 2,                   # warped plane in, cost out
                      warp=cells * 1,                   # warped plane out (neighbour image cached)
-                     wta=cells * 2)                    # S in
+                     wta=cells * 9)                    # cost + eight path bytes in (S = 8 C + sum, on the fly)
     sgm = {}
     for i, nme in enumerate(names):
         if cnt[i] == 0:
@@ -441,9 +441,9 @@ def secondary_workloads(args):
         sgm[nme] = line
     out["sgm_front_end"] = dict(kernels=sgm, size=[sw, sh, 128],
         note="HIP-event times of one reconstruct_sgm_depth_for_view (4 x run_sgm); "
-             "algorithmic bytes per launch: paths 8 cost reads + 8 read-modify-writes of "
-             "the u16 S entry (through u32 atomics on packed pairs) per cell, cost 1 B in + 1 B out, warp "
-             "1 B out, wta 2 B in per cell")
+             "algorithmic bytes per launch: paths 8 x (1 B cost in + 1 B path byte out) per "
+             "cell, wta (sum of the eight path bytes + 8 C, winner-takes-all) 9 B in per cell, "
+             "cost 1 B in + 1 B out, warp 1 B out")
     return out
 
 def optimize_workload(args):

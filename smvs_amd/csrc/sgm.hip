@@ -62,62 +62,88 @@ struct WarpArgs {
     uint8_t *warped;   // [h][w][D]
 };
 
-// sgm_stereo.cc:150-190, one thread per (pixel, plane): a wave is 64 planes
-// of one pixel, a workgroup 4 pixels of a row; grid x = plane chunks x pixel
-// groups, grid y = image row (no per-thread division: the 64-bit quotients of
-// a flat index cost more than the sample itself).
-constexpr int WARP_PIXELS = 4;
+// sgm_stereo.cc:150-190.  One wavefront = 64 pixels of a row x 64 planes: a
+// lane keeps its pixel's M p (plane independent) and walks the planes, so the
+// 64 samples of an instruction are neighbours in the neighbour image; the
+// bytes go through an LDS tile [pixel][plane] and leave as 64 contiguous
+// bytes per pixel.  (One thread per (pixel, plane) spent twice the
+// instructions: M p, the plane's depth and the address arithmetic per sample.)
+constexpr int WARP_TILE = 64;            // pixels and planes per wave
+constexpr int WARP_PITCH = WARP_TILE + 4;   // bytes per pixel row of the tile (17 dwords: no bank conflicts)
 
-__global__ void __launch_bounds__(64 * WARP_PIXELS)
+__global__ void __launch_bounds__(WARP_TILE)
 warp_kernel(WarpArgs A)
 {
 #pragma clang fp contract(off)
-    int const chunks = (A.D + 63) >> 6;
-    int const group = (int)blockIdx.x / chunks;
-    int const d = ((int)blockIdx.x - group * chunks) * 64 + (int)threadIdx.x;
-    int const x = group * WARP_PIXELS + (int)threadIdx.y;
+    __shared__ uint8_t tile[WARP_TILE * WARP_PITCH];
+    int const lane = (int)threadIdx.x;
+    int const x0 = (int)blockIdx.x * WARP_TILE;
+    int const x = x0 + lane;
     int const y = (int)blockIdx.y;
-    if (d >= A.D || x >= A.w)
-        return;
-    size_t const gid = ((size_t)y * A.w + x) * A.D + d;
-    float const px = 0.5f + (float)x, py = 0.5f + (float)y;
-    float tp[3];
+    int const dbase = (int)blockIdx.z * WARP_TILE;
+    int const nd = min(WARP_TILE, A.D - dbase);
+    if (x < A.w) {
+        float const px = 0.5f + (float)x, py = 0.5f + (float)y;
+        float tp[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        float s = 0.0f;
-        s += A.M[3 * r + 0] * px;
-        s += A.M[3 * r + 1] * py;
-        s += A.M[3 * r + 2] * 1.f;
-        tp[r] = s;
-    }
-    float const depth = A.depths[d];
-    float p0 = tp[0] * depth + A.t[0];
-    float p1 = tp[1] * depth + A.t[1];
-    float const p2 = tp[2] * depth + A.t[2];
-    uint8_t out = 0;
-    if (!(p2 < 0)) {
-        p0 /= p2;
-        p1 /= p2;
-        p0 -= 0.5f;
-        p1 -= 0.5f;
-        if (!(p0 < 0 || p1 < 0 || p0 > (float)(A.nw - 1)
-                || p1 > (float)(A.nh - 1))) {
-            // mve::Image<uint8_t>::linear_at [MVE-unverified]
-            float fx = fmaxf(0.0f, fminf((float)(A.nw - 1), p0));
-            float fy = fmaxf(0.0f, fminf((float)(A.nh - 1), p1));
-            int const ix = (int)fx, iy = (int)fy;
-            int const ix1 = min(ix + 1, A.nw - 1), iy1 = min(iy + 1, A.nh - 1);
-            float const w1 = fx - (float)ix, w0 = 1.0f - w1;
-            float const w3 = fy - (float)iy, w2 = 1.0f - w3;
-            float const v1 = (float)A.neighbor[(size_t)iy * A.nw + ix];
-            float const v2 = (float)A.neighbor[(size_t)iy * A.nw + ix1];
-            float const v3 = (float)A.neighbor[(size_t)iy1 * A.nw + ix];
-            float const v4 = (float)A.neighbor[(size_t)iy1 * A.nw + ix1];
-            out = (uint8_t)(v1 * (w0 * w2) + v2 * (w1 * w2) + v3 * (w0 * w3)
-                + v4 * (w1 * w3) + 0.5f);
+        for (int r = 0; r < 3; ++r) {
+            float s = 0.0f;
+            s += A.M[3 * r + 0] * px;
+            s += A.M[3 * r + 1] * py;
+            s += A.M[3 * r + 2] * 1.f;
+            tp[r] = s;
+        }
+        float const xmax = (float)(A.nw - 1), ymax = (float)(A.nh - 1);
+#pragma unroll 4
+        for (int dd = 0; dd < nd; ++dd) {
+            float const depth = A.depths[dbase + dd];
+            float p0 = tp[0] * depth + A.t[0];
+            float p1 = tp[1] * depth + A.t[1];
+            float const p2 = tp[2] * depth + A.t[2];
+            uint8_t out = 0;
+            if (!(p2 < 0)) {
+                p0 /= p2;
+                p1 /= p2;
+                p0 -= 0.5f;
+                p1 -= 0.5f;
+                if (!(p0 < 0 || p1 < 0 || p0 > xmax || p1 > ymax)) {
+                    // mve::Image<uint8_t>::linear_at [MVE-unverified]
+                    float const fx = fmaxf(0.0f, fminf(xmax, p0));
+                    float const fy = fmaxf(0.0f, fminf(ymax, p1));
+                    int const ix = (int)fx, iy = (int)fy;
+                    int const ix1 = min(ix + 1, A.nw - 1), iy1 = min(iy + 1, A.nh - 1);
+                    float const w1 = fx - (float)ix, w0 = 1.0f - w1;
+                    float const w3 = fy - (float)iy, w2 = 1.0f - w3;
+                    const uint8_t *r0 = A.neighbor + (size_t)iy * A.nw;
+                    const uint8_t *r1 = A.neighbor + (size_t)iy1 * A.nw;
+                    float const v1 = (float)r0[ix];
+                    float const v2 = (float)r0[ix1];
+                    float const v3 = (float)r1[ix];
+                    float const v4 = (float)r1[ix1];
+                    out = (uint8_t)(v1 * (w0 * w2) + v2 * (w1 * w2) + v3 * (w0 * w3)
+                        + v4 * (w1 * w3) + 0.5f);
+                }
+            }
+            tile[lane * WARP_PITCH + dd] = out;
         }
     }
-    A.warped[gid] = out;
+    __syncthreads();
+    // 16 lanes x 4 bytes per pixel, 4 pixels per sweep
+    bool const quads = (A.D & 3) == 0;
+    for (int idx = lane; idx < WARP_TILE * (WARP_TILE / 4); idx += WARP_TILE) {
+        int const pix = idx >> 4, q = idx & 15;
+        int const gx = x0 + pix, dd = 4 * q;
+        if (gx >= A.w || dd >= nd)
+            continue;
+        size_t const o = ((size_t)y * A.w + gx) * A.D + dbase + dd;
+        const uint8_t *src = tile + pix * WARP_PITCH + dd;
+        if (quads) {
+            *reinterpret_cast<uint32_t *>(A.warped + o) = *reinterpret_cast<const uint32_t *>(src);
+        } else {
+            for (int k = 0; k < 4 && dd + k < nd; ++k)
+                A.warped[o + k] = src[k];
+        }
+    }
 }
 
 // Cost volume (sgm_stereo.cc:192-244): census of the warped planes + Hamming
@@ -205,6 +231,8 @@ struct PathArgs {
     uint32_t p1, p2;
     int first;         // 1: S is written, not accumulated
     int last;          // 1: last path, fuse the winner-takes-all
+    uint8_t *delta;    // all-paths kernel, DELTA form: eight [h][w][D] u8 volumes
+    size_t vol;        // bytes of one of them
 };
 
 // Wave-wide unsigned minimum with DPP row operations (VALU latency instead of
@@ -394,7 +422,17 @@ path_line(PathArgs const &A, int line, int *x, int *y, int *len, int *extra)
 // is bit-exact for any interleaving.  ~9000 wavefronts instead of <= 1500 per
 // launch, and the wall time is the longest line instead of the sum over
 // directions.  S must be zeroed first.
-template <int K>
+//
+// DELTA form (penalty2 <= 255): what a path adds to S at a pixel is
+// L = C + (u - min_prev) with 0 <= u - min_prev <= P2 (sgm_stereo.cc:310-346:
+// u is the minimum of terms that are all >= min_prev, one of them min_prev +
+// P2), and C -- or 2 C at a doubly seeded corner -- at the start of a line.
+// So every direction stores L - C as ONE BYTE per cell into its own volume
+// with plain coalesced stores (each cell lies on exactly one line per
+// direction: no atomics, no zero fill) and sgm_sum_wta_kernel forms
+// S = 8 C + the eight bytes on the fly: 16 + 9 bytes per cost cell instead of
+// 8 x (1 + 4) + 2 with the read-modify-writes of the u16 volume.
+template <int K, bool DELTA>
 __global__ void __launch_bounds__(64)
 sgm_all_paths_kernel(PathArgs A)
 {
@@ -432,9 +470,18 @@ sgm_all_paths_kernel(PathArgs A)
     int const pairs = D >> 1;
     bool const ok = lane < pairs;
     int const li = ok ? lane : 0;
-    const uint16_t *__restrict__ C16 = reinterpret_cast<const uint16_t *>(A.cost);
-    uint32_t *__restrict__ S32 = reinterpret_cast<uint32_t *>(A.sgm);
-    uint32_t const BIG = 0xFFFFu;
+    // The line as two running pointers (cost in, path bytes / S out): the
+    // cell of step s is `step` u16 pairs behind the cell of step s - 1.
+    size_t const o0 = (((size_t)y0 * w + x0) * D >> 1) + li;
+    ptrdiff_t const step = ((ptrdiff_t)A.dy * w + A.dx) * D / 2;
+    const uint16_t *__restrict__ cin = reinterpret_cast<const uint16_t *>(A.cost) + o0;
+    uint32_t *__restrict__ s32 = reinterpret_cast<uint32_t *>(A.sgm) + o0;
+    uint16_t *__restrict__ e16
+        = reinterpret_cast<uint16_t *>(A.delta + (size_t)dir * A.vol) + o0;
+    // "no such plane" / "lane without planes": above every path cost
+    // (L <= 255 + P2 < 2^15 by check_sgm_options), and BIG + P1 still fits 16
+    // bits, so no sum below needs a mask
+    uint32_t const BIG = 0x7FFFu;
     uint32_t prev0 = BIG, prev1 = BIG;
 
     uint32_t c_cur[K], c_next[K], addv[K];
@@ -442,62 +489,66 @@ sgm_all_paths_kernel(PathArgs A)
     for (int k = 0; k < K; ++k) {
         c_cur[k] = 0;
         if (k < len)
-            c_cur[k] = C16[(((size_t)(y0 + k * A.dy) * w + (x0 + k * A.dx)) * D >> 1) + li];
+            c_cur[k] = cin[(ptrdiff_t)k * step];
     }
+    cin += (ptrdiff_t)K * step;
     for (int base = 0; base < len; base += K) {
         int const n = min(K, len - base);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             c_next[k] = 0;
-            int const s = base + K + k;
-            if (s < len)
-                c_next[k] = C16[(((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li];
+            if (base + K + k < len)
+                c_next[k] = cin[(ptrdiff_t)k * step];
         }
+        cin += (ptrdiff_t)K * step;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             addv[k] = 0;
             if (k < n) {
                 int const s = base + k;
                 uint32_t const c0 = c_cur[k] & 0xFFu, c1 = c_cur[k] >> 8;
-                uint32_t l0, l1;
+                uint32_t e0, e1;     // what the path adds beyond C
                 if (s == 0) {
-                    l0 = c0;
-                    l1 = c1;
+                    // sgm_stereo.cc:457-464: the line starts with L = C; a corner
+                    // that is seeded from its row and from its column adds C twice
+                    e0 = extra_seed ? c0 : 0u;
+                    e1 = extra_seed ? c1 : 0u;
+                    prev0 = c0;
+                    prev1 = c1;
                 } else {
+                    // :310-346: L = C + min(L'(d), L'(d -+ 1) + P1, min L' + P2) - min L'
                     uint32_t const mn = wave_min_u32(min(prev0, prev1));
                     uint32_t const left = lane_prev(prev1, BIG);
                     uint32_t const right = lane_next(prev0, BIG);
-                    uint32_t const far = (mn + A.p2) & 0xFFFFu;
-                    uint32_t u0 = prev0;
-                    u0 = min(u0, left == BIG ? BIG : ((left + A.p1) & 0xFFFFu));
-                    u0 = min(u0, (prev1 + A.p1) & 0xFFFFu);
-                    u0 = min(u0, far);
-                    uint32_t u1 = prev1;
-                    u1 = min(u1, (prev0 + A.p1) & 0xFFFFu);
-                    u1 = min(u1, right == BIG ? BIG : ((right + A.p1) & 0xFFFFu));
-                    u1 = min(u1, far);
-                    l0 = (c0 + u0 - mn) & 0xFFFFu;
-                    l1 = (c1 + u1 - mn) & 0xFFFFu;
+                    uint32_t const far = mn + A.p2;
+                    uint32_t const u0 = min(min(prev0, left + A.p1), min(prev1 + A.p1, far));
+                    uint32_t const u1 = min(min(prev1, prev0 + A.p1), min(right + A.p1, far));
+                    e0 = u0 - mn;
+                    e1 = u1 - mn;
+                    prev0 = c0 + e0;
+                    prev1 = c1 + e1;
                 }
-                uint32_t add0 = l0, add1 = l1;
-                if (s == 0 && extra_seed) {
-                    add0 = (2 * c0) & 0xFFFFu;
-                    add1 = (2 * c1) & 0xFFFFu;
-                }
-                addv[k] = add0 | (add1 << 16);
-                prev0 = ok ? l0 : BIG;
-                prev1 = ok ? l1 : BIG;
+                if (DELTA)
+                    addv[k] = e0 | (e1 << 8);
+                else
+                    addv[k] = (c0 + e0) | ((c1 + e1) << 16);
+                if (!ok)
+                    prev0 = prev1 = BIG;
             }
         }
+        if (ok) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k < n && ok) {
-                int const s = base + k;
-                size_t const o = (((size_t)(y0 + s * A.dy) * w + (x0 + s * A.dx)) * D >> 1) + li;
-                (void)__hip_atomic_fetch_add(&S32[o], addv[k], __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int k = 0; k < K; ++k)
+                if (k < n) {
+                    if (DELTA)
+                        e16[(ptrdiff_t)k * step] = (uint16_t)addv[k];
+                    else
+                        (void)__hip_atomic_fetch_add(&s32[(ptrdiff_t)k * step], addv[k],
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
         }
+        e16 += (ptrdiff_t)K * step;
+        s32 += (ptrdiff_t)K * step;
 #pragma unroll
         for (int k = 0; k < K; ++k)
             c_cur[k] = c_next[k];
@@ -527,6 +578,66 @@ wta_rows_kernel(const uint16_t *__restrict__ sgm,
     key = min(key, SMVS_DPP(key, 0x118));
 #undef SMVS_DPP
     if (sub == 15 && p < npix) {
+        int const min_index = (int)(key & 0xFFu);
+        if (argmin != nullptr)
+            argmin[p] = min_index;
+        if (depth != nullptr)
+            depth[p] = (min_index < 2 || main_img[p] < 25) ? 0.0f
+                : depths[min_index];
+    }
+}
+
+// S = 8 C + the eight path bytes of the DELTA form, and the winner-takes-all of
+// wta_rows_kernel on it, 32 lanes per pixel with four planes each (one u32
+// per volume and lane).  S itself is only written when the caller wants the
+// volume (smvs_sgm_run's `sgm` output).
+__global__ void __launch_bounds__(256)
+sgm_sum_wta_kernel(const uint8_t *__restrict__ cost, const uint8_t *__restrict__ delta,
+    size_t vol, const uint8_t *__restrict__ main_img, const float *__restrict__ depths,
+    size_t npix, int D, float *__restrict__ depth, int32_t *__restrict__ argmin,
+    uint16_t *__restrict__ sgm_out)
+{
+    size_t const p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    int const sub = threadIdx.x & 31;
+    int const d0 = 4 * sub;
+    uint32_t key = 0xFFFFFFFFu;
+    if (p < npix && d0 < D) {
+        size_t const o = p * (size_t)D + d0;   // D % 4 == 0: aligned u32
+        uint32_t const c = *reinterpret_cast<const uint32_t *>(cost + o);
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            e[k] = *reinterpret_cast<const uint32_t *>(delta + (size_t)k * vol + o);
+        uint32_t sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t sum = 8u * ((c >> (8 * j)) & 0xFFu);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                sum += (e[k] >> (8 * j)) & 0xFFu;
+            sv[j] = sum & 0xFFFFu;
+            key = min(key, sv[j] * 256u + (uint32_t)(d0 + j));
+        }
+        if (sgm_out != nullptr) {
+            uint2 const packed = make_uint2(sv[0] | (sv[1] << 16), sv[2] | (sv[3] << 16));
+            *reinterpret_cast<uint2 *>(sgm_out + o) = packed;
+        }
+    }
+    // minimum over the 32 lanes of the pixel: inside the rows of 16 by DPP
+    // shifts, then across the two rows
+    uint32_t const ident = 0xFFFFFFFFu;
+#define SMVS_DPP(x, ctrl)                                                     \
+    (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)(x), ctrl, 0xf,   \
+        0xf, false)
+    key = min(key, SMVS_DPP(key, 0x111));
+    key = min(key, SMVS_DPP(key, 0x112));
+    key = min(key, SMVS_DPP(key, 0x114));
+    key = min(key, SMVS_DPP(key, 0x118));
+#undef SMVS_DPP
+    // lanes 15 and 31 of the pixel hold the row minima
+    uint32_t const other = (uint32_t)__shfl_xor((int)key, 16);
+    key = min(key, other);
+    if (sub == 31 && p < npix) {
         int const min_index = (int)(key & 0xFFu);
         if (argmin != nullptr)
             argmin[p] = min_index;
@@ -725,7 +836,8 @@ enum {
     WS_DEPTHS = 0, WS_CENSUS, WS_WARPED, WS_COST, WS_SGM, WS_ARGMIN,   // one run_sgm
     WS_MAIN, WS_NBR0, WS_NBR1, WS_FWD0, WS_FWD1, WS_BWD, WS_COST16,   // a view's front end
     WS_RAW, WS_RAW0, WS_RAW1,                                         // raw u8 images + scratch
-    WS_BIL_DM, WS_BIL_CI, WS_BIL_OUT                                  // bilateral upsample
+    WS_BIL_DM, WS_BIL_CI, WS_BIL_OUT,                                 // bilateral upsample
+    WS_DELTA                                                          // eight path-byte volumes
 };
 
 // Work buffers of one run_sgm inside a pooled workspace; reused by the runs of
@@ -738,20 +850,32 @@ struct SgmWorkspace {
     float *depths = nullptr;
     unsigned long long *census = nullptr;
     uint8_t *warped = nullptr, *cost = nullptr;
-    uint16_t *sgm = nullptr;
+    uint16_t *sgm = nullptr;     // S: only when the caller wants it or the DELTA form does not apply
+    uint8_t *delta = nullptr;    // the eight path-byte volumes of the DELTA form
     int32_t *argmin = nullptr;
     int runs = 0;
+    bool want_sgm = false;       // smvs_sgm_run hands the S volume to its caller
     explicit SgmWorkspace(Workspace *w) : ws(w) {}
-    int ensure(size_t npix, int num_steps)
+    // penalty2 <= 255: L - C fits a byte; planes in fours: the u32 accesses of
+    // sgm_sum_wta_kernel
+    static bool delta_form(int num_steps, unsigned penalty2)
+    {
+        return (num_steps % 4) == 0 && penalty2 <= 255u;
+    }
+    int ensure(size_t npix, int num_steps, unsigned penalty2)
     {
         size_t const vol = npix * (size_t)num_steps;
+        bool const df = delta_form(num_steps, penalty2);
         int rc;
         if ((rc = ws->ensure(WS_DEPTHS, (size_t)128 * MAX_RUNS, &depths))
             || (rc = ws->ensure(WS_CENSUS, npix, &census))
             || (rc = ws->ensure(WS_WARPED, vol, &warped))
             || (rc = ws->ensure(WS_COST, vol, &cost))
-            || (rc = ws->ensure(WS_SGM, vol, &sgm))
             || (rc = ws->ensure(WS_ARGMIN, npix, &argmin)))
+            return rc;
+        if (df && (rc = ws->ensure(WS_DELTA, 8 * vol, &delta)))
+            return rc;
+        if ((!df || want_sgm) && (rc = ws->ensure(WS_SGM, vol, &sgm)))
             return rc;
         return SMVS_OK;
     }
@@ -791,7 +915,7 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     hipStream_t const stream = B.ws->stream;
     size_t const npix = (size_t)w * h;
     size_t const vol = npix * num_steps;
-    if ((rc = B.ensure(npix, num_steps)) != SMVS_OK)
+    if ((rc = B.ensure(npix, num_steps, penalty2)) != SMVS_OK)
         return rc;
     // sgm_stereo.cc:195-203: inverse-depth planes by repeated float addition
     float depths[128];
@@ -827,10 +951,9 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     W.warped = B.warped;
     {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_WARP);
-        unsigned const chunks = (unsigned)((num_steps + 63) / 64);
-        unsigned const groups = (unsigned)((w + WARP_PIXELS - 1) / WARP_PIXELS);
-        hipLaunchKernelGGL(warp_kernel, dim3(chunks * groups, (unsigned)h),
-            dim3(64, WARP_PIXELS), 0, stream, W);
+        hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((w + WARP_TILE - 1) / WARP_TILE),
+            (unsigned)h, (unsigned)((num_steps + WARP_TILE - 1) / WARP_TILE)),
+            dim3(WARP_TILE), 0, stream, W);
     }
     {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_COST);
@@ -855,13 +978,23 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     P.p1 = penalty1;
     P.p2 = penalty2;
     P.last = 0;
-    if ((num_steps % 2) == 0) {
+    P.delta = B.delta;
+    P.vol = vol;
+    bool const df = SgmWorkspace::delta_form(num_steps, penalty2);
+    if (df) {
+        P.dx = P.dy = 0;
+        P.first = 0;
+        int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_PATHS);
+        hipLaunchKernelGGL((sgm_all_paths_kernel<16, true>), dim3(lines), dim3(64), 0,
+            stream, P);
+    } else if ((num_steps % 2) == 0) {
         SMVS_HIP_CHECK(hipMemsetAsync(B.sgm, 0, sizeof(uint16_t) * vol, stream));
         P.dx = P.dy = 0;
         P.first = 0;
         int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_PATHS);
-        hipLaunchKernelGGL((sgm_all_paths_kernel<16>), dim3(lines), dim3(64), 0,
+        hipLaunchKernelGGL((sgm_all_paths_kernel<16, false>), dim3(lines), dim3(64), 0,
             stream, P);
     } else {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_PATHS);
@@ -878,10 +1011,16 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     SMVS_HIP_CHECK(hipGetLastError());
     {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_WTA);
-        hipLaunchKernelGGL(wta_rows_kernel,
-            dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
-            B.sgm, d_main, d_depths, npix, num_steps, d_depth,
-            B.argmin);
+        if (df)
+            hipLaunchKernelGGL(sgm_sum_wta_kernel,
+                dim3((unsigned)((npix * 32 + 255) / 256)), dim3(256), 0, stream,
+                B.cost, B.delta, vol, d_main, d_depths, npix, num_steps, d_depth,
+                B.argmin, B.want_sgm ? B.sgm : nullptr);
+        else
+            hipLaunchKernelGGL(wta_rows_kernel,
+                dim3((unsigned)((npix * 16 + 255) / 256)), dim3(256), 0, stream,
+                B.sgm, d_main, d_depths, npix, num_steps, d_depth,
+                B.argmin);
     }
     SMVS_HIP_CHECK(hipGetLastError());
     return SMVS_OK;
@@ -913,6 +1052,7 @@ smvs_sgm_run(int device, const uint8_t *main_img, int w, int h,
     SgmProfile prof;
     SgmWorkspace B(&ws);
     B.prof = &prof;
+    B.want_sgm = sgm != nullptr;
     uint8_t *d_main = nullptr, *d_nbr = nullptr;
     float *d_depth = nullptr;
     if ((rc = ws.ensure(WS_MAIN, npix, &d_main)) || (rc = ws.ensure(WS_NBR0, nnpix, &d_nbr))
@@ -1080,7 +1220,7 @@ sgm_depth_for_view_impl(int device, const uint8_t *main_img, int w, int h,
             return rc;
     }
     if ((rc = ws.ensure(WS_BWD, max_nnpix, &d_bwd))
-        || (rc = B.ensure(npix > max_nnpix ? npix : max_nnpix, num_steps)))
+        || (rc = B.ensure(npix > max_nnpix ? npix : max_nnpix, num_steps, penalty2)))
         return rc;
     for (int k = 0; k < n_neighbors; ++k) {
         smvs_sgm_neighbor const &N = neighbors[k];

@@ -213,22 +213,31 @@ def _sgm_pair(w, h, seed):
     return main, nbr, M, t
 
 
-@pytest.mark.parametrize("w,h,D", [(96, 64, 128), (71, 45, 128), (64, 40, 37)])
-def test_sgm_bit_exact(hip, oracle, w, h, D):
+@pytest.mark.parametrize("w,h,D,p1,p2", [(96, 64, 128, 6, 96), (71, 45, 128, 6, 96),
+                                          (64, 40, 37, 6, 96),       # odd plane count: one launch per direction
+                                          (80, 56, 64, 10, 255),     # the largest penalty the byte form takes
+                                          (80, 56, 64, 10, 300),     # above it: u16 volume, atomics
+                                          (72, 48, 62, 6, 96),       # even, not a multiple of 4: atomics
+                                          (150, 41, 20, 3, 40)])
+def test_sgm_bit_exact(hip, oracle, w, h, D, p1, p2):
     """cost volume, aggregated volume, argmin and depth map are bit-exact
     with the oracle (sgm_stereo.cc:98-306), ragged sizes and odd plane counts
-    included."""
+    included; every form of the aggregation (path bytes summed on the fly,
+    u16 volume with atomics, one launch per direction)."""
     main, nbr, M, t = _sgm_pair(w, h, seed=w)
-    out = hip.sgm_run(main, nbr, M, t, 1.0, 12.0, D, 6, 96, want_volumes=True)
+    out = hip.sgm_run(main, nbr, M, t, 1.0, 12.0, D, p1, p2, want_volumes=True)
     depths = oracle.sgm_depths(1.0, 12.0, D)
     cost = oracle.sgm_cost_volume(main, nbr, M, t, depths)
     assert np.array_equal(out["cost"], cost)
-    sgm = oracle.sgm_aggregate(cost, 6, 96)
+    sgm = oracle.sgm_aggregate(cost, p1, p2)
     assert np.array_equal(out["sgm"], sgm)
     depth, argmin = oracle.sgm_depth_from_volume(sgm, main, depths)
     assert np.array_equal(out["argmin"], argmin)
     assert np.array_equal(out["depth"], depth)
     assert (depth > 0).sum() > 0
+    # the same call without the volumes (S is then never formed in memory)
+    lean = hip.sgm_run(main, nbr, M, t, 1.0, 12.0, D, p1, p2)
+    assert np.array_equal(lean["depth"], depth)
 
 
 def test_sgm_rejects_bad_arguments(hip):
