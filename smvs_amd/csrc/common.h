@@ -192,6 +192,7 @@ struct smvs_ctx {
     bool sgm_resident = false;   // topo_sgm holds smvs_ctx_sgm_init_depth's result
     float *sgm_lowres = nullptr; // its input, SGM resolution
     size_t sgm_lowres_cap = 0;
+    float *bil_lut = nullptr;    // compressed colour-weight table of the bilateral filter (sgm.hip)
     smvs_topo::NccSample *topo_ncc = nullptr;
     int topo_ncc_off[33] = { 0 };
     int topo_ncc_ps = 0;

@@ -332,6 +332,8 @@ ctx_free(smvs_ctx *ctx)
         (void)hipFree(ctx->topo_sgm);
     if (ctx->sgm_lowres)
         (void)hipFree(ctx->sgm_lowres);
+    if (ctx->bil_lut)
+        (void)hipFree(ctx->bil_lut);
     if (ctx->topo_ncc)
         (void)hipFree(ctx->topo_ncc);
     if (ctx->topo_mse)

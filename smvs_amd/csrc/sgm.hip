@@ -22,6 +22,8 @@
 // read-modify-writes S once.
 #include "common.h"
 
+#include <mutex>
+
 #include <cmath>
 #include <vector>
 
@@ -713,6 +715,128 @@ bilateral_kernel(BilateralArgs A)
     A.out[(size_t)y * A.w + x] = acc_w > 0 ? acc_v / acc_w : 0.0f;
 }
 
+// The same filter when the guidance image is a byte image divided by 255 (the
+// main image a context holds): the colour weight of a tap is a function of the
+// two bytes only.  The HOST evaluates the reference's own float expression
+// with expf for all 256 x 256 pairs (math::gaussian is std::exp on floats, and
+// glibc's expf is not correctly rounded in ~0.3 % of its arguments, so only the
+// host's own values give the CPU path's weights bit for bit) and compresses
+// them for LDS: the weight depends on the pair almost only through the
+// difference d = tap - centre -- the float rounding of the two quotients
+// leaves at most four distinct values per d -- so the table is 511 x 4 floats
+// plus a 2-bit selector per pair: 24 KB.  No exponential on the device; the
+// spatial weights of the (2 k + 1)^2 taps are kernel arguments.
+constexpr int BIL_MAX_K = 7;
+constexpr int BIL_VALS = 2048;            // 511 differences x 4 candidates (floats)
+constexpr int BIL_SEL = 65536 / 16;       // 2-bit selectors, 16 per word
+constexpr int BIL_TABLE_WORDS = BIL_VALS + BIL_SEL;
+struct BilateralSpatial { float w[(2 * BIL_MAX_K + 1) * (2 * BIL_MAX_K + 1)]; };
+
+// f = (float)b / 255.0f is inverted exactly by rounding f * 255
+__global__ void __launch_bounds__(256)
+float_to_byte_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, size_t n)
+{
+#pragma clang fp contract(off)
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = (uint8_t)(in[i] * 255.0f + 0.5f);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+bilateral_table_kernel(BilateralArgs A, const uint8_t *__restrict__ ci8,
+    const uint32_t *__restrict__ table, BilateralSpatial S)
+{
+#pragma clang fp contract(off)
+    __shared__ uint32_t lds[BIL_TABLE_WORDS];
+    for (int i = threadIdx.x; i < BIL_TABLE_WORDS; i += 256)
+        lds[i] = table[i];
+    __syncthreads();
+    const float *vals = reinterpret_cast<const float *>(lds);
+    const uint32_t *sel = lds + BIL_VALS;
+    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    int const y = blockIdx.y;
+    if (x >= A.w)
+        return;
+    float const scale_x = (float)A.dm_w / (float)A.w;
+    float const scale_y = (float)A.dm_h / (float)A.h;
+    int const ks = A.kernel_size, kw = 2 * ks + 1;
+    unsigned centre[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        centre[c] = ci8[((size_t)y * A.w + x) * C + c];
+    float acc_v = 0.0f, acc_w = 0.0f;
+    for (int ky = -ks; ky <= ks; ++ky) {
+        int const ci_y = min(max(y + ky, 0), A.h - 1);
+        float fy = scale_y * (float)ci_y;
+        fy = fminf(fmaxf(fy, 0.f), (float)A.dm_h - 1.f);
+        const float *dm_row = A.dm + (size_t)(int)fy * A.dm_w;
+        const uint8_t *ci_row = ci8 + (size_t)ci_y * A.w * C;
+        for (int kx = -ks; kx <= ks; ++kx) {
+            int const ci_x = min(max(x + kx, 0), A.w - 1);
+            float fx = scale_x * (float)ci_x;
+            fx = fminf(fmaxf(fx, 0.f), (float)A.dm_w - 1.f);
+            float const dv = dm_row[(int)fx];
+            if (dv == 0.0f)
+                continue;
+            float weight = 1.0f;
+            weight *= S.w[(ky + ks) * kw + (kx + ks)];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                unsigned const b = ci_row[ci_x * C + c];
+                unsigned const pair = (centre[c] << 8) | b;
+                unsigned const which = (sel[pair >> 4] >> ((pair & 15u) * 2u)) & 3u;
+                weight *= vals[((b + 255u - centre[c]) << 2) | which];
+            }
+            acc_v += dv * weight;
+            acc_w += weight;
+        }
+    }
+    A.out[(size_t)y * A.w + x] = acc_w > 0 ? acc_v / acc_w : 0.0f;
+}
+
+// The compressed colour-weight table, or nullptr when some difference has
+// more than four distinct weights (another libm: the exponentials are then
+// taken on the device as in bilateral_kernel).
+static const uint32_t *
+bilateral_colour_table(void)
+{
+#pragma clang fp contract(off)
+    static std::vector<uint32_t> table;
+    static bool usable = false;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        std::vector<uint32_t> t(BIL_TABLE_WORDS, 0u);
+        int count[511] = { 0 };
+        bool ok = true;
+        for (int a = 0; a < 256 && ok; ++a)
+            for (int b = 0; b < 256; ++b) {
+                // gaussian(tap - centre, 0.1) as the reference evaluates it on floats
+                float const diff = (float)b / 255.0f - (float)a / 255.0f;
+                float const wgt = expf(-(diff * diff) / (2.0f * 0.1f * 0.1f));
+                uint32_t bits;
+                memcpy(&bits, &wgt, sizeof(bits));
+                int const d = b + 255 - a;
+                int k = 0;
+                while (k < count[d] && t[(size_t)d * 4 + k] != bits)
+                    k += 1;
+                if (k == count[d]) {
+                    if (k == 4) {
+                        ok = false;
+                        break;
+                    }
+                    t[(size_t)d * 4 + k] = bits;
+                    count[d] += 1;
+                }
+                unsigned const pair = ((unsigned)a << 8) | (unsigned)b;
+                t[BIL_VALS + (pair >> 4)] |= (uint32_t)k << ((pair & 15u) * 2u);
+            }
+        usable = ok;
+        table.swap(t);
+    });
+    return usable ? table.data() : nullptr;
+}
+
 // ------------------------------------------------------- L/R check + merge
 // SGMStereo::reconstruct, sgm_stereo.cc:64-91: the main view's depth is kept
 // where its correspondence in the neighbour (integer pixel coordinates, no
@@ -1382,10 +1506,52 @@ smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
     A.kernel_size = kernel_size;
     A.sigma = sigma;
     SgmProfile prof;
+    const uint32_t *host_table = nullptr;
+    if (kernel_size <= BIL_MAX_K && (A.channels == 1 || A.channels == 3))
+        host_table = bilateral_colour_table();
+    bool const tabled = host_table != nullptr;
+    BilateralSpatial S = {};
+    size_t const n_img = n * (size_t)A.channels;
+    if (tabled) {
+#pragma clang fp contract(off)
+        if (ctx->bil_lut == nullptr) {
+            if ((rc = device_alloc(&ctx->bil_lut, BIL_TABLE_WORDS)) != SMVS_OK
+                || (rc = ctx_upload(ctx, ctx->bil_lut, host_table,
+                        BIL_TABLE_WORDS * sizeof(uint32_t))) != SMVS_OK)
+                return rc;
+        }
+        // (the byte staging buffer of the image uploads is free between them)
+        if (ctx->byte_stage_cap < n_img) {
+            if ((rc = device_alloc(&ctx->byte_stage, n_img)) != SMVS_OK) {
+                ctx->byte_stage_cap = 0;
+                return rc;
+            }
+            ctx->byte_stage_cap = n_img;
+        }
+        // math::gaussian_2d as bilateral_kernel evaluates it, with the host's expf
+        int const kw = 2 * kernel_size + 1;
+        for (int ky = -kernel_size; ky <= kernel_size; ++ky)
+            for (int kx = -kernel_size; kx <= kernel_size; ++kx)
+                S.w[(ky + kernel_size) * kw + (kx + kernel_size)]
+                    = expf(-((float)kx * (float)kx / (2.0f * sigma * sigma)
+                        + (float)ky * (float)ky / (2.0f * sigma * sigma)));
+    }
     {
         SgmKernelTimer timer(&prof, ctx->stream, SMVS_SGM_K_BILATERAL);
-        hipLaunchKernelGGL(bilateral_kernel, dim3((ctx->width + 255) / 256, ctx->height),
-            dim3(256), 0, ctx->stream, A);
+        dim3 const grid((ctx->width + 255) / 256, ctx->height);
+        if (tabled) {
+            hipLaunchKernelGGL(float_to_byte_kernel, dim3((unsigned)((n_img + 255) / 256)),
+                dim3(256), 0, ctx->stream, ctx->images[0].data, ctx->byte_stage, n_img);
+            const uint32_t *table = reinterpret_cast<const uint32_t *>(ctx->bil_lut);
+            if (A.channels == 3)
+                hipLaunchKernelGGL(bilateral_table_kernel<3>, grid, dim3(256), 0, ctx->stream,
+                    A, ctx->byte_stage, table, S);
+            else
+                hipLaunchKernelGGL(bilateral_table_kernel<1>, grid, dim3(256), 0, ctx->stream,
+                    A, ctx->byte_stage, table, S);
+        } else {
+            hipLaunchKernelGGL(bilateral_kernel, grid, dim3(256), 0, ctx->stream, A);
+        }
     }
     SMVS_HIP_CHECK(hipGetLastError());
     if (out != nullptr) {

@@ -643,8 +643,14 @@ def test_context_sgm_init_depth_is_the_bilateral_filter_and_stays_resident(hip, 
     # before anything is resident: NULL means no SGM splat
     vis_none = ctx.topology_subviews(None, use_ncc=False)
     full = ctx.sgm_init_depth(low)
-    assert np.array_equal(full, hip.bilateral_upsample(low, ci))
+    # the colour and spatial weights come from tables the host fills with expf:
+    # the CPU path's weights exactly
     assert np.array_equal(full, oracle.bilateral_upsample(low, ci))
+    # the stand-alone entry point (any float guidance image) takes the
+    # exponentials on the device, in double, rounded once: an ulp here and there
+    alone = hip.bilateral_upsample(low, ci)
+    assert np.array_equal(full == 0, alone == 0)
+    assert np.max(np.abs(full - alone)) <= 4e-7 * np.max(np.abs(full))
     vis_resident = ctx.topology_subviews(None, use_ncc=False)
     assert np.array_equal(vis_resident, tp.subviews(full))
     assert not np.array_equal(vis_resident, vis_none)   # the wrong blob occludes
