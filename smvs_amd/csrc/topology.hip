@@ -78,6 +78,19 @@ atomic_min_float(float *addr, float v)
         atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
+// the per-centre minima of every neighbour's z-buffer start at 10000
+// (depth_optimizer.cc:441-446)
+__global__ void __launch_bounds__(256)
+topo_clear_kernel(TopoArgs A)
+{
+    int const s = blockIdx.z;
+    TopoView const sv = A.views[1 + s];
+    size_t const cells = (size_t)(sv.w + 1) * (sv.h + 1);
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cells)
+        A.zraw[s][i] = 10000.0f;
+}
+
 // ---- z-buffer splat (depth_optimizer.cc:441-470), one thread per pixel ----
 __global__ void __launch_bounds__(256)
 topo_splat_kernel(TopoArgs A)
@@ -594,12 +607,15 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         // the map smvs_ctx_sgm_init_depth left on the device
         A.sgm_depth = ctx->topo_sgm;
     }
-    for (int s = 0; s < ctx->n_subs; ++s) {
-        size_t const n = (size_t)(ctx->images[1 + s].w + 1)
-            * (ctx->images[1 + s].h + 1);
-        // 10000.0f
-        SMVS_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(ctx->topo_zbuf[s] + n),
-            0x461C4000, n, ctx->stream));
+    {
+        // every neighbour's per-centre minima start at 10000 (one launch; a
+        // memset per neighbour is two runtime kernels each)
+        size_t cells = 0;
+        for (int s = 0; s < ctx->n_subs; ++s)
+            cells = std::max(cells, (size_t)(ctx->images[1 + s].w + 1)
+                * (ctx->images[1 + s].h + 1));
+        hipLaunchKernelGGL(topo_clear_kernel, dim3((unsigned)((cells + 255) / 256), 1,
+            (unsigned)ctx->n_subs), dim3(256), 0, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->patch_vis, 0,
         sizeof(uint32_t) * ctx->num_patches, ctx->stream));
