@@ -188,8 +188,24 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
     FitMatrix fit, float2 *__restrict__ grad, float4 *__restrict__ hess)
 {
 #pragma clang fp contract(off)
-    int const x = blockIdx.x * blockDim.x + threadIdx.x;
+    // The luminance of a pixel is needed by its nine neighbours: a workgroup
+    // (256 pixels of a row) forms it once per pixel for the three rows of its
+    // windows in LDS -- the same float expression, so the same values.
+    __shared__ float lum[3][256 + 2];
+    int const x0 = blockIdx.x * blockDim.x;
+    int const t = threadIdx.x;
     int const y = blockIdx.y;
+    for (int col = t; col < 256 + 2; col += 256) {
+        int const gx = min(max(x0 + col - 1, 0), w - 1);
+#pragma unroll
+        for (int row = 0; row < 3; ++row) {
+            int const gy = min(max(y + row - 1, 0), h - 1);
+            const float *px = img + ((size_t)gy * w + gx) * c;
+            lum[row][col] = c >= 3 ? px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f : px[0];
+        }
+    }
+    __syncthreads();
+    int const x = x0 + t;
     if (x >= w)
         return;
     size_t const p = (size_t)y * w + x;
@@ -199,15 +215,8 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
         double v[9];
         int k = 0;
         for (int a = -1; a < 2; ++a)
-            for (int b = -1; b < 2; ++b) {
-                const float *px = img + ((size_t)(y + b) * w + (x + a)) * c;
-                float lum;
-                if (c >= 3)
-                    lum = px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f;
-                else
-                    lum = px[0];
-                v[k++] = lum;
-            }
+            for (int b = -1; b < 2; ++b)
+                v[k++] = lum[b + 1][t + 1 + a];
         double r[6];
         for (int q = 0; q < 6; ++q) {
             double s = 0.0;
