@@ -444,3 +444,41 @@ def test_reconstruct_scene_end_to_end(hip, oracle, oracle_threads, tmp_path):
     done2, skipped2, _ = host.reconstruct_scene(d, view_ids=[0], num_neighbors=3,
                                                 min_neighbors=2, output_scale=2)
     assert done2 == [] and skipped2 == 1
+
+
+def test_bench_contract_small(hip):
+    """bench.py prints ONE JSON line with the fields the driver reads; run at
+    the 480x270 debug size (the numbers mean nothing, the structure does)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "3",
+           "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--no-peaks"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key, want in (("unit", "active-patch-steps/s"), ("n_gpus", 1), ("steps", 3), ("warmup", 1),
+                      ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None),
+                      ("dtype", "f64"), ("data", "synthetic")):
+        assert out[key] == want, (key, out[key])
+    assert out["metric"].startswith("Gauss-Newton iters/sec x active patches")
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert "workload" in out["config"] and "model" not in out["config"]
+    roof = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_frac", "per_kernel"):
+        assert key in roof, key
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert out["cpu_baseline"] is None                 # --no-cpu-baseline
+    sec = out["secondary"]
+    assert "error" not in sec, sec
+    assert sec["optimize"]["value"] > 0 and sec["views_per_s"]["per_gpu"]["sgm_in_flight_8"]["views_per_s"] > 0
+    assert sec["sgm_front_end"]["kernels"]["paths"]["frac"] > 0
+    # the whole-optimize workload as its own line
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--small", "--workload",
+                          "optimize", "--steps", "2", "--warmup", "1"], capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert line["unit"] == "active-patch-steps/s" and line["value"] > 0 and line["steps"] == 2
+    assert "optimize" in line["config"]["workload"]
