@@ -46,6 +46,9 @@ struct TopoArgs {
     const NccSample *ncc;           // 32 concatenated templates
     int ncc_off[33];
     int W, H, npx, npy, stride, ps, start_x, start_y, n_subs, num_patches;
+    int ps_log2;       // ps = 1 << ps_log2 (Surface: patchsize = 2^scale): shifts and an
+                       // exact reciprocal instead of integer and double divisions
+    double inv_ps;     // 1.0 / ps
     int use_ncc;
     // cut_boundaries
     uint8_t *patch_valid_rw;
@@ -103,14 +106,14 @@ topo_splat_kernel(TopoArgs A)
     // Surface::get_depth_map (surface.cc:155-168): float of the patch value
     int const gx = x - A.start_x, gy = y - A.start_y;
     if (gx >= 0 && gy >= 0 && gx < A.npx * A.ps && gy < A.npy * A.ps) {
-        int const ix = gx / A.ps, iy = gy / A.ps;
+        int const ix = gx >> A.ps_log2, iy = gy >> A.ps_log2;
         int const p = iy * A.npx + ix;
         if (A.patch_valid[p]) {
             double n16[16];
             load_patch_nodes(A, p, n16);
             int const i = gx - ix * A.ps, j = gy - iy * A.ps;
-            depths[0] = (float)smvs_topo::patch_eval(n16, (i + 0.5) / A.ps,
-                (j + 0.5) / A.ps, 0, 0);
+            depths[0] = (float)smvs_topo::patch_eval(n16, (i + 0.5) * A.inv_ps,
+                (j + 0.5) * A.inv_ps, 0, 0);
         }
     }
     if (A.sgm_depth != nullptr)
@@ -218,10 +221,13 @@ topo_visibility_kernel(TopoArgs A)
     int const ps = A.ps;
     int const G = group_size(ps);
     int const lane = threadIdx.x & 63;
-    int const gl = threadIdx.x % G;           // lane inside the group
-    long long const gid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    int const p = (int)(gid / A.n_subs);
-    int const s = (int)(gid - (long long)p * A.n_subs);
+    int const g_log2 = min(2 * A.ps_log2, 6);   // G = 1 << g_log2
+    int const gl = threadIdx.x & (G - 1);     // lane inside the group
+    // (group index < num_patches * n_subs: 32 bits)
+    unsigned const gid = (unsigned)(((unsigned long long)blockIdx.x * blockDim.x
+        + threadIdx.x) >> g_log2);
+    int const p = (int)(gid / (unsigned)A.n_subs);
+    int const s = (int)(gid - (unsigned)p * (unsigned)A.n_subs);
     bool alive = p < A.num_patches && A.patch_valid[p];
     int const pc = alive ? p : 0;
     double n16[16];
@@ -242,8 +248,9 @@ topo_visibility_kernel(TopoArgs A)
     double worst = 0.0;
     if (alive)
         for (int k = gl; k < ps * ps; k += G) {
-            int const i = k % ps, j = k / ps;
-            double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
+            int const i = k & (ps - 1), j = k >> A.ps_log2;
+            // (x / ps == x * (1 / ps) exactly: ps is a power of two)
+            double const u = (i + 0.5) * A.inv_ps, v = (j + 0.5) * A.inv_ps;
             double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
             Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
             double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
@@ -258,8 +265,8 @@ topo_visibility_kernel(TopoArgs A)
                     if (wp.d * 0.95 > zbuf[(size_t)(cy + dy) * zw + (cx + dx)])
                         visible = false;
             // ratio of the squared singular values of the warp Jacobian
-            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
-            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) / ps;
+            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) * A.inv_ps;
+            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) * A.inv_ps;
             double jac[4];
             wp.jacobian(M, w, wx, wy, jac);
             double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
@@ -294,8 +301,8 @@ topo_visibility_kernel(TopoArgs A)
                     double depth;
                     if (smp.src >= 0)
                         depth = smvs_topo::patch_eval(n16,
-                            (smp.src % ps + 0.5) / ps,
-                            (smp.src / ps + 0.5) / ps, 0, 0);
+                            ((smp.src & (ps - 1)) + 0.5) * A.inv_ps,
+                            ((smp.src >> A.ps_log2) + 0.5) * A.inv_ps, 0, 0);
                     else
                         depth = n16[4 * (-1 - smp.src)];
                     double const sx = (double)(px + smp.dx);
@@ -355,8 +362,9 @@ topo_mse_kernel(TopoArgs A)
 #pragma clang fp contract(off)
     int const ps = A.ps;
     int const G = group_size(ps);
-    int const gl = threadIdx.x % G;
-    int const p = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) / G);
+    int const gl = threadIdx.x & (G - 1);
+    int const p = (int)(((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x)
+        >> min(2 * A.ps_log2, 6));
     bool const in_range = p < A.num_patches;
     bool const alive = in_range && A.patch_valid[p];
     int const pc = alive ? p : 0;
@@ -368,11 +376,12 @@ topo_mse_kernel(TopoArgs A)
     double error = 0.0, counter = 0.0;
     if (alive)
         for (int k = gl; k < ps * ps; k += G) {
-            int const i = k % ps, j = k / ps;
-            double const u = (i + 0.5) / ps, v = (j + 0.5) / ps;
+            int const i = k & (ps - 1), j = k >> A.ps_log2;
+            // (x / ps == x * (1 / ps) exactly: ps is a power of two)
+            double const u = (i + 0.5) * A.inv_ps, v = (j + 0.5) * A.inv_ps;
             double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
-            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) / ps;
-            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) / ps;
+            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) * A.inv_ps;
+            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) * A.inv_ps;
             float2 const gm = A.main_grad[(size_t)(py + j) * A.W + (px + i)];
             double const gm0 = gm.x, gm1 = gm.y;
             for (int s = 0; s < A.n_subs; ++s) {
@@ -529,6 +538,10 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     A->npy = ctx->npy;
     A->stride = ctx->node_stride;
     A->ps = ctx->patchsize;
+    A->ps_log2 = 0;
+    while ((1 << A->ps_log2) < ctx->patchsize)
+        A->ps_log2 += 1;
+    A->inv_ps = 1.0 / (double)ctx->patchsize;
     A->start_x = ctx->start_x;
     A->start_y = ctx->start_y;
     A->n_subs = ctx->n_subs;
