@@ -294,45 +294,80 @@ topo_visibility_kernel(TopoArgs A)
         double sum0[3] = { 0, 0, 0 }, sum1[3] = { 0, 0, 0 };
         double mean0[3], mean1[3];
         double n0 = 0.0, n1 = 0.0, dot = 0.0;
+        // The colours of a sample, main view and warped neighbour.  The second
+        // pass (centred products) needs the same values as the first (sums):
+        // a lane keeps its first NCC_KEEP samples in registers -- all of them
+        // at the fine scales, where the border samples make the templates
+        // 2 - 3 x the patch -- and recomputes the rest.
+        constexpr int NCC_KEEP = 4;
+        double keep_m[NCC_KEEP][3], keep_s[NCC_KEEP][3];
+        auto colours = [&](int i, double (&cm)[3], double (&cs)[3], bool check) -> bool {
+            NccSample const smp = tpl[i];
+            double depth;
+            if (smp.src >= 0)
+                depth = smvs_topo::patch_eval(n16,
+                    ((smp.src & (ps - 1)) + 0.5) * A.inv_ps,
+                    ((smp.src >> A.ps_log2) + 0.5) * A.inv_ps, 0, 0);
+            else
+                depth = n16[4 * (-1 - smp.src)];
+            double const sx = (double)(px + smp.dx);
+            double const sy = (double)(py + smp.dy);
+            Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
+            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+            if (check && (qx < 1 || qx > sv.w - 2 || qy < 1 || qy > sv.h - 2))
+                return false;
+            for (int c = 0; c < 3; ++c) {
+                int const cmi = c < mv.c - 1 ? c : mv.c - 1;
+                int const csi = c < sv.c - 1 ? c : sv.c - 1;
+                cm[c] = mv.image[((size_t)(py + smp.dy) * mv.w + (px + smp.dx)) * mv.c + cmi];
+                cs[c] = smvs_topo::linear_at(sv.image, sv.w, sv.h, sv.c, (float)qx,
+                    (float)qy, csi);
+            }
+            return true;
+        };
         for (int pass = 0; pass < 2; ++pass) {
-            if (alive && inside)
-                for (int i = gl; i < n; i += G) {
-                    NccSample const smp = tpl[i];
-                    double depth;
-                    if (smp.src >= 0)
-                        depth = smvs_topo::patch_eval(n16,
-                            ((smp.src & (ps - 1)) + 0.5) * A.inv_ps,
-                            ((smp.src >> A.ps_log2) + 0.5) * A.inv_ps, 0, 0);
-                    else
-                        depth = n16[4 * (-1 - smp.src)];
-                    double const sx = (double)(px + smp.dx);
-                    double const sy = (double)(py + smp.dy);
-                    Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
-                    double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-                    if (pass == 0 && (qx < 1 || qx > sv.w - 2 || qy < 1
-                        || qy > sv.h - 2)) {
-                        inside = false;
-                        break;
-                    }
-                    for (int c = 0; c < 3; ++c) {
-                        int const cmi = c < mv.c - 1 ? c : mv.c - 1;
-                        int const csi = c < sv.c - 1 ? c : sv.c - 1;
-                        double const cm = mv.image[((size_t)(py + smp.dy) * mv.w
-                            + (px + smp.dx)) * mv.c + cmi];
-                        double const cs = smvs_topo::linear_at(sv.image, sv.w,
-                            sv.h, sv.c, (float)qx, (float)qy, csi);
-                        if (pass == 0) {
-                            sum0[c] += cm;
-                            sum1[c] += cs;
+            if (alive && inside) {
+                int slot = 0;
+                for (int i = gl; i < n; i += G, ++slot) {
+                    double cm[3], cs[3];
+                    if (pass == 0) {
+                        if (!colours(i, cm, cs, true)) {
+                            inside = false;
+                            break;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NCC_KEEP; ++k)
+                            if (slot == k)
+                                for (int c = 0; c < 3; ++c) {
+                                    keep_m[k][c] = cm[c];
+                                    keep_s[k][c] = cs[c];
+                                }
+                        for (int c = 0; c < 3; ++c) {
+                            sum0[c] += cm[c];
+                            sum1[c] += cs[c];
+                        }
+                    } else {
+                        if (slot < NCC_KEEP) {
+#pragma unroll
+                            for (int k = 0; k < NCC_KEEP; ++k)
+                                if (slot == k)
+                                    for (int c = 0; c < 3; ++c) {
+                                        cm[c] = keep_m[k][c];
+                                        cs[c] = keep_s[k][c];
+                                    }
                         } else {
-                            double const a = cm - mean0[c];
-                            double const b = cs - mean1[c];
+                            (void)colours(i, cm, cs, false);
+                        }
+                        for (int c = 0; c < 3; ++c) {
+                            double const a = cm[c] - mean0[c];
+                            double const b = cs[c] - mean1[c];
                             n0 += a * a;
                             n1 += b * b;
                             dot += a * b;
                         }
                     }
                 }
+            }
             if (pass == 0) {
                 inside = group_all(inside, G, lane);
                 for (int c = 0; c < 3; ++c) {
