@@ -215,23 +215,30 @@ Surface::initialize_node_from_depth(int idx, int idy)
         return;
     int const x = idx * patchsize + start_x, y = idy * patchsize + start_y;
     int const window = patchsize / 2;
-    std::vector<double> all;
+    // (the quadrant minima and the median do not depend on the order the
+    // window is walked in: rows of the depth map, not columns, and one list
+    // for all nodes instead of an allocation per node)
+    std::vector<double>& all = window_depths;
+    all.clear();
     double lowest[4] = { 0, 0, 0, 0 };
     int quadrants = 4;
+    int const dw = depth->width(), dh = depth->height();
+    float const* dmap = depth->begin();
     for (int q = 0; q < 4; ++q) {
         int const i0 = (q & 1) ? 0 : -window, j0 = (q & 2) ? 0 : -window;
         bool any = false;
-        for (int i = i0; i < i0 + window; ++i)
-            for (int j = j0; j < j0 + window; ++j) {
-                int const xx = x + i, yy = y + j;
-                if (xx < 0 || xx >= depth->width() || yy < 0
-                    || yy >= depth->height() || !(depth->at(xx, yy, 0) > 0.0))
+        int const xa = std::max(x + i0, 0), xb = std::min(x + i0 + window, dw);
+        for (int yy = std::max(y + j0, 0); yy < std::min(y + j0 + window, dh); ++yy) {
+            float const* row = dmap + (size_t)yy * dw;
+            for (int xx = xa; xx < xb; ++xx) {
+                if (!(row[xx] > 0.0))
                     continue;
-                double const d = depth->at(xx, yy, 0);
+                double const d = row[xx];
                 lowest[q] = any ? std::min(lowest[q], d) : d;
                 any = true;
                 all.push_back(d);
             }
+        }
         if (!any)
             quadrants -= 1;
     }
@@ -363,10 +370,27 @@ Surface::subdivide_patches(void)
     std::vector<double> new_nodes((size_t)new_stride * (new_npy + 1) * 4, 0.0);
     std::vector<uint8_t> new_valid((size_t)new_stride * (new_npy + 1), 0);
 
-    // five new nodes per patch: edge midpoints and the centre
-    struct Split { double u, v; int ox, oy; };
-    static Split const splits[5] = { { 0.5, 0.0, 1, 0 }, { 0.0, 0.5, 0, 1 },
-        { 0.5, 0.5, 1, 1 }, { 1.0, 0.5, 2, 1 }, { 0.5, 1.0, 1, 2 } };
+    // five new nodes per patch: edge midpoints and the centre.  The patch is
+    // only ever evaluated at 0, 1/2 and 1: the Hermite basis values of those
+    // three parameters (value and first derivative) are formed once, the sums
+    // are patch_eval's own, term by term.
+    struct Split { int iu, iv; int ox, oy; };   // parameter = index / 2
+    static Split const splits[5] = { { 1, 0, 1, 0 }, { 0, 1, 0, 1 },
+        { 1, 1, 1, 1 }, { 2, 1, 2, 1 }, { 1, 2, 1, 2 } };
+    double basis[3][2][4];
+    for (int t = 0; t < 3; ++t)
+        for (int k = 0; k < 2; ++k)
+            smvs_topo::hermite(0.5 * t, k, basis[t][k]);
+    auto combine = [](double const* n, double const* bx, double const* by) {
+        double r = 0.0;
+        for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < 2; ++a) {
+                double const* nd = n + 4 * (2 * b + a);
+                r += nd[0] * bx[a] * by[b] + nd[1] * bx[2 + a] * by[b]
+                    + nd[2] * bx[a] * by[2 + b] + nd[3] * bx[2 + a] * by[2 + b];
+            }
+        return r;
+    };
     for (std::size_t p = 0; p < patch_valid.size(); ++p) {
         if (!patch_valid[p])
             continue;
@@ -374,13 +398,14 @@ Surface::subdivide_patches(void)
         int const ny = 2 * (int)(p / old_npx) + off_y;
         double n16[16];
         fill_patch_nodes(p, n16);
-        PatchEval pe(n16);
         for (Split const& s : splits) {
             std::size_t const id = (size_t)(ny + s.oy) * new_stride + nx + s.ox;
-            new_nodes[4 * id + 0] = pe.f(s.u, s.v);
-            new_nodes[4 * id + 1] = pe.dx(s.u, s.v) / 2;
-            new_nodes[4 * id + 2] = pe.dy(s.u, s.v) / 2;
-            new_nodes[4 * id + 3] = pe.dxy(s.u, s.v) / 4;
+            double const (*bu)[4] = basis[s.iu];
+            double const (*bv)[4] = basis[s.iv];
+            new_nodes[4 * id + 0] = combine(n16, bu[0], bv[0]);
+            new_nodes[4 * id + 1] = combine(n16, bu[1], bv[0]) / 2;
+            new_nodes[4 * id + 2] = combine(n16, bu[0], bv[1]) / 2;
+            new_nodes[4 * id + 3] = combine(n16, bu[1], bv[1]) / 4;
             new_valid[id] = 1;
         }
     }

@@ -86,6 +86,7 @@ private:
     void initialize_depth_from_bundle(Bundle::ConstPtr bundle,
         CameraInfo const& cam, int view_id);
     void initialize_node_from_depth(int idx, int idy);
+    std::vector<double> window_depths;   // scratch of initialize_node_from_depth
     int fill_holes(void);
 
 private:
