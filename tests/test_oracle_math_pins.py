@@ -1,0 +1,136 @@
+"""More mathematical pins of oracle pieces for which the reference holds no
+test or vector (no GPU): each is compared with an independently written
+numpy implementation of the published algorithm.
+
+ * the 8-path semi-global aggregation (lib/sgm_stereo.cc:408-667) against
+   Hirschmueller's recurrence written per path with numpy;
+ * the reprojection-based re-activation of nodes after a Newton step
+   (lib/depth_optimizer.cc:271-303, 647-677) against a direct evaluation of
+   the two projections per pixel.
+"""
+import numpy as np
+import pytest
+
+
+# --------------------------------------------------------------------- SGM
+def _textbook_paths(cost, p1, p2):
+    """L_r(p, d) = C(p, d) + min(L_r(p - r, d), L_r(p - r, d -+ 1) + P1,
+    min_k L_r(p - r, k) + P2) - min_k L_r(p - r, k), L_r = C where p - r is
+    outside the image; returns the eight L_r."""
+    h, w, D = cost.shape
+    C = cost.astype(np.int64)
+    out = []
+    for dx, dy in ((1, 0), (-1, 0), (0, 1), (1, 1), (-1, 1), (0, -1), (1, -1), (-1, -1)):
+        L = np.zeros_like(C)
+        ys = range(h) if dy >= 0 else range(h - 1, -1, -1)
+        xs = range(w) if dx >= 0 else range(w - 1, -1, -1)
+        for y in ys:
+            for x in xs:
+                px, py = x - dx, y - dy
+                if px < 0 or px >= w or py < 0 or py >= h:
+                    L[y, x] = C[y, x]
+                    continue
+                prev = L[py, px]
+                m = prev.min()
+                big = np.iinfo(np.int64).max // 4
+                left = np.concatenate(([big], prev[:-1])) + p1
+                right = np.concatenate((prev[1:], [big])) + p1
+                L[y, x] = C[y, x] + np.minimum(np.minimum(prev, left), np.minimum(right, m + p2)) - m
+        out.append(L)
+    return out
+
+
+@pytest.mark.parametrize("p1,p2", [(6, 96), (3, 20)])
+def test_sgm_aggregation_is_the_eight_path_recurrence(oracle, p1, p2):
+    rng = np.random.default_rng(12)
+    h, w, D = 9, 11, 8
+    cost = rng.integers(0, 64, size=(h, w, D)).astype(np.uint16)
+    cost[rng.random((h, w)) < 0.1] = 255          # unwarped pixels, as the cost volume marks them
+    S = oracle.sgm_aggregate(cost, p1, p2).astype(np.int64)
+    paths = _textbook_paths(cost, p1, p2)
+    T = sum(paths)
+    # interior pixels: exactly the sum of the eight path costs
+    assert np.array_equal(S[1:-1, 1:-1], T[1:-1, 1:-1])
+    # On the border the reference seeds its sweeps per entry row AND per entry
+    # column (sgm_stereo.cc:457-464, 511-534, 589-612, Q19): a border pixel
+    # collects C once more per extra seed, never anything else.
+    extra = S - T
+    C = cost.astype(np.int64)
+    border = np.ones((h, w), bool); border[1:-1, 1:-1] = False
+    for y, x in zip(*np.nonzero(border)):
+        d = int(np.argmax(C[y, x]))
+        k = int(round(extra[y, x, d] / max(C[y, x, d], 1)))
+        assert 0 <= k <= 4 and np.array_equal(extra[y, x], k * C[y, x]), (y, x, k, extra[y, x])
+    # ... and the four corners are where the doubled diagonal seeds sit
+    assert extra[0, 0].sum() > 0 and extra[h - 1, w - 1].sum() > 0
+
+
+# ------------------------------------------------- re-activation of nodes
+def _patch_depth_at_pixels(nodes16, ps):
+    """bicubic Hermite patch (lib/bicubic_patch.cc) at the pixel centres
+    (i + 0.5) / ps, written with numpy from the textbook basis"""
+    def basis(t):
+        return np.array([1 - 3 * t**2 + 2 * t**3, 3 * t**2 - 2 * t**3,
+                         t - 2 * t**2 + t**3, t**3 - t**2])
+    u = (np.arange(ps) + 0.5) / ps
+    B = np.stack([basis(t) for t in u])            # [ps][4]: v0, v1, s0, s1
+    n = nodes16.reshape(2, 2, 4)                   # [b][a][f, dx, dy, dxy]
+    out = np.zeros((ps, ps))
+    for b in range(2):
+        for a in range(2):
+            f, dx, dy, dxy = n[b, a]
+            out += (f * np.outer(B[:, b], B[:, a]) + dx * np.outer(B[:, b], B[:, 2 + a])
+                    + dy * np.outer(B[:, 2 + b], B[:, a]) + dxy * np.outer(B[:, 2 + b], B[:, 2 + a]))
+    return out                                      # [j][i]
+
+
+def test_reactivation_is_the_reprojection_shift_test(oracle):
+    """After x is added to the nodes, a node stays active iff one of its
+    patches has a pixel whose projection into a visible neighbour moved by more
+    than 0.15 px (depth_optimizer.cc:277-303); projections as in
+    correspondence.cc:36-51 without the half-pixel offsets (:669-672)."""
+    from smvs_amd import synth
+    prob = synth.make_problem(192, 128, 3, scale=3, noise=0.02, seed=4)
+    surf, views = prob["surf"], prob["views"]
+    orc = oracle.OracleProblem(surf, views)
+    active = surf["node_valid"].copy()
+    sysm = orc.gn_construct(active, 0.01)
+    x, _, _ = orc.cg_solve(sysm["H9"], sysm["present"], sysm["P"], -sysm["g"], 200,
+                           0.01 * np.linalg.norm(sysm["g"]), 1e-3)
+    nodes0 = surf["nodes"].copy()
+    new_active, count, _ = orc.update_and_reactivate(x, active)
+    nodes1 = nodes0 + x.reshape(-1, 4) * surf["node_valid"][:, None]
+    assert np.allclose(orc.nodes, nodes1, rtol=0, atol=0)      # Surface::update_nodes
+
+    ps, npx, npy = 1 << surf["scale"], surf["npx"], surf["npy"]
+    stride = npx + 1
+    M = np.asarray(views["M"]).reshape(-1, 3, 3); t = np.asarray(views["t"]).reshape(-1, 3)
+    want = np.zeros_like(active)
+    margin = []
+    for p in np.flatnonzero(surf["patch_valid"]):
+        ix, iy = p % npx, p // npx
+        ids = [iy * stride + ix, iy * stride + ix + 1, (iy + 1) * stride + ix, (iy + 1) * stride + ix + 1]
+        if not active[ids].any():
+            continue
+        w0 = _patch_depth_at_pixels(nodes0[ids].reshape(16), ps)
+        w1 = _patch_depth_at_pixels(nodes1[ids].reshape(16), ps)
+        jj, ii = np.mgrid[0:ps, 0:ps]
+        px = np.stack([surf["start_x"] + ix * ps + ii, surf["start_y"] + iy * ps + jj,
+                       np.ones_like(ii)], -1).astype(float)
+        moved = 0.0
+        for s in range(len(views["subs"])):
+            if not (surf["patch_vis"][p] >> s) & 1:
+                continue
+            ray = px @ M[s].T
+            q0 = ray * w0[..., None] + t[s]
+            q1 = ray * w1[..., None] + t[s]
+            d = q0[..., :2] / q0[..., 2:] - q1[..., :2] / q1[..., 2:]
+            moved = max(moved, np.sqrt((d ** 2).sum(-1)).max())
+        margin.append(abs(moved - 0.15))
+        if moved > 0.15:
+            want[ids] = 1
+    # decisions closer than 1e-9 px to the threshold could go either way under
+    # a different summation order: none in this scene
+    assert min(margin) > 1e-9
+    assert np.array_equal(new_active, want)
+    assert count == int(want.sum()) and 0 < count < int(active.sum())
