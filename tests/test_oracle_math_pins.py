@@ -134,3 +134,56 @@ def test_reactivation_is_the_reprojection_shift_test(oracle):
     assert min(margin) > 1e-9
     assert np.array_equal(new_active, want)
     assert count == int(want.sum()) and 0 < count < int(active.sum())
+
+
+# ------------------------------------------------ spherical harmonics basis
+def test_sh_basis_spans_the_real_spherical_harmonics_of_bands_0_to_3(oracle):
+    """The 16 functions of spherical_harmonics.h are (unnormalised) real
+    spherical harmonics: on the unit sphere each one is a constant multiple of
+    exactly one real Y_lm of scipy, l = 0..3, every (l, m) hit once."""
+    sp = pytest.importorskip("scipy.special")
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal((400, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ours = np.stack([oracle.sh_evaluate_4_band(n) for n in v])           # [400][16]
+    # the reference's axes are a permutation of the textbook's (its "z" term
+    # 2 z^2 - x^2 - y^2 sits at index 6 with z = n[2]); the span is what matters
+    theta = np.arccos(np.clip(v[:, 2], -1, 1)); phi = np.arctan2(v[:, 1], v[:, 0])
+    real = []
+    for l in range(4):
+        for m in range(-l, l + 1):
+            if hasattr(sp, "sph_harm_y"):
+                y = sp.sph_harm_y(l, abs(m), theta, phi)
+            else:
+                y = sp.sph_harm(abs(m), l, phi, theta)
+            real.append(np.sqrt(2) * y.imag if m < 0 else (y.real if m == 0 else np.sqrt(2) * y.real))
+    real = np.stack(real, 1)                                              # [400][16]
+    hit = set()
+    for k in range(16):
+        # correlation with every real harmonic: one of them is +-1, the rest 0
+        c = np.array([abs(np.dot(ours[:, k], real[:, j])) / (np.linalg.norm(ours[:, k])
+                      * np.linalg.norm(real[:, j])) for j in range(16)])
+        j = int(np.argmax(c))
+        assert c[j] > 1 - 1e-9, (k, c)
+        hit.add(j)
+    assert len(hit) == 16
+
+
+# ------------------------------------------- image gradients of a StereoView
+def test_image_gradients_are_the_least_squares_quadratic_fit(oracle):
+    """stereo_view.cc:97-188 fits a quadratic to every 3 x 3 window; gradient
+    and Hessian at the centre are the coefficients of numpy's least-squares
+    fit of the same model (to float rounding of the stored planes)."""
+    rng = np.random.default_rng(5)
+    img = rng.random((12, 14)).astype(np.float32)
+    g, hs = oracle.gradients_and_hessian(img)
+    a, b = np.meshgrid([-1.0, 0.0, 1.0], [-1.0, 0.0, 1.0], indexing="ij")   # a = x offset, b = y offset
+    A = np.stack([a.ravel() ** 2, b.ravel() ** 2, (a * b).ravel(), a.ravel(), b.ravel(),
+                  np.ones(9)], 1)
+    for (y, x) in [(1, 1), (5, 7), (10, 12), (3, 9)]:
+        win = np.array([[img[y + bb, x + aa] for bb in (-1, 0, 1)] for aa in (-1, 0, 1)], dtype=float)
+        cxx, cyy, cxy, cx, cy, _ = np.linalg.lstsq(A, win.ravel(), rcond=None)[0]
+        assert np.allclose(g[y, x], [cx, cy], rtol=0, atol=2e-6)
+        assert np.allclose(hs[y, x], [2 * cxx, cxy, 2 * cyy], rtol=0, atol=4e-6)
+    # the one-pixel border carries no fit
+    assert not g[0].any() and not g[:, 0].any() and not g[-1].any() and not g[:, -1].any()
