@@ -187,3 +187,31 @@ def test_image_gradients_are_the_least_squares_quadratic_fit(oracle):
         assert np.allclose(hs[y, x], [2 * cxx, cxy, 2 * cyy], rtol=0, atol=4e-6)
     # the one-pixel border carries no fit
     assert not g[0].any() and not g[:, 0].any() and not g[-1].any() and not g[:, -1].any()
+
+
+# --------------------------------------------------------- normals of a surface
+def test_normal_map_is_the_cross_product_of_the_surface_tangents(oracle):
+    """Surface::get_normal_map (surface.cc:170-183, surface_patch.cc:30-55): with
+    P(x, y) = w(x, y) (x / f, y / f, 1) the stored normal is P_x x P_y
+    normalised, its first component negated (the reference's axis convention)
+    -- checked with central differences of the depth map (1e-3: the
+    differences straddle patch borders)."""
+    from smvs_amd import synth
+    prob = synth.make_problem(192, 128, 2, scale=4, noise=0.0, seed=3)
+    orc = oracle.OracleProblem(prob["surf"], prob["views"])
+    d = orc.depth_map().astype(np.float64)
+    n = orc.normal_map().astype(np.float64)
+    H, W = d.shape
+    f = prob["views"]["flen"]
+    ys, xs = np.mgrid[0:H, 0:W]
+    P = np.stack([d * (xs + 0.5 - W / 2.0) / f, d * (ys + 0.5 - H / 2.0) / f, d], -1)
+    Px = (P[1:-1, 2:] - P[1:-1, :-2]) / 2
+    Py = (P[2:, 1:-1] - P[:-2, 1:-1]) / 2
+    c = np.cross(Px, Py)
+    ok = ((d[1:-1, 1:-1] > 0) & (d[1:-1, 2:] > 0) & (d[1:-1, :-2] > 0) & (d[2:, 1:-1] > 0)
+          & (d[:-2, 1:-1] > 0))
+    c = c[ok] / np.linalg.norm(c[ok], axis=-1, keepdims=True)
+    err = np.abs(n[1:-1, 1:-1][ok] - c * np.array([-1.0, 1.0, 1.0]))
+    assert ok.sum() > 4000
+    assert np.median(err) < 2e-4 and np.percentile(err, 99) < 3e-3, (np.median(err), np.percentile(err, 99))
+    assert np.abs(np.linalg.norm(n[1:-1, 1:-1][ok], axis=-1) - 1).max() < 1e-5
