@@ -215,3 +215,40 @@ def test_normal_map_is_the_cross_product_of_the_surface_tangents(oracle):
     assert ok.sum() > 4000
     assert np.median(err) < 2e-4 and np.percentile(err, 99) < 3e-3, (np.median(err), np.percentile(err, 99))
     assert np.abs(np.linalg.norm(n[1:-1, 1:-1][ok], axis=-1) - 1).max() < 1e-5
+
+
+# ---------------------------- invariants the device kernels' data layouts rest on
+def test_path_cost_minus_cost_fits_a_byte():
+    """csrc/sgm.hip stores L - C as ONE BYTE per cell and direction when
+    P2 <= 255: along every path 0 <= L - C <= P2 (the minimum in
+    Hirschmueller's recurrence is over terms >= min L', one of them min L' + P2)."""
+    rng = np.random.default_rng(3)
+    cost = rng.integers(0, 256, size=(7, 9, 10)).astype(np.uint16)
+    for p1, p2 in ((6, 96), (10, 255), (1, 1)):
+        for L in _textbook_paths(cost, p1, p2):
+            extra = L - cost.astype(np.int64)
+            assert extra.min() >= 0 and extra.max() <= p2
+
+
+def test_bilateral_colour_weight_depends_on_the_pair_almost_only_through_the_difference():
+    """csrc/sgm.hip compresses the 256 x 256 colour weights
+    expf(-(b/255 - a/255)^2 / (2 * 0.1^2)) (float arithmetic, the host's expf)
+    to 511 differences x <= 4 candidates + a 2-bit selector; with another libm
+    the device falls back to exponentials, this test says which one applies here."""
+    import ctypes, ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    f = np.float32
+    q = (np.arange(256, dtype=np.float32) / f(255.0)).astype(np.float32)
+    diff = (q[None, :] - q[:, None]).astype(np.float32)           # [a][b] = b/255 - a/255
+    arg = (-(diff * diff) / (f(2.0) * f(0.1) * f(0.1))).astype(np.float32)
+    uniq = np.unique(arg)
+    table = {float(v): libm.expf(float(v)) for v in uniq}
+    wgt = np.vectorize(table.get, otypes=[np.float32])(arg)
+    worst = 0
+    for d in range(-255, 256):
+        vals = np.unique(np.diagonal(wgt, offset=d))
+        worst = max(worst, vals.size)
+    assert worst <= 4, worst
+    assert wgt[0, 0] == 1.0 and wgt[0, 255] > 0.0        # no weight underflows to zero
