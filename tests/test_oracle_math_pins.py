@@ -252,3 +252,34 @@ def test_bilateral_colour_weight_depends_on_the_pair_almost_only_through_the_dif
         worst = max(worst, vals.size)
     assert worst <= 4, worst
     assert wgt[0, 0] == 1.0 and wgt[0, 255] > 0.0        # no weight underflows to zero
+
+
+# ------------------------------------------------------ joint bilateral upsample
+def test_bilateral_upsample_is_a_normalised_joint_bilateral_filter(oracle):
+    """depth_optimizer.cc:957-1004: out(p) = sum_q d(q) g_s(q - p) prod_c g_c(I_c(q) - I_c(p))
+    / sum_q (the same weights) over the (2k + 1)^2 window, d looked up in the
+    low-resolution map (nearest, towards zero), zero depths skipped, borders
+    clamped -- evaluated here in float64 with numpy (1e-5: the filter runs in float)."""
+    rng = np.random.default_rng(8)
+    h, w, ks, sigma = 18, 22, 3, 2.0
+    dm = (2.0 + rng.random((h // 2, w // 2))).astype(np.float32)
+    dm[rng.random(dm.shape) < 0.25] = 0.0
+    ci = rng.integers(0, 256, size=(h, w, 3)).astype(np.float32) / np.float32(255.0)
+    got = oracle.bilateral_upsample(dm, ci, sigma=sigma, kernel_size=ks)
+    sx, sy = dm.shape[1] / w, dm.shape[0] / h
+    want = np.zeros((h, w))
+    for y in range(h):
+        for x in range(w):
+            qy = np.clip(y + np.arange(-ks, ks + 1), 0, h - 1)
+            qx = np.clip(x + np.arange(-ks, ks + 1), 0, w - 1)
+            QY, QX = np.meshgrid(qy, qx, indexing="ij")
+            KY, KX = np.meshgrid(np.arange(-ks, ks + 1), np.arange(-ks, ks + 1), indexing="ij")
+            d = dm[np.minimum((sy * QY).astype(int), dm.shape[0] - 1),
+                   np.minimum((sx * QX).astype(int), dm.shape[1] - 1)].astype(float)
+            ws = np.exp(-(KX ** 2 + KY ** 2) / (2 * sigma ** 2))
+            wc = np.exp(-((ci[QY, QX].astype(float) - ci[y, x].astype(float)) ** 2).sum(-1) / (2 * 0.1 ** 2))
+            wgt = ws * wc * (d != 0)
+            want[y, x] = (wgt * d).sum() / wgt.sum() if wgt.sum() > 0 else 0.0
+    assert np.array_equal(got == 0, want == 0)
+    assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
+    assert (got == 0).sum() < got.size // 2
