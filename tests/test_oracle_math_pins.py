@@ -283,3 +283,29 @@ def test_bilateral_upsample_is_a_normalised_joint_bilateral_filter(oracle):
     assert np.array_equal(got == 0, want == 0)
     assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want))
     assert (got == 0).sum() < got.size // 2
+
+
+# ---------------------------------------------------------------- lighting fit
+def test_lighting_fit_is_the_least_squares_fit_of_the_image_to_the_sh_basis(oracle):
+    """light_optimizer.cc:22-55: the 16 lighting parameters minimise
+    sum_p (l . sh(n_p) - I_p)^2 over the pixels with a unit normal and an
+    intensity of at least 0.05; the pseudo inverse of the normal equations
+    gives what numpy's lstsq gives on the stacked rows."""
+    rng = np.random.default_rng(6)
+    n = rng.standard_normal((3000, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n[::17] = 0.0                                     # pixels without a surface
+    truth = rng.standard_normal(16) * 0.2; truth[0] = 0.7
+    sh = np.stack([oracle.sh_evaluate_4_band(v.astype(np.float64)) for v in n])
+    img = (sh @ truth + 0.01 * rng.standard_normal(len(n))).astype(np.float32)
+    img[5::23] = 0.01                                 # too dark: skipped
+    A, b = oracle.light_accumulate(n, img)
+    got = oracle.light_solve(A, b)
+    use = (np.abs(np.linalg.norm(n.astype(np.float64), axis=1) - 1.0) <= 1e-6) & (img >= np.float32(0.05))
+    assert 0.8 * len(n) < use.sum() < len(n)
+    R = sh[use]
+    assert np.allclose(A, R.T @ R, rtol=1e-12, atol=1e-9)
+    assert np.allclose(b, R.T @ img[use].astype(np.float64), rtol=1e-12, atol=1e-9)
+    want = np.linalg.lstsq(R, img[use].astype(np.float64), rcond=None)[0]
+    assert np.allclose(got, want, rtol=1e-7, atol=1e-9)
+    assert np.allclose(got, truth, atol=5e-3)         # and it recovers the lighting
