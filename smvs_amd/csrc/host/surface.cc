@@ -154,17 +154,23 @@ Surface::fill_holes(void)
 {
     touch();
     // lib/surface.cc:630-651
+    // (a patch is filled from its four nodes only: any order gives the same
+    // result; rows of the grid, the way the arrays lie in memory)
     int filled = 0;
-    for (int x = 0; x < npx; ++x)
-        for (int y = 0; y < npy; ++y) {
-            if (patch_exists(x, y))
+    int const stride = npx + 1;
+    for (int y = 0; y < npy; ++y) {
+        uint8_t* pv = &patch_valid[(size_t)y * npx];
+        uint8_t const* n0 = &node_valid[(size_t)y * stride];
+        uint8_t const* n1 = n0 + stride;
+        for (int x = 0; x < npx; ++x) {
+            if (pv[x])
                 continue;
-            if (node_exists(x, y) && node_exists(x + 1, y)
-                && node_exists(x, y + 1) && node_exists(x + 1, y + 1)) {
-                patch_valid[(size_t)y * npx + x] = 1;
+            if (n0[x] && n0[x + 1] && n1[x] && n1[x + 1]) {
+                pv[x] = 1;
                 filled += 1;
             }
         }
+    }
     return filled;
 }
 
@@ -174,33 +180,47 @@ Surface::remove_nodes_without_patch(void)
     touch();
     // lib/surface.cc:762-869: a node lives while one incident patch lives
     int const stride = npx + 1;
-    for (std::size_t i = 0; i < node_valid.size(); ++i) {
-        if (!node_valid[i])
-            continue;
-        int const idx = (int)(i % stride), idy = (int)(i / stride);
-        if (!patch_exists(idx - 1, idy - 1) && !patch_exists(idx, idy - 1)
-            && !patch_exists(idx - 1, idy) && !patch_exists(idx, idy))
-            node_valid[i] = 0;
-    }
+    for (int idy = 0; idy <= npy; ++idy)
+        for (int idx = 0; idx <= npx; ++idx) {
+            std::size_t const i = (size_t)idy * stride + idx;
+            if (!node_valid[i])
+                continue;
+            if (!patch_exists(idx - 1, idy - 1) && !patch_exists(idx, idy - 1)
+                && !patch_exists(idx - 1, idy) && !patch_exists(idx, idy))
+                node_valid[i] = 0;
+        }
 }
 
 void
 Surface::remove_isolated_patches(void)
 {
     touch();
-    // lib/surface.cc:887-927
-    for (int x = 0; x < npx; ++x)
+    // lib/surface.cc:887-927.  The reference walks the grid column by column
+    // and deletes in place, so a deletion changes the counts of the patches
+    // visited after it: the order is part of the result.  The walk runs on a
+    // transposed copy with a one-cell border of zeros (columns contiguous),
+    // same visits in the same order.
+    int const th = npy + 2;   // cells per (padded) column
+    std::vector<uint8_t> t((size_t)(npx + 2) * th, 0);
+    for (int y = 0; y < npy; ++y)
+        for (int x = 0; x < npx; ++x)
+            t[(size_t)(x + 1) * th + y + 1] = patch_valid[(size_t)y * npx + x] ? 1 : 0;
+    for (int x = 0; x < npx; ++x) {
+        uint8_t* c0 = &t[(size_t)x * th];        // column x - 1
+        uint8_t* c1 = c0 + th;                   // column x
+        uint8_t* c2 = c1 + th;                   // column x + 1
         for (int y = 0; y < npy; ++y) {
-            if (!patch_exists(x, y))
+            if (!c1[y + 1])
                 continue;
-            int neighbours = 0;
-            for (int dx = -1; dx <= 1; ++dx)
-                for (int dy = -1; dy <= 1; ++dy)
-                    if ((dx || dy) && patch_exists(x + dx, y + dy))
-                        neighbours += 1;
+            int const neighbours = c0[y] + c0[y + 1] + c0[y + 2] + c1[y] + c1[y + 2]
+                + c2[y] + c2[y + 1] + c2[y + 2];
             if (neighbours < 3)
-                patch_valid[(size_t)y * npx + x] = 0;
+                c1[y + 1] = 0;
         }
+    }
+    for (int y = 0; y < npy; ++y)
+        for (int x = 0; x < npx; ++x)
+            patch_valid[(size_t)y * npx + x] = t[(size_t)(x + 1) * th + y + 1];
     remove_nodes_without_patch();
 }
 
