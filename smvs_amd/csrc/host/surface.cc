@@ -401,16 +401,23 @@ Surface::subdivide_patches(void)
     for (int t = 0; t < 3; ++t)
         for (int k = 0; k < 2; ++k)
             smvs_topo::hermite(0.5 * t, k, basis[t][k]);
-    auto combine = [](double const* n, double const* bx, double const* by) {
-        double r = 0.0;
-        for (int b = 0; b < 2; ++b)
-            for (int a = 0; a < 2; ++a) {
-                double const* nd = n + 4 * (2 * b + a);
-                r += nd[0] * bx[a] * by[b] + nd[1] * bx[2 + a] * by[b]
-                    + nd[2] * bx[a] * by[2 + b] + nd[3] * bx[2 + a] * by[2 + b];
+    // The 5 x 4 results of a patch (split point x {f, dx, dy, dxy}) as 20
+    // independent lanes that all run patch_eval's sequence of operations on
+    // their own basis values: the compiler vectorises across the lanes, every
+    // lane's bits are the scalar evaluation's.
+    constexpr int LANES = 20;
+    double bx[4][LANES], by[4][LANES], post[LANES];
+    for (int si = 0; si < 5; ++si)
+        for (int q = 0; q < 4; ++q) {
+            int const lane = 4 * si + q;
+            double const* u = basis[splits[si].iu][q & 1];        // d/dx for q = 1, 3
+            double const* v = basis[splits[si].iv][(q >> 1) & 1]; // d/dy for q = 2, 3
+            for (int k = 0; k < 4; ++k) {
+                bx[k][lane] = u[k];
+                by[k][lane] = v[k];
             }
-        return r;
-    };
+            post[lane] = q == 0 ? 1.0 : (q == 3 ? 4.0 : 2.0);
+        }
     for (std::size_t p = 0; p < patch_valid.size(); ++p) {
         if (!patch_valid[p])
             continue;
@@ -418,14 +425,22 @@ Surface::subdivide_patches(void)
         int const ny = 2 * (int)(p / old_npx) + off_y;
         double n16[16];
         fill_patch_nodes(p, n16);
-        for (Split const& s : splits) {
-            std::size_t const id = (size_t)(ny + s.oy) * new_stride + nx + s.ox;
-            double const (*bu)[4] = basis[s.iu];
-            double const (*bv)[4] = basis[s.iv];
-            new_nodes[4 * id + 0] = combine(n16, bu[0], bv[0]);
-            new_nodes[4 * id + 1] = combine(n16, bu[1], bv[0]) / 2;
-            new_nodes[4 * id + 2] = combine(n16, bu[0], bv[1]) / 2;
-            new_nodes[4 * id + 3] = combine(n16, bu[1], bv[1]) / 4;
+        double r[LANES];
+        for (int l = 0; l < LANES; ++l)
+            r[l] = 0.0;
+        for (int bb = 0; bb < 2; ++bb)
+            for (int aa = 0; aa < 2; ++aa) {
+                double const* nd = n16 + 4 * (2 * bb + aa);
+                for (int l = 0; l < LANES; ++l)
+                    r[l] += nd[0] * bx[aa][l] * by[bb][l] + nd[1] * bx[2 + aa][l] * by[bb][l]
+                        + nd[2] * bx[aa][l] * by[2 + bb][l]
+                        + nd[3] * bx[2 + aa][l] * by[2 + bb][l];
+            }
+        for (int si = 0; si < 5; ++si) {
+            Split const& sp = splits[si];
+            std::size_t const id = (size_t)(ny + sp.oy) * new_stride + nx + sp.ox;
+            for (int q = 0; q < 4; ++q)
+                new_nodes[4 * id + q] = r[4 * si + q] / post[4 * si + q];
             new_valid[id] = 1;
         }
     }
