@@ -62,6 +62,19 @@ def test_surface_operations_match_oracle(host, oracle, scene, ops):
     assert got["scale"] == 5 - ops.count(2)
 
 
+@pytest.mark.parametrize("delete_every", [3, 5])
+def test_isolated_patch_removal_keeps_the_reference_order(host, oracle, scene, delete_every):
+    """remove_isolated_patches deletes in place while it walks the grid column
+    by column (surface.cc:887-927): with every second / third patch gone the
+    deletions cascade, so the result depends on the visiting order -- the
+    host mirror (which walks a transposed copy) must still equal the oracle."""
+    ops = [2, 2, 5, 4, 1, 4]
+    got = host.surface_script(scene, 5, ops, delete_every=delete_every)
+    want = oracle.surface_script(scene, 5, ops, delete_every=delete_every)
+    _same(got, want, exact=False)
+    assert 0 < got["patch_valid"].sum() < got["patch_valid"].size
+
+
 def test_surface_from_an_initial_depth_map(host, oracle, scene):
     """Surface::create with the SGM-style initial depth (surface.cc:46-50):
     a depth map with holes and a discontinuity."""
