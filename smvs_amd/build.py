@@ -44,7 +44,11 @@ def build_host(force=False, verbose=False):
     if not force and not _host_stale():
         return HOST_LIB
     cxx = os.environ.get("CXX", "g++")
-    cmd = [cxx, "-std=c++17", "-O3", "-fPIC", "-Wall", "-pthread", "-shared", "-o", HOST_LIB] \
+    # -ffp-contract=off: the float routines that must round like the reference
+    # (fill_reprojection, the grid surgery, topo_math.h) may not be fused into
+    # FMAs whatever -march the caller's CXX / CXXFLAGS select
+    cmd = [cxx, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall", "-pthread",
+           "-shared", "-o", HOST_LIB] \
         + [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] \
         + ["-L" + CSRC, "-lsmvs_hip", "-Wl,-rpath,$ORIGIN/..",
            "-Wl,-rpath,/opt/rocm/lib"]

@@ -45,6 +45,7 @@
 #include <cmath>
 #include <mutex>
 #include <string>
+#include <thread>
 
 namespace smvs_hip {
 
@@ -497,6 +498,16 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
     unsigned const tag = solve_tag | epoch;
     double *res = red + RES_KINDS * RES_WAVES;   // [K] results, behind the partial sums
     block_partials<K>(v, red);
+    if (nblocks == 1) {
+        // a grid of one tile (the coarse scales, the tiny systems of the fuzz
+        // sweep): nothing to exchange -- the workgroup's sums are the totals,
+        // no granule leaves the CU (6 us per iteration on a loaded chip)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            v[k] = block_total(red, k);
+        __syncthreads();   // (the partial sums are free for the next reduction)
+        return true;
+    }
     // (nothing to drain: everything that crosses workgroups is a granule, the
     // vectors of the solve live in registers and LDS)
     unsigned const par = epoch & 1u;
@@ -1021,7 +1032,9 @@ cg_resident_kernel(ResArgs A)
     int const li = ly * tw + lx;             // index in the tile
     TileGeom const G = { tw, th, LW, lx, ly, li, lcore };
     // the exchanged vector of a rim node is read by the neighbouring tiles
-    bool const rim = mine && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
+    // (a grid of one tile has no neighbours: nothing is published)
+    bool const rim = nblocks > 1 && mine
+        && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
     size_t const N = (size_t)A.num_nodes;
 
     // halo ring position served by this thread
@@ -1760,11 +1773,49 @@ choose_tiling(int stride, int rows, int max_tiles, bool one, int *tw_out, int *t
     return best >= 0;
 }
 
-// Which of the two resident solvers a context runs (smvs_ctx_set_solver).
+// Which of the two resident solvers a context runs (smvs_ctx_set_solver), and
+// on which tiles.  The one-exchange recurrence exists to save a grid-wide
+// exchange per iteration; on a grid of ONE tile nothing is exchanged, so AUTO
+// runs the reference's operation order there (conjugate_gradient.h:121-198:
+// d.Ad, then r.r, z.r, x.(b + r) of the updated vectors summed directly) --
+// the tiny ill-conditioned systems of the fuzz sweep live on such grids.
+// SMVS_REF_ORDER_TILES=n widens that to grids of <= n tiles (measurements).
+struct ResidentPlan {
+    int tw, th;
+    bool one;
+};
+
 static bool
-resident_one_exchange(const smvs_ctx *ctx)
+resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
 {
-    return ctx->solver_mode != SMVS_SOLVER_RESIDENT_REF;
+    int const stride = ctx->node_stride;
+    int const rows = ctx->num_nodes / stride;
+    int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
+        ? ctx->resident_cus : RES_MAX_BLOCKS;
+    static int const ref_order_tiles = [] {
+        const char *e = std::getenv("SMVS_REF_ORDER_TILES");
+        int const n = e != nullptr ? std::atoi(e) : 1;
+        return n < 0 ? 0 : n;
+    }();
+    int tw = 0, th = 0;
+    bool const have_ref = choose_tiling(stride, rows, max_tiles, false, &tw, &th);
+    if (have_ref) {
+        long const tiles = (long)((stride + tw - 1) / tw) * ((rows + th - 1) / th);
+        if (ctx->solver_mode == SMVS_SOLVER_RESIDENT_REF || tiles <= ref_order_tiles) {
+            plan->tw = tw;
+            plan->th = th;
+            plan->one = false;
+            return true;
+        }
+    } else if (ctx->solver_mode == SMVS_SOLVER_RESIDENT_REF) {
+        return false;
+    }
+    if (!choose_tiling(stride, rows, max_tiles, true, &tw, &th))
+        return false;
+    plan->tw = tw;
+    plan->th = th;
+    plan->one = true;
+    return true;
 }
 
 // Does the resident solver take this system?  (grid fits the chip's CUs and
@@ -1791,12 +1842,8 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
             return false;
         ctx->resident_cus = prop.multiProcessorCount;
     }
-    int const stride = ctx->node_stride;
-    int const rows = ctx->num_nodes / stride;
-    int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
-        ? ctx->resident_cus : RES_MAX_BLOCKS;
-    int tw = 0, th = 0;
-    if (!choose_tiling(stride, rows, max_tiles, resident_one_exchange(ctx), &tw, &th))
+    ResidentPlan plan;
+    if (!resident_plan(ctx, &plan))
         return false;
     if ((size_t)ctx->num_nodes * 5 * 16 >= (size_t)1 << 32)
         return false;
@@ -1820,27 +1867,64 @@ DeviceBarrierLock::bind(int device)
     for (char *c = bus; *c != 0; ++c)
         if (*c == ':' || *c == '/')
             *c = '_';
+    // SMVS_LOCK_DIR, else the user's runtime directory, else /tmp.  The file
+    // is never followed through a symlink; when another user created it
+    // (O_RDWR refused) a read-only descriptor serves flock() just as well.
     const char *dir = std::getenv("SMVS_LOCK_DIR");
-    std::string const path = std::string(dir != nullptr ? dir : "/tmp") + "/smvs_hip_barrier_"
-        + bus + ".lock";
-    fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    // (no file: the lock protects this process only, as before)
+    if (dir == nullptr || dir[0] == 0)
+        dir = std::getenv("XDG_RUNTIME_DIR");
+    if (dir == nullptr || dir[0] == 0)
+        dir = "/tmp";
+    std::string const path = std::string(dir) + "/smvs_hip_barrier_" + bus + ".lock";
+    fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+    if (fd < 0)
+        fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+    if (fd < 0)
+        std::fprintf(stderr, "[smvs_hip] no lock file %s (%s): the resident solver is "
+            "serialised inside this process only; a second process on the same GPU may "
+            "push it into the streaming kernels\n", path.c_str(), std::strerror(errno));
 }
 
 void
 DeviceBarrierLock::lock(void)
 {
     mutex.lock();
-    if (fd >= 0)
-        while (::flock(fd, LOCK_EX) != 0 && errno == EINTR) {
+    if (fd < 0)
+        return;
+    // A Newton loop holds the lock for milliseconds.  Somebody who holds it
+    // for 20 s is not one of ours (or is stuck): go on without the file lock --
+    // the worst case is a resident solve that times out into the streaming
+    // kernels, not a hang.
+    auto const t0 = std::chrono::steady_clock::now();
+    file_locked = false;
+    for (long spin = 0;; ++spin) {
+        if (::flock(fd, LOCK_EX | LOCK_NB) == 0) {
+            file_locked = true;
+            return;
         }
+        if (errno != EWOULDBLOCK && errno != EINTR)
+            return;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            static bool warned = false;
+            if (!warned)
+                std::fprintf(stderr, "[smvs_hip] barrier lock file busy for 20 s: "
+                    "continuing without it\n");
+            warned = true;
+            return;
+        }
+        if (spin < 64)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 void
 DeviceBarrierLock::unlock(void)
 {
-    if (fd >= 0)
+    if (fd >= 0 && file_locked)
         (void)::flock(fd, LOCK_UN);
+    file_locked = false;
     mutex.unlock();
 }
 
@@ -1864,13 +1948,15 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
 {
     int const stride = ctx->node_stride;
     int const rows = ctx->num_nodes / stride;
-    int const max_tiles = ctx->resident_cus < RES_MAX_BLOCKS
-        ? ctx->resident_cus : RES_MAX_BLOCKS;
-    int tw = 0, th = 0;
-    (void)choose_tiling(stride, rows, max_tiles, resident_one_exchange(ctx), &tw, &th);
+    ResidentPlan plan;
+    if (!resident_plan(ctx, &plan)) {
+        set_error("resident_enqueue: the grid does not fit the resident solver");
+        return SMVS_ERR_STATE;
+    }
+    int const tw = plan.tw, th = plan.th;
     int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
     int const num_tiles = tiles_x * tiles_y;
-    bool const one = resident_one_exchange(ctx);
+    bool const one = plan.one;
     size_t const lds_bytes = resident_lds_bytes(tw, th, one);
 
     int rc;
@@ -2041,7 +2127,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         if (FILE *f = std::fopen(trace_path, "a")) {
             std::fprintf(f, "solve nodes=%d tiles=%d its=%d exchanges=%d\n",
                 ctx->num_nodes, num_tiles, progress[3],
-                resident_one_exchange(ctx) ? 1 : 2);
+                [&] { ResidentPlan p; return resident_plan(ctx, &p) && p.one; }() ? 1 : 2);
             for (int k = 0; k <= TRACE_ITERS; ++k) {
                 for (int q = 0; q < TRACE_POINTS; ++q)
                     std::fprintf(f, "%lld ", tr[(size_t)k * TRACE_POINTS + q]);

@@ -220,6 +220,14 @@ int ctx_pool_release(void);   // frees the parked contexts (ctx.hip) -> how many
 int ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
+// hipMalloc that does not give up on memory the library itself is holding:
+// when the driver reports out-of-memory, the parked contexts and the idle
+// workspaces (pool.hip; hundreds of MB each, kept for the next view of the
+// same geometry) go back to the driver and the allocation is tried once more.
+int device_malloc(void **ptr, size_t bytes);
+// Returns what the pools hold idle to the driver; -> objects freed.
+int release_idle_device_memory(void);
+
 template <typename T>
 int device_alloc(T **ptr, size_t count)
 {
@@ -229,13 +237,7 @@ int device_alloc(T **ptr, size_t count)
     }
     if (count == 0)
         return SMVS_OK;
-    hipError_t err = hipMalloc(reinterpret_cast<void **>(ptr), count * sizeof(T));
-    if (err != hipSuccess) {
-        set_error("hipMalloc(%zu bytes): %s", count * sizeof(T),
-            hipGetErrorString(err));
-        return SMVS_ERR_NOMEM;
-    }
-    return SMVS_OK;
+    return device_malloc(reinterpret_cast<void **>(ptr), count * sizeof(T));
 }
 
 // A reusable device workspace of the context-free entry points (pool.hip): a
@@ -405,6 +407,7 @@ private:
     std::mutex mutex;
     int fd = -1;
     bool bound = false;
+    bool file_locked = false;   // (guarded by mutex)
 };
 DeviceBarrierLock &cg_resident_mutex(int device);
 int cg_resident_enqueue(smvs_ctx *ctx, int max_iterations, double q_tolerance,

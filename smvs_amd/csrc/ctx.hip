@@ -280,11 +280,40 @@ smvs_ctx_destroy(smvs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream != nullptr && hipStreamSynchronize(ctx->stream) == hipSuccess) {
         ctx_reset_for_reuse(ctx);
-        std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
-        if (g_ctx_pool.size() < CTX_POOL_MAX) {
+        // The pool is bounded by count AND by what it leaves of the device:
+        // parked contexts are keyed on their exact geometry, so a scene of
+        // mixed image sizes would otherwise pin one idle context (~0.9 GB at
+        // 1920x1080 x 8) per size.  While less than a quarter of the device is
+        // free, the contexts parked longest go back to the driver.
+        std::vector<smvs_ctx *> evict;
+        int const device = ctx->device;   // (once parked, ctx may be taken or evicted)
+        {
+            std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
             g_ctx_pool.push_back(ctx);
-            return SMVS_OK;
+            while (g_ctx_pool.size() > CTX_POOL_MAX) {
+                evict.push_back(g_ctx_pool.front());
+                g_ctx_pool.erase(g_ctx_pool.begin());
+            }
         }
+        for (;;) {
+            for (smvs_ctx *c : evict)
+                (void)ctx_free(c);
+            evict.clear();
+            size_t free_b = 0, total_b = 0;
+            (void)hipSetDevice(device);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= total_b / 4)
+                break;
+            std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
+            for (size_t i = 0; i < g_ctx_pool.size(); ++i)
+                if (g_ctx_pool[i]->device == device) {
+                    evict.push_back(g_ctx_pool[i]);
+                    g_ctx_pool.erase(g_ctx_pool.begin() + (long)i);
+                    break;
+                }
+            if (evict.empty())
+                break;
+        }
+        return SMVS_OK;
     }
     return ctx_free(ctx);
 }
@@ -292,6 +321,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
 int
 smvs_hip::ctx_pool_release(void)
 {
+    int current = 0;
+    bool const have_device = hipGetDevice(&current) == hipSuccess;
     std::vector<smvs_ctx *> all;
     {
         std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
@@ -299,6 +330,10 @@ smvs_hip::ctx_pool_release(void)
     }
     for (smvs_ctx *c : all)
         (void)ctx_free(c);
+    // (ctx_free selects the context's device; the caller may be in the middle
+    // of an allocation on another one)
+    if (have_device && !all.empty())
+        (void)hipSetDevice(current);
     return (int)all.size();
 }
 

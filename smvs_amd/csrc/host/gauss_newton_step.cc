@@ -70,13 +70,13 @@ GaussNewtonStep::upload_planes(bool with_shading)
     if (with_shading && (sh == nullptr || shg == nullptr))
         throw std::invalid_argument("GaussNewtonStep: lighting without a "
             "shading image (StereoView::create(..., initialize_linear))");
-    if (uploaded[0] != grad.get() || (with_shading && uploaded[1] != sh.get())) {
+    if (uploaded[0] != grad || (with_shading && uploaded[1] != sh)) {
         check(smvs_ctx_upload_main(ctx, grad->begin(),
             with_shading ? sh->begin() : nullptr,
             with_shading ? shg->begin() : nullptr), "smvs_ctx_upload_main");
-        uploaded[0] = grad.get();
+        uploaded[0] = grad;
         if (with_shading)
-            uploaded[1] = sh.get();
+            uploaded[1] = sh;
     }
     for (std::size_t j = 0; j < sub_views.size(); ++j) {
         FloatImage::ConstPtr g = sub_views[j]->get_image_gradients();
@@ -84,11 +84,11 @@ GaussNewtonStep::upload_planes(bool with_shading)
         if (g == nullptr || h == nullptr)
             throw std::invalid_argument("GaussNewtonStep: a neighbour has no "
                 "gradient / Hessian planes (StereoView::set_scale)");
-        if (uploaded[2 + j] == g.get())
+        if (uploaded[2 + j] == g)
             continue;
         check(smvs_ctx_upload_sub(ctx, (int)j, g->width(), g->height(), g->begin(),
             h->begin()), "smvs_ctx_upload_sub");
-        uploaded[2 + j] = g.get();
+        uploaded[2 + j] = g;
     }
 }
 

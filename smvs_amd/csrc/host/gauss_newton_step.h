@@ -63,14 +63,21 @@ private:
     void upload_planes(bool with_shading);
 
 private:
-    Options const& opts;
+    // (copies: the reference keeps references, lib/gauss_newton_step.h:83-90,
+    // which dangle when a caller passes temporaries)
+    Options const opts;
     StereoView::ConstPtr main_view;
-    std::vector<StereoView::Ptr> const& sub_views;
-    std::vector<Matrix3d> const& Mi;
-    std::vector<Vec3d> const& ti;
+    std::vector<StereoView::Ptr> const sub_views;
+    std::vector<Matrix3d> const Mi;
+    std::vector<Vec3d> const ti;
     smvs_ctx* ctx = nullptr;
-    // the planes the device holds (re-uploaded when a view's scale changed)
-    std::vector<void const*> uploaded;
+    // The planes the device holds, re-uploaded when a view's scale changed.
+    // StereoView::set_scale / set_scale_planes install NEW image objects; the
+    // shared pointers kept here keep the uploaded ones alive, so an address
+    // cannot be recycled by a later image and compare equal by accident.
+    // (Planes are immutable once a view hands them out; writing into one in
+    // place is not detected.)
+    std::vector<FloatImage::ConstPtr> uploaded;
 };
 
 } // namespace smvs_amd

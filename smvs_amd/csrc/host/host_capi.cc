@@ -620,7 +620,8 @@ smvs_host_gn_solve_step(const smvs_host_view *main_in, const smvs_host_view *sub
 extern "C" int
 smvs_host_reconstruct_scene(const char *scene_dir,
     const smvs_host_recon_settings *o, const int *view_ids, int n_view_ids,
-    int *reconstructed_out, int *n_reconstructed, int *n_skipped, double *seconds)
+    int *reconstructed_out, int max_reconstructed, int *n_reconstructed,
+    int *n_skipped, double *seconds)
 {
     try {
         if (scene_dir == nullptr || o == nullptr)
@@ -646,9 +647,10 @@ smvs_host_reconstruct_scene(const char *scene_dir,
         if (view_ids != nullptr)
             conf.view_ids.assign(view_ids, view_ids + n_view_ids);
         ReconReport const report = reconstruct_scene(scene_dir, conf);
-        if (reconstructed_out != nullptr)
-            std::copy(report.reconstructed.begin(), report.reconstructed.end(),
-                reconstructed_out);
+        if (reconstructed_out != nullptr && max_reconstructed > 0)
+            std::copy_n(report.reconstructed.begin(),
+                std::min<std::size_t>(report.reconstructed.size(),
+                    (std::size_t)max_reconstructed), reconstructed_out);
         if (n_reconstructed != nullptr)
             *n_reconstructed = (int)report.reconstructed.size();
         if (n_skipped != nullptr)

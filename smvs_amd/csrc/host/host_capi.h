@@ -120,7 +120,11 @@ int smvs_host_gn_solve_step(const smvs_host_view *main_view,
  * directory whose input embedding exists as <image_embedding>.mvei: view list,
  * ViewSelection, one ViewQueue task per reference view, result embeddings
  * written into the view directories.  view_ids may be NULL (every view).
- * reconstructed_out: room for the scene's view count; *n_reconstructed. */
+ * reconstructed_out[max_reconstructed] receives the ids of the reconstructed
+ * views (may be NULL with max_reconstructed = 0); *n_reconstructed is their
+ * number -- when it exceeds max_reconstructed only the first
+ * max_reconstructed ids were stored (the scene has been reconstructed; the
+ * caller can size the buffer from smvs_host_scene_info). */
 typedef struct {
     const char *image_embedding;    /* "undistorted" */
     float regularization;           /* alpha, 1.0 */
@@ -133,7 +137,8 @@ typedef struct {
 } smvs_host_recon_settings;
 int smvs_host_reconstruct_scene(const char *scene_dir,
     const smvs_host_recon_settings *settings, const int *view_ids, int n_view_ids,
-    int *reconstructed_out, int *n_reconstructed, int *n_skipped, double *seconds);
+    int *reconstructed_out, int max_reconstructed, int *n_reconstructed,
+    int *n_skipped, double *seconds);
 
 /* MVE scene I/O without a device: parses the scene (views/<x>.mve/meta.ini,
  * synth_0.out) -> number of list entries, and per entry (caller-sized arrays of

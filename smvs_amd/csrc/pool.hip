@@ -25,6 +25,33 @@ std::vector<Workspace *> g_free[MAX_DEVICES];
 int g_created[MAX_DEVICES] = { 0 };
 }
 
+static int release_idle_workspaces(void);
+
+int
+device_malloc(void **ptr, size_t bytes)
+{
+    hipError_t err = hipMalloc(ptr, bytes);
+    if (err == hipErrorOutOfMemory) {
+        // the memory may be ours: parked contexts, idle workspaces
+        (void)hipGetLastError();
+        if (release_idle_device_memory() > 0)
+            err = hipMalloc(ptr, bytes);
+    }
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(err));
+        return SMVS_ERR_NOMEM;
+    }
+    return SMVS_OK;
+}
+
+int
+release_idle_device_memory(void)
+{
+    return release_idle_workspaces() + ctx_pool_release();
+}
+
 int
 Workspace::ensure(int slot, size_t bytes, void **out)
 {
@@ -38,11 +65,10 @@ Workspace::ensure(int slot, size_t bytes, void **out)
             b.cap = 0;
         }
         size_t const want = bytes ? bytes : 1;
-        hipError_t const e = hipMalloc(&b.p, want);
-        if (e != hipSuccess) {
-            set_error("hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        int const rc = device_malloc(&b.p, want);
+        if (rc != SMVS_OK) {
             b.p = nullptr;
-            return SMVS_ERR_NOMEM;
+            return rc;
         }
         b.cap = want;
     }
@@ -183,13 +209,13 @@ workspace_destroy(Workspace *w)
     delete w;
 }
 
-} // namespace smvs_hip
-
-using namespace smvs_hip;
-
-extern "C" int
-smvs_release_workspaces(void)
+// The workspaces nobody has checked out (a checked-out one is in use by its
+// caller and stays).
+static int
+release_idle_workspaces(void)
 {
+    int current = 0;
+    bool const have_device = hipGetDevice(&current) == hipSuccess;
     std::vector<Workspace *> all;
     {
         std::lock_guard<std::mutex> guard(g_pool_mutex);
@@ -200,5 +226,17 @@ smvs_release_workspaces(void)
     }
     for (Workspace *w : all)
         workspace_destroy(w);
-    return (int)all.size() + ctx_pool_release();
+    if (have_device && !all.empty())
+        (void)hipSetDevice(current);
+    return (int)all.size();
+}
+
+} // namespace smvs_hip
+
+using namespace smvs_hip;
+
+extern "C" int
+smvs_release_workspaces(void)
+{
+    return release_idle_device_memory();
 }

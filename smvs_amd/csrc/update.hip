@@ -348,17 +348,20 @@ finish_step_kernel(FinishArgs A)
             base = (int)(old & 0xFFFFFFull);
             seen = old + add;
         } else {
-            // the counts no longer fit beside the arrivals: the counts first
-            // (the returned value orders it before the arrival), then the
-            // arrival; the last arriver reads the totals back
+            // the counts no longer fit beside the arrivals: the counts first,
+            // then the arrival as a release / acquire (the counts of every
+            // workgroup whose arrival the last one observes are visible to
+            // its read-back); the last arriver reads the totals back
             unsigned long long const add = (unsigned long long)total
                 | ((unsigned long long)cnt_on << 32);
             unsigned long long const old = atomicAdd(A.counter, add);
             base = (int)(old & 0xFFFFFFFFull);
-            unsigned long long const arrived = atomicAdd(A.counter + 1, 1ull) + 1ull;
+            unsigned long long const arrived = __hip_atomic_fetch_add(A.counter + 1, 1ull,
+                __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
             unsigned long long totals = 0ull;
             if (arrived == (unsigned long long)gridDim.x)
-                totals = atomicAdd(A.counter, 0ull);
+                totals = __hip_atomic_fetch_add(A.counter, 0ull, __ATOMIC_ACQUIRE,
+                    __HIP_MEMORY_SCOPE_AGENT);
             // same layout as the packed word: length, active nodes, arrivals
             // (the packed fields are only decoded below)
             seen = arrived == (unsigned long long)gridDim.x ? totals : 0ull;

@@ -229,15 +229,19 @@ def reconstruct_scene(scene_dir, view_ids=None, image_embedding="undistorted",
                        sgm_range[0], sgm_range[1], sgm_scale, num_neighbors, min_neighbors,
                        first_device, num_devices, views_in_flight)
     ids = None if view_ids is None else np.asarray(view_ids, dtype=np.int32)
-    out = np.zeros(4096, np.int32)
+    # (room for every view of the scene: smvs_host_scene_info)
+    cap = C.c_int(0)
+    lib.smvs_host_scene_info(scene_dir.encode(), image_embedding.encode(), C.c_int(0),
+                             C.byref(cap), None, None, None, None, None, None, None)
+    out = np.zeros(max(cap.value, 1), np.int32)
     n = C.c_int(0); sk = C.c_int(0); secs = C.c_double(0.0)
     rc = lib.smvs_host_reconstruct_scene(scene_dir.encode(), C.byref(st),
         ids.ctypes.data_as(_i32p) if ids is not None else None,
         C.c_int(0 if ids is None else ids.size), out.ctypes.data_as(_i32p),
-        C.byref(n), C.byref(sk), C.byref(secs))
+        C.c_int(out.size), C.byref(n), C.byref(sk), C.byref(secs))
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
-    return [int(x) for x in out[:n.value]], sk.value, secs.value
+    return [int(x) for x in out[:min(n.value, out.size)]], sk.value, secs.value
 
 
 def scene_info(scene_dir, image_embedding="undistorted", max_views=4096):

@@ -189,6 +189,37 @@ def test_full_size_optimize_with_sgm_matches_oracle(hip, oracle, oracle_threads)
     assert np.median(np.abs(got["depth"][ok] - truth[ok]) / truth[ok]) < 5e-3
 
 
+def test_full_size_optimize_basic_matches_oracle(hip, oracle, oracle_threads):
+    """BASELINE.json configs[1] as a whole -- the scene and options of
+    `bench.py --workload optimize` / `secondary.optimize`: 1920x1080 textured
+    sphere, 1 + 8 views, --no-sgm (surface from the bundle, NCC visibility
+    test, expand), shading off, scales init .. 2, five iterations per scale.
+    C++ host + HIP against the oracle's optimize(): identical batch log (scale,
+    iteration, Newton steps, valid patches), identical valid pixels, depth
+    within 1e-4 relative L2; the per-batch active patch-steps and CG iteration
+    totals are printed side by side (they are the units of the bench value)."""
+    from smvs_amd import host
+    import bench
+    inputs = _full_size_inputs()
+    got = host.optimize(inputs, regularization=bench.REG, num_iterations=5,
+                        min_scale=bench.SCALE)
+    want = oracle.optimize(inputs, regularization=bench.REG, num_iterations=5,
+                           min_scale=bench.SCALE)
+    for a, b in zip(got["log"], want["log"]):
+        print("scale %d iter %d: steps %d / %d, valid %d / %d, CG %s / %s"
+              % (a["scale"], a["iter"], a["newton_steps"], b["newton_steps"],
+                 a["valid_patches"], b["valid_patches"], a.get("cg_iterations"),
+                 b.get("cg_iterations")))
+    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert (want["depth"] > 0).mean() > 0.2
+    print("configs[1] whole optimize: depth rel. L2 %.2e" % _rel(got["depth"], want["depth"]))
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
+    truth = inputs["truth"]
+    ok = want["depth"] > 0
+    assert np.median(np.abs(got["depth"][ok] - truth[ok]) / truth[ok]) < 5e-3
+
+
 def test_full_size_optimize_shading_aware_matches_oracle(hip, oracle, oracle_threads):
     """BASELINE.json configs[3]: 1920x1080, 1 + 8 views, -S (GlobalLighting SH
     fit at scales < 4 + shading residual), no SGM: identical batch log and
