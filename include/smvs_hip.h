@@ -336,8 +336,9 @@ int smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
  * in every neighbour, then border / occlusion test (:505-530),
  * warp anisotropy <= 8 (:532-575) and, if use_ncc (the reference's !use_sgm,
  * :577-580), ncc_for_patch >= 0 (:792-912).
- * patch_vis_out[num_patches]: bit j = patch visible in neighbour j; 0 for
- * invalid patches.  The mask also becomes the context's patch visibility.
+ * patch_vis_out[num_patches] (may be NULL: nothing is copied back): bit j =
+ * patch visible in neighbour j; 0 for invalid patches.  The mask also becomes
+ * the context's patch visibility.
  * Deleting the patches without any neighbour (:592-603) stays with the
  * caller, which owns the topology. */
 int smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
@@ -356,10 +357,78 @@ int smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out);
  * a node with more than one missing neighbour node and mse_for_patch > 0.05
  * (:401-428), then nodes without a patch (Surface::remove_nodes_without_patch).
  * inv_calibration9: CameraInfo::fill_inverse_calibration of the main view.
- * patch_valid_out[num_patches], node_valid_out[num_nodes]: validity after the
- * last pass (also the context's); *total_deleted (may be NULL). */
+ * patch_valid_out[num_patches], node_valid_out[num_nodes] (either may be NULL:
+ * not copied back): validity after the last pass (also the context's);
+ * *total_deleted (may be NULL). */
 int smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     uint8_t *patch_valid_out, uint8_t *node_valid_out, int *total_deleted);
+
+/* ------------------------------------------------------------------ */
+/* grid surgery of the surface on the device          */
+/* ------------------------------------------------------------------ */
+
+/* smvs::Surface's topology operations (lib/surface.h:36-57) on the surface the
+ * context holds, so that DepthOptimizer::optimize (depth_optimizer.cc:53-162)
+ * never moves the surface across PCIe between its Newton batches.  The grid
+ * geometry follows the reference's integer rules (surface.cc:28-37, 983-1012)
+ * and is mirrored on the host by smvs_surface_info; node values are the
+ * reference's double arithmetic in its operation order.  Every call leaves the
+ * number of valid (non-null) patches in *num_valid_patches (may be NULL) --
+ * the one quantity the optimiser's outer loop needs (:339-356) -- and resets
+ * the visibility masks when the grid changed. */
+typedef struct {
+    int scale, patchsize;      /* patchsize = 2^scale */
+    int npx, npy;              /* patches; nodes = (npx + 1) * (npy + 1) */
+    int start_x, start_y;      /* pixel of node (0, 0) */
+} smvs_surface_geometry;
+
+/* Surface::create, surface.cc:19-53: the grid of `scale` with its nodes
+ * initialised from a depth map (initialize_node_from_depth :667-760 for every
+ * node, fill_holes :630-651, remove_nodes_without_patch :762-869).  The map --
+ * Surface::depth, kept in the context for the fill_patches_from_depth calls
+ * that follow every subdivision (depth_optimizer.cc:97-106) -- is
+ *   depth != NULL                  depth[W*H], positive = valid (:74-79);
+ *   depth == NULL, n_points > 0    zero except the listed pixels: the bundle's
+ *                                  features projected into the view by the
+ *                                  caller (initialize_depth_from_bundle
+ *                                  :90-130), at most one entry per pixel;
+ *   depth == NULL, n_points == 0   the filtered SGM map that
+ *                                  smvs_ctx_sgm_init_depth left in the context
+ *                                  (create_initial_surface,
+ *                                  depth_optimizer.cc:41-45). */
+int smvs_surface_create(smvs_ctx *ctx, int scale, const float *depth,
+    const int32_t *point_pixel, const float *point_depth, int n_points,
+    int *num_valid_patches);
+/* Surface::fill_patches_from_depth, surface.cc:140-152 */
+int smvs_surface_fill_patches_from_depth(smvs_ctx *ctx, int *num_valid_patches);
+/* Surface::subdivide_patches, surface.cc:983-1107: scale - 1, five new nodes
+ * per patch (a later patch overwrites an earlier one's edge midpoints, as the
+ * reference's loop does), old nodes with rescaled derivatives, then
+ * fill_holes + remove_nodes_without_patch. */
+int smvs_surface_subdivide(smvs_ctx *ctx, int *num_valid_patches);
+/* Surface::expand, surface.cc:482-628: two rounds of extrapolated border
+ * nodes (check_swap_nodes :472-480), fill_holes, remove_nodes_without_patch.
+ * *num_filled (may be NULL) = its return value, the patches filled. */
+int smvs_surface_expand(smvs_ctx *ctx, int *num_filled, int *num_valid_patches);
+/* Surface::remove_isolated_patches, surface.cc:887-927 (the in-place,
+ * column-by-column walk reproduced exactly) + remove_nodes_without_patch. */
+int smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches);
+/* The tail of create_subview_surfaces, depth_optimizer.cc:592-603: patches
+ * whose visibility mask (smvs_topology_subviews) is empty are deleted, then
+ * remove_nodes_without_patch. */
+int smvs_surface_delete_unseen_patches(smvs_ctx *ctx, int *num_deleted,
+    int *num_valid_patches);
+/* Test hook of the scripted sequences (tests/test_host_surface_cpu.py runs the
+ * same scripts on the host mirror): deletes every `every`-th valid patch in
+ * id order, then remove_nodes_without_patch. */
+int smvs_surface_delete_every(smvs_ctx *ctx, int every, int *num_valid_patches);
+/* Geometry of the context's surface (either pointer may be NULL). */
+int smvs_surface_info(smvs_ctx *ctx, smvs_surface_geometry *geometry,
+    int *num_valid_patches);
+/* The arrays of smvs_ctx_set_surface back on the host (any may be NULL):
+ * nodes[(npx+1)*(npy+1)][4], node_valid, patch_valid, patch_vis. */
+int smvs_surface_download(smvs_ctx *ctx, double *nodes, uint8_t *node_valid,
+    uint8_t *patch_valid, uint32_t *patch_vis);
 
 /* ------------------------------------------------------------------ */
 /* consumer of the depth / normal maps                */

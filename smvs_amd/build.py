@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmvs_hip.so")
 SOURCES = ["ctx.hip", "gn_construct.hip", "cg.hip", "cg_resident.hip", "update.hip", "sgm.hip",
-           "scale.hip", "topology.hip", "mesh.hip", "pool.hip"]
+           "scale.hip", "topology.hip", "mesh.hip", "pool.hip", "surface.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 
@@ -16,7 +16,8 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + ["common.h", os.path.join("host", "topo_math.h")]]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ["common.h", os.path.join("host", "topo_math.h"),
+                                                      os.path.join("host", "surface_math.h")]]
     deps.append(os.path.join(HERE, "..", "include", "smvs_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

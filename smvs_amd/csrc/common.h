@@ -67,6 +67,8 @@ enum {
     I_STOP,          // pipelined Newton loop: the loop has ended, enqueued steps do nothing
     I_STEP_ABORT,    // pipelined Newton loop: this step was abandoned (ABORT_*); it and
                      // the steps enqueued behind it change nothing
+    I_SURF_VALID,    // valid patches of the device surface (surface.hip)
+    I_SURF_CHANGED,  // patches filled / deleted by the last grid operation
     I_NUM = 16
 };
 
@@ -127,7 +129,8 @@ struct smvs_ctx {
     uint8_t *active = nullptr, *active_next = nullptr;
     int *live_list = nullptr;       // [P] patches with an active node, compacted
     uint16_t *cg_mask = nullptr;    // per node: stencil slots present in the CG matrix
-    double *hermite_tab = nullptr;  // [ps][12] 1-D Hermite basis table
+    double *hermite_tab = nullptr;  // [ps][12] 1-D Hermite basis table (inside hermite_all)
+    double *hermite_all = nullptr;  // the tables of ps = 1 .. 1024, [ps - 1 + row][12]
     int hermite_tab_ps = 0;
 
     // Gauss-Newton system
@@ -199,6 +202,17 @@ struct smvs_ctx {
     double *topo_mse = nullptr;
     size_t topo_mse_cap = 0;
 
+    // grid surgery on the device (surface.hip)
+    float *surf_depth = nullptr;       // [H][W] Surface::depth (surface.cc:46-50): the
+    size_t surf_depth_cap = 0;         // initial depth the nodes are (re)filled from
+    bool surf_depth_ok = false;
+    double *surf_tmp = nullptr;        // scratch: the nodes before a subdivision,
+    size_t surf_tmp_cap = 0;           // the proposals of expand (doubles)
+    uint8_t *surf_tmp_bytes = nullptr; // scratch: validity before a subdivision, proposed flags
+    size_t surf_tmp_bytes_cap = 0;
+    unsigned *surf_bits = nullptr;     // global fallback of the isolated-patch bit columns
+    size_t surf_bits_cap = 0;
+
     smvs_hip::Profile prof;
 };
 
@@ -219,6 +233,11 @@ int ctx_pool_release(void);   // frees the parked contexts (ctx.hip) -> how many
 // when the caller's buffer may be reused / is filled.
 int ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+// Geometry of the surface the context holds (Surface::create, surface.cc:28-37)
+// and room for it in every per-node / per-patch buffer; the buffers only grow.
+// Contents of the node / patch arrays are unspecified afterwards when the grid
+// grew.  Leaves has_surface untouched.
+int ctx_ensure_grid(smvs_ctx *ctx, int scale, int npx, int npy, int start_x, int start_y);
 
 // hipMalloc that does not give up on memory the library itself is holding:
 // when the driver reports out-of-memory, the parked contexts and the idle

@@ -175,6 +175,7 @@ ctx_reset_for_reuse(smvs_ctx *ctx)
 {
     ctx->image_ok = ctx->planes_ok = 0;
     ctx->sgm_resident = false;
+    ctx->surf_depth_ok = false;
     ctx->has_cameras = ctx->has_surface = ctx->has_system = false;
     ctx->has_shading = false;
     ctx->update_prepared = false;
@@ -347,13 +348,14 @@ ctx_free(smvs_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = { ctx->main_grad, ctx->main_shading, ctx->main_shading_grad,
         ctx->cams, ctx->subs_dev, ctx->nodes, ctx->node_valid, ctx->patch_valid,
-        ctx->patch_vis, ctx->active, ctx->active_next, ctx->cg_mask, ctx->hermite_tab,
+        ctx->patch_vis, ctx->active, ctx->active_next, ctx->cg_mask, ctx->hermite_all,
         ctx->Hp, ctx->gp, ctx->H9, ctx->Pinv, ctx->g, ctx->lighting, ctx->x,
         ctx->r, ctx->z, ctx->Ad, ctx->d, ctx->d2, ctx->b, ctx->partials,
         ctx->cg_state, ctx->scalars,
         ctx->status, ctx->lightAb, ctx->stage, ctx->map_scratch,
         ctx->light_partial, ctx->res_work, ctx->res_zx, ctx->live_list,
-        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage };
+        ctx->step_counter, ctx->nodes_saved, ctx->zero_block, ctx->byte_stage,
+        ctx->surf_depth, ctx->surf_tmp, ctx->surf_tmp_bytes, ctx->surf_bits };
     for (void *p : bufs)
         if (p)
             (void)hipFree(p);
@@ -564,13 +566,10 @@ init_active_kernel(const uint8_t *__restrict__ node_valid,
         active[i] = node_valid[i] ? 1 : 0;
 }
 
-extern "C" int
-smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
-    int start_y, const double *nodes, const uint8_t *node_valid,
-    const uint8_t *patch_valid, const uint32_t *patch_vis)
+int
+smvs_hip::ctx_ensure_grid(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
+    int start_y)
 {
-    SMVS_REQUIRE(ctx && nodes && node_valid && patch_valid && patch_vis,
-        "null argument");
     SMVS_REQUIRE(scale >= 0 && scale <= 10, "scale out of range");
     SMVS_REQUIRE(npx >= 1 && npy >= 1, "empty patch grid");
     int const ps = 1 << scale;
@@ -631,15 +630,42 @@ smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
     ctx->num_patches = (int)P;
     ctx->node_stride = npx + 1;
 
-    if (ctx->hermite_tab_ps != ps) {
-        std::vector<double> tab;
-        build_hermite_table(ps, &tab);
-        if ((rc = device_alloc(&ctx->hermite_tab, tab.size())) != SMVS_OK)
+    if (ctx->hermite_all == nullptr) {
+        // the tables of all patch sizes, once per context: [ps - 1 + row][12]
+        // for ps = 1, 2, 4, .. 1024 (a table per scale change was a device
+        // allocation, i.e. a device-wide synchronisation, per scale)
+        std::vector<double> all, tab;
+        for (int s = 0; s <= 10; ++s) {
+            build_hermite_table(1 << s, &tab);
+            all.insert(all.end(), tab.begin(), tab.end());
+        }
+        if ((rc = device_alloc(&ctx->hermite_all, all.size())) != SMVS_OK)
             return rc;
-        SMVS_HIP_CHECK(hipMemcpy(ctx->hermite_tab, tab.data(),
-            tab.size() * sizeof(double), hipMemcpyHostToDevice));
-        ctx->hermite_tab_ps = ps;
+        SMVS_HIP_CHECK(hipMemcpy(ctx->hermite_all, all.data(),
+            all.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    ctx->hermite_tab = ctx->hermite_all + (size_t)(ps - 1) * 12;
+    ctx->hermite_tab_ps = ps;
+    ctx->has_system = false;
+    ctx->cg_use_active = false;
+    // saved nodes belong to the surface they were saved from (same grid size
+    // does not mean same surface)
+    ctx->nodes_saved_count = 0;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_ctx_set_surface(smvs_ctx *ctx, int scale, int npx, int npy, int start_x,
+    int start_y, const double *nodes, const uint8_t *node_valid,
+    const uint8_t *patch_valid, const uint32_t *patch_vis)
+{
+    SMVS_REQUIRE(ctx && nodes && node_valid && patch_valid && patch_vis,
+        "null argument");
+    int rc = ctx_ensure_grid(ctx, scale, npx, npy, start_x, start_y);
+    if (rc != SMVS_OK)
+        return rc;
+    size_t const N = (size_t)ctx->num_nodes;
+    size_t const P = (size_t)ctx->num_patches;
     if ((rc = ctx_upload(ctx, ctx->nodes, nodes, N * 4 * sizeof(double))) != SMVS_OK)
         return rc;
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->node_valid, node_valid, N,

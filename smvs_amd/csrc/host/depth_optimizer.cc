@@ -135,24 +135,29 @@ DepthOptimizer::dump_state(int iter, char const* tag) const
     char const* dir = std::getenv("SMVS_DUMP_DIR");
     if (dir == nullptr)
         return;
+    Surface::Ptr const surf = this->download_surface();
     std::string const path = std::string(dir) + "/s"
-        + std::to_string(surface->get_scale()) + "_i" + std::to_string(iter)
+        + std::to_string(surf->get_scale()) + "_i" + std::to_string(iter)
         + "_" + tag + ".bin";
     std::FILE* f = std::fopen(path.c_str(), "wb");
     if (f == nullptr)
         return;
-    int const hdr[3] = { surface->get_scale(), surface->get_num_patches_x(),
-        surface->get_num_patches_y() };
-    std::size_t const nn = surface->get_num_nodes();
-    std::size_t const np = surface->get_num_patches();
+    int const hdr[3] = { surf->get_scale(), surf->get_num_patches_x(),
+        surf->get_num_patches_y() };
+    std::size_t const nn = surf->get_num_nodes();
+    std::size_t const np = surf->get_num_patches();
     std::vector<uint32_t> vis(np, 0);
-    for (std::size_t p = 0; p < np && p < subsurfaces.size(); ++p)
-        vis[p] = subsurfaces[p];
+    if (device_surface)
+        check(smvs_surface_download(ctx, nullptr, nullptr, nullptr, vis.data()),
+            "smvs_surface_download");
+    else
+        for (std::size_t p = 0; p < np && p < subsurfaces.size(); ++p)
+            vis[p] = subsurfaces[p];
     std::fwrite(hdr, sizeof(int), 3, f);
-    std::fwrite(static_cast<Surface const&>(*surface).node_values().data(),
+    std::fwrite(static_cast<Surface const&>(*surf).node_values().data(),
         sizeof(double), 4 * nn, f);
-    std::fwrite(surface->node_validity().data(), 1, nn, f);
-    std::fwrite(surface->patch_validity().data(), 1, np, f);
+    std::fwrite(surf->node_validity().data(), 1, nn, f);
+    std::fwrite(surf->patch_validity().data(), 1, np, f);
     std::fwrite(vis.data(), sizeof(uint32_t), np, f);
     std::fclose(f);
 }
@@ -171,6 +176,9 @@ DepthOptimizer::DepthOptimizer(StereoView::Ptr main_view,
 {
     if (main_view == nullptr || sub_views.empty())
         throw std::invalid_argument("DepthOptimizer: missing views");
+    // debugging aid: the grid surgery on the host Surface with an upload /
+    // download per batch, as before round 4 (A/B against the device path)
+    this->host_surgery = std::getenv("SMVS_HOST_SURGERY") != nullptr;
     this->prepare_correspondences();
     check(smvs_ctx_create(opts.device, main_view->get_width(),
         main_view->get_height(), (int)sub_views.size(), &this->ctx),
@@ -240,6 +248,16 @@ DepthOptimizer::create_initial_surface(void)
         // the main image on the device; the filtered map also stays there for
         // create_subview_surfaces (:463-466 splats the same map)
         this->upload_images();
+        if (!host_surgery) {
+            // ... and for Surface::create: the nodes are initialised from it
+            // where it lies (no 8 MB round trip, no host Surface)
+            check(smvs_ctx_sgm_init_depth(ctx, init->begin(), init->width(),
+                init->height(), 5.0f, 5, nullptr), "smvs_ctx_sgm_init_depth");
+            check(smvs_surface_create(ctx, init_scale, nullptr, nullptr, nullptr, 0,
+                &valid_patches), "smvs_surface_create");
+            this->surface_on_device();
+            return;
+        }
         FloatImage::Ptr full = FloatImage::create_for_overwrite(main_view->get_width(),
             main_view->get_height(), 1);
         check(smvs_ctx_sgm_init_depth(ctx, init->begin(), init->width(),
@@ -251,8 +269,39 @@ DepthOptimizer::create_initial_surface(void)
         if (bundle == nullptr)
             throw std::invalid_argument("DepthOptimizer: no bundle to "
                 "initialise the surface from (use_sgm is off)");
+        if (!host_surgery) {
+            // initialize_depth_from_bundle (surface.cc:90-130) on the host --
+            // a few thousand projections -- the node initialisation on the device
+            std::vector<int32_t> pixels;
+            std::vector<float> depths;
+            Surface::project_bundle(bundle, main_view->get_camera(),
+                main_view->get_view_id(), main_view->get_width(),
+                main_view->get_height(), &pixels, &depths);
+            check(smvs_surface_create(ctx, init_scale + 1, nullptr, pixels.data(),
+                depths.data(), (int)pixels.size(), &valid_patches),
+                "smvs_surface_create");
+            this->surface_on_device();
+            return;
+        }
         this->surface = Surface::create(bundle, main_view, init_scale + 1);
     }
+}
+
+// The context's surface is the one that counts; a host Surface object is
+// only materialised on demand (download_surface).
+void
+DepthOptimizer::surface_on_device(void)
+{
+    check(smvs_surface_info(ctx, &geom, nullptr), "smvs_surface_info");
+    device_surface = true;
+    surface.reset();
+    uploaded_surface = nullptr;
+}
+
+int
+DepthOptimizer::current_scale(void) const
+{
+    return device_surface ? geom.scale : surface->get_scale();
 }
 
 void
@@ -318,6 +367,8 @@ DepthOptimizer::upload_surface(void)
     // Newton loop's result is downloaded into the host surface, so the
     // cut_boundaries / get_depth / get_normals that follow it find the
     // device copy current.
+    if (device_surface)
+        return;   // (it lives in the context)
     if (surface == nullptr)
         throw std::logic_error("DepthOptimizer: no surface (call optimize() "
             "first or use the constructor that takes one)");
@@ -347,7 +398,8 @@ void
 DepthOptimizer::fit_lighting(void)
 {
     // LightOptimizer::fit_lighting_to_image, lib/light_optimizer.cc:22-55
-    if (subsurfaces.size() != (std::size_t)surface->get_num_patches()) {
+    if (!device_surface
+        && subsurfaces.size() != (std::size_t)surface->get_num_patches()) {
         subsurfaces.resize(surface->get_num_patches(), 0);
         subs_rev += 1;
     }
@@ -366,20 +418,29 @@ DepthOptimizer::optimize(void)
         ScopedHostTimer timer("create_initial_surface");
         this->create_initial_surface();
     }
-    this->set_scale_everywhere(surface->get_scale());
+    this->set_scale_everywhere(current_scale());
     this->run_newton_iterations(opts.num_iterations);
 
-    while (surface->get_scale() > opts.min_scale && surface->get_scale() > 0) {
+    while (current_scale() > opts.min_scale && current_scale() > 0) {
         {
             ScopedHostTimer timer("subdivide_patches");
-            surface->subdivide_patches();
+            if (device_surface) {
+                check(smvs_surface_subdivide(ctx, &valid_patches),
+                    "smvs_surface_subdivide");
+                check(smvs_surface_info(ctx, &geom, nullptr), "smvs_surface_info");
+            } else
+                surface->subdivide_patches();
         }
-        this->set_scale_everywhere(surface->get_scale());
+        this->set_scale_everywhere(current_scale());
         {
             ScopedHostTimer timer("fill_patches_from_depth");
-            surface->fill_patches_from_depth();
+            if (device_surface)
+                check(smvs_surface_fill_patches_from_depth(ctx, &valid_patches),
+                    "smvs_surface_fill_patches_from_depth");
+            else
+                surface->fill_patches_from_depth();
         }
-        if (opts.use_shading && surface->get_scale() < 4) {
+        if (opts.use_shading && current_scale() < 4) {
             ScopedHostTimer timer("fit_lighting");
             this->fit_lighting();
         }
@@ -392,6 +453,22 @@ DepthOptimizer::optimize(void)
             opts.output_name + "N");
     }
     g_timers.report();
+}
+
+// The device surface as a host Surface object (debugging, dump_state).
+Surface::Ptr
+DepthOptimizer::download_surface(void) const
+{
+    if (!device_surface)
+        return surface;
+    std::size_t const N = (std::size_t)(geom.npx + 1) * (geom.npy + 1);
+    std::size_t const P = (std::size_t)geom.npx * geom.npy;
+    std::vector<double> nodes(4 * N);
+    std::vector<uint8_t> nv(N), pv(P);
+    check(smvs_surface_download(ctx, nodes.data(), nv.data(), pv.data(), nullptr),
+        "smvs_surface_download");
+    return Surface::from_arrays(main_view->get_width(), main_view->get_height(),
+        geom.scale, geom.npx, geom.npy, geom.start_x, geom.start_y, nodes, nv, pv);
 }
 
 FloatImage::Ptr
@@ -422,7 +499,8 @@ DepthOptimizer::run_newton_iterations(int num_iters)
     // lib/depth_optimizer.cc:164-358
     bool finished = false;
     for (int iter = 0; iter < num_iters; ++iter) {
-        int const num_valid_patches = surface->count_valid_patches();
+        int const num_valid_patches = device_surface ? valid_patches
+            : surface->count_valid_patches();
         if (iter == 0) {
             {
                 ScopedHostTimer timer("create_subview_surfaces");
@@ -457,13 +535,15 @@ DepthOptimizer::run_newton_iterations(int num_iters)
             check(smvs_gn_run_loop(ctx, &prm, &stats), "smvs_gn_run_loop");
             loop_seconds = std::chrono::duration<double>(
                 std::chrono::steady_clock::now() - t0).count();
-            check(smvs_get_nodes(ctx, surface->node_values().data()),
-                "smvs_get_nodes");
-            // host and device nodes are the same again
-            if (uploaded_surface == surface.get())
-                uploaded_rev = surface->revision();
+            if (!device_surface) {
+                check(smvs_get_nodes(ctx, surface->node_values().data()),
+                    "smvs_get_nodes");
+                // host and device nodes are the same again
+                if (uploaded_surface == surface.get())
+                    uploaded_rev = surface->revision();
+            }
         }
-        log.push_back({ surface->get_scale(), iter, stats.newton_steps,
+        log.push_back({ current_scale(), iter, stats.newton_steps,
             num_valid_patches, stats.linear_iterations, stats.active_patch_steps,
             loop_seconds });
         this->dump_state(iter, "newton");
@@ -478,7 +558,11 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         if (!opts.use_sgm) {
             {
                 ScopedHostTimer timer("expand");
-                surface->expand();
+                if (device_surface)
+                    check(smvs_surface_expand(ctx, nullptr, &valid_patches),
+                        "smvs_surface_expand");
+                else
+                    surface->expand();
             }
             {
                 ScopedHostTimer timer("create_subview_surfaces");
@@ -489,15 +573,20 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         }
         {
             ScopedHostTimer timer("remove_isolated_patches");
-            surface->remove_isolated_patches();
+            if (device_surface)
+                check(smvs_surface_remove_isolated_patches(ctx, &valid_patches),
+                    "smvs_surface_remove_isolated_patches");
+            else
+                surface->remove_isolated_patches();
         }
 
-        int const num_valid_new = surface->count_valid_patches();
+        int const num_valid_new = device_surface ? valid_patches
+            : surface->count_valid_patches();
         double const change = 1.0
             - (double)std::min(num_valid_new, num_valid_patches)
             / (double)std::max(num_valid_new, num_valid_patches);
         if (iter > 0 && (num_valid_new <= num_valid_patches
-            || change < 0.05 * surface->get_scale()))
+            || change < 0.05 * current_scale()))
             finished = true;
     }
 }
@@ -507,15 +596,22 @@ DepthOptimizer::cut_boundaries_until_stable(void)
 {
     // The `while (deleted > 10) cut_boundaries()` loops of
     // lib/depth_optimizer.cc:186-190, 323-337 with cut_boundaries (:360-431)
-    // and mse_for_patch (:747-790) on the device; the host applies the
-    // resulting validity to its Surface.
+    // and mse_for_patch (:747-790) on the device.
     this->upload_surface();
     float invproj[9];
     main_view->get_camera().fill_inverse_calibration(invproj,
         (float)main_view->get_width(), (float)main_view->get_height());
+    int total = 0;
+    if (device_surface) {
+        // (validity stays where it is; every deletion is one valid patch less)
+        check(smvs_topology_cut_boundaries(ctx, invproj, nullptr, nullptr, &total),
+            "smvs_topology_cut_boundaries");
+        valid_patches -= total;
+        return total;
+    }
+    // host surgery: the host applies the resulting validity to its Surface
     std::size_t const num_patches = surface->get_num_patches();
     std::vector<uint8_t> pv(num_patches), nv(surface->get_num_nodes());
-    int total = 0;
     check(smvs_topology_cut_boundaries(ctx, invproj, pv.data(), nv.data(),
         &total), "smvs_topology_cut_boundaries");
     for (std::size_t p = 0; p < num_patches; ++p)
@@ -530,12 +626,20 @@ DepthOptimizer::create_subview_surfaces(void)
 {
     // lib/depth_optimizer.cc:433-604.  The per-(patch, neighbour) tests --
     // z-buffer visibility, warp anisotropy, NCC -- run on the device
-    // (smvs_topology_subviews); deleting the patches nobody sees stays here.
+    // (smvs_topology_subviews), and so does the deletion of the patches
+    // nobody sees (:592-603, smvs_surface_delete_unseen_patches).
+    if (device_surface) {
+        // (use_sgm: the filtered SGM map is resident, create_initial_surface)
+        check(smvs_topology_subviews(ctx, nullptr, opts.use_sgm ? 0 : 1, nullptr),
+            "smvs_topology_subviews");
+        check(smvs_surface_delete_unseen_patches(ctx, nullptr, &valid_patches),
+            "smvs_surface_delete_unseen_patches");
+        return;
+    }
     std::size_t const num_patches = surface->get_num_patches();
     subsurfaces.assign(num_patches, 0);
     subs_rev += 1;
     this->upload_surface();
-    // (use_sgm: the filtered SGM map is resident, create_initial_surface)
     check(smvs_topology_subviews(ctx, nullptr, opts.use_sgm ? 0 : 1,
         subsurfaces.data()), "smvs_topology_subviews");
     subs_rev += 1;   // (the device still holds the masks that were uploaded)

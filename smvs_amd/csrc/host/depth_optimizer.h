@@ -2,7 +2,8 @@
 // Same Options, constructor and optimize() / get_depth() / get_normals()
 // surface; the Newton loop (lib/depth_optimizer.cc:219-304), the lighting
 // accumulation and the bilateral upsample run on the GPU through the C ABI of
-// include/smvs_hip.h, topology operations stay on the host.
+// include/smvs_hip.h, and so do the topology operations between the batches
+// (csrc/topology.hip, csrc/surface.hip): the surface stays in the context.
 #pragma once
 
 #include <string>
@@ -12,7 +13,7 @@
 #include "stereo_view.h"
 #include "surface.h"
 
-struct smvs_ctx;
+#include "../../../include/smvs_hip.h"
 
 namespace smvs_amd {
 
@@ -82,6 +83,11 @@ private:
         FloatImage::ConstPtr ci, float sigma = 5, int kernel_size = 5);
     void fit_lighting(void);
 
+    // the surface lives in the device context between the batches
+    void surface_on_device(void);
+    int current_scale(void) const;
+    Surface::Ptr download_surface(void) const;
+
     void set_scale_everywhere(int scale);
     void upload_images(void);
     void upload_surface(void);
@@ -95,7 +101,15 @@ private:
     std::vector<StereoView::Ptr> const& sub_views;
     std::vector<double> Mi, ti;          // 9 / 3 per neighbour
     FloatImage::ConstPtr sgm_depth;
+    // optimize() keeps the surface in the device context (device_surface):
+    // `geom` mirrors its geometry, `valid_patches` its number of non-null
+    // patches; `surface` is only set by the constructor that takes one (and by
+    // the SMVS_HOST_SURGERY debugging path)
     Surface::Ptr surface;
+    bool device_surface = false;
+    bool host_surgery = false;
+    smvs_surface_geometry geom = { 0, 0, 0, 0, 0, 0 };
+    int valid_patches = 0;
     std::vector<uint32_t> subsurfaces;   // bit j: neighbour j sees the patch
     // what the device context holds (upload_surface skips a repeat)
     Surface const* uploaded_surface = nullptr;

@@ -236,6 +236,77 @@ smvs_host_surface_script(const smvs_host_view *main_in,
     }
 }
 
+// The same script on the surface of a device context (csrc/surface.hip).
+extern "C" int
+smvs_host_surface_script_device(const smvs_host_view *main_in,
+    const smvs_host_bundle *bundle_in, const float *init_depth, int init_scale,
+    const int *ops, int n_ops, int delete_every, int device, int *info,
+    double *nodes_out, uint8_t *node_valid_out, uint8_t *patch_valid_out)
+{
+    smvs_ctx *ctx = nullptr;
+    try {
+        if (main_in == nullptr || info == nullptr || nodes_out == nullptr
+            || node_valid_out == nullptr || patch_valid_out == nullptr
+            || (n_ops > 0 && ops == nullptr) || delete_every < 1)
+            throw std::invalid_argument("smvs_host_surface_script_device: bad argument");
+        auto check = [](int rc, char const* what) {
+            if (rc != SMVS_OK)
+                throw std::runtime_error(std::string(what) + ": " + smvs_last_error());
+        };
+        StereoView::Ptr main_view = make_view(*main_in, false);
+        check(smvs_ctx_create(device, main_in->width, main_in->height, 1, &ctx),
+            "smvs_ctx_create");
+        int valid = 0;
+        if (init_depth != nullptr) {
+            check(smvs_surface_create(ctx, init_scale, init_depth, nullptr, nullptr, 0,
+                &valid), "smvs_surface_create");
+        } else {
+            Bundle::Ptr bundle = make_bundle(bundle_in);
+            std::vector<int32_t> pixels;
+            std::vector<float> depths;
+            Surface::project_bundle(bundle, main_view->get_camera(),
+                main_view->get_view_id(), main_in->width, main_in->height, &pixels,
+                &depths);
+            if (pixels.empty())
+                throw std::invalid_argument("smvs_host_surface_script_device: the "
+                    "bundle has no feature in this view");
+            check(smvs_surface_create(ctx, init_scale, nullptr, pixels.data(),
+                depths.data(), (int)pixels.size(), &valid), "smvs_surface_create");
+        }
+        for (int k = 0; k < n_ops; ++k)
+            switch (ops[k]) {
+            case 1: check(smvs_surface_expand(ctx, nullptr, &valid), "expand"); break;
+            case 2: check(smvs_surface_subdivide(ctx, &valid), "subdivide"); break;
+            case 3: check(smvs_surface_fill_patches_from_depth(ctx, &valid), "fill"); break;
+            case 4: check(smvs_surface_remove_isolated_patches(ctx, &valid), "isolated"); break;
+            case 5: check(smvs_surface_delete_every(ctx, delete_every, &valid), "delete"); break;
+            default:
+                throw std::invalid_argument("smvs_host_surface_script_device: unknown operation");
+            }
+        smvs_surface_geometry g;
+        int counted = 0;
+        check(smvs_surface_info(ctx, &g, &counted), "smvs_surface_info");
+        if (counted != valid)
+            throw std::runtime_error("smvs_host_surface_script_device: the operation's "
+                "count of valid patches differs from a recount");
+        info[0] = g.scale;
+        info[1] = g.npx;
+        info[2] = g.npy;
+        info[3] = g.start_x;
+        info[4] = g.start_y;
+        info[5] = valid;
+        check(smvs_surface_download(ctx, nodes_out, node_valid_out, patch_valid_out,
+            nullptr), "smvs_surface_download");
+        smvs_ctx_destroy(ctx);
+        return 0;
+    } catch (std::exception const& e) {
+        if (ctx != nullptr)
+            smvs_ctx_destroy(ctx);
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
 extern "C" int
 smvs_host_depth_range(const smvs_host_view *view_in,
     const smvs_host_bundle *bundle_in, float *range2)

@@ -81,6 +81,12 @@ int smvs_host_surface_script(const smvs_host_view *main_view,
     const smvs_host_bundle *bundle, const float *init_depth, int init_scale,
     const int *ops, int n_ops, int delete_every, int *info, double *nodes_out,
     uint8_t *node_valid_out, uint8_t *patch_valid_out);
+/* The same script on the surface of a device context (include/smvs_hip.h,
+ * "grid surgery"); info[5] = valid patches as the last operation reported. */
+int smvs_host_surface_script_device(const smvs_host_view *main_view,
+    const smvs_host_bundle *bundle, const float *init_depth, int init_scale,
+    const int *ops, int n_ops, int delete_every, int device, int *info6,
+    double *nodes_out, uint8_t *node_valid_out, uint8_t *patch_valid_out);
 
 /* The per-view tasks of smvsrecon (app/smvsrecon.cc:658-733) for n_jobs
  * reference views on a smvs_amd::ViewQueue: per job StereoView::create for the

@@ -3,10 +3,12 @@
 // Newton batches.
 #include "surface.h"
 #include "topo_math.h"
+#include "surface_math.h"
 
 #include <atomic>
 #include <algorithm>
 #include <cmath>
+#include <stdexcept>
 
 namespace smvs_amd {
 
@@ -41,15 +43,17 @@ Surface::create(Bundle::ConstPtr bundle, StereoView::Ptr main_view, int scale,
     int const width = main_view->get_width(), height = main_view->get_height();
     s->pixel_width = width;
     s->pixel_height = height;
-    s->scale = scale;
-    s->patchsize = 1 << scale;
-    s->npx = (width - 2) / s->patchsize - 1;
-    s->npy = (height - 2) / s->patchsize - 1;
+    // (the integer rules of :28-37, shared with the device: surface_math.h)
+    smvs_surf::Grid const g = smvs_surf::grid_for_scale(width, height, scale);
+    s->scale = g.scale;
+    s->patchsize = g.ps;
+    s->npx = g.npx;
+    s->npy = g.npy;
     s->patch_valid.assign((size_t)s->npx * s->npy, 0);
     s->node_valid.assign((size_t)(s->npx + 1) * (s->npy + 1), 0);
     s->nodes.assign(s->node_valid.size() * 4, 0.0);
-    s->start_x = (width - s->npx * s->patchsize) / 2;
-    s->start_y = (height - s->npy * s->patchsize) / 2;
+    s->start_x = g.start_x;
+    s->start_y = g.start_y;
     if (init_depth == nullptr) {
         s->depth = FloatImage::create(width, height, 1);
         s->initialize_depth_from_bundle(bundle, main_view->get_camera(),
@@ -68,11 +72,12 @@ Surface::create(Bundle::ConstPtr bundle, StereoView::Ptr main_view, int scale,
 }
 
 void
-Surface::initialize_depth_from_bundle(Bundle::ConstPtr bundle,
-    CameraInfo const& cam, int view_id)
+Surface::project_bundle(Bundle::ConstPtr bundle, CameraInfo const& cam, int view_id,
+    int width, int height, std::vector<int32_t>* pixels, std::vector<float>* depths)
 {
     // lib/surface.cc:90-130
-    int const width = pixel_width, height = pixel_height;
+    pixels->clear();
+    depths->clear();
     double const fwidth2 = (double)width / 2.0, fheight2 = (double)height / 2.0;
     double const fnorm = (double)std::max(width, height);
     for (auto const& feat : bundle->features)
@@ -89,10 +94,66 @@ Surface::initialize_depth_from_bundle(Bundle::ConstPtr bundle,
                 float const ix = (float)(proj[0] * fnorm + fwidth2);
                 float const iy = (float)(proj[1] * fnorm + fheight2);
                 int const x = (int)std::floor(ix), y = (int)std::floor(iy);
-                if (x >= 0 && x < width && y >= 0 && y < height)
-                    depth->at(x, y, 0) = d;
+                if (x >= 0 && x < width && y >= 0 && y < height) {
+                    pixels->push_back(y * width + x);
+                    depths->push_back(d);
+                }
                 break;
             }
+    // one entry per pixel, the last write wins: stable sort by pixel, keep the
+    // last of every run
+    std::vector<std::size_t> order(pixels->size());
+    for (std::size_t i = 0; i < order.size(); ++i)
+        order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](std::size_t a, std::size_t b) {
+        return (*pixels)[a] < (*pixels)[b]; });
+    std::vector<int32_t> up;
+    std::vector<float> ud;
+    for (std::size_t k = 0; k < order.size(); ++k) {
+        if (k + 1 < order.size() && (*pixels)[order[k + 1]] == (*pixels)[order[k]])
+            continue;
+        up.push_back((*pixels)[order[k]]);
+        ud.push_back((*depths)[order[k]]);
+    }
+    pixels->swap(up);
+    depths->swap(ud);
+}
+
+void
+Surface::initialize_depth_from_bundle(Bundle::ConstPtr bundle,
+    CameraInfo const& cam, int view_id)
+{
+    // lib/surface.cc:90-130 (the list form is what the device path uploads)
+    std::vector<int32_t> pixels;
+    std::vector<float> depths;
+    project_bundle(bundle, cam, view_id, pixel_width, pixel_height, &pixels, &depths);
+    float* dst = depth->begin();
+    for (std::size_t i = 0; i < pixels.size(); ++i)
+        dst[pixels[i]] = depths[i];
+}
+
+Surface::Ptr
+Surface::from_arrays(int pixel_width, int pixel_height, int scale, int npx, int npy,
+    int start_x, int start_y, std::vector<double> const& nodes,
+    std::vector<uint8_t> const& node_valid, std::vector<uint8_t> const& patch_valid)
+{
+    if (node_valid.size() != (std::size_t)(npx + 1) * (npy + 1)
+        || nodes.size() != 4 * node_valid.size()
+        || patch_valid.size() != (std::size_t)npx * npy)
+        throw std::invalid_argument("Surface::from_arrays: array sizes");
+    Ptr s(new Surface());
+    s->pixel_width = pixel_width;
+    s->pixel_height = pixel_height;
+    s->scale = scale;
+    s->patchsize = 1 << scale;
+    s->npx = npx;
+    s->npy = npy;
+    s->start_x = start_x;
+    s->start_y = start_y;
+    s->nodes = nodes;
+    s->node_valid = node_valid;
+    s->patch_valid = patch_valid;
+    return s;
 }
 
 bool
@@ -265,24 +326,12 @@ Surface::initialize_node_from_depth(int idx, int idy)
     if (quadrants == 0 || all.size() < 2)
         return;
     std::nth_element(all.begin(), all.begin() + all.size() / 2, all.end());
-    double* node = &nodes[4 * id];
-    node[0] = all[all.size() / 2];
-    node[1] = node[2] = node[3] = 0.0;
-    double const* a = lowest;
-    if (quadrants == 4) {
-        node[1] = ((a[1] + a[3]) - (a[0] + a[2])) / 2.0;
-        node[2] = ((a[2] + a[3]) - (a[0] + a[1])) / 2.0;
-        node[3] = ((a[3] - a[2]) - (a[1] - a[0]));
-    } else {
-        if ((a[1] == 0 || a[0] == 0) && a[3] != 0 && a[2] != 0)
-            node[1] = a[3] - a[2];
-        else if ((a[2] == 0 || a[3] == 0) && a[1] != 0 && a[0] != 0)
-            node[1] = a[1] - a[0];
-        if ((a[0] == 0 || a[2] == 0) && a[3] != 0 && a[1] != 0)
-            node[2] = a[3] - a[1];
-        else if ((a[1] == 0 || a[2] == 0) && a[0] != 0 && a[2] != 0)
-            node[2] = a[2] - a[0];
-    }
+    // (:703-758, shared with the device kernel)
+    double node[4];
+    if (!smvs_surf::node_from_window(all[all.size() / 2], lowest, quadrants,
+            all.size(), node))
+        return;
+    std::copy(node, node + 4, &nodes[4 * id]);
     node_valid[id] = 1;
 }
 
@@ -366,98 +415,35 @@ void
 Surface::subdivide_patches(void)
 {
     touch();
-    // lib/surface.cc:983-1107
-    int const old_npx = npx, old_npy = npy, old_stride = npx + 1;
-    scale -= 1;
-    patchsize = 1 << scale;
-    int new_npx = (pixel_width - 2) / patchsize;
-    int new_npy = (pixel_height - 2) / patchsize;
+    // lib/surface.cc:983-1107.  Gather form, one new node at a time
+    // (smvs_surf::subdivide_node: the arithmetic and the "later patch wins"
+    // rule the device kernel runs, csrc/surface.hip).
+    smvs_surf::Grid old;
+    old.width = pixel_width; old.height = pixel_height;
+    old.scale = scale; old.ps = patchsize;
+    old.npx = npx; old.npy = npy;
+    old.start_x = start_x; old.start_y = start_y;
     int off_x = 0, off_y = 0;
-    if (new_npx - old_npx * 2 >= 2) {
-        new_npx = old_npx * 2 + 2;
-        start_x = (pixel_width - new_npx * patchsize) / 2;
-        off_x = 1;
-    } else
-        new_npx = old_npx * 2;
-    if (new_npy - old_npy * 2 >= 2) {
-        new_npy = old_npy * 2 + 2;
-        start_y = (pixel_height - new_npy * patchsize) / 2;
-        off_y = 1;
-    } else
-        new_npy = old_npy * 2;
-
-    int const new_stride = new_npx + 1;
-    std::vector<double> new_nodes((size_t)new_stride * (new_npy + 1) * 4, 0.0);
-    std::vector<uint8_t> new_valid((size_t)new_stride * (new_npy + 1), 0);
-
-    // five new nodes per patch: edge midpoints and the centre.  The patch is
-    // only ever evaluated at 0, 1/2 and 1: the Hermite basis values of those
-    // three parameters (value and first derivative) are formed once, the sums
-    // are patch_eval's own, term by term.
-    struct Split { int iu, iv; int ox, oy; };   // parameter = index / 2
-    static Split const splits[5] = { { 1, 0, 1, 0 }, { 0, 1, 0, 1 },
-        { 1, 1, 1, 1 }, { 2, 1, 2, 1 }, { 1, 2, 1, 2 } };
-    double basis[3][2][4];
-    for (int t = 0; t < 3; ++t)
-        for (int k = 0; k < 2; ++k)
-            smvs_topo::hermite(0.5 * t, k, basis[t][k]);
-    // The 5 x 4 results of a patch (split point x {f, dx, dy, dxy}) as 20
-    // independent lanes that all run patch_eval's sequence of operations on
-    // their own basis values: the compiler vectorises across the lanes, every
-    // lane's bits are the scalar evaluation's.
-    constexpr int LANES = 20;
-    double bx[4][LANES], by[4][LANES], post[LANES];
-    for (int si = 0; si < 5; ++si)
-        for (int q = 0; q < 4; ++q) {
-            int const lane = 4 * si + q;
-            double const* u = basis[splits[si].iu][q & 1];        // d/dx for q = 1, 3
-            double const* v = basis[splits[si].iv][(q >> 1) & 1]; // d/dy for q = 2, 3
-            for (int k = 0; k < 4; ++k) {
-                bx[k][lane] = u[k];
-                by[k][lane] = v[k];
+    smvs_surf::Grid const g = smvs_surf::grid_subdivided(old, &off_x, &off_y);
+    int const new_stride = g.npx + 1;
+    std::vector<double> new_nodes((size_t)new_stride * (g.npy + 1) * 4, 0.0);
+    std::vector<uint8_t> new_valid((size_t)new_stride * (g.npy + 1), 0);
+    for (int Y = 0; Y <= g.npy; ++Y)
+        for (int X = 0; X <= g.npx; ++X) {
+            std::size_t const id = (size_t)Y * new_stride + X;
+            double out[4];
+            if (smvs_surf::subdivide_node(old.npx, old.npy, off_x, off_y, nodes.data(),
+                    node_valid.data(), patch_valid.data(), X, Y, out)) {
+                std::copy(out, out + 4, &new_nodes[4 * id]);
+                new_valid[id] = 1;
             }
-            post[lane] = q == 0 ? 1.0 : (q == 3 ? 4.0 : 2.0);
         }
-    for (std::size_t p = 0; p < patch_valid.size(); ++p) {
-        if (!patch_valid[p])
-            continue;
-        int const nx = 2 * (int)(p % old_npx) + off_x;
-        int const ny = 2 * (int)(p / old_npx) + off_y;
-        double n16[16];
-        fill_patch_nodes(p, n16);
-        double r[LANES];
-        for (int l = 0; l < LANES; ++l)
-            r[l] = 0.0;
-        for (int bb = 0; bb < 2; ++bb)
-            for (int aa = 0; aa < 2; ++aa) {
-                double const* nd = n16 + 4 * (2 * bb + aa);
-                for (int l = 0; l < LANES; ++l)
-                    r[l] += nd[0] * bx[aa][l] * by[bb][l] + nd[1] * bx[2 + aa][l] * by[bb][l]
-                        + nd[2] * bx[aa][l] * by[2 + bb][l]
-                        + nd[3] * bx[2 + aa][l] * by[2 + bb][l];
-            }
-        for (int si = 0; si < 5; ++si) {
-            Split const& sp = splits[si];
-            std::size_t const id = (size_t)(ny + sp.oy) * new_stride + nx + sp.ox;
-            for (int q = 0; q < 4; ++q)
-                new_nodes[4 * id + q] = r[4 * si + q] / post[4 * si + q];
-            new_valid[id] = 1;
-        }
-    }
-    // old nodes keep their values, derivatives rescaled to the new patch size
-    for (std::size_t i = 0; i < node_valid.size(); ++i) {
-        if (!node_valid[i])
-            continue;
-        std::size_t const id = (size_t)(2 * (i / old_stride) + off_y) * new_stride
-            + 2 * (i % old_stride) + off_x;
-        new_nodes[4 * id + 0] = nodes[4 * i + 0];
-        new_nodes[4 * id + 1] = nodes[4 * i + 1] / 2;
-        new_nodes[4 * id + 2] = nodes[4 * i + 2] / 2;
-        new_nodes[4 * id + 3] = nodes[4 * i + 3] / 4;
-        new_valid[id] = 1;
-    }
-    npx = new_npx;
-    npy = new_npy;
+    scale = g.scale;
+    patchsize = g.ps;
+    start_x = g.start_x;
+    start_y = g.start_y;
+    npx = g.npx;
+    npy = g.npy;
     nodes.swap(new_nodes);
     node_valid.swap(new_valid);
     patch_valid.assign((size_t)npx * npy, 0);
@@ -470,53 +456,20 @@ Surface::expand(void)
 {
     touch();
     // lib/surface.cc:482-628: two rounds of extrapolating new nodes from
-    // complete triples of neighbours; a later candidate replaces an earlier
-    // one only when it is more than 1/0.9 deeper (check_swap_nodes :472-480)
+    // complete triples of neighbours (smvs_surf::expand_node: the rules, their
+    // order and check_swap_nodes :472-480, shared with the device kernel).
+    // A round reads the surface as it was at its start; its proposals are
+    // applied after every node has been visited.
     int const stride = npx + 1;
     std::size_t const count = node_valid.size();
     std::vector<double> proposal(count, 0.0);
     std::vector<uint8_t> proposed(count, 0);
-    static int const off[8][2] = { { -1, -1 }, { 0, -1 }, { 1, -1 }, { -1, 0 },
-        { 1, 0 }, { -1, 1 }, { 0, 1 }, { 1, 1 } };
-    // triples and the (neighbour, axis, sign) terms averaged for each
-    struct Term { int nb; int axis; double sign; };
-    struct Rule { int need[3]; int nterms; Term terms[3]; };
-    static Rule const rules[8] = {
-        { { 0, 1, 3 }, 2, { { 3, 1, +1 }, { 1, 2, +1 }, { 0, 0, 0 } } },
-        { { 1, 2, 4 }, 2, { { 4, 1, -1 }, { 1, 2, +1 }, { 0, 0, 0 } } },
-        { { 3, 5, 6 }, 2, { { 3, 1, +1 }, { 6, 2, -1 }, { 0, 0, 0 } } },
-        { { 4, 6, 7 }, 2, { { 4, 1, -1 }, { 6, 2, -1 }, { 0, 0, 0 } } },
-        { { 0, 1, 2 }, 3, { { 0, 2, +1 }, { 1, 2, +1 }, { 2, 2, +1 } } },
-        { { 0, 3, 5 }, 3, { { 0, 1, +1 }, { 3, 1, +1 }, { 5, 1, +1 } } },
-        { { 5, 6, 7 }, 3, { { 5, 2, -1 }, { 6, 2, -1 }, { 7, 2, -1 } } },
-        { { 2, 4, 7 }, 3, { { 2, 1, -1 }, { 4, 1, -1 }, { 7, 1, -1 } } } };
     for (int round = 0; round < 2; ++round) {
         for (std::size_t id = 0; id < count; ++id) {
             if (node_valid[id] && !proposed[id])
                 continue;
-            int const idx = (int)(id % stride), idy = (int)(id / stride);
-            double const* nb[8];
-            for (int k = 0; k < 8; ++k)
-                nb[k] = node_exists(idx + off[k][0], idy + off[k][1])
-                    ? &nodes[4 * ((size_t)(idy + off[k][1]) * stride + idx
-                        + off[k][0])] : nullptr;
-            for (Rule const& r : rules) {
-                if (!nb[r.need[0]] || !nb[r.need[1]] || !nb[r.need[2]])
-                    continue;
-                double sum = 0.0;
-                for (int t = 0; t < r.nterms; ++t) {
-                    Term const& tm = r.terms[t];
-                    double const term = tm.sign > 0
-                        ? nb[tm.nb][0] + nb[tm.nb][tm.axis] / 2.0
-                        : nb[tm.nb][0] - nb[tm.nb][tm.axis] / 2.0;
-                    sum = t == 0 ? term : sum + term;
-                }
-                double const cand = sum / (double)r.nterms;
-                if (!proposed[id] || cand * 0.9 > proposal[id]) {
-                    proposal[id] = cand;
-                    proposed[id] = 1;
-                }
-            }
+            smvs_surf::expand_node(npx, npy, nodes.data(), node_valid.data(),
+                (int)(id % stride), (int)(id / stride), &proposal[id], &proposed[id]);
         }
         for (std::size_t id = 0; id < count; ++id)
             if (proposed[id]) {

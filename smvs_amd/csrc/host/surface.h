@@ -40,6 +40,20 @@ public:
     static Ptr create(Bundle::ConstPtr bundle, StereoView::Ptr main_view,
         int scale, FloatImage::ConstPtr init_depth = nullptr);
 
+    // A surface from its flat arrays (what smvs_surface_download returns): the
+    // host view of a surface that lives in a device context.
+    static Ptr from_arrays(int pixel_width, int pixel_height, int scale, int npx,
+        int npy, int start_x, int start_y, std::vector<double> const& nodes,
+        std::vector<uint8_t> const& node_valid,
+        std::vector<uint8_t> const& patch_valid);
+    // initialize_depth_from_bundle (lib/surface.cc:90-130) as a list: the
+    // features seen by view_id projected into the image -> pixel index
+    // (y * width + x) and depth, at most one entry per pixel (where the
+    // reference's loop writes a pixel twice, the later feature's depth).
+    static void project_bundle(Bundle::ConstPtr bundle, CameraInfo const& cam,
+        int view_id, int width, int height, std::vector<int32_t>* pixels,
+        std::vector<float>* depths);
+
     FloatImage::Ptr get_depth_map(void) const;
     FloatImage::Ptr get_normal_map(float inv_flen) const;
     int get_scale(void) const { return scale; }

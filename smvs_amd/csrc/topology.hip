@@ -599,7 +599,7 @@ extern "C" int
 smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
     uint32_t *patch_vis_out)
 {
-    SMVS_REQUIRE(ctx && patch_vis_out, "null argument");
+    SMVS_REQUIRE(ctx != nullptr, "null argument");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     if ((ctx->image_ok & 1u) != 0u
         && (ctx->images[0].w != ctx->width || ctx->images[0].h != ctx->height)) {
@@ -684,6 +684,8 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
     hipLaunchKernelGGL(topo_visibility_kernel,
         dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
     SMVS_HIP_CHECK(hipGetLastError());
+    if (patch_vis_out == nullptr)
+        return SMVS_OK;   // (the masks stay on the device: surface.hip)
     SMVS_HIP_CHECK(hipMemcpyAsync(patch_vis_out, ctx->patch_vis,
         sizeof(uint32_t) * ctx->num_patches, hipMemcpyDeviceToHost,
         ctx->stream));
@@ -740,8 +742,7 @@ extern "C" int
 smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     uint8_t *patch_valid_out, uint8_t *node_valid_out, int *total_deleted)
 {
-    SMVS_REQUIRE(ctx && inv_calibration9 && patch_valid_out && node_valid_out,
-        "null argument");
+    SMVS_REQUIRE(ctx && inv_calibration9, "null argument");
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     TopoArgs A;
     int const rc = launch_patch_mse(ctx, &A, "smvs_topology_cut_boundaries");
@@ -768,11 +769,14 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
         deleted = ctx->status_host[I_TOPO_DELETED];
         total += deleted;
     }
-    SMVS_HIP_CHECK(hipMemcpyAsync(patch_valid_out, ctx->patch_valid,
-        (size_t)ctx->num_patches, hipMemcpyDeviceToHost, ctx->stream));
-    SMVS_HIP_CHECK(hipMemcpyAsync(node_valid_out, ctx->node_valid,
-        (size_t)ctx->num_nodes, hipMemcpyDeviceToHost, ctx->stream));
-    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (patch_valid_out != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(patch_valid_out, ctx->patch_valid,
+            (size_t)ctx->num_patches, hipMemcpyDeviceToHost, ctx->stream));
+    if (node_valid_out != nullptr)
+        SMVS_HIP_CHECK(hipMemcpyAsync(node_valid_out, ctx->node_valid,
+            (size_t)ctx->num_nodes, hipMemcpyDeviceToHost, ctx->stream));
+    if (patch_valid_out != nullptr || node_valid_out != nullptr)
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (total_deleted != nullptr)
         *total_deleted = total;
     return SMVS_OK;

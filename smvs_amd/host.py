@@ -342,33 +342,46 @@ def select_neighbors(scene, view, num_neighbors=6, use_bundle=True):
     return [int(x) for x in out[:n_out.value]]
 
 
-def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3):
+def surface_script(inputs, init_scale, ops, init_depth=None, delete_every=3, device=None):
     """smvs_amd::Surface on its own (csrc/host/surface.cc, mirror of
     lib/surface.cc): create + a script of operations (1 expand,
     2 subdivide_patches, 3 fill_patches_from_depth, 4 remove_isolated_patches,
     5 delete every delete_every-th valid patch + remove_nodes_without_patch).
-    No device involved."""
+    device=None: the host mirror, no device involved; device=k: the same
+    script on the surface of a device context (csrc/surface.hip), result
+    downloaded (plus valid_patches as the last operation reported it)."""
     lib = load()
     keep = []
     main, _, _, bundle = _marshal(inputs, keep)
     h, w = np.asarray(inputs["images"][0]).shape[:2]
     cap_n, cap_p = (w + 2) * (h + 2), (w + 1) * (h + 1)
     nodes = np.zeros(cap_n * 4); nv = np.zeros(cap_n, np.uint8); pv = np.zeros(cap_p, np.uint8)
-    info = np.zeros(5, np.int32)
+    info = np.zeros(6, np.int32)
     ops_a = np.asarray(list(ops) + [0], dtype=np.int32)
     depth = None if init_depth is None else np.ascontiguousarray(init_depth, dtype=np.float32)
-    rc = lib.smvs_host_surface_script(C.byref(main), C.byref(bundle),
-        depth.ctypes.data_as(_fp) if depth is not None else None, C.c_int(init_scale),
-        ops_a.ctypes.data_as(_i32p), C.c_int(len(ops)), C.c_int(delete_every),
-        info.ctypes.data_as(_i32p), nodes.ctypes.data_as(C.POINTER(C.c_double)),
-        nv.ctypes.data_as(_u8p), pv.ctypes.data_as(_u8p))
+    dptr = depth.ctypes.data_as(_fp) if depth is not None else None
+    if device is None:
+        rc = lib.smvs_host_surface_script(C.byref(main), C.byref(bundle), dptr,
+            C.c_int(init_scale), ops_a.ctypes.data_as(_i32p), C.c_int(len(ops)),
+            C.c_int(delete_every), info.ctypes.data_as(_i32p),
+            nodes.ctypes.data_as(C.POINTER(C.c_double)), nv.ctypes.data_as(_u8p),
+            pv.ctypes.data_as(_u8p))
+    else:
+        rc = lib.smvs_host_surface_script_device(C.byref(main), C.byref(bundle), dptr,
+            C.c_int(init_scale), ops_a.ctypes.data_as(_i32p), C.c_int(len(ops)),
+            C.c_int(delete_every), C.c_int(device), info.ctypes.data_as(_i32p),
+            nodes.ctypes.data_as(C.POINTER(C.c_double)), nv.ctypes.data_as(_u8p),
+            pv.ctypes.data_as(_u8p))
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
-    scale, npx, npy, sx, sy = (int(x) for x in info)
+    scale, npx, npy, sx, sy = (int(x) for x in info[:5])
     nn, npatch = (npx + 1) * (npy + 1), npx * npy
-    return dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
-                nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
-                patch_valid=pv[:npatch].copy())
+    out = dict(scale=scale, npx=npx, npy=npy, start_x=sx, start_y=sy,
+               nodes=nodes[:4 * nn].reshape(nn, 4).copy(), node_valid=nv[:nn].copy(),
+               patch_valid=pv[:npatch].copy())
+    if device is not None:
+        out["valid_patches"] = int(info[5])
+    return out
 
 
 def surface_maps(inputs, init_scale, init_depth=None, device=0):
