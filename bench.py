@@ -183,7 +183,38 @@ def cpu_baseline(prob, all_cores=True):
                                 wall_s=round(wall, 2),
                                 note="one view (one full Newton step) per process, "
                                      "all at once")
+        # BASELINE.md's timed region on the CPU: all Newton loops of one whole
+        # optimize() of the `--workload optimize` scene (the oracle's own loop
+        # timers), OpenMP inside the view
+        try:
+            out["optimize"] = cpu_optimize_baseline(prob["surf"]["width"] < 1000, th)
+        except Exception as e:   # a report, never a reason to lose the rest
+            out["optimize"] = dict(error=repr(e))
     return out
+
+
+def cpu_optimize_baseline(small, threads):
+    """The oracle's DepthOptimizer::optimize on the scene of `--workload
+    optimize` / secondary.optimize: sum of active patch-steps over the sum of
+    its Newton loops' wall time (orc_opt_log.loop_seconds), `threads` OpenMP
+    threads inside the one view."""
+    from oracle import pyoracle
+    from smvs_amd import synth
+    w, h = (480, 270) if small else (W, H)
+    inp = synth.pipeline_inputs("sphere", w, h, NSUBS, flen=1.2)
+    pyoracle.lib().orc_set_threads(threads)
+    t = time.perf_counter()
+    r = pyoracle.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+    wall = time.perf_counter() - t
+    pyoracle.lib().orc_set_threads(1)
+    aps = sum(e["active_patch_steps"] for e in r["log"])
+    loop_s = sum(e["loop_seconds"] for e in r["log"])
+    return dict(value=aps / loop_s, unit="active-patch-steps/s", threads=threads,
+                active_patch_steps=int(aps), newton_loop_s=round(loop_s, 2),
+                optimize_wall_s=round(wall, 2), batches=len(r["log"]),
+                sample="one whole optimize() (scales init .. %d, %d batches) of the %dx%d / "
+                       "%d-neighbour sphere scene, --no-sgm; the same scene and units as "
+                       "value_optimize" % (SCALE, len(r["log"]), w, h, NSUBS))
 
 
 # ------------------------------------------------------------------- roofline
@@ -244,12 +275,16 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     n_nodes = ctx.num_nodes
     patch_steps = sum(p for _, p, _ in per_step)
     cg_its = sum(c for _, _, c in per_step)
-    traffic = None
-    for tf in ("traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in
+    # their own rocprofv3 passes, tools/collect_profiles.sh): a committed
+    # measurement of this command on an earlier box, NOT taken in this run
+    traffic = traffic_source = None
+    for tf in ("traffic_r4.json", "traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
         tfile = os.path.join(ROOT, "profiles", tf)
         if os.path.exists(tfile):
             with open(tfile) as f:
                 traffic = json.load(f).get(name)
+            traffic_source = "profiles/" + tf + " (rocprofv3 --pmc, committed; not measured in this run)"
             break
     # ---- T_min of the whole step over the measured time ----
     #   T_min = sum_steps [ max(F_construct / pi, B_construct / beta)
@@ -259,6 +294,16 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     # per patch prices the unfactored rows and is reported beside it).
     beta = HBM_PEAK_GBPS * 1e9
     pi = FP64_PEAK_TFLOPS * 1e12
+    peaks = measured_peaks() if with_peaks else None
+    hbm_measured = (peaks or {}).get("hbm_read_GBps")   # tools/peaks.py on this box
+
+    def hbm_fracs(achieved_GBps):
+        """Fractions of the assumed 8 TB/s and of the read peak measured here."""
+        out = dict(frac=round(achieved_GBps / HBM_PEAK_GBPS, 4))
+        if hbm_measured:
+            out["frac_of_measured_read_peak"] = round(achieved_GBps / hbm_measured, 4)
+            out["measured_read_peak_GBps"] = hbm_measured
+        return out
     cg_bytes_node = CG_BYTES["cg_spmv"] + CG_BYTES["cg_update"]
     t_min = t_min_survey = t_min_resident = 0.0
     for nodes_act, patches, its in per_step:
@@ -273,7 +318,7 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
                                          + RESIDENT_BYTES_PER_NODE * n_nodes) / beta \
             + its * EXCHANGE_FLOOR_S
     t_meas = ms_per_step * 1e-3 * steps
-    out = dict(kernel=name, traffic=traffic, kernels=kernels,
+    out = dict(kernel=name, traffic=traffic, traffic_source=traffic_source, kernels=kernels,
                step_frac=round(t_min_resident / t_meas, 4),
                step_t_min_us=round(1e6 * t_min_resident / steps, 1),
                step_frac_streaming_model=round(t_min / t_meas, 4),
@@ -294,7 +339,7 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
                             RESIDENT_BYTES_PER_NODE, HBM_PEAK_GBPS, 1e6 * EXCHANGE_FLOOR_S,
                             cg_bytes_node),
                peaks_assumed=dict(hbm_GBps=HBM_PEAK_GBPS, fp64_TFLOPs=FP64_PEAK_TFLOPS),
-               peaks_measured=measured_peaks() if with_peaks else None)
+               peaks_measured=peaks)
     def cg_resident_line():
         # One launch per solve.  Inside the Newton loop the kernel assembles H,
         # g, P itself from the per-patch systems (1,280 + 128 B per live patch,
@@ -310,7 +355,7 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
         avg_s = ms_k * 1e-3 / max(cnt_k, 1)
         achieved = bytes_per_launch / avg_s / 1e9
         return dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                    unit="GB/s", **hbm_fracs(achieved),
                     bytes_per_launch=int(bytes_per_launch), avg_us=round(avg_s * 1e6, 2),
                     note="whole PCG solve in one launch (%.1f iterations on average, "
                          "system assembled in the kernel: %s): after the one pass over "
@@ -351,7 +396,7 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
         avg_s = ms * 1e-3 / work
         achieved = bytes_per_launch / avg_s / 1e9
         out.update(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
-                   unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                   unit="GB/s", **hbm_fracs(achieved),
                    bytes_per_launch=bytes_per_launch, avg_us=round(avg_s * 1e6, 2),
                    launches_with_work=work)
     out["cg_iterations"] = cg_its
@@ -446,6 +491,128 @@ def secondary_workloads(args):
              "cost 1 B in + 1 B out, warp 1 B out")
     return out
 
+# ------------------------------------------------- whole views on N GPUs
+def _views_inputs(small, shading):
+    from smvs_amd import synth
+    w, h = (480, 270) if small else (W, H)
+    lighting = None
+    if shading:
+        rng = np.random.default_rng(3000)
+        lighting = np.zeros(16); lighting[0] = 0.9
+        lighting[1:4] = rng.uniform(-0.2, 0.2, 3)
+    return synth.pipeline_inputs("sphere", w, h, NSUBS, flen=1.2, lighting=lighting), w, h
+
+
+def views_worker(args):
+    """`bench.py --views-worker`: one process of the multi-GPU views workload.
+    Runs --views whole per-view tasks (9 x StereoView::create, SGM front end,
+    optimize() of all scales [-S with --shading], depth + normal maps;
+    app/smvsrecon.cc:658-733) through the C++ ViewQueue on devices
+    [--first-device, --first-device + --num-devices), --views-in-flight per
+    GPU.  After its warm-up it waits for the go file of --sync-dir so that all
+    workers of a measurement start together.  Prints one JSON line."""
+    from smvs_amd import host
+    inp, w, h = _views_inputs(args.small, args.shading)
+    kw = dict(regularization=REG, min_scale=SCALE, sgm_scale=1, use_shading=args.shading,
+              first_device=args.first_device, num_devices=args.num_devices)
+    host.optimize_views(inp, max(2, args.num_devices * args.views_in_flight),
+                        views_in_flight=args.views_in_flight, **kw)
+    if args.sync_dir:
+        open(os.path.join(args.sync_dir, "ready_%d" % args.worker_id), "w").close()
+        go = os.path.join(args.sync_dir, "go")
+        t_wait = time.perf_counter()
+        while not os.path.exists(go):
+            if time.perf_counter() - t_wait > 300:
+                raise RuntimeError("views worker: no go signal")
+            time.sleep(0.0005)
+    t0 = time.time()
+    v = host.optimize_views(inp, args.views, views_in_flight=args.views_in_flight, **kw)
+    t1 = time.time()
+    aps = sum(e["active_patch_steps"] for lg in v["logs"] for e in lg)
+    print(json.dumps(dict(worker=args.worker_id, views=args.views, t_start=t0, t_end=t1,
+                          seconds=t1 - t0, views_per_s=args.views / (t1 - t0),
+                          mean_task_ms=round(1e3 * float(np.mean(v["job_seconds"])), 1),
+                          active_patch_steps=int(aps))))
+
+
+def multi_gpu_views(args, n_gpus, shading):
+    """What can fail to scale (app/smvsrecon.cc:658-733: one task per reference
+    view): whole per-view tasks on the N GPUs of this node, measured two ways --
+    (a) N processes, one per GPU, started together (how the driver's ranks
+    run), (b) ONE process driving all N GPUs through ViewQueue(N,
+    views_in_flight), the reference's single process with a thread pool.  Each
+    in fresh child processes after the distributed job has ended: a failure
+    there cannot take the headline with it."""
+    import tempfile
+    per_gpu_views = max(args.views_per_rank, 1)
+    in_flight = max(args.views_in_flight, 4)
+    base = [sys.executable, os.path.abspath(__file__), "--views-worker",
+            "--views-in-flight", str(in_flight)]
+    if args.small:
+        base.append("--small")
+    if shading:
+        base.append("--shading")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+              "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = dict(views_in_flight_per_gpu=in_flight, views_per_gpu=per_gpu_views,
+               shading=bool(shading), nproc=os.cpu_count(),
+               note="whole per-view tasks (9 x StereoView::create, SGM front end, "
+                    "optimize() of all scales%s, depth + normal maps), %dx%d, %d neighbours"
+                    % (" with -S (SH lighting fit + shading residual)" if shading else "",
+                       *((480, 270) if args.small else (W, H)), NSUBS))
+
+    def run(workers):
+        """workers: list of (first_device, num_devices, views)."""
+        with tempfile.TemporaryDirectory() as d:
+            procs = []
+            for i, (first, num, views) in enumerate(workers):
+                cmd = base + ["--first-device", str(first), "--num-devices", str(num),
+                              "--views", str(views), "--sync-dir", d, "--worker-id", str(i)]
+                procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
+                                              stderr=subprocess.PIPE, text=True))
+            t_wait = time.perf_counter()
+            while not all(os.path.exists(os.path.join(d, "ready_%d" % i))
+                          for i in range(len(workers))):
+                if any(p.poll() is not None for p in procs) \
+                        or time.perf_counter() - t_wait > 240:
+                    for p in procs:
+                        p.kill()
+                    errs = [p.communicate()[1][-300:] for p in procs]
+                    raise RuntimeError("views worker failed to start: %r" % errs)
+                time.sleep(0.01)
+            open(os.path.join(d, "go"), "w").close()
+            res = []
+            for p in procs:
+                so, se = p.communicate(timeout=600)
+                if p.returncode != 0:
+                    raise RuntimeError("views worker: %s" % se[-500:])
+                res.append(json.loads(so.strip().splitlines()[-1]))
+        span = max(r["t_end"] for r in res) - min(r["t_start"] for r in res)
+        total = sum(r["views"] for r in res)
+        return dict(views=total, seconds=round(span, 3), views_per_s=round(total / span, 2),
+                    views_per_s_per_gpu=round(total / span / n_gpus, 2),
+                    per_worker_views_per_s=[round(r["views_per_s"], 2) for r in res],
+                    mean_task_ms=round(float(np.mean([r["mean_task_ms"] for r in res])), 1),
+                    host_threads=len(workers) + n_gpus * in_flight)
+
+    try:
+        out["one_process_per_gpu"] = run([(g, 1, per_gpu_views) for g in range(n_gpus)])
+    except Exception as e:
+        out["one_process_per_gpu"] = dict(error=repr(e))
+    try:
+        out["one_process_view_queue"] = run([(0, n_gpus, per_gpu_views * n_gpus)])
+    except Exception as e:
+        out["one_process_view_queue"] = dict(error=repr(e))
+    if n_gpus > 1:
+        try:
+            out["single_gpu_reference"] = run([(0, 1, per_gpu_views)])
+        except Exception as e:
+            out["single_gpu_reference"] = dict(error=repr(e))
+    return out
+
+
 def optimize_workload(args):
     """--workload optimize: a "step" is one whole DepthOptimizer::optimize of one
     reference view (all scales, init .. 2) through the C++ host mirror; value =
@@ -530,11 +697,23 @@ def main():
                          "scale 2; optimize: BASELINE.md's timed region literally -- all "
                          "Newton loops of all scales of --steps whole optimize() calls of the "
                          "same scene (also reported as secondary.optimize of the default run)")
+    ap.add_argument("--views-worker", action="store_true",
+                    help="internal: one process of the multi-GPU views workload")
+    ap.add_argument("--first-device", type=int, default=0, help="--views-worker")
+    ap.add_argument("--num-devices", type=int, default=1, help="--views-worker")
+    ap.add_argument("--views", type=int, default=8, help="--views-worker")
+    ap.add_argument("--shading", action="store_true", help="--views-worker: -S")
+    ap.add_argument("--sync-dir", default="", help="--views-worker")
+    ap.add_argument("--worker-id", type=int, default=0, help="--views-worker")
+    ap.add_argument("--no-multi-gpu-views", action="store_true",
+                    help="N > 1: skip the whole-view throughput measurement over the GPUs")
     ap.add_argument("--views-in-flight", type=int, default=1,
                     help="reference views processed concurrently per GPU (own context, "
                          "stream and host thread each); the headline number uses 1")
     args = ap.parse_args()
 
+    if args.views_worker:
+        return views_worker(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
 
@@ -664,11 +843,61 @@ def main():
         roof = roofline(ctx, prob, args.steps, 1e3 * secs / args.steps, lighting,
                         with_peaks=not args.no_peaks)
 
+    # --shared-lighting: what one RCCL round of the lighting normal equations
+    # costs (2,176 bytes all-reduced in place on the device buffers)
+    rccl_round = None
+    if native is not None:
+        try:
+            ctx.light_accumulate_dev()
+            barrier()
+            t0 = time.perf_counter()
+            rounds = 50
+            for _ in range(rounds):
+                native.allreduce_lighting([ctx])
+            torch.cuda.synchronize()
+            rccl_round = dict(us_per_round=round(1e6 * (time.perf_counter() - t0) / rounds, 1),
+                              rounds=rounds, world=world, bytes=272 * 8,
+                              note="smvs_light_allreduce (device sum + ncclAllReduce + copy "
+                                   "back) of one view's buffer per rank, host-timed")
+        except Exception as e:
+            rccl_round = dict(error=repr(e))
+
+    # The distributed job ends here: contexts, communicator and process group
+    # go away, the other ranks exit.  What follows runs on rank 0 alone, the
+    # multi-GPU part in fresh child processes (it cannot take the headline
+    # with it).
+    if native is not None:
+        native.close()
+        native = None
+    for c in ctxs:
+        c.close()
+    ctxs = []
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+    if rank != 0:
+        return
+
     # The GPU phase comes first (what the driver's samplers watch at the start
     # of the run); the CPU baseline forks one oracle process per view, so it
     # runs afterwards in a child process that never loads the HIP runtime.
     secondary = cpu = None
-    if rank == 0 and world == 1 and args.config == 1:
+    if world > 1 or args.config == 5:
+        secondary = {}
+        if rccl_round is not None:
+            secondary["rccl_lighting_round"] = rccl_round
+        if not args.no_multi_gpu_views and not args.no_secondary:
+            try:
+                smvs_amd._capi.load().smvs_release_workspaces()
+                time.sleep(1.0)   # (the other ranks are leaving their GPUs)
+                secondary["views_per_s"] = multi_gpu_views(args, world, args.config == 5)
+            except Exception as e:
+                secondary["views_per_s"] = dict(error=repr(e))
+        secondary["scaling_note"] = ("the headline scales by construction (independent "
+                                     "views, no data-path collective); views_per_s is the "
+                                     "whole per-view task whose host side can fail to scale")
+    if world == 1 and args.config == 1:
         if not args.no_secondary:
             try:
                 secondary = secondary_workloads(args)
@@ -714,13 +943,17 @@ def main():
                        "ms_per_step_max": 1e3 * repeats[0][1] / args.steps},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
+        # BASELINE.md's own timed region (all Newton loops of all scales of one
+        # optimize() of the same scene) beside the headline's scale-2 replay
+        if isinstance(secondary, dict) and isinstance(secondary.get("optimize"), dict) \
+                and "value" in secondary["optimize"]:
+            out["value_optimize"] = secondary["optimize"]["value"]
+            out["value_optimize_note"] = (
+                "active patch-steps / second over ALL Newton loops (scales init .. %d) of "
+                "one whole DepthOptimizer::optimize of the same scene -- BASELINE.md's "
+                "timed region; `value` replays the scale-%d loop of that workload from a "
+                "resident start surface (see secondary.optimize)" % (SCALE, SCALE))
         print(json.dumps(out))
-    if native is not None:
-        native.close()
-    for c in ctxs:
-        c.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -480,7 +480,9 @@ class OptLog(C.Structure):
                 ("iter", C.c_int * 256), ("newton_steps", C.c_int * 256),
                 ("valid_patches", C.c_int * 256), ("cg_iterations", C.c_int * 256),
                 ("final_scale", C.c_int), ("final_patches", C.c_int),
-                ("has_lighting", C.c_int), ("lighting", C.c_double * 16)]
+                ("has_lighting", C.c_int), ("lighting", C.c_double * 16),
+                ("loop_seconds", C.c_double * 256),
+                ("active_patch_steps", C.c_longlong * 256)]
 
 
 def _view_input(img, cam, view_id, keep):
@@ -539,7 +541,9 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
     steps = [dict(scale=log.scale[i], iter=log.iter[i],
                   newton_steps=log.newton_steps[i],
                   valid_patches=log.valid_patches[i],
-                  cg_iterations=log.cg_iterations[i]) for i in range(log.count)]
+                  cg_iterations=log.cg_iterations[i],
+                  loop_seconds=log.loop_seconds[i],
+                  active_patch_steps=log.active_patch_steps[i]) for i in range(log.count)]
     return dict(depth=depth, normals=normals, log=steps,
                 final_patches=log.final_patches,
                 lighting=np.array(log.lighting[:]) if log.has_lighting else None)

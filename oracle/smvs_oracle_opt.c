@@ -12,6 +12,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1193,13 +1194,23 @@ orc_topology_cut_boundaries(orc_surface *s, const orc_topo_view *main_view,
     return total;
 }
 
+static double
+wall_seconds(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static void
 log_push(orc_opt_log *log, int scale, int iter, int steps, int patches,
-    int cg_iterations)
+    int cg_iterations, double loop_seconds, long long active_patch_steps)
 {
     if (log == NULL || log->count >= ORC_OPT_LOG_MAX)
         return;
     int const i = log->count++;
+    log->loop_seconds[i] = loop_seconds;
+    log->active_patch_steps[i] = active_patch_steps;
     log->scale[i] = scale;
     log->iter[i] = iter;
     log->newton_steps[i] = steps;
@@ -1272,10 +1283,12 @@ opt_run_newton_iterations(OOpt *O, int num_iters)
         make_views(O, &V, sv);
         orc_gn_options gopts = { O->opts->regularization,
             O->opts->light_surf_regularization };
+        double const t_loop = wall_seconds();
+        long long patch_steps = 0;
         for (; newton_step < 200 && num_active > num_initial / 20;)
         {
             newton_step += 1;
-            orc_gn_construct(&V, &S->s, &gopts,
+            patch_steps += orc_gn_construct(&V, &S->s, &gopts,
                 O->has_lighting ? O->lighting : NULL, active, H9, present, g, P);
             double const gnorm = sqrt(orc_vec_dot(g, g, 4 * (size_t)nn));
             for (int i = 0; i < 4 * nn; ++i)
@@ -1298,10 +1311,11 @@ opt_run_newton_iterations(OOpt *O, int num_iters)
             }
             num_active = (size_t)r;
         }
+        double const loop_seconds = wall_seconds() - t_loop;
         free(H9); free(present); free(g); free(P); free(x); free(sv);
         free(active);
         log_push(O->log, S->s.scale, iter, (int)newton_step, num_valid_patches,
-            cg_total);
+            cg_total, loop_seconds, patch_steps);
         opt_dump(O, iter, "newton");
         if (finished)
             break;

@@ -49,6 +49,12 @@ typedef struct {
     int final_scale, final_patches;
     int has_lighting;
     double lighting[16];
+    /* measurement (bench.py's cpu_baseline.optimize), not part of the
+     * algorithm: wall time of each batch's Newton loop (construct + solve +
+     * update; depth_optimizer.cc:219-304) and the sum over its steps of the
+     * patches with an active node (gauss_newton_step.cc:73-79) */
+    double loop_seconds[ORC_OPT_LOG_MAX];
+    long long active_patch_steps[ORC_OPT_LOG_MAX];
 } orc_opt_log;
 
 /* Test access to the topology tests between Newton batches on caller-provided

@@ -513,3 +513,151 @@ def test_bench_contract_small(hip):
     line = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
     assert line["unit"] == "active-patch-steps/s" and line["value"] > 0 and line["steps"] == 2
     assert "optimize" in line["config"]["workload"]
+
+
+def test_bench_contract_value_optimize_and_traffic_source(hip):
+    """The honesty fields: `value_optimize` (BASELINE.md's timed region) at the
+    top level beside the headline, the committed source of `roofline.traffic`,
+    HBM fractions also against the read peak measured on the box."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "3",
+           "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert out["value_optimize"] == out["secondary"]["optimize"]["value"] > 0
+    assert "BASELINE.md" in out["value_optimize_note"]
+    roof = out["roofline"]
+    assert roof["traffic_source"].startswith("profiles/traffic_r")
+    cg = roof["per_kernel"]["cg_resident"]
+    assert cg["measured_read_peak_GBps"] > 1000
+    assert abs(cg["frac_of_measured_read_peak"]
+               - cg["achieved"] / cg["measured_read_peak_GBps"]) < 1e-3
+
+
+def test_bench_config5_runs_whole_views_in_child_processes(hip):
+    """`bench.py --config 5` (configs[4] as one rank sees it): besides the
+    headline, whole per-view tasks with -S -- SGM front end, optimize() of all
+    scales with the SH lighting fit, maps -- through the ViewQueue, measured in
+    fresh child processes both as one process per GPU and as ONE process
+    driving every GPU (here: one GPU, so the two coincide in kind), plus the
+    cost of a native RCCL lighting round."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--small", "--config", "5",
+           "--views-per-rank", "2", "--shared-lighting", "--steps", "4", "--warmup", "1",
+           "--repeats", "2", "--no-peaks", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert "configs[4]" in out["config"]["workload"]
+    sec = out["secondary"]
+    assert sec["rccl_lighting_round"]["us_per_round"] > 0
+    v = sec["views_per_s"]
+    assert v["shading"] is True and v["views_per_gpu"] == 2
+    for mode in ("one_process_per_gpu", "one_process_view_queue"):
+        assert "error" not in v[mode], v[mode]
+        assert v[mode]["views"] == 2 and v[mode]["views_per_s"] > 0
+
+
+_RCCL_WORLD2_PROBE = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import smvs_amd
+from smvs_amd import synth, shard
+rank = int(os.environ["RANK"]); local = int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+prob = synth.make_problem(224, 160, 3, 2, shading=True, noise=0.003)
+rng = np.random.default_rng(100 + rank)
+ctxs, mine = [], []
+for v in range(2):
+    s = dict(prob["surf"])
+    nodes = prob["surf"]["nodes"].copy()
+    nodes[:, 0] *= 1.0 + 0.003 * rng.standard_normal(nodes.shape[0])
+    s["nodes"] = nodes
+    c = smvs_amd.ViewContext(224, 160, 3, device=local)
+    c.set_views(prob["views"]); c.set_surface(s)
+    c.light_accumulate_dev()
+    mine.append(np.concatenate([x.reshape(-1) for x in c.light_download()]))
+    ctxs.append(c)
+comm = shard.NativeComm(local, dist)
+assert (comm.rank, comm.world) == (rank, dist.get_world_size())
+comm.allreduce_lighting(ctxs)
+box = [None] * dist.get_world_size()
+dist.all_gather_object(box, mine)
+want = sum(sum(m) for m in box)
+for c in ctxs:
+    got = np.concatenate([x.reshape(-1) for x in c.light_download()])
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert err < 1e-12, err
+# and once more (the communicator is reusable, results deterministic)
+for c in ctxs:
+    c.light_accumulate_dev()
+comm.allreduce_lighting(ctxs)
+got2 = np.concatenate([x.reshape(-1) for x in ctxs[0].light_download()])
+assert np.array_equal(got2, got)
+comm.close()
+for c in ctxs:
+    c.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+"""
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_native_rccl_lighting_allreduce_world_2(hip, tmp_path):
+    """include/smvs_rccl.h across RANKS: two processes, one GPU each, two views
+    per rank; smvs_light_allreduce (device sum over the rank's views ->
+    ncclAllReduce over xGMI -> copy back) must leave the sum over all four
+    views in every context.  Needs two GPUs: skipped on the one-GPU box, run by
+    the driver's multi-GPU node."""
+    import subprocess, sys
+    if hip.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's multi-GPU node)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = tmp_path / "rccl_probe.py"
+    probe.write_text(_RCCL_WORLD2_PROBE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(probe), root]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
+
+
+def test_bench_two_gpus_reports_whole_views(hip):
+    """`bench.py --gpus 2`: the headline as two ranks over RCCL plumbing, then
+    whole views per second on both GPUs as two processes and as ONE process
+    with ViewQueue(2, in_flight).  Skipped without two GPUs."""
+    import json, subprocess, sys
+    if hip.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's multi-GPU node)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--small", "--steps",
+           "4", "--warmup", "1", "--repeats", "2", "--views-per-rank", "3"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    v = out["secondary"]["views_per_s"]
+    for mode in ("one_process_per_gpu", "one_process_view_queue", "single_gpu_reference"):
+        assert "error" not in v[mode], v[mode]
+    assert v["one_process_per_gpu"]["views"] == 6
+    assert v["one_process_view_queue"]["views"] == 6
