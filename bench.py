@@ -740,7 +740,9 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        with shard.quiet_stdout():   # (RCCL's version banner)
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
 
     surf = prob["surf"]
     w, h = surf["width"], surf["height"]
@@ -866,16 +868,17 @@ def main():
     # go away, the other ranks exit.  What follows runs on rank 0 alone, the
     # multi-GPU part in fresh child processes (it cannot take the headline
     # with it).
-    if native is not None:
-        native.close()
-        native = None
-    for c in ctxs:
-        c.close()
-    ctxs = []
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-        dist = None
+    with shard.quiet_stdout():
+        if native is not None:
+            native.close()
+            native = None
+        for c in ctxs:
+            c.close()
+        ctxs = []
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+            dist = None
     if rank != 0:
         return
 
@@ -953,7 +956,9 @@ def main():
                 "one whole DepthOptimizer::optimize of the same scene -- BASELINE.md's "
                 "timed region; `value` replays the scale-%d loop of that workload from a "
                 "resident start surface (see secondary.optimize)" % (SCALE, SCALE))
+        shard.flush_c_stdio()   # (whatever a C library still holds goes out first)
         print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,42 @@ rank optimises its own views.  Collectives appear only
     latency, ring-vs-tree and xGMI link bandwidth are irrelevant).
 torch.distributed is plumbing here: "nccl" is RCCL on ROCm, "gloo" on CPU.
 """
+import contextlib
+import os
+import sys
+
 import numpy as np
+
+
+def flush_c_stdio():
+    """fflush(NULL): what C libraries in this process (RCCL prints a version
+    banner on stdout when a communicator is created) still hold in their stdio
+    buffers."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+@contextlib.contextmanager
+def quiet_stdout():
+    """File descriptor 1 points to /dev/null inside the block (C stdio is
+    flushed on both sides): RCCL's banner does not end up beside the ONE JSON
+    line bench.py owes its caller."""
+    sys.stdout.flush()
+    flush_c_stdio()
+    saved = os.dup(1)
+    null = os.open(os.devnull, os.O_WRONLY)
+    try:
+        os.dup2(null, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        flush_c_stdio()
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(null)
 
 
 def assign_views(num_views, world_size, rank):
@@ -112,8 +147,9 @@ class NativeComm:
             dist.broadcast_object_list(box, src=0)
             ident = (C.c_char * 128).from_buffer_copy(box[0])
         self.handle = C.c_void_p()
-        _capi.check(self.lib.smvs_comm_create(device_index, rank, world, ident,
-                                              C.byref(self.handle)))
+        with quiet_stdout():
+            _capi.check(self.lib.smvs_comm_create(device_index, rank, world, ident,
+                                                  C.byref(self.handle)))
         self.rank, self.world = rank, world
 
     def allreduce_lighting(self, ctxs):

@@ -2,7 +2,8 @@
 """Where the resident PCG spends a solve: 100 MHz wall-clock stamps (SMVS_CG_TRACE) of
 workgroup 0 per iteration and of every workgroup in the prologue, on the three Newton
 steps of a batch of the bench workload (SMVS_LOOP_TEST=unpipelined: the host waits
-for each solve)."""
+for each solve).  Usage: cg_trace.py [out.txt [scale]] -- scale 6 / 5 / 4: the same
+view at a coarse scale (1 / 4 / 16 tiles of the resident solver)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/cg_trace.txt"
@@ -12,7 +13,12 @@ if os.path.exists(path):
     os.remove(path)
 import numpy as np
 import bench, smvs_amd
-prob = bench.make_problem(0, False)
+scale = int(sys.argv[2]) if len(sys.argv) > 2 else bench.SCALE
+if scale == bench.SCALE:
+    prob = bench.make_problem(0, False)
+else:
+    from smvs_amd import synth
+    prob = synth.make_problem(bench.W, bench.H, bench.NSUBS, scale, noise=bench.NOISE, seed=2000)
 surf = prob["surf"]
 ctx = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
 ctx.set_views(prob["views"]); ctx.set_surface(surf)
