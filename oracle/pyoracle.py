@@ -800,3 +800,16 @@ def view_reprojection(inputs, src, dst):
     f.restype = None
     f(C.byref(a), C.byref(b), _p(M, c_float_p), _p(t, c_float_p))
     return M, t
+
+
+def rescale_half_size_gaussian(img):
+    """mve::image::rescale_half_size_gaussian<uint8_t> as restated in
+    oracle/smvs_oracle_front.c ([MVE-unverified] M29)."""
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    squeeze = a.ndim == 2
+    if squeeze:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2, c), np.uint8)
+    lib().orc_rescale_half_size_gaussian_u8(_p(a, c_u8_p), w, h, c, _p(out, c_u8_p))
+    return out[:, :, 0] if squeeze else out

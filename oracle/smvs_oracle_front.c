@@ -554,3 +554,54 @@ orc_view_reprojection(const orc_view_input *src, const orc_view_input *dst,
     orc_fill_reprojection(Ksi, src->rot, src->trans, Kd, dst->rot, dst->trans,
         M, t);
 }
+
+/* mve::image::rescale_half_size_gaussian<uint8_t>(img, sigma2 = 0.75f)
+ * [MVE-unverified, tests/golden/README.md M29] -- the filter smvsrecon
+ * pre-scales its input embedding with (app/smvsrecon.cc:634-647).  Restated as
+ * MVE writes it: four clamped row pointers, four clamped column offsets, and
+ * sixteen math::Accum<unsigned char>::add calls per channel in row-major order
+ * (a float value sum and a float weight sum), normalized() = the value sum
+ * divided by the weight sum, rounded with math::round (half away from zero).
+ * out: ((w + 1) / 2) * ((h + 1) / 2) * c bytes. */
+void
+orc_rescale_half_size_gaussian_u8(const uint8_t *in, int iw, int ih, int ic,
+    uint8_t *out)
+{
+    int const ow = (iw + 1) >> 1, oh = (ih + 1) >> 1;
+    float const sigma2 = 0.75f;
+    float const w1 = expf(-0.5f / (2.0f * sigma2));
+    float const w2 = expf(-2.5f / (2.0f * sigma2));
+    float const w3 = expf(-4.5f / (2.0f * sigma2));
+    size_t outpos = 0;
+    size_t const rowstride = (size_t)iw * ic;
+    for (int y = 0; y < oh; ++y)
+    {
+        int const y2 = y << 1;
+        const uint8_t *row[4];
+        row[0] = in + (size_t)(y2 - 1 > 0 ? y2 - 1 : 0) * rowstride;
+        row[1] = in + (size_t)y2 * rowstride;
+        row[2] = in + (size_t)(y2 + 1 < ih - 1 ? y2 + 1 : ih - 1) * rowstride;
+        row[3] = in + (size_t)(y2 + 2 < ih - 1 ? y2 + 2 : ih - 1) * rowstride;
+        for (int x = 0; x < ow; ++x)
+        {
+            int const x2 = x << 1;
+            int xi[4];
+            xi[0] = (x2 - 1 > 0 ? x2 - 1 : 0) * ic;
+            xi[1] = x2 * ic;
+            xi[2] = (x2 + 1 < iw - 1 ? x2 + 1 : iw - 1) * ic;
+            xi[3] = (x2 + 2 < iw - 1 ? x2 + 2 : iw - 1) * ic;
+            for (int c = 0; c < ic; ++c)
+            {
+                float v = 0.0f, w = 0.0f;
+#define ORC_ACC(r, k, wt) do { v += (float)row[r][xi[k] + c] * (wt); w += (wt); } while (0)
+                ORC_ACC(0, 0, w3); ORC_ACC(0, 1, w2); ORC_ACC(0, 2, w2); ORC_ACC(0, 3, w3);
+                ORC_ACC(1, 0, w2); ORC_ACC(1, 1, w1); ORC_ACC(1, 2, w1); ORC_ACC(1, 3, w2);
+                ORC_ACC(2, 0, w2); ORC_ACC(2, 1, w1); ORC_ACC(2, 2, w1); ORC_ACC(2, 3, w2);
+                ORC_ACC(3, 0, w3); ORC_ACC(3, 1, w2); ORC_ACC(3, 2, w2); ORC_ACC(3, 3, w3);
+#undef ORC_ACC
+                float const q = v / w;
+                out[outpos++] = (uint8_t)(q > 0.0f ? floorf(q + 0.5f) : ceilf(q - 0.5f));
+            }
+        }
+    }
+}

@@ -101,6 +101,8 @@ void orc_scale_planes(const uint8_t *bytes, int w, int h, int c, int scale,
     float *grad2, float *hess3);
 /* mve::image::rescale_half_size<uint8_t> [MVE-unverified] */
 void orc_rescale_half_size_u8(const uint8_t *in, int w, int h, uint8_t *out);
+/* mve::image::rescale_half_size_gaussian<uint8_t> [MVE-unverified M29] (smvs_oracle_front.c) */
+void orc_rescale_half_size_gaussian_u8(const uint8_t *in, int w, int h, int c, uint8_t *out);
 
 
 /* ---- callers either side of the optimiser (smvs_oracle_front.c) ---- */

@@ -26,7 +26,7 @@ HOST_DIR = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libsmvs_host.so")
 HOST_SOURCES = ["camera.cc", "stereo_view.cc", "surface.cc", "sgm_stereo.cc",
                 "depth_optimizer.cc", "view_selection.cc", "view_queue.cc", "conjugate_gradient.cc",
-                "gauss_newton_step.cc", "scene_io.cc", "host_capi.cc"]
+                "gauss_newton_step.cc", "scene_io.cc", "png_io.cc", "host_capi.cc"]
 
 
 def _host_stale():
@@ -51,7 +51,7 @@ def build_host(force=False, verbose=False):
     cmd = [cxx, "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-Wall", "-pthread",
            "-shared", "-o", HOST_LIB] \
         + [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] \
-        + ["-L" + CSRC, "-lsmvs_hip", "-Wl,-rpath,$ORIGIN/..",
+        + ["-L" + CSRC, "-lsmvs_hip", "-lz", "-Wl,-rpath,$ORIGIN/..",
            "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))

@@ -1,4 +1,5 @@
 #include "host_capi.h"
+#include "png_io.h"
 
 #include <algorithm>
 #include <cstring>
@@ -692,7 +693,7 @@ extern "C" int
 smvs_host_reconstruct_scene(const char *scene_dir,
     const smvs_host_recon_settings *o, const int *view_ids, int n_view_ids,
     int *reconstructed_out, int max_reconstructed, int *n_reconstructed,
-    int *n_skipped, double *seconds)
+    int *n_skipped, double *seconds, int *input_scale_used)
 {
     try {
         if (scene_dir == nullptr || o == nullptr)
@@ -715,6 +716,9 @@ smvs_host_reconstruct_scene(const char *scene_dir,
         conf.first_device = o->first_device;
         conf.num_devices = o->num_devices;
         conf.views_in_flight = o->views_in_flight;
+        conf.input_scale = o->input_scale;
+        if (o->max_pixels > 0)
+            conf.max_pixels = (std::size_t)o->max_pixels;
         if (view_ids != nullptr)
             conf.view_ids.assign(view_ids, view_ids + n_view_ids);
         ReconReport const report = reconstruct_scene(scene_dir, conf);
@@ -729,6 +733,8 @@ smvs_host_reconstruct_scene(const char *scene_dir,
                 + report.already_done.size());
         if (seconds != nullptr)
             *seconds = report.seconds;
+        if (input_scale_used != nullptr)
+            *input_scale_used = report.input_scale;
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();
@@ -755,11 +761,11 @@ smvs_host_scene_info(const char *scene_dir, const char *image_embedding,
             flen[i] = v.camera.flen;
             std::copy(v.camera.rot, v.camera.rot + 9, rot9 + 9 * i);
             std::copy(v.camera.trans, v.camera.trans + 3, trans3 + 3 * i);
-            int whct[4] = { 0, 0, 0, 0 };
-            if (v.present)
-                (void)mvei_header(v.image_path(image_embedding), whct);
-            width[i] = whct[0];
-            height[i] = whct[1];
+            int whc[3] = { 0, 0, 0 };
+            if (v.present && v.has_image(image_embedding))
+                (void)v.image_size(image_embedding, whc);
+            width[i] = whc[0];
+            height[i] = whc[1];
         }
         if (n_features != nullptr) {
             try {
@@ -788,6 +794,67 @@ smvs_host_mvei_roundtrip(const char *in_path, const char *out_path)
             save_mvei(out_path, ByteImage::ConstPtr(load_mvei_u8(in_path)));
         else
             save_mvei(out_path, FloatImage::ConstPtr(load_mvei_float(in_path)));
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_load_byte_image(const char *path, int *whc, uint8_t *pixels, size_t capacity)
+{
+    try {
+        if (path == nullptr || whc == nullptr)
+            throw std::invalid_argument("smvs_host_load_byte_image: bad argument");
+        std::string const p = path;
+        ByteImage::Ptr img = p.size() > 4 && p.substr(p.size() - 4) == ".png"
+            ? load_png_u8(p) : load_mvei_u8(p);
+        whc[0] = img->width();
+        whc[1] = img->height();
+        whc[2] = img->channels();
+        std::size_t const n = (std::size_t)img->width() * img->height() * img->channels();
+        if (pixels != nullptr) {
+            if (capacity < n)
+                throw std::invalid_argument("smvs_host_load_byte_image: buffer too small");
+            std::memcpy(pixels, img->begin(), n);
+        }
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_save_png(const char *path, const uint8_t *pixels, int width, int height,
+    int channels)
+{
+    try {
+        if (path == nullptr || pixels == nullptr || width < 1 || height < 1)
+            throw std::invalid_argument("smvs_host_save_png: bad argument");
+        ByteImage::Ptr img = ByteImage::create_for_overwrite(width, height, channels);
+        std::memcpy(img->begin(), pixels, (std::size_t)width * height * channels);
+        save_png_u8(path, img);
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_rescale_half_size_gaussian(const uint8_t *pixels, int width, int height,
+    int channels, uint8_t *out)
+{
+    try {
+        if (pixels == nullptr || out == nullptr || channels < 1)
+            throw std::invalid_argument("smvs_host_rescale_half_size_gaussian: bad argument");
+        ByteImage::Ptr img = ByteImage::create_for_overwrite(width, height, channels);
+        std::memcpy(img->begin(), pixels, (std::size_t)width * height * channels);
+        ByteImage::Ptr half = rescale_half_size_gaussian(img);
+        std::memcpy(out, half->begin(),
+            (std::size_t)half->width() * half->height() * half->channels());
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();

@@ -4,6 +4,7 @@
 #ifndef SMVS_HOST_CAPI_H
 #define SMVS_HOST_CAPI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -140,11 +141,25 @@ typedef struct {
     int sgm_scale;
     int num_neighbors, min_neighbors;
     int first_device, num_devices, views_in_flight;
+    int input_scale;                /* -s; < 0: automatic (app/smvsrecon.cc:477-500) */
+    int max_pixels;                 /* --max-pixels, 1700000 */
 } smvs_host_recon_settings;
 int smvs_host_reconstruct_scene(const char *scene_dir,
     const smvs_host_recon_settings *settings, const int *view_ids, int n_view_ids,
     int *reconstructed_out, int max_reconstructed, int *n_reconstructed,
-    int *n_skipped, double *seconds);
+    int *n_skipped, double *seconds, int *input_scale_used);
+
+/* Byte-image containers of a view directory (csrc/host/png_io.cc,
+ * scene_io.cc): load `path` (.png or .mvei, u8) -> width, height, channels and,
+ * if pixels != NULL with room for capacity bytes, the interleaved data;
+ * save a u8 image as PNG; mve::image::rescale_half_size_gaussian<uint8_t>
+ * (out sized ((w + 1) / 2) * ((h + 1) / 2) * c). */
+int smvs_host_load_byte_image(const char *path, int *whc, uint8_t *pixels,
+    size_t capacity);
+int smvs_host_save_png(const char *path, const uint8_t *pixels, int width, int height,
+    int channels);
+int smvs_host_rescale_half_size_gaussian(const uint8_t *pixels, int width, int height,
+    int channels, uint8_t *out);
 
 /* MVE scene I/O without a device: parses the scene (views/<x>.mve/meta.ini,
  * synth_0.out) -> number of list entries, and per entry (caller-sized arrays of

@@ -14,6 +14,7 @@
 #include <stdexcept>
 
 #include "depth_optimizer.h"
+#include "png_io.h"
 #include "sgm_stereo.h"
 #include "stereo_view.h"
 #include "view_queue.h"
@@ -181,13 +182,94 @@ mvei_header(std::string const& path, int* whct)
 bool
 SceneView::has_image(std::string const& embedding) const
 {
-    return present && file_exists(image_path(embedding));
+    return present && (file_exists(directory + "/" + embedding + ".mvei")
+        || file_exists(directory + "/" + embedding + ".png"));
 }
 
 std::string
 SceneView::image_path(std::string const& embedding) const
 {
-    return directory + "/" + embedding + ".mvei";
+    std::string const base = directory + "/" + embedding;
+    if (!file_exists(base + ".mvei") && file_exists(base + ".png"))
+        return base + ".png";
+    return base + ".mvei";
+}
+
+ByteImage::Ptr
+SceneView::load_byte_image(std::string const& embedding) const
+{
+    std::string const path = image_path(embedding);
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".png")
+        return load_png_u8(path);
+    if (!file_exists(path) && file_exists(directory + "/" + embedding + ".jpg"))
+        throw std::runtime_error("embedding " + embedding + " of " + directory
+            + " exists only as JPEG, which is not decoded here: convert it to PNG "
+            "or .mvei");
+    return load_mvei_u8(path);
+}
+
+bool
+SceneView::image_size(std::string const& embedding, int* whc) const
+{
+    std::string const path = image_path(embedding);
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".png")
+        return png_header(path, whc);
+    int whct[4] = { 0, 0, 0, 0 };
+    if (!mvei_header(path, whct))
+        return false;
+    whc[0] = whct[0];
+    whc[1] = whct[1];
+    whc[2] = whct[2];
+    return true;
+}
+
+ByteImage::Ptr
+rescale_half_size_gaussian(ByteImage::ConstPtr img)
+{
+    // mve::image::rescale_half_size_gaussian<uint8_t>(img, sigma2 = 0.75f)
+    // [MVE-unverified M29]: output ((w + 1) / 2, (h + 1) / 2); every output
+    // pixel accumulates the 4 x 4 input window around (2x, 2y) .. (2x+1, 2y+1)
+    // (indices clamped to the image) with the weights exp(-d^2 / (2 sigma^2))
+    // of the three distances of a 4 x 4 window's cells from its centre, in a
+    // float accumulator (math::Accum<unsigned char>), normalised by the sum of
+    // the weights and rounded half away from zero.
+    int const iw = img->width(), ih = img->height(), ic = img->channels();
+    if (iw < 2 || ih < 2)
+        throw std::invalid_argument("rescale_half_size_gaussian: image too small");
+    int const ow = (iw + 1) >> 1, oh = (ih + 1) >> 1;
+    ByteImage::Ptr out = ByteImage::create_for_overwrite(ow, oh, ic);
+    float const sigma2 = 0.75f;
+    float const w1 = std::exp(-0.5f / (2.0f * sigma2));
+    float const w2 = std::exp(-2.5f / (2.0f * sigma2));
+    float const w3 = std::exp(-4.5f / (2.0f * sigma2));
+    float const wrow[4][4] = { { w3, w2, w2, w3 }, { w2, w1, w1, w2 },
+        { w2, w1, w1, w2 }, { w3, w2, w2, w3 } };
+    uint8_t const* src = img->begin();
+    uint8_t* dst = out->begin();
+    std::size_t const rowstride = (std::size_t)iw * ic;
+    for (int y = 0; y < oh; ++y) {
+        int const y2 = y << 1;
+        uint8_t const* row[4] = { src + (std::size_t)std::max(0, y2 - 1) * rowstride,
+            src + (std::size_t)y2 * rowstride,
+            src + (std::size_t)std::min(ih - 1, y2 + 1) * rowstride,
+            src + (std::size_t)std::min(ih - 1, y2 + 2) * rowstride };
+        for (int x = 0; x < ow; ++x) {
+            int const x2 = x << 1;
+            int const xi[4] = { std::max(0, x2 - 1) * ic, x2 * ic,
+                std::min(iw - 1, x2 + 1) * ic, std::min(iw - 1, x2 + 2) * ic };
+            for (int c = 0; c < ic; ++c) {
+                float v = 0.0f, w = 0.0f;
+                for (int r = 0; r < 4; ++r)
+                    for (int k = 0; k < 4; ++k) {
+                        v += (float)row[r][xi[k] + c] * wrow[r][k];
+                        w += wrow[r][k];
+                    }
+                float const q = v / w;
+                *dst++ = (uint8_t)(q > 0.0f ? std::floor(q + 0.5f) : std::ceil(q - 0.5f));
+            }
+        }
+    }
+    return out;
 }
 
 Scene::Ptr
@@ -277,10 +359,6 @@ reconstruct_scene(std::string const& scene_path, ReconSettings const& conf_in)
 {
     typedef std::chrono::steady_clock Clock;
     ReconSettings conf = conf_in;
-    if (conf.input_scale != 0)
-        throw std::invalid_argument("reconstruct_scene: input_scale > 0 needs "
-            "mve::image::rescale_half_size_gaussian (not built): pre-scale the "
-            "embedding and pass input_scale 0");
     Scene::Ptr scene = Scene::create(scene_path);
     std::vector<SceneView>& views = scene->get_views();
 
@@ -301,8 +379,32 @@ reconstruct_scene(std::string const& scene_path, ReconSettings const& conf_in)
             if (v.present && v.is_camera_valid())
                 conf.view_ids.push_back(v.id);
 
-    std::string const input_name = conf.image_embedding;              // :503-508
+    // automatic input scale, :477-500: the average pixel count of the views
+    // that hold the embedding against --max-pixels
+    if (conf.input_scale < 0) {
+        double avg_image_size = 0.0;
+        int view_counter = 0;
+        for (auto const& v : views) {
+            int whc[3] = { 0, 0, 0 };
+            if (!v.present || !v.has_image(conf.image_embedding)
+                || !v.image_size(conf.image_embedding, whc))
+                continue;
+            avg_image_size += (double)((uint32_t)whc[0] * (uint32_t)whc[1]);
+            view_counter += 1;
+        }
+        conf.input_scale = 0;
+        if (view_counter > 0) {
+            avg_image_size /= (double)view_counter;
+            if (avg_image_size > (double)conf.max_pixels)
+                conf.input_scale = (int)std::ceil(std::log2(
+                    avg_image_size / (double)conf.max_pixels) / 2);
+        }
+    }
+    std::string const input_name = conf.input_scale > 0                // :502-508
+        ? "undist-L" + std::to_string(conf.input_scale) : conf.image_embedding;
     ReconReport report;
+    report.input_name = input_name;
+    report.input_scale = conf.input_scale;
     report.output_name = std::string(conf.use_shading ? "smvs-S" : "smvs-B")
         + std::to_string(conf.input_scale);                           // :510-515
 
@@ -326,10 +428,11 @@ reconstruct_scene(std::string const& scene_path, ReconSettings const& conf_in)
         info.present = v.present;
         info.id = v.id;
         info.cam = v.camera;
-        int whct[4] = { 0, 0, 0, 0 };
-        info.has_image = v.present && mvei_header(v.image_path(conf.image_embedding), whct);
-        info.width = whct[0];
-        info.height = whct[1];
+        int whc[3] = { 0, 0, 0 };
+        info.has_image = v.present && v.has_image(conf.image_embedding)
+            && v.image_size(conf.image_embedding, whc);
+        info.width = whc[0];
+        info.height = whc[1];
     }
     ViewSelection::Options select_opts;
     select_opts.num_neighbors = conf.num_neighbors;
@@ -347,6 +450,33 @@ reconstruct_scene(std::string const& scene_path, ReconSettings const& conf_in)
         neighbors.push_back(nb);
     }
 
+    // the input embedding at the input scale, :621-650: created once for every
+    // view a task will read and saved into the view directory (as the PNG
+    // mve::View::save_view writes for a byte image)
+    if (conf.input_scale > 0) {
+        std::vector<char> needed(views.size(), 0);
+        for (std::size_t v = 0; v < final_list.size(); ++v) {
+            needed[(std::size_t)final_list[v]] = 1;
+            for (std::size_t n : neighbors[v])
+                needed[n] = 1;
+        }
+        std::vector<std::future<void>> resize_tasks;
+        for (std::size_t i = 0; i < views.size(); ++i) {
+            SceneView const& view = views[i];
+            if (!needed[i] || !view.present || !view.has_image(conf.image_embedding)
+                || view.has_image(input_name))
+                continue;
+            resize_tasks.push_back(std::async(std::launch::async, [&view, &conf, &input_name] {
+                ByteImage::Ptr scaled = view.load_byte_image(conf.image_embedding);
+                for (int s = 0; s < conf.input_scale; ++s)
+                    scaled = rescale_half_size_gaussian(scaled);
+                save_png_u8(view.directory + "/" + input_name + ".png", scaled);
+            }));
+        }
+        for (auto& t : resize_tasks)
+            t.get();
+    }
+
     // one task per reference view, :658-733
     Clock::time_point const t0 = Clock::now();
     std::vector<std::future<void>> results;
@@ -357,14 +487,14 @@ reconstruct_scene(std::string const& scene_path, ReconSettings const& conf_in)
             results.push_back(queue.add_task([&, v, id](ViewQueue::Slot const& slot) {
                 SceneView const& view = views[(std::size_t)id];
                 StereoView::Ptr main_view = StereoView::create(view.id,
-                    load_mvei_u8(view.image_path(input_name)), view.camera,
+                    view.load_byte_image(input_name), view.camera,
                     conf.use_shading, conf.gamma_correction);
                 std::vector<StereoView::Ptr> stereo_views;
                 for (std::size_t n = 0; n < conf.num_neighbors && n < neighbors[v].size();
                      ++n) {
                     SceneView const& nv = views[neighbors[v][n]];
                     stereo_views.push_back(StereoView::create(nv.id,
-                        load_mvei_u8(nv.image_path(input_name)), nv.camera));
+                        nv.load_byte_image(input_name), nv.camera));
                 }
                 int const device = conf.first_device + slot.device;
                 if (conf.use_sgm) {

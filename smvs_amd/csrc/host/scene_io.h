@@ -5,10 +5,11 @@
 //
 // What is read: views/view_XXXX.mve/meta.ini ([camera] focal_length,
 // pixel_aspect, principal_point, rotation, translation; [view] id, name), the
-// bundle synth_0.out ("drews 1.0"), and raw .mvei images (u8 / float).  PNG /
-// JPEG embeddings are NOT decoded (no codec in this tree): the input embedding
-// has to exist as <name>.mvei, e.g. written by MVE's own tools or by
-// smvs_amd/mve_scene.py.  Results are written like StereoView::
+// bundle synth_0.out ("drews 1.0"), raw .mvei images (u8 / float) and PNG
+// byte images (csrc/host/png_io.cc, on zlib) -- what makescene leaves in a
+// view directory ("undistorted.png").  JPEG embeddings are not decoded (no
+// codec in this tree; a view whose only copy of the embedding is a .jpg is
+// reported with that reason).  Results are written like StereoView::
 // write_depth_to_view / write_image_to_view do (lib/stereo_view.h:100-130):
 // <output>.mvei (depth, MVE ray-length convention), <output>N.mvei (normals),
 // smvs-sgm.mvei.
@@ -37,9 +38,22 @@ struct SceneView
     std::string name, directory;
     CameraInfo camera;
     bool is_camera_valid(void) const { return camera.flen > 0.0f; }
+    // mve::View::has_image: <embedding>.mvei or <embedding>.png (a .jpg alone
+    // does not count: it cannot be decoded here)
     bool has_image(std::string const& embedding) const;
+    // the file of an embedding: the existing .mvei, else the existing .png,
+    // else where a NEW embedding of that name is written (.mvei)
     std::string image_path(std::string const& embedding) const;
+    // byte image of an embedding (mve::View::get_byte_image), any container
+    ByteImage::Ptr load_byte_image(std::string const& embedding) const;
+    // width, height, channels without decoding (mve::View::get_image_proxy)
+    bool image_size(std::string const& embedding, int* whc) const;
 };
+
+// mve::image::rescale_half_size_gaussian<uint8_t> (sigma^2 = 0.75), the filter
+// smvsrecon pre-scales its input embedding with (app/smvsrecon.cc:634-647)
+// [MVE-unverified, tests/golden/README.md M29]
+ByteImage::Ptr rescale_half_size_gaussian(ByteImage::ConstPtr image);
 
 class Scene
 {
@@ -65,7 +79,8 @@ struct ReconSettings
     std::string image_embedding = "undistorted";
     float regularization = 1.0f;            // alpha
     int output_scale = 2;                   // -o
-    int input_scale = 0;                    // -s (only 0: no rescaling here)
+    int input_scale = -1;                   // -s; < 0: automatic (:477-500)
+    std::size_t max_pixels = 1700000;       // --max-pixels (:48)
     bool use_shading = false;               // -S
     float light_surf_regularization = 0.0f;
     bool gamma_correction = false;
@@ -82,6 +97,8 @@ struct ReconReport
     std::vector<int> reconstructed, skipped_few_neighbors, already_done;
     double seconds = 0.0;
     std::string output_name;
+    std::string input_name;      // the embedding the views were read from
+    int input_scale = 0;         // as used (the automatic choice resolved)
 };
 
 // The body of smvsrecon's main between scene loading and mesh generation

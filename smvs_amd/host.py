@@ -212,36 +212,86 @@ class ReconSettings(C.Structure):
                 ("full_optimization", C.c_int), ("sgm_min", C.c_float),
                 ("sgm_max", C.c_float), ("sgm_scale", C.c_int), ("num_neighbors", C.c_int),
                 ("min_neighbors", C.c_int), ("first_device", C.c_int),
-                ("num_devices", C.c_int), ("views_in_flight", C.c_int)]
+                ("num_devices", C.c_int), ("views_in_flight", C.c_int),
+                ("input_scale", C.c_int), ("max_pixels", C.c_int)]
 
 
 def reconstruct_scene(scene_dir, view_ids=None, image_embedding="undistorted",
                       regularization=1.0, output_scale=2, use_shading=False, use_sgm=True,
                       force_recon=False, force_sgm=False, sgm_range=(0.0, 0.0), sgm_scale=1,
                       num_neighbors=6, min_neighbors=3, first_device=0, num_devices=1,
-                      views_in_flight=2):
+                      views_in_flight=2, input_scale=0, max_pixels=1700000, details=False):
     """smvsrecon's scene-level run (app/smvsrecon.cc:400-745) through
-    smvs_amd::reconstruct_scene: returns (reconstructed ids, skipped, seconds)."""
+    smvs_amd::reconstruct_scene: returns (reconstructed ids, skipped, seconds)
+    [, input scale used if `details`].  input_scale < 0: smvsrecon's automatic
+    choice from max_pixels (:477-500); > 0: the views are read from the
+    embedding undist-L<input_scale>, created with rescale_half_size_gaussian
+    where missing (:621-650), and the outputs are named smvs-B<input_scale>."""
     lib = load()
     st = ReconSettings(image_embedding.encode(), regularization, output_scale,
                        1 if use_shading else 0, 1 if use_sgm else 0,
                        1 if force_recon else 0, 1 if force_sgm else 0, 0,
                        sgm_range[0], sgm_range[1], sgm_scale, num_neighbors, min_neighbors,
-                       first_device, num_devices, views_in_flight)
+                       first_device, num_devices, views_in_flight, input_scale, max_pixels)
     ids = None if view_ids is None else np.asarray(view_ids, dtype=np.int32)
     # (room for every view of the scene: smvs_host_scene_info)
     cap = C.c_int(0)
     lib.smvs_host_scene_info(scene_dir.encode(), image_embedding.encode(), C.c_int(0),
                              C.byref(cap), None, None, None, None, None, None, None)
     out = np.zeros(max(cap.value, 1), np.int32)
-    n = C.c_int(0); sk = C.c_int(0); secs = C.c_double(0.0)
+    n = C.c_int(0); sk = C.c_int(0); secs = C.c_double(0.0); used = C.c_int(0)
     rc = lib.smvs_host_reconstruct_scene(scene_dir.encode(), C.byref(st),
         ids.ctypes.data_as(_i32p) if ids is not None else None,
         C.c_int(0 if ids is None else ids.size), out.ctypes.data_as(_i32p),
-        C.c_int(out.size), C.byref(n), C.byref(sk), C.byref(secs))
+        C.c_int(out.size), C.byref(n), C.byref(sk), C.byref(secs), C.byref(used))
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
-    return [int(x) for x in out[:min(n.value, out.size)]], sk.value, secs.value
+    res = ([int(x) for x in out[:min(n.value, out.size)]], sk.value, secs.value)
+    return res + (used.value,) if details else res
+
+
+def load_byte_image(path):
+    """A u8 image embedding (.png via csrc/host/png_io.cc, or .mvei)."""
+    lib = load()
+    whc = (C.c_int * 3)()
+    rc = lib.smvs_host_load_byte_image(path.encode(), whc, None, C.c_size_t(0))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    w, h, c = whc[0], whc[1], whc[2]
+    out = np.zeros((h, w, c), np.uint8)
+    rc = lib.smvs_host_load_byte_image(path.encode(), whc, out.ctypes.data_as(_u8p),
+                                       C.c_size_t(out.size))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return out if c > 1 else out.reshape(h, w)
+
+
+def save_png(path, array):
+    lib = load()
+    a = np.ascontiguousarray(array, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    rc = lib.smvs_host_save_png(path.encode(), a.ctypes.data_as(_u8p), C.c_int(a.shape[1]),
+                                C.c_int(a.shape[0]), C.c_int(a.shape[2]))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+
+
+def rescale_half_size_gaussian(array):
+    """mve::image::rescale_half_size_gaussian<uint8_t> of the host mirror."""
+    lib = load()
+    a = np.ascontiguousarray(array, dtype=np.uint8)
+    squeeze = a.ndim == 2
+    if squeeze:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2, c), np.uint8)
+    rc = lib.smvs_host_rescale_half_size_gaussian(a.ctypes.data_as(_u8p), C.c_int(w),
+                                                  C.c_int(h), C.c_int(c),
+                                                  out.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return out[:, :, 0] if squeeze else out
 
 
 def scene_info(scene_dir, image_embedding="undistorted", max_views=4096):

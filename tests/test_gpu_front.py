@@ -477,6 +477,59 @@ def test_reconstruct_scene_end_to_end(hip, oracle, oracle_threads, tmp_path):
     assert done2 == [] and skipped2 == 1
 
 
+def test_reconstruct_scene_makescene_directory_with_automatic_input_scale(
+        hip, oracle, oracle_threads, tmp_path):
+    """SURVEY 8(f)-4, what round 3 refused: a view directory as makescene
+    leaves it (undistorted.png) and smvsrecon's default automatic input scale
+    (app/smvsrecon.cc:477-505): with --max-pixels below the images' size the
+    run halves the inputs once with rescale_half_size_gaussian (:634-647),
+    saves them as undist-L1.png, reads the views from that embedding and names
+    its outputs smvs-B1.  Against the oracle's pipeline on the oracle's own
+    half-size images ([MVE-unverified] M29)."""
+    from smvs_amd import synth, host, mve_scene
+    inputs = synth.pipeline_inputs("sphere", 768, 512, 3, flen=1.2)
+    d = str(tmp_path)
+    mve_scene.write_scene(d, inputs, container="png")
+    done, skipped, secs, scale = host.reconstruct_scene(
+        d, view_ids=[0], num_neighbors=3, min_neighbors=2, output_scale=2, input_scale=-1,
+        max_pixels=150000, details=True)
+    # 768 x 512 = 393,216 pixels: ceil(log2(393216 / 150000) / 2) = 1
+    assert scale == 1 and done == [0] and skipped == 0
+    vdir = os.path.join(d, "views", "view_0000.mve")
+    half = host.load_byte_image(os.path.join(vdir, "undist-L1.png"))
+    want_half = oracle.rescale_half_size_gaussian(np.asarray(inputs["images"][0], np.uint8))
+    assert half.shape == (256, 384, 3) and np.array_equal(half, want_half)
+    depth_mve = mve_scene.load_mvei(os.path.join(vdir, "smvs-B1.mvei"))
+    assert depth_mve.shape == (256, 384)
+    assert not os.path.exists(os.path.join(vdir, "smvs-B0.mvei"))
+    # the oracle on the same half-size views (cameras are resolution independent)
+    scene = dict(views=[dict(id=i, flen=c.flen, rot=c.R, trans=c.t, width=768, height=512)
+                        for i, c in enumerate(inputs["cams"])],
+                 features=inputs["features"],
+                 refs=[list(range(4))] * len(inputs["features"]))
+    nb = host.select_neighbors(scene, 0, num_neighbors=3)
+    order = [0] + nb
+    sel = dict(inputs, cams=[inputs["cams"][i] for i in order],
+               images=[oracle.rescale_half_size_gaussian(np.asarray(inputs["images"][i], np.uint8))
+                       for i in order], view_ids=order)
+    sgm_o = oracle.sgm_depth_for_view(sel, sgm_scale=1, roundtrip=True)
+    want = oracle.optimize(sel, regularization=0.01, num_iterations=5, min_scale=2,
+                           sgm_depth=sgm_o)
+    xs, ys = np.meshgrid(np.arange(384, dtype=np.float32) + np.float32(0.5),
+                         np.arange(256, dtype=np.float32) + np.float32(0.5))
+    f = np.float32(inputs["cams"][0].flen) * np.float32(384)
+    vx = (xs - np.float32(192)) / f; vy = (ys - np.float32(128)) / f
+    ray = np.sqrt(vx * vx + vy * vy + np.float32(1)).astype(np.float64)
+    z = depth_mve.astype(np.float64) / ray
+    assert np.array_equal(z > 0, want["depth"] > 0)
+    assert _rel(z, want["depth"]) <= 1e-4
+    # a second run reuses undist-L1 and finds the view reconstructed
+    done2, skipped2, _, scale2 = host.reconstruct_scene(
+        d, view_ids=[0], num_neighbors=3, min_neighbors=2, output_scale=2, input_scale=-1,
+        max_pixels=150000, details=True)
+    assert done2 == [] and skipped2 == 1 and scale2 == 1
+
+
 def test_bench_contract_small(hip):
     """bench.py prints ONE JSON line with the fields the driver reads; run at
     the 480x270 debug size (the numbers mean nothing, the structure does)."""

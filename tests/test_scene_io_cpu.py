@@ -69,3 +69,108 @@ def test_mvei_round_trip(tmp_path, dtype, channels):
         f.write(b"not an image")
     with pytest.raises(Exception):
         host.mvei_roundtrip(str(tmp_path / "bad.mvei"), dst)
+
+
+# ------------------------------------------------------------------ PNG
+# csrc/host/png_io.cc (reader / writer on zlib) against the independent
+# pure-Python codec of smvs_amd/mve_scene.py.
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_reader_decodes_every_filter_and_layout(tmp_path, channels, interlace):
+    """Scanline filters None / Sub / Up / Average / Paeth cycling over the rows,
+    grey, grey + alpha, RGB, RGBA, plain and Adam7, IDAT split into many
+    chunks, odd sizes (Adam7 passes that are empty)."""
+    from smvs_amd import host
+    rng = np.random.default_rng(10 * channels + interlace)
+    for h, w in ((37, 53), (1, 1), (3, 2), (8, 9), (64, 5)):
+        a = rng.integers(0, 256, size=(h, w, channels), dtype=np.uint8)
+        if h > 8:
+            a[: h // 3] = a[0:1]                      # long runs for the inflater
+        p = str(tmp_path / ("f_%d_%d.png" % (h, w)))
+        mve_scene.save_png(p, a, filters=(0, 1, 2, 3, 4), interlace=interlace, idat_chunk=300)
+        got = host.load_byte_image(p)
+        assert np.array_equal(got.reshape(a.shape), a), (h, w)
+    for ft in range(5):                               # one filter type for all rows
+        a = rng.integers(0, 256, size=(19, 23, channels), dtype=np.uint8)
+        p = str(tmp_path / ("one_%d.png" % ft))
+        mve_scene.save_png(p, a, filters=(ft,), interlace=interlace)
+        assert np.array_equal(host.load_byte_image(p).reshape(a.shape), a), ft
+
+
+def test_png_palette_and_writer_and_errors(tmp_path):
+    from smvs_amd import host
+    rng = np.random.default_rng(77)
+    pal = (rng.integers(0, 5, size=(20, 31, 3)) * 50).astype(np.uint8)
+    p = str(tmp_path / "pal.png")
+    mve_scene.save_png(p, pal, palette=True)
+    assert np.array_equal(host.load_byte_image(p), pal)
+    # the C++ writer, read back by the Python reader
+    for c in (1, 2, 3, 4):
+        a = rng.integers(0, 256, size=(33, 17, c), dtype=np.uint8)
+        q = str(tmp_path / ("w%d.png" % c))
+        host.save_png(q, a)
+        assert np.array_equal(mve_scene.load_png(q).reshape(a.shape), a)
+        assert np.array_equal(host.load_byte_image(q).reshape(a.shape), a)
+    # corrupt files are errors, not garbage
+    data = bytearray(open(p, "rb").read())
+    data[40] ^= 0xFF                                     # breaks a chunk checksum
+    bad = str(tmp_path / "bad.png")
+    open(bad, "wb").write(bytes(data))
+    with pytest.raises(Exception):
+        host.load_byte_image(bad)
+    open(bad, "wb").write(bytes(open(p, "rb").read()[:60]))   # truncated
+    with pytest.raises(Exception):
+        host.load_byte_image(bad)
+    # 16-bit samples are refused (mve::ByteImage has none)
+    import struct, zlib
+    raw = b"".join(b"\x00" + bytes(2 * 4) for _ in range(3))
+    sixteen = (b"\x89PNG\r\n\x1a\n" + mve_scene._png_chunk(b"IHDR", struct.pack(
+        ">IIBBBBB", 4, 3, 16, 0, 0, 0, 0)) + mve_scene._png_chunk(b"IDAT", zlib.compress(raw))
+        + mve_scene._png_chunk(b"IEND", b""))
+    open(bad, "wb").write(sixteen)
+    with pytest.raises(Exception):
+        host.load_byte_image(bad)
+
+
+@pytest.mark.parametrize("shape", [(37, 53, 3), (64, 64, 1), (5, 2, 3), (101, 7, 1), (2, 2, 1)])
+def test_rescale_half_size_gaussian_matches_oracle(oracle, shape):
+    """mve::image::rescale_half_size_gaussian<uint8_t> [MVE-unverified M29]:
+    the host mirror (4 x 4 weight table) against the oracle's restatement (the
+    sixteen Accum::add calls written out), bit for bit, and both against the
+    definition in float64 (a Gaussian-weighted mean of the clamped 4 x 4 window,
+    sigma^2 = 0.75) to within the final rounding."""
+    from smvs_amd import host
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    got = host.rescale_half_size_gaussian(a)
+    want = oracle.rescale_half_size_gaussian(a)
+    assert got.shape == ((shape[0] + 1) // 2, (shape[1] + 1) // 2, shape[2])
+    assert np.array_equal(got, want)
+    w = np.array([np.exp(-4.5 / 1.5), np.exp(-2.5 / 1.5), np.exp(-0.5 / 1.5)])
+    k = np.array([[w[0], w[1], w[1], w[0]], [w[1], w[2], w[2], w[1]],
+                  [w[1], w[2], w[2], w[1]], [w[0], w[1], w[1], w[0]]])
+    pad = np.pad(a.astype(np.float64), ((1, 2), (1, 2), (0, 0)), mode="edge")
+    for y in range(got.shape[0]):
+        for x in range(got.shape[1]):
+            ref = (pad[2 * y:2 * y + 4, 2 * x:2 * x + 4] * k[:, :, None]).sum((0, 1)) / k.sum()
+            assert np.all(np.abs(got[y, x] - ref) <= 0.5 + 1e-4)
+
+
+def test_scene_with_png_embeddings_is_read(tmp_path):
+    """What makescene leaves in a view directory: undistorted.png.  The scene
+    reader reports its size from the IHDR chunk; a view that holds both
+    containers prefers the .mvei; a .jpg alone does not count as an image."""
+    from smvs_amd import host
+    inputs = synth.pipeline_inputs("plane", 96, 64, 2, n_features=20)
+    d = str(tmp_path)
+    mve_scene.write_scene(d, inputs, container="png")
+    info = host.scene_info(d)
+    assert info["present"].tolist() == [1, 1, 1]
+    assert info["width"].tolist() == [96, 96, 96] and info["height"].tolist() == [64, 64, 64]
+    v0 = os.path.join(d, "views", "view_0000.mve")
+    got = host.load_byte_image(os.path.join(v0, "undistorted.png"))
+    assert np.array_equal(got, np.asarray(inputs["images"][0], np.uint8))
+    os.rename(os.path.join(d, "views", "view_0001.mve", "undistorted.png"),
+              os.path.join(d, "views", "view_0001.mve", "undistorted.jpg"))
+    info = host.scene_info(d)
+    assert info["width"].tolist() == [96, 0, 96]
