@@ -237,6 +237,21 @@ int smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *params,
 int smvs_get_depth_map(smvs_ctx *ctx, float *depth);
 int smvs_get_normal_map(smvs_ctx *ctx, float *normals);
 
+/* Both maps in one pass over the surface (one kernel, two transfers, one
+ * synchronisation); either pointer may be NULL. */
+int smvs_get_maps(smvs_ctx *ctx, float *depth, float *normals);
+
+/* Page-locked host memory for the large buffers that cross the boundary (the
+ * views' u8 images, the 33 MB of depth + normal maps per 1920x1080 view): a
+ * transfer from / to such a buffer is one DMA at link rate, a pageable buffer
+ * goes through a staging copy on the host (3-4 ms per view at 1920x1080 x 9).
+ * Not in the reference, whose images live in pageable mve::Image storage; any
+ * pointer works everywhere, pinned ones are just faster.  Buffers are pooled
+ * by size (page-locking costs more than the copy it saves) and go back to the
+ * driver with smvs_release_workspaces(). */
+int smvs_host_alloc(size_t bytes, void **out);
+int smvs_host_free(void *ptr);
+
 /* LightOptimizer::fit_lighting_to_image accumulation,
  * light_optimizer.cc:32-49, over the uploaded shading image: A[16][16],
  * b[16] (the 16x16 pseudo inverse stays on the host).  The _dev variant

@@ -177,7 +177,8 @@ struct smvs_ctx {
     int resident_cus = 0, resident_lds = 0;
     bool resident_disabled = false;
     int solver_mode = 0;            // smvs_solver_mode (smvs_ctx_set_solver)
-    float *map_scratch = nullptr;   // depth / normal map output, W*H*3 floats
+    float *map_scratch = nullptr;   // depth / normal map output, W*H*3 (or *4) floats
+    size_t map_scratch_floats = 0;
     double *light_partial = nullptr;  // per-block lighting sums (update.hip)
 
     // scale space on the device (scale.hip): float images of the views
@@ -233,6 +234,10 @@ int ctx_pool_release(void);   // frees the parked contexts (ctx.hip) -> how many
 // when the caller's buffer may be reused / is filled.
 int ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+// Is `p` page-locked host memory the device can DMA from / to directly
+// (smvs_host_alloc, hipHostMalloc, hipHostRegister)?
+bool host_pointer_is_pinned(const void *p);
+int pinned_pool_release(void);   // pool.hip -> buffers returned to the driver
 // Geometry of the surface the context holds (Surface::create, surface.cc:28-37)
 // and room for it in every per-node / per-patch buffer; the buffers only grow.
 // Contents of the node / patch arrays are unspecified afterwards when the grid

@@ -95,11 +95,31 @@ ensure_pinned(smvs_ctx *ctx, size_t bytes)
     return SMVS_OK;
 }
 
+bool
+host_pointer_is_pinned(const void *p)
+{
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    hipError_t const e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // (a pageable pointer is not an error here)
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 int
 ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0)
         return SMVS_OK;
+    if (bytes >= ((size_t)1 << 20) && host_pointer_is_pinned(src_host)) {
+        // page-locked source (smvs_host_alloc): one DMA, no staging copy
+        SMVS_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice,
+            ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return SMVS_OK;
+    }
     int const rc = ensure_pinned(ctx, bytes);
     if (rc != SMVS_OK)
         return rc;
@@ -116,6 +136,12 @@ ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
 {
     if (bytes == 0)
         return SMVS_OK;
+    if (bytes >= ((size_t)1 << 20) && host_pointer_is_pinned(dst_host)) {
+        SMVS_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost,
+            ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return SMVS_OK;
+    }
     int const rc = ensure_pinned(ctx, bytes);
     if (rc != SMVS_OK)
         return rc;

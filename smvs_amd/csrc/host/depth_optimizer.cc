@@ -447,10 +447,16 @@ DepthOptimizer::optimize(void)
         this->run_newton_iterations(opts.num_iterations);
     }
     {
+        // get_depth() + get_normals() (:150-160) in one pass over the surface
         ScopedHostTimer timer("depth + normal maps");
-        main_view->write_depth_to_view(this->get_depth(), opts.output_name);
-        main_view->write_image_to_view(this->get_normals(),
-            opts.output_name + "N");
+        this->upload_surface();
+        FloatImage::Ptr dm = FloatImage::create_for_overwrite(main_view->get_width(),
+            main_view->get_height(), 1);
+        FloatImage::Ptr nm = FloatImage::create_for_overwrite(main_view->get_width(),
+            main_view->get_height(), 3);
+        check(smvs_get_maps(ctx, dm->begin(), nm->begin()), "smvs_get_maps");
+        main_view->write_depth_to_view(dm, opts.output_name);
+        main_view->write_image_to_view(nm, opts.output_name + "N");
     }
     g_timers.report();
 }

@@ -4,6 +4,8 @@
 // channels, row-major, index (y*w + x)*c + ch.
 #pragma once
 
+#include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <memory>
 #include <utility>
@@ -30,6 +32,21 @@ struct DefaultInitAllocator : std::allocator<T>
     }
 };
 
+// Where large images live.  By default in a std::vector; the host library
+// installs a hook (host/pinned_images.cc) that serves images of a megabyte and
+// more from page-locked memory (smvs_host_alloc, include/smvs_hip.h): the
+// views' u8 images and the depth / normal maps then cross PCIe as one DMA each
+// instead of through a staging copy.  The hook may decline (returns null: no
+// device, out of pinned memory); the vector is the fallback.
+struct ImageMemory
+{
+    typedef void* (*AllocFn)(std::size_t bytes);
+    typedef void (*FreeFn)(void* ptr);
+    static AllocFn& alloc_hook(void) { static AllocFn f = nullptr; return f; }
+    static FreeFn& free_hook(void) { static FreeFn f = nullptr; return f; }
+    static constexpr std::size_t MIN_BYTES = (std::size_t)1 << 20;
+};
+
 template <typename T>
 class Image
 {
@@ -40,10 +57,8 @@ public:
     static Ptr create(int width, int height, int channels)
     {
         Ptr img(new Image<T>());
-        img->w = width;
-        img->h = height;
-        img->c = channels;
-        img->data.assign((size_t)width * height * channels, T(0));
+        img->allocate(width, height, channels);
+        std::fill(img->ptr, img->ptr + img->count(), T(0));
         return img;
     }
     // For images whose every value is written right away (a download from the
@@ -52,37 +67,68 @@ public:
     static Ptr create_for_overwrite(int width, int height, int channels)
     {
         Ptr img(new Image<T>());
-        img->w = width;
-        img->h = height;
-        img->c = channels;
-        img->data.resize((size_t)width * height * channels);
+        img->allocate(width, height, channels);
         return img;
     }
-    Ptr duplicate(void) const { return Ptr(new Image<T>(*this)); }
+    Ptr duplicate(void) const
+    {
+        Ptr img(new Image<T>());
+        img->allocate(w, h, c);
+        std::copy(ptr, ptr + count(), img->ptr);
+        return img;
+    }
+    Image(void) = default;
+    Image(Image const&) = delete;
+    Image& operator=(Image const&) = delete;
+    ~Image(void)
+    {
+        if (external != nullptr && ImageMemory::free_hook() != nullptr)
+            ImageMemory::free_hook()(external);
+    }
 
     int width(void) const { return w; }
     int height(void) const { return h; }
     int channels(void) const { return c; }
     int get_pixel_amount(void) const { return w * h; }
-    void fill(T const& v) { std::fill(data.begin(), data.end(), v); }
+    void fill(T const& v) { std::fill(ptr, ptr + count(), v); }
 
-    T& at(int64_t i) { return data[i]; }
-    T const& at(int64_t i) const { return data[i]; }
-    T& at(int64_t p, int64_t ch) { return data[p * c + ch]; }
-    T const& at(int64_t p, int64_t ch) const { return data[p * c + ch]; }
-    T& at(int64_t x, int64_t y, int64_t ch) { return data[(y * w + x) * c + ch]; }
+    T& at(int64_t i) { return ptr[i]; }
+    T const& at(int64_t i) const { return ptr[i]; }
+    T& at(int64_t p, int64_t ch) { return ptr[p * c + ch]; }
+    T const& at(int64_t p, int64_t ch) const { return ptr[p * c + ch]; }
+    T& at(int64_t x, int64_t y, int64_t ch) { return ptr[(y * w + x) * c + ch]; }
     T const& at(int64_t x, int64_t y, int64_t ch) const
     {
-        return data[(y * w + x) * c + ch];
+        return ptr[(y * w + x) * c + ch];
     }
-    T* begin(void) { return data.data(); }
-    T const* begin(void) const { return data.data(); }
+    T* begin(void) { return ptr; }
+    T const* begin(void) const { return ptr; }
 
     // bilinear sample with clamping; float weights [MVE-unverified]
     T linear_at(float x, float y, int64_t ch) const;
 
 private:
+    std::size_t count(void) const { return (std::size_t)w * h * c; }
+    void allocate(int width, int height, int channels)
+    {
+        w = width;
+        h = height;
+        c = channels;
+        std::size_t const bytes = count() * sizeof(T);
+        if (bytes >= ImageMemory::MIN_BYTES && ImageMemory::alloc_hook() != nullptr)
+            external = ImageMemory::alloc_hook()(bytes);
+        if (external != nullptr) {
+            ptr = static_cast<T*>(external);
+        } else {
+            data.resize(count());
+            ptr = data.data();
+        }
+    }
+
+private:
     int w = 0, h = 0, c = 0;
+    T* ptr = nullptr;
+    void* external = nullptr;   // page-locked storage from the hook, or null
     std::vector<T, DefaultInitAllocator<T>> data;
 };
 

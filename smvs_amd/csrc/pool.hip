@@ -52,6 +52,33 @@ release_idle_device_memory(void)
     return release_idle_workspaces() + ctx_pool_release();
 }
 
+// ---- page-locked host buffers (smvs_host_alloc), pooled by exact size ----
+// hipHostMalloc of the 6 MB of a 1920x1080 RGB image costs more than the
+// staging copy it saves; a view's buffers come in a handful of sizes (its
+// images, its maps), so freed buffers wait in per-size free lists for the next
+// view.  The pool keeps at most PINNED_POOL_BYTES idle.
+namespace {
+std::mutex g_pinned_mutex;
+std::vector<std::pair<size_t, void *>> g_pinned_free;    // (bytes, ptr), idle
+std::vector<std::pair<void *, size_t>> g_pinned_live;    // handed out
+size_t g_pinned_idle_bytes = 0;
+constexpr size_t PINNED_POOL_BYTES = (size_t)4 << 30;
+}
+
+int
+pinned_pool_release(void)
+{
+    std::vector<std::pair<size_t, void *>> all;
+    {
+        std::lock_guard<std::mutex> guard(g_pinned_mutex);
+        all.swap(g_pinned_free);
+        g_pinned_idle_bytes = 0;
+    }
+    for (auto &e : all)
+        (void)hipHostFree(e.second);
+    return (int)all.size();
+}
+
 int
 Workspace::ensure(int slot, size_t bytes, void **out)
 {
@@ -238,5 +265,61 @@ using namespace smvs_hip;
 extern "C" int
 smvs_release_workspaces(void)
 {
-    return release_idle_device_memory();
+    return release_idle_device_memory() + pinned_pool_release();
+}
+
+extern "C" int
+smvs_host_alloc(size_t bytes, void **out)
+{
+    SMVS_REQUIRE(out != nullptr && bytes > 0, "bad argument");
+    {
+        std::lock_guard<std::mutex> guard(g_pinned_mutex);
+        for (size_t i = 0; i < g_pinned_free.size(); ++i)
+            if (g_pinned_free[i].first == bytes) {
+                *out = g_pinned_free[i].second;
+                g_pinned_free.erase(g_pinned_free.begin() + (long)i);
+                g_pinned_idle_bytes -= bytes;
+                g_pinned_live.push_back({ *out, bytes });
+                return SMVS_OK;
+            }
+    }
+    void *p = nullptr;
+    hipError_t const e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        *out = nullptr;
+        return e == hipErrorOutOfMemory ? SMVS_ERR_NOMEM : SMVS_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> guard(g_pinned_mutex);
+    g_pinned_live.push_back({ p, bytes });
+    *out = p;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_host_free(void *ptr)
+{
+    if (ptr == nullptr)
+        return SMVS_OK;
+    size_t bytes = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> guard(g_pinned_mutex);
+        for (size_t i = 0; i < g_pinned_live.size(); ++i)
+            if (g_pinned_live[i].first == ptr) {
+                bytes = g_pinned_live[i].second;
+                g_pinned_live.erase(g_pinned_live.begin() + (long)i);
+                break;
+            }
+        SMVS_REQUIRE(bytes != 0, "pointer was not handed out by smvs_host_alloc");
+        if (g_pinned_idle_bytes + bytes <= PINNED_POOL_BYTES) {
+            g_pinned_free.push_back({ bytes, ptr });
+            g_pinned_idle_bytes += bytes;
+            keep = true;
+        }
+    }
+    if (!keep)
+        (void)hipHostFree(ptr);
+    return SMVS_OK;
 }

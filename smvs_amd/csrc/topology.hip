@@ -177,36 +177,69 @@ topo_dilate_kernel(TopoArgs A)
 // quantity here is a conjunction, a maximum or a sum, so only the summation
 // order differs (by rounding, far below the 0.05 / 8.0 / 0.0 thresholds the
 // results are compared with).
-__device__ __forceinline__ int
-group_size(int ps)
+__device__ __host__ __forceinline__ int
+group_size(int ps, int whole_workgroup_from)
 {
+    // ps is a power of two: 1, 4, 16, 64 lanes for ps = 1, 2, 4, 8 and above.
+    // From ps = whole_workgroup_from on the whole 256-thread workgroup works
+    // on one item: at the coarse scales a few hundred patches of thousands of
+    // pixels each are a latency chain per lane, not a throughput problem
+    // (measured, 341 patches at scale 6: mse 554 -> 190 us, visibility
+    // 705 -> 585 us; at ps = 16 the barriers of the workgroup-wide reductions
+    // cost the visibility kernel more than the shorter chains save:
+    // 840 -> 1640 us, so it switches at 64, the mse kernel at 16).
     int const pp = ps * ps;
-    return pp >= 64 ? 64 : pp;   // ps is a power of two: 1, 4, 16, 64
+    if (ps >= whole_workgroup_from)
+        return 256;
+    return pp >= 64 ? 64 : pp;
 }
+constexpr int VIS_WORKGROUP_FROM = 64;   // topo_visibility_kernel
+constexpr int MSE_WORKGROUP_FROM = 16;   // topo_mse_kernel
 
+// Reductions over a lane group.  G <= 64: xor-shuffles inside the wave.
+// G == 256: the workgroup is the group -- per-wave results meet in LDS (every
+// thread of the workgroup must call; `red` holds 4 doubles).
 template <typename T>
 __device__ __forceinline__ T
-group_sum(T v, int G)
+group_sum(T v, int G, double *red)
 {
-    for (int off = G >> 1; off > 0; off >>= 1)
+    for (int off = (G < 64 ? G : 64) >> 1; off > 0; off >>= 1)
         v += __shfl_xor(v, off);
+    if (G > 64) {
+        __syncthreads();   // (the previous reduction's readers are done)
+        if ((threadIdx.x & 63) == 0)
+            red[threadIdx.x >> 6] = (double)v;
+        __syncthreads();
+        v = (T)(((red[0] + red[1]) + red[2]) + red[3]);
+    }
     return v;
 }
 
 __device__ __forceinline__ double
-group_max(double v, int G)
+group_max(double v, int G, double *red)
 {
-    for (int off = G >> 1; off > 0; off >>= 1) {
+    for (int off = (G < 64 ? G : 64) >> 1; off > 0; off >>= 1) {
         double const o = __shfl_xor(v, off);
         v = v < o ? o : v;
+    }
+    if (G > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+            red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w)
+            v = v < red[w] ? red[w] : v;
     }
     return v;
 }
 
 __device__ __forceinline__ bool
-group_all(bool ok, int G, int lane)
+group_all(bool ok, int G, int lane, double *red)
 {
     unsigned long long const b = __ballot(ok);
+    if (G > 64)
+        return __syncthreads_and(b == ~0ull) != 0;
+    (void)red;
     unsigned long long const gmask = G >= 64 ? ~0ull
         : (((1ull << G) - 1ull) << ((lane / G) * G));
     return (b & gmask) == gmask;
@@ -218,10 +251,11 @@ __global__ void __launch_bounds__(256)
 topo_visibility_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
+    __shared__ double red[4];
     int const ps = A.ps;
-    int const G = group_size(ps);
+    int const G = group_size(ps, VIS_WORKGROUP_FROM);
     int const lane = threadIdx.x & 63;
-    int const g_log2 = min(2 * A.ps_log2, 6);   // G = 1 << g_log2
+    int const g_log2 = 31 - __clz(G);           // G = 1 << g_log2
     int const gl = threadIdx.x & (G - 1);     // lane inside the group
     // (group index < num_patches * n_subs: 32 bits)
     unsigned const gid = (unsigned)(((unsigned long long)blockIdx.x * blockDim.x
@@ -246,12 +280,20 @@ topo_visibility_kernel(TopoArgs A)
     // patch's pixels
     bool visible = true;
     double worst = 0.0;
+    // the patch depth at this lane's pixel: with one pixel per lane
+    // (G == ps^2, i.e. ps <= 16) the NCC samples below take their depth from
+    // the lane that owns the source pixel, through LDS, instead of evaluating
+    // the patch again (the same expression: the same bits)
+    __shared__ double wpix[256];
+    double w_mine = 0.0;
     if (alive)
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
             // (x / ps == x * (1 / ps) exactly: ps is a power of two)
             double const u = (i + 0.5) * A.inv_ps, v = (j + 0.5) * A.inv_ps;
             double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
+            if (k == gl)
+                w_mine = w;
             Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
             double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
             if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
@@ -280,8 +322,13 @@ topo_visibility_kernel(TopoArgs A)
             // std::max(worst, ratio): a NaN ratio leaves worst unchanged
             worst = worst < ratio ? ratio : worst;
         }
-    visible = group_all(visible, G, lane);
-    worst = group_max(worst, G);
+    bool const depth_in_lds = A.use_ncc && G == ps * ps;
+    if (depth_in_lds) {
+        wpix[threadIdx.x] = w_mine;
+        __syncthreads();
+    }
+    visible = group_all(visible, G, lane, red);
+    worst = group_max(worst, G, red);
     alive = alive && visible && !(worst > 8.0);
 
     // ncc_for_patch
@@ -305,9 +352,10 @@ topo_visibility_kernel(TopoArgs A)
             NccSample const smp = tpl[i];
             double depth;
             if (smp.src >= 0)
-                depth = smvs_topo::patch_eval(n16,
-                    ((smp.src & (ps - 1)) + 0.5) * A.inv_ps,
-                    ((smp.src >> A.ps_log2) + 0.5) * A.inv_ps, 0, 0);
+                depth = depth_in_lds ? wpix[(threadIdx.x & ~(G - 1)) + smp.src]
+                    : smvs_topo::patch_eval(n16,
+                        ((smp.src & (ps - 1)) + 0.5) * A.inv_ps,
+                        ((smp.src >> A.ps_log2) + 0.5) * A.inv_ps, 0, 0);
             else
                 depth = n16[4 * (-1 - smp.src)];
             double const sx = (double)(px + smp.dx);
@@ -369,16 +417,16 @@ topo_visibility_kernel(TopoArgs A)
                 }
             }
             if (pass == 0) {
-                inside = group_all(inside, G, lane);
+                inside = group_all(inside, G, lane, red);
                 for (int c = 0; c < 3; ++c) {
-                    mean0[c] = group_sum(sum0[c], G) / n;
-                    mean1[c] = group_sum(sum1[c], G) / n;
+                    mean0[c] = group_sum(sum0[c], G, red) / n;
+                    mean1[c] = group_sum(sum1[c], G, red) / n;
                 }
             }
         }
-        n0 = sqrt(group_sum(n0, G));
-        n1 = sqrt(group_sum(n1, G));
-        dot = group_sum(dot, G);
+        n0 = sqrt(group_sum(n0, G, red));
+        n1 = sqrt(group_sum(n1, G, red));
+        dot = group_sum(dot, G, red);
         if (!inside)
             ncc = -1.0;
         else if (n0 + n1 < 0.001 * n)
@@ -395,11 +443,12 @@ __global__ void __launch_bounds__(256)
 topo_mse_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
+    __shared__ double red[4];
     int const ps = A.ps;
-    int const G = group_size(ps);
+    int const G = group_size(ps, MSE_WORKGROUP_FROM);
     int const gl = threadIdx.x & (G - 1);
     int const p = (int)(((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x)
-        >> min(2 * A.ps_log2, 6));
+        >> (31 - __clz(G)));
     bool const in_range = p < A.num_patches;
     bool const alive = in_range && A.patch_valid[p];
     int const pc = alive ? p : 0;
@@ -440,8 +489,8 @@ topo_mse_kernel(TopoArgs A)
                 counter += 1.0;
             }
         }
-    error = group_sum(error, G);
-    counter = group_sum(counter, G);
+    error = group_sum(error, G, red);
+    counter = group_sum(counter, G, red);
     if (in_range && gl == 0)
         A.mse_out[p] = !alive ? -1.0
             : (counter == 0.0 ? 1.0 : error / counter);
@@ -678,8 +727,7 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         hipLaunchKernelGGL(topo_dilate_kernel, dim3((zw + 255) / 256, zh, ctx->n_subs),
             dim3(256), 0, ctx->stream, A);
     }
-    int const pp = ctx->patchsize * ctx->patchsize;
-    long long const group = pp >= 64 ? 64 : pp;
+    long long const group = group_size(ctx->patchsize, VIS_WORKGROUP_FROM);
     long long const items = (long long)ctx->num_patches * ctx->n_subs * group;
     hipLaunchKernelGGL(topo_visibility_kernel,
         dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
@@ -714,8 +762,7 @@ launch_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
     }
     if ((rc = fill_args(ctx, A, who)) != SMVS_OK)
         return rc;
-    int const pp = ctx->patchsize * ctx->patchsize;
-    long long const group = pp >= 64 ? 64 : pp;
+    long long const group = group_size(ctx->patchsize, MSE_WORKGROUP_FROM);
     long long const items = (long long)ctx->num_patches * group;
     hipLaunchKernelGGL(topo_mse_kernel,
         dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, *A);

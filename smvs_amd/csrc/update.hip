@@ -1165,10 +1165,12 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
 static int
 ensure_map_scratch(smvs_ctx *ctx)
 {
-    if (ctx->map_scratch != nullptr)
+    size_t const want = (size_t)ctx->width * ctx->height * 3;
+    if (ctx->map_scratch != nullptr && ctx->map_scratch_floats >= want)
         return SMVS_OK;
-    return device_alloc(&ctx->map_scratch,
-        (size_t)ctx->width * ctx->height * 3);
+    int const rc = device_alloc(&ctx->map_scratch, want);
+    ctx->map_scratch_floats = rc == SMVS_OK ? want : 0;
+    return rc;
 }
 
 extern "C" int
@@ -1221,6 +1223,47 @@ smvs_get_normal_map(smvs_ctx *ctx, float *normals)
     if (rc != SMVS_OK)
         return rc;
     return ctx_download(ctx, normals, buf, n * sizeof(float));
+}
+
+extern "C" int
+smvs_get_maps(smvs_ctx *ctx, float *depth, float *normals)
+{
+    SMVS_REQUIRE(ctx != nullptr, "null context");
+    if (depth == nullptr)
+        return normals != nullptr ? smvs_get_normal_map(ctx, normals) : SMVS_OK;
+    if (normals == nullptr)
+        return smvs_get_depth_map(ctx, depth);
+    if (!ctx->has_surface) {
+        set_error("smvs_get_maps: no surface");
+        return SMVS_ERR_STATE;
+    }
+    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t const npix = (size_t)ctx->width * ctx->height;
+    // depth behind the normals in one scratch buffer of W*H*4 floats
+    if (ctx->map_scratch_floats < npix * 4) {
+        int const rc = device_alloc(&ctx->map_scratch, npix * 4);
+        if (rc != SMVS_OK) {
+            ctx->map_scratch_floats = 0;
+            return rc;
+        }
+        ctx->map_scratch_floats = npix * 4;
+    }
+    float *nbuf = ctx->map_scratch, *dbuf = ctx->map_scratch + npix * 3;
+    SMVS_HIP_CHECK(hipMemsetAsync(nbuf, 0, npix * 4 * sizeof(float), ctx->stream));
+    int rc = launch_maps(ctx, dbuf, nbuf);
+    if (rc != SMVS_OK)
+        return rc;
+    if (host_pointer_is_pinned(depth) && host_pointer_is_pinned(normals)) {
+        SMVS_HIP_CHECK(hipMemcpyAsync(depth, dbuf, npix * sizeof(float),
+            hipMemcpyDeviceToHost, ctx->stream));
+        SMVS_HIP_CHECK(hipMemcpyAsync(normals, nbuf, npix * 3 * sizeof(float),
+            hipMemcpyDeviceToHost, ctx->stream));
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return SMVS_OK;
+    }
+    if ((rc = ctx_download(ctx, depth, dbuf, npix * sizeof(float))) != SMVS_OK)
+        return rc;
+    return ctx_download(ctx, normals, nbuf, npix * 3 * sizeof(float));
 }
 
 extern "C" int

@@ -615,7 +615,7 @@ def _inverse_calibration(flen, w, h):
 
 @pytest.mark.parametrize("size,n_subs,scale", [((320, 256), 4, 2), ((384, 256), 3, 3),
                                                ((512, 384), 2, 4), ((160, 128), 2, 1),
-                                               ((640, 512), 3, 6)])
+                                               ((640, 512), 3, 6), ((576, 416), 3, 5)])
 def test_topology_subviews_mse_and_cuts_match_oracle(hip, oracle, size, n_subs, scale):
     """create_subview_surfaces, mse_for_patch and the cut_boundaries loop
     (depth_optimizer.cc:360-604, 747-912) on the device against the oracle:
