@@ -238,8 +238,14 @@ int smvs_get_depth_map(smvs_ctx *ctx, float *depth);
 int smvs_get_normal_map(smvs_ctx *ctx, float *normals);
 
 /* Both maps in one pass over the surface (one kernel, two transfers, one
- * synchronisation); either pointer may be NULL. */
-int smvs_get_maps(smvs_ctx *ctx, float *depth, float *normals);
+ * synchronisation) -- the end of DepthOptimizer::optimize,
+ * depth_optimizer.cc:150-160.  inv_calibration9 != NULL: the depth map comes
+ * back as StereoView::write_depth_to_view stores it (stereo_view.h:100-119:
+ * MVE's ray-length convention, depth times the length of the pixel's viewing
+ * ray under CameraInfo::fill_inverse_calibration); NULL: z-depth, as
+ * smvs_get_depth_map. */
+int smvs_get_maps(smvs_ctx *ctx, const float *inv_calibration9, float *depth,
+    float *normals);
 
 /* Page-locked host memory for the large buffers that cross the boundary (the
  * views' u8 images, the 33 MB of depth + normal maps per 1920x1080 view): a
@@ -249,8 +255,8 @@ int smvs_get_maps(smvs_ctx *ctx, float *depth, float *normals);
  * pointer works everywhere, pinned ones are just faster.  Buffers are pooled
  * by size (page-locking costs more than the copy it saves) and go back to the
  * driver with smvs_release_workspaces(). */
-int smvs_host_alloc(size_t bytes, void **out);
-int smvs_host_free(void *ptr);
+int smvs_pinned_alloc(size_t bytes, void **out);
+int smvs_pinned_free(void *ptr);
 
 /* LightOptimizer::fit_lighting_to_image accumulation,
  * light_optimizer.cc:32-49, over the uploaded shading image: A[16][16],

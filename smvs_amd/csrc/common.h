@@ -235,7 +235,7 @@ int ctx_pool_release(void);   // frees the parked contexts (ctx.hip) -> how many
 int ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ctx_download(smvs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 // Is `p` page-locked host memory the device can DMA from / to directly
-// (smvs_host_alloc, hipHostMalloc, hipHostRegister)?
+// (smvs_pinned_alloc, hipHostMalloc, hipHostRegister)?
 bool host_pointer_is_pinned(const void *p);
 int pinned_pool_release(void);   // pool.hip -> buffers returned to the driver
 // Geometry of the surface the context holds (Surface::create, surface.cc:28-37)

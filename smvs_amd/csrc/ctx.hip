@@ -114,7 +114,7 @@ ctx_upload(smvs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
     if (bytes == 0)
         return SMVS_OK;
     if (bytes >= ((size_t)1 << 20) && host_pointer_is_pinned(src_host)) {
-        // page-locked source (smvs_host_alloc): one DMA, no staging copy
+        // page-locked source (smvs_pinned_alloc): one DMA, no staging copy
         SMVS_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice,
             ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -454,8 +454,13 @@ DepthOptimizer::optimize(void)
             main_view->get_height(), 1);
         FloatImage::Ptr nm = FloatImage::create_for_overwrite(main_view->get_width(),
             main_view->get_height(), 3);
-        check(smvs_get_maps(ctx, dm->begin(), nm->begin()), "smvs_get_maps");
-        main_view->write_depth_to_view(dm, opts.output_name);
+        // (the depth already in the convention write_depth_to_view stores,
+        // stereo_view.h:100-119: converted where it is computed)
+        float invproj[9];
+        main_view->get_camera().fill_inverse_calibration(invproj,
+            (float)main_view->get_width(), (float)main_view->get_height());
+        check(smvs_get_maps(ctx, invproj, dm->begin(), nm->begin()), "smvs_get_maps");
+        main_view->write_image_to_view(dm, opts.output_name);
         main_view->write_image_to_view(nm, opts.output_name + "N");
     }
     g_timers.report();

@@ -34,7 +34,7 @@ struct DefaultInitAllocator : std::allocator<T>
 
 // Where large images live.  By default in a std::vector; the host library
 // installs a hook (host/pinned_images.cc) that serves images of a megabyte and
-// more from page-locked memory (smvs_host_alloc, include/smvs_hip.h): the
+// more from page-locked memory (smvs_pinned_alloc, include/smvs_hip.h): the
 // views' u8 images and the depth / normal maps then cross PCIe as one DMA each
 // instead of through a staging copy.  The hook may decline (returns null: no
 // device, out of pinned memory); the vector is the fallback.

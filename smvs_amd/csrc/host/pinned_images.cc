@@ -1,6 +1,6 @@
 // Installs the host mirror's image-memory hook (host/image.h): images of a
 // megabyte and more live in page-locked memory from the device library's pool
-// (smvs_host_alloc, include/smvs_hip.h), so that the views' u8 images go to the
+// (smvs_pinned_alloc, include/smvs_hip.h), so that the views' u8 images go to the
 // device and the depth / normal maps come back as one DMA each.  Without a
 // device (the CPU-only tests of the host logic) the first allocation fails and
 // the hook retires: images are plain vectors again.
@@ -20,7 +20,7 @@ pinned_alloc(std::size_t bytes)
     if (g_retired.load(std::memory_order_relaxed))
         return nullptr;
     void* p = nullptr;
-    if (smvs_host_alloc(bytes, &p) != SMVS_OK) {
+    if (smvs_pinned_alloc(bytes, &p) != SMVS_OK) {
         // no device / no pinned memory left: stop asking
         g_retired.store(true, std::memory_order_relaxed);
         return nullptr;
@@ -31,7 +31,7 @@ pinned_alloc(std::size_t bytes)
 void
 pinned_free(void* p)
 {
-    (void)smvs_host_free(p);
+    (void)smvs_pinned_free(p);
 }
 
 struct Install

@@ -52,7 +52,7 @@ release_idle_device_memory(void)
     return release_idle_workspaces() + ctx_pool_release();
 }
 
-// ---- page-locked host buffers (smvs_host_alloc), pooled by exact size ----
+// ---- page-locked host buffers (smvs_pinned_alloc), pooled by exact size ----
 // hipHostMalloc of the 6 MB of a 1920x1080 RGB image costs more than the
 // staging copy it saves; a view's buffers come in a handful of sizes (its
 // images, its maps), so freed buffers wait in per-size free lists for the next
@@ -269,7 +269,7 @@ smvs_release_workspaces(void)
 }
 
 extern "C" int
-smvs_host_alloc(size_t bytes, void **out)
+smvs_pinned_alloc(size_t bytes, void **out)
 {
     SMVS_REQUIRE(out != nullptr && bytes > 0, "bad argument");
     {
@@ -298,7 +298,7 @@ smvs_host_alloc(size_t bytes, void **out)
 }
 
 extern "C" int
-smvs_host_free(void *ptr)
+smvs_pinned_free(void *ptr)
 {
     if (ptr == nullptr)
         return SMVS_OK;
@@ -312,7 +312,7 @@ smvs_host_free(void *ptr)
                 g_pinned_live.erase(g_pinned_live.begin() + (long)i);
                 break;
             }
-        SMVS_REQUIRE(bytes != 0, "pointer was not handed out by smvs_host_alloc");
+        SMVS_REQUIRE(bytes != 0, "pointer was not handed out by smvs_pinned_alloc");
         if (g_pinned_idle_bytes + bytes <= PINNED_POOL_BYTES) {
             g_pinned_free.push_back({ bytes, ptr });
             g_pinned_idle_bytes += bytes;

@@ -305,7 +305,7 @@ surf_expand_apply_kernel(SurfArgs A)
 // 160 KB -- and thread x handles column x of a step.  Within a step no two
 // threads write the same word (they own different columns) and no thread reads
 // a bit another one writes.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
 {
     extern __shared__ unsigned lds_bits[];
@@ -759,10 +759,9 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
         attr_set[ctx->device] = true;
     }
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_SURF_CHANGED, 0, sizeof(int), ctx->stream));
-    // (256 threads: a step is a barrier over 4 waves, not 16 -- the walk is
-    // 2 npx + npy - 2 barriers long; measured 494 us with 1024 threads at
-    // 478 x 268 patches)
-    hipLaunchKernelGGL(surf_isolated_kernel, dim3(1), dim3(256), lds, ctx->stream, A,
+    // (one column per thread: 494 us at 478 x 268 patches, i.e. 0.4 us per
+    // step of the 1,222; with 256 threads and two columns each 651 us)
+    hipLaunchKernelGGL(surf_isolated_kernel, dim3(1), dim3(1024), lds, ctx->stream, A,
         global_bits, wpc);
     launch_remove_nodes(ctx, A);
     SMVS_HIP_CHECK(hipGetLastError());

@@ -573,6 +573,8 @@ struct MapArgs {
     float *normals;   // [H][W][3] or nullptr
     int W, H, npx, stride, ps, start_x, start_y, num_patches;
     double inv_flen;
+    int to_mve;          // depth in MVE's ray-length convention
+    float invproj[9];    // CameraInfo::fill_inverse_calibration (to_mve)
 };
 
 __global__ void __launch_bounds__(256)
@@ -599,8 +601,26 @@ surface_maps_kernel(MapArgs A)
     int const px = A.start_x + ix * A.ps + ci;
     int const py = A.start_y + iy * A.ps + cj;
     size_t const o = (size_t)py * A.W + px;
-    if (A.depth != nullptr)
-        A.depth[o] = (float)w;
+    if (A.depth != nullptr) {
+        float d = (float)w;
+        if (A.to_mve) {
+#pragma clang fp contract(off)
+            // StereoView::write_depth_to_view (stereo_view.h:100-119):
+            // mve::image::depthmap_convert_conventions, z-depth -> ray length
+            // (`double len = px.norm(); dm *= len`, tests/golden/README.md M10;
+            // the float operations of host/stereo_view.cc, the inverse of
+            // mesh.hip's mesh_prepare_kernel)
+            float const fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+            float v[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                v[r] = A.invproj[3 * r] * fx + A.invproj[3 * r + 1] * fy
+                    + A.invproj[3 * r + 2];
+            float const len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            d = (float)((double)d * (double)len);
+        }
+        A.depth[o] = d;
+    }
     if (A.normals != nullptr) {
         // surface_derivative.cc:17-28
         double const x = (double)px + 0.5 - (double)A.W / 2.0;
@@ -614,9 +634,13 @@ surface_maps_kernel(MapArgs A)
 }
 
 static int
-launch_maps(smvs_ctx *ctx, float *depth_dev, float *normals_dev)
+launch_maps(smvs_ctx *ctx, float *depth_dev, float *normals_dev,
+    const float *inv_calibration9 = nullptr)
 {
     MapArgs A;
+    A.to_mve = inv_calibration9 != nullptr ? 1 : 0;
+    for (int i = 0; i < 9; ++i)
+        A.invproj[i] = inv_calibration9 != nullptr ? inv_calibration9[i] : 0.0f;
     A.nodes = ctx->nodes;
     A.patch_valid = ctx->patch_valid;
     A.hermite_tab = ctx->hermite_tab;
@@ -1226,13 +1250,10 @@ smvs_get_normal_map(smvs_ctx *ctx, float *normals)
 }
 
 extern "C" int
-smvs_get_maps(smvs_ctx *ctx, float *depth, float *normals)
+smvs_get_maps(smvs_ctx *ctx, const float *inv_calibration9, float *depth, float *normals)
 {
     SMVS_REQUIRE(ctx != nullptr, "null context");
-    if (depth == nullptr)
-        return normals != nullptr ? smvs_get_normal_map(ctx, normals) : SMVS_OK;
-    if (normals == nullptr)
-        return smvs_get_depth_map(ctx, depth);
+    SMVS_REQUIRE(depth != nullptr && normals != nullptr, "null output");
     if (!ctx->has_surface) {
         set_error("smvs_get_maps: no surface");
         return SMVS_ERR_STATE;
@@ -1250,7 +1271,7 @@ smvs_get_maps(smvs_ctx *ctx, float *depth, float *normals)
     }
     float *nbuf = ctx->map_scratch, *dbuf = ctx->map_scratch + npix * 3;
     SMVS_HIP_CHECK(hipMemsetAsync(nbuf, 0, npix * 4 * sizeof(float), ctx->stream));
-    int rc = launch_maps(ctx, dbuf, nbuf);
+    int rc = launch_maps(ctx, dbuf, nbuf, inv_calibration9);
     if (rc != SMVS_OK)
         return rc;
     if (host_pointer_is_pinned(depth) && host_pointer_is_pinned(normals)) {

@@ -256,6 +256,34 @@ class ViewContext:
         check(self.lib.smvs_get_normal_map(self.handle, _p(out, _fp)))
         return out
 
+    def maps(self, inv_calibration=None, pinned=False):
+        """smvs_get_maps: depth and normal map in one pass; inv_calibration
+        (9 floats) -> the depth in MVE's ray-length convention; pinned: the
+        outputs live in page-locked memory from smvs_pinned_alloc (direct DMA)."""
+        import ctypes as C
+        inv = None if inv_calibration is None \
+            else np.ascontiguousarray(inv_calibration, dtype=np.float32).reshape(9)
+        n = self.height * self.width
+        if not pinned:
+            depth = np.zeros((self.height, self.width), dtype=np.float32)
+            normals = np.zeros((self.height, self.width, 3), dtype=np.float32)
+            check(self.lib.smvs_get_maps(self.handle, _p(inv, _fp) if inv is not None else None,
+                                         _p(depth, _fp), _p(normals, _fp)))
+            return depth, normals
+        pd, pn = C.c_void_p(), C.c_void_p()
+        check(self.lib.smvs_pinned_alloc(C.c_size_t(4 * n), C.byref(pd)))
+        check(self.lib.smvs_pinned_alloc(C.c_size_t(12 * n), C.byref(pn)))
+        try:
+            check(self.lib.smvs_get_maps(self.handle, _p(inv, _fp) if inv is not None else None,
+                                         C.cast(pd, _fp), C.cast(pn, _fp)))
+            depth = np.ctypeslib.as_array(C.cast(pd, _fp), (self.height, self.width)).copy()
+            normals = np.ctypeslib.as_array(C.cast(pn, _fp),
+                                            (self.height, self.width, 3)).copy()
+        finally:
+            check(self.lib.smvs_pinned_free(pd))
+            check(self.lib.smvs_pinned_free(pn))
+        return depth, normals
+
     def light_accumulate(self):
         A = np.zeros((16, 16)); b = np.zeros(16)
         check(self.lib.smvs_light_accumulate(self.handle, _p(A, _dp), _p(b, _dp)))

@@ -161,6 +161,33 @@ def test_depth_and_normal_maps_match_oracle(hip, oracle):
     ctx.close()
 
 
+def test_maps_in_one_pass_pinned_buffers_and_mve_convention(hip, oracle):
+    """smvs_get_maps: the two maps of smvs_get_depth_map / smvs_get_normal_map
+    bit for bit, into pageable and into page-locked buffers (smvs_pinned_alloc);
+    with the inverse calibration the depth comes back in MVE's ray-length
+    convention -- StereoView::write_depth_to_view, stereo_view.h:100-119:
+    `dm *= len` with len the float norm of the pixel's viewing ray widened to
+    double (tests/golden/README.md M10) -- bit-identical with those float
+    operations done in numpy."""
+    prob, ctx, orc = _setup(hip, oracle, 352, 288, 3, 2, noise=0.01)
+    d0, n0 = ctx.depth_map(), ctx.normal_map()
+    for pinned in (False, True):
+        d1, n1 = ctx.maps(pinned=pinned)
+        assert np.array_equal(d1, d0) and np.array_equal(n1, n0)
+    f = np.float32
+    inv = _inverse_calibration(prob["main"].flen, 352, 288)
+    xs, ys = np.meshgrid(np.arange(352, dtype=f) + f(0.5), np.arange(288, dtype=f) + f(0.5))
+    v = [(inv[3 * r] * xs + inv[3 * r + 1] * ys) + inv[3 * r + 2] for r in range(3)]
+    length = np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]).astype(f)
+    want = (d0.astype(np.float64) * length.astype(np.float64)).astype(f)
+    for pinned in (False, True):
+        d2, n2 = ctx.maps(inv, pinned=pinned)
+        assert np.array_equal(n2, n0)
+        assert np.array_equal(d2, want)
+    assert (want > d0).sum() > 0.2 * d0.size      # off-axis rays are longer
+    ctx.close()
+
+
 def test_light_fit_matches_oracle(hip, oracle):
     """LightOptimizer accumulation (light_optimizer.cc:32-49)."""
     prob, ctx, orc = _setup(hip, oracle, 256, 192, 2, 2, shading=True)
