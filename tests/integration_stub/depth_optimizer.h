@@ -88,6 +88,7 @@ public:
     void setup_hip(int device);
     void upload_scale_planes_hip(void);
     void run_newton_loop_hip(void);
+    void run_newton_iterations_hip(int num_iters);
 private:
     Options const& opts;
     StereoView::Ptr main_view;
@@ -99,5 +100,7 @@ private:
     GlobalLighting::Ptr lighting;
     std::vector<double> depths;
     smvs_ctx* ctx;     // added by the binding
+    int valid_patches_hip;   // added by the binding: non-null patches of the device surface
+    float invproj_hip[9];    // added by the binding: CameraInfo::fill_inverse_calibration
 };
 }

@@ -30,7 +30,9 @@ def test_integration_stub_compiles_and_links(tmp_path):
                         text=True).stdout
     wanted = set(re.findall(r"\b(smvs_[a-z_0-9]+)\b", nm))
     assert {"smvs_ctx_create", "smvs_ctx_set_surface", "smvs_gn_run_loop",
-            "smvs_get_nodes", "smvs_ctx_upload_sub"} <= wanted
+            "smvs_get_nodes", "smvs_ctx_upload_sub", "smvs_surface_expand",
+            "smvs_surface_remove_isolated_patches", "smvs_surface_delete_unseen_patches",
+            "smvs_topology_cut_boundaries", "smvs_surface_info"} <= wanted
     exported = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True,
                               text=True).stdout
     for sym in wanted:
