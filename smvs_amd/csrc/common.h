@@ -202,6 +202,8 @@ struct smvs_ctx {
     int topo_ncc_ps = 0;
     double *topo_mse = nullptr;
     size_t topo_mse_cap = 0;
+    uint8_t *topo_border = nullptr;   // nodes with > 1 missing neighbour (cut_boundaries)
+    size_t topo_border_cap = 0;
 
     // grid surgery on the device (surface.hip)
     float *surf_depth = nullptr;       // [H][W] Surface::depth (surface.cc:46-50): the

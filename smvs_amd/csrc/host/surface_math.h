@@ -273,16 +273,12 @@ depth_key(float d)
 // ---------------------------------------------------- isolated patches
 // Surface::remove_isolated_patches, lib/surface.cc:887-927, deletes in place
 // while it walks the grid column by column, so a deletion changes the counts
-// of the patches visited after it.  Cell (x, y) reads the processed state of
-// (x-1, y-1..y+1) and (x, y-1) and the unprocessed state of the rest; with
-// step(x, y) = 2 x + y every processed neighbour has a smaller step and every
-// unprocessed one a larger: all cells of one step are independent, and
-// 2 npx + npy - 2 steps reproduce the sequential walk exactly.
-SMVS_HD int
-isolated_step_count(int npx, int npy)
-{
-    return 2 * (npx - 1) + (npy - 1) + 1;
-}
+// of the patches visited after it.  Cell (x, y) reads the visited state of
+// (x-1, y-1..y+1) and (x, y-1) and the unvisited state of the rest.  A
+// schedule in which column x runs at least one row plus a step behind column
+// x - 1 reproduces the sequential walk exactly; csrc/surface.hip's kernel
+// (one thread per column, ISO_ROWS rows per step) and the host mirror's
+// transposed walk are the two users.
 
 } // namespace smvs_surf
 
