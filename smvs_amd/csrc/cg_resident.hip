@@ -1850,15 +1850,20 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
     return true;
 }
 
-static DeviceBarrierLock g_resident_mutex[16];   // one barrier kernel per device at a time
+static DeviceTileBudget g_resident_budget[16];
 
 void
-DeviceBarrierLock::bind(int device)
+DeviceTileBudget::bind(int device)
 {
-    std::lock_guard<std::mutex> guard(mutex);
+    // (caller holds the mutex)
     if (bound)
         return;
     bound = true;
+    hipDeviceProp_t prop;
+    capacity = RES_MAX_BLOCKS;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess
+        && prop.multiProcessorCount < capacity)
+        capacity = prop.multiProcessorCount;
     // the same GPU may have different indices in different processes
     // (HIP_VISIBLE_DEVICES): name the file after the PCI bus id
     char bus[64] = "";
@@ -1886,9 +1891,10 @@ DeviceBarrierLock::bind(int device)
 }
 
 void
-DeviceBarrierLock::lock(void)
+DeviceTileBudget::lock_file(void)
 {
-    mutex.lock();
+    // (caller holds the mutex; the first holder of this process takes the
+    // file lock, the last one returns it)
     if (fd < 0)
         return;
     // A Newton loop holds the lock for milliseconds.  Somebody who holds it
@@ -1920,23 +1926,69 @@ DeviceBarrierLock::lock(void)
 }
 
 void
-DeviceBarrierLock::unlock(void)
+DeviceTileBudget::unlock_file(void)
 {
     if (fd >= 0 && file_locked)
         (void)::flock(fd, LOCK_UN);
     file_locked = false;
-    mutex.unlock();
 }
 
-DeviceBarrierLock &
-cg_resident_mutex(int device)
+void
+DeviceTileBudget::acquire(int device, int tiles)
 {
-    DeviceBarrierLock &l = g_resident_mutex[device & 15];
-    l.bind(device);
-    return l;
+    std::unique_lock<std::mutex> guard(mutex);
+    bind(device);
+    if (tiles > capacity)
+        tiles = capacity;
+    unsigned long long const ticket = next_ticket++;
+    // in arrival order; the head of the line waits for its tiles, the others
+    // wait for the head
+    turn.wait(guard, [&] { return serving == ticket && used + tiles <= capacity; });
+    used += tiles;
+    serving += 1;
+    if (holders++ == 0)
+        lock_file();
+    guard.unlock();
+    turn.notify_all();   // (the next in line may fit beside this one)
 }
 
-// Launches the solver (the caller holds cg_resident_mutex and has checked
+void
+DeviceTileBudget::release(int tiles)
+{
+    {
+        std::lock_guard<std::mutex> guard(mutex);
+        if (tiles > capacity)
+            tiles = capacity;
+        used -= tiles;
+        if (--holders == 0)
+            unlock_file();
+    }
+    turn.notify_all();
+}
+
+DeviceTileBudget &
+cg_resident_budget(int device)
+{
+    return g_resident_budget[device & 15];
+}
+
+int
+cg_resident_tiles(smvs_ctx *ctx)
+{
+    ResidentPlan plan;
+    if (ctx->resident_cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess)
+            return 0;
+        ctx->resident_cus = prop.multiProcessorCount;
+    }
+    if (!resident_plan(ctx, &plan))
+        return 0;
+    int const stride = ctx->node_stride, rows = ctx->num_nodes / stride;
+    return ((stride + plan.tw - 1) / plan.tw) * ((rows + plan.th - 1) / plan.th);
+}
+
+// Launches the solver (the caller holds its tiles of the budget and has checked
 // cg_resident_applies).  pipelined: the Newton loop's launch-ahead mode -- the
 // kernel leaves at once when status[I_STOP] / [I_STEP_ABORT] is set, raises
 // I_STEP_ABORT itself when it gives up, and nobody waits on the progress words.
@@ -2089,7 +2141,7 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         SMVS_HIP_CHECK(hipMemsetAsync(trace_dev, 0, trace_n * sizeof(long long),
             ctx->stream));
     }
-    std::lock_guard<DeviceBarrierLock> guard(cg_resident_mutex(ctx->device));
+    ScopedTileBudget guard(ctx->device, cg_resident_tiles(ctx));
     int solve_tag = 0, num_tiles = 0;
     int const rc = resident_enqueue(ctx, max_iterations, error_tolerance,
         q_tolerance, fused, false, trace_dev, &solve_tag, &num_tiles);

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <condition_variable>
 #include <mutex>
 #include <cstdio>
 #include <cstring>
@@ -417,25 +418,50 @@ int cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     double q_tolerance, int *num_iterations, int *info, bool *ran,
     bool fused = false);
 bool cg_resident_applies(smvs_ctx *ctx, int max_iterations);
-// The launch-ahead Newton loop (update.hip): holds cg_resident_mutex for the
-// whole loop and enqueues fused solves without waiting for them.
-// One barrier kernel per DEVICE at a time -- across the threads of this process
-// (a mutex) and across processes that share the GPU (an advisory lock on a
-// file named after the device's PCI bus id): two such kernels started together
+// Barrier kernels (the resident PCG: every workgroup of a launch must be
+// co-resident, one per CU) share a device by a TILE BUDGET: a Newton loop
+// (update.hip holds its share for the whole loop, patch kernels included) or a
+// single solve acquires as many tiles as its grid has workgroups and waits
+// while the tiles in use plus its own exceed the device's CUs.  A full-size
+// solve (256 tiles at 1920x1080, scale 2) therefore still runs alone, but the
+// loops of the coarse scales -- 1, 4, 16, 64 tiles -- of several views in
+// flight run side by side instead of taking turns (round 3's exclusive lock).
+// Requests are served in arrival order, so a large request is not starved by
+// a stream of small ones.  Across PROCESSES that share the GPU the budget
+// cannot be shared; there an advisory lock on a file named after the device's
+// PCI bus id still makes the processes take turns (held while any loop of this
+// process holds tiles): two such kernels of two processes started together
 // could each hold half of the CUs and wait for the other half for ever.
-// BasicLockable, for std::lock_guard.
-class DeviceBarrierLock {
+class DeviceTileBudget {
 public:
-    void lock(void);
-    void unlock(void);
-    void bind(int device);   // opens the lock file once
+    void acquire(int device, int tiles);
+    void release(int tiles);
 private:
+    void bind(int device);      // capacity, lock file: once
+    void lock_file(void);
+    void unlock_file(void);
     std::mutex mutex;
+    std::condition_variable turn;
+    int capacity = 0, used = 0, holders = 0;
+    unsigned long long next_ticket = 0, serving = 0;
     int fd = -1;
-    bool bound = false;
-    bool file_locked = false;   // (guarded by mutex)
+    bool bound = false, file_locked = false;
 };
-DeviceBarrierLock &cg_resident_mutex(int device);
+DeviceTileBudget &cg_resident_budget(int device);
+// workgroups (= tiles = CUs) the resident solver launches for this context's
+// grid; 0 when it does not apply
+int cg_resident_tiles(smvs_ctx *ctx);
+struct ScopedTileBudget {
+    DeviceTileBudget &budget;
+    int tiles;
+    ScopedTileBudget(int device, int tiles_) : budget(cg_resident_budget(device)), tiles(tiles_)
+    {
+        budget.acquire(device, tiles);
+    }
+    ~ScopedTileBudget() { budget.release(tiles); }
+    ScopedTileBudget(ScopedTileBudget const &) = delete;
+    ScopedTileBudget &operator=(ScopedTileBudget const &) = delete;
+};
 int cg_resident_enqueue(smvs_ctx *ctx, int max_iterations, double q_tolerance,
     bool test_give_up = false);
 size_t cg_resident_exchange_bytes(void);   // size of ctx->res_work

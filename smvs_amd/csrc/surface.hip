@@ -298,24 +298,19 @@ surf_expand_apply_kernel(SurfArgs A)
 
 // ---- remove_isolated_patches (surface.cc:887-927) ----
 // The reference deletes in place while it walks the grid column by column, so
-// the walk's order is part of the result.  ONE workgroup replays it as a
-// wavefront (surface_math.h): the patch validity lives as bit columns
-// (one-cell border of zeros, rows packed into 32-bit words) in LDS -- or in
-// global memory when the grid is too large for 160 KB -- and thread x owns
-// column x.  Per step a thread walks ISO_ROWS consecutive rows of its column
-// in registers (its column's bits, and the two neighbour columns', as 64-bit
-// windows); thread x runs ISO_ROWS + 1 rows behind thread x - 1, which is
-// exactly the lead the walk's dependencies need: every neighbour a cell reads
-// as "already visited" (column x - 1 up to one row below, the cell above) was
-// finished in an earlier step, every neighbour it reads as "not yet visited"
-// is written, if at all, by nobody in this step.  ((ISO_ROWS + 1) (npx - 1) +
-// npy) / ISO_ROWS steps instead of 2 npx + npy: 664 instead of 1,222 at
-// 478 x 268 with four rows per step (measured at that size: one row per step
-// 494 us -- the LDS round trip and the barrier of a step dominate; eight rows
-// with 64-bit window arithmetic 812 us -- the one CU's ALUs dominate).  Within
-// a step no two threads write the same word (they own different columns).
-constexpr int ISO_ROWS = 4;
-
+// the walk's order is part of the result.  ONE workgroup replays it as
+// 2 npx + npy - 2 steps of independent cells (surface_math.h): the patch
+// validity lives as bit columns (one-cell border of zeros, rows packed into
+// 32-bit words) in LDS -- or in global memory when the grid is too large for
+// 160 KB -- and thread x handles column x of a step.  Within a step no two
+// threads write the same word (they own different columns) and no thread reads
+// a bit another one writes.  494 us at 478 x 268 patches (0.4 us per step: one
+// LDS round trip and one barrier).  Tried and not kept: 256 threads with two
+// columns each (651 us); several rows of a column per step with the column
+// (ISO_ROWS + 1) rows behind its left neighbour, which needs only
+// ((R + 1) npx + npy) / R steps -- 812 us with R = 8 and 64-bit windows, 522
+// with R = 4 and 32-bit windows: the per-step work then runs into the one
+// CU's ALUs.
 __global__ void __launch_bounds__(1024)
 surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
 {
@@ -323,7 +318,7 @@ surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
     unsigned *bits = global_bits != nullptr ? global_bits : lds_bits;
     int const npx = A.g.npx, npy = A.g.npy;
     int const cols = npx + 2;
-    int const words = cols * wpc + 1;   // (+1: the 64-bit windows read a word ahead)
+    int const words = cols * wpc;
     for (int i = threadIdx.x; i < words; i += blockDim.x)
         bits[i] = 0u;
     __syncthreads();
@@ -339,53 +334,30 @@ surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
         bits[(x + 1) * wpc + w] = word;
     }
     __syncthreads();
-    // bit i of the result = row r0 + i of column c
-    auto window = [&](int c, int r0) -> unsigned long long {
-        const unsigned *w = bits + c * wpc + (r0 >> 5);
-        unsigned long long const v = (unsigned long long)w[0]
-            | ((unsigned long long)w[1] << 32);
-        return v >> (r0 & 31);
+    auto get = [&](int c, int r) -> int {
+        return (int)((bits[c * wpc + (r >> 5)] >> (r & 31)) & 1u);
     };
-    int const steps = ((ISO_ROWS + 1) * (npx - 1) + npy + ISO_ROWS - 1) / ISO_ROWS;
-    for (int s = 0; s < steps; ++s) {
+    int const steps = 2 * (npx - 1) + (npy - 1) + 1;   // step(x, y) = 2 x + y
+    for (int t = 0; t < steps; ++t) {
         for (int x = threadIdx.x; x < npx; x += blockDim.x) {
-            int const y0 = ISO_ROWS * s - (ISO_ROWS + 1) * x;
-            int const ya = y0 > 0 ? y0 : 0;
-            int const yb = y0 + ISO_ROWS < npy ? y0 + ISO_ROWS : npy;
-            if (ya >= yb)
+            int const y = t - 2 * x;
+            if (y < 0 || y >= npy)
                 continue;
-            int const c = x + 1, r0 = ya;   // padded row r0 = the row above ya
-            // (32-bit from here on: the windows hold ISO_ROWS + 2 <= 32 rows, and
-            // 64-bit shifts run at a quarter of the rate)
-            unsigned const left = (unsigned)window(c - 1, r0);
-            unsigned const right = (unsigned)window(c + 1, r0);
-            unsigned own = (unsigned)window(c, r0);
-            unsigned long long clear = 0ull;
-            for (int i = 1; i <= yb - ya; ++i) {
-                if (!((own >> i) & 1u))
-                    continue;
-                int const neighbours = __popc((left >> (i - 1)) & 7u)
-                    + __popc((right >> (i - 1)) & 7u)
-                    + (int)((own >> (i - 1)) & 1u) + (int)((own >> (i + 1)) & 1u);
-                if (neighbours < 3) {
-                    own &= ~(1u << i);
-                    clear |= 1ull << i;
-                }
-            }
-            if (clear != 0ull) {
-                unsigned long long const m = clear << (r0 & 31);
-                unsigned *w = bits + c * wpc + (r0 >> 5);
-                w[0] &= ~(unsigned)m;
-                if ((m >> 32) != 0ull)
-                    w[1] &= ~(unsigned)(m >> 32);
-            }
+            int const c = x + 1, r = y + 1;
+            if (!get(c, r))
+                continue;
+            int const neighbours = get(c - 1, r - 1) + get(c - 1, r) + get(c - 1, r + 1)
+                + get(c, r - 1) + get(c, r + 1)
+                + get(c + 1, r - 1) + get(c + 1, r) + get(c + 1, r + 1);
+            if (neighbours < 3)
+                bits[c * wpc + (r >> 5)] &= ~(1u << (r & 31));
         }
         __syncthreads();
     }
     int removed = 0;
     for (int p = threadIdx.x; p < npx * npy; p += blockDim.x) {
         int const x = p % npx, y = p / npx;
-        uint8_t const now = (uint8_t)((bits[(x + 1) * wpc + ((y + 1) >> 5)] >> ((y + 1) & 31)) & 1u);
+        uint8_t const now = (uint8_t)get(x + 1, y + 1);
         removed += (A.patch_valid[p] != 0 && now == 0) ? 1 : 0;
         A.patch_valid[p] = now;
     }
@@ -772,7 +744,7 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
     SurfArgs A;
     fill_surf_args(ctx, &A);
     int const wpc = (A.g.npy + 2 + 31) / 32;
-    size_t const bytes = ((size_t)(A.g.npx + 2) * wpc + 1) * sizeof(unsigned);
+    size_t const bytes = (size_t)(A.g.npx + 2) * wpc * sizeof(unsigned);
     unsigned *global_bits = nullptr;
     size_t lds = bytes;
     if (bytes > (size_t)150 * 1024) {

@@ -958,8 +958,10 @@ static int
 run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     smvs_gn_loop_stats *stats, LoopState &L)
 {
-    // barrier kernels of two loops must not interleave on one device
-    std::lock_guard<DeviceBarrierLock> guard(cg_resident_mutex(ctx->device));
+    // the loop's share of the device's CUs (common.h, DeviceTileBudget): the
+    // barrier kernels running side by side never ask for more workgroups than
+    // the device can keep resident together
+    ScopedTileBudget guard(ctx->device, cg_resident_tiles(ctx));
     static_assert(I_STEP_ABORT == I_STOP + 1, "cleared together");
     int const test_mode = loop_test_mode();
     int rc;
