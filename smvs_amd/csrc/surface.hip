@@ -337,8 +337,31 @@ surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
     auto get = [&](int c, int r) -> int {
         return (int)((bits[c * wpc + (r >> 5)] >> (r & 31)) & 1u);
     };
+    auto count_neighbours = [&](int c, int r) -> int {
+        return get(c - 1, r - 1) + get(c - 1, r) + get(c - 1, r + 1)
+            + get(c, r - 1) + get(c, r + 1)
+            + get(c + 1, r - 1) + get(c + 1, r) + get(c + 1, r + 1);
+    };
+    // Nothing is ever deleted before the first patch (in walk order) that has
+    // fewer than three neighbours to begin with -- a deletion needs an earlier
+    // deletion or such a patch -- so the walk starts at that patch's column,
+    // and does not run at all when there is none (the usual case once the
+    // boundary cuts have settled: 5 us instead of 0.5 ms at 478 x 268).
+    __shared__ int first_column;
+    if (threadIdx.x == 0)
+        first_column = npx;
+    __syncthreads();
+    for (int x = threadIdx.x; x < npx; x += blockDim.x) {
+        bool seed = false;
+        for (int y = 0; y < npy && !seed; ++y)
+            seed = get(x + 1, y + 1) && count_neighbours(x + 1, y + 1) < 3;
+        if (seed)
+            atomicMin(&first_column, x);
+    }
+    __syncthreads();
+    int const x_first = first_column;
     int const steps = 2 * (npx - 1) + (npy - 1) + 1;   // step(x, y) = 2 x + y
-    for (int t = 0; t < steps; ++t) {
+    for (int t = x_first < npx ? 2 * x_first : steps; t < steps; ++t) {
         for (int x = threadIdx.x; x < npx; x += blockDim.x) {
             int const y = t - 2 * x;
             if (y < 0 || y >= npy)
@@ -761,7 +784,8 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
     if (ctx->device < 16 && !attr_set[ctx->device]) {
         SMVS_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(surf_isolated_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            // (the kernel's static __shared__ word counts against the 160 KB too)
+            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set[ctx->device] = true;
     }
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_SURF_CHANGED, 0, sizeof(int), ctx->stream));
