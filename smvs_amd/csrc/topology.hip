@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include "host/topo_math.h"
 
 #include <vector>
@@ -24,6 +25,9 @@ namespace smvs_hip {
 
 using smvs_topo::NccSample;
 using smvs_topo::Warp;
+
+// three packed floats (4-byte aligned): one global_load_dwordx3
+struct __attribute__((packed, aligned(4))) float3_r { float x, y, z; };
 
 struct TopoView {
     int w, h, c;
@@ -252,7 +256,10 @@ group_all(bool ok, int G, int lane, double *red)
 
 // ---- visibility of every patch in every neighbour (:472-590), incl.
 // ncc_for_patch (:792-912) ----
-__global__ void __launch_bounds__(256)
+// (192 VGPRs, two waves per SIMD; forcing three or four by launch bounds
+// measured no gain / a loss to spills: the kernel issues two thirds of the
+// time, profiles/r4_visibility_counters.txt)
+__global__ void __launch_bounds__(256, 2)
 topo_visibility_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
@@ -352,7 +359,9 @@ topo_visibility_kernel(TopoArgs A)
         // at the fine scales, where the border samples make the templates
         // 2 - 3 x the patch -- and recomputes the rest.
         constexpr int NCC_KEEP = 4;
-        double keep_m[NCC_KEEP][3], keep_s[NCC_KEEP][3];
+        // (float: the kept values ARE floats -- an image value, linear_at's
+        // float result -- widened when they are used)
+        float keep_m[NCC_KEEP][3], keep_s[NCC_KEEP][3];
         auto colours = [&](int i, double (&cm)[3], double (&cs)[3], bool check) -> bool {
             NccSample const smp = tpl[i];
             double depth;
@@ -369,6 +378,33 @@ topo_visibility_kernel(TopoArgs A)
             double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
             if (check && (qx < 1 || qx > sv.w - 2 || qy < 1 || qy > sv.h - 2))
                 return false;
+            if (mv.c == 3 && sv.c == 3) {
+                // RGB views: the three channels of a tap lie side by side, so a
+                // sample is 1 + 4 twelve-byte loads instead of 3 + 12 four-byte
+                // ones; per channel the arithmetic is linear_at's
+                // (topo_math.h), term for term
+                float3_r const m3 = *reinterpret_cast<const float3_r *>(mv.image
+                    + ((size_t)(py + smp.dy) * mv.w + (px + smp.dx)) * 3);
+                cm[0] = m3.x; cm[1] = m3.y; cm[2] = m3.z;
+                float x = (float)qx, y = (float)qy;
+                x = x < 0.0f ? 0.0f : (x > (float)(sv.w - 1) ? (float)(sv.w - 1) : x);
+                y = y < 0.0f ? 0.0f : (y > (float)(sv.h - 1) ? (float)(sv.h - 1) : y);
+                int const fx = (int)x, fy = (int)y;
+                int const fx1 = fx + 1 < sv.w - 1 ? fx + 1 : sv.w - 1;
+                int const fy1 = fy + 1 < sv.h - 1 ? fy + 1 : sv.h - 1;
+                float const w1 = x - (float)fx, w0 = 1.0f - w1;
+                float const w3 = y - (float)fy, w2 = 1.0f - w3;
+                float const k00 = w0 * w2, k10 = w1 * w2, k01 = w0 * w3, k11 = w1 * w3;
+                const float *img = sv.image;
+                float3_r const v00 = *reinterpret_cast<const float3_r *>(img + ((long)fy * sv.w + fx) * 3);
+                float3_r const v10 = *reinterpret_cast<const float3_r *>(img + ((long)fy * sv.w + fx1) * 3);
+                float3_r const v01 = *reinterpret_cast<const float3_r *>(img + ((long)fy1 * sv.w + fx) * 3);
+                float3_r const v11 = *reinterpret_cast<const float3_r *>(img + ((long)fy1 * sv.w + fx1) * 3);
+                cs[0] = v00.x * k00 + v10.x * k10 + v01.x * k01 + v11.x * k11;
+                cs[1] = v00.y * k00 + v10.y * k10 + v01.y * k01 + v11.y * k11;
+                cs[2] = v00.z * k00 + v10.z * k10 + v01.z * k01 + v11.z * k11;
+                return true;
+            }
             for (int c = 0; c < 3; ++c) {
                 int const cmi = c < mv.c - 1 ? c : mv.c - 1;
                 int const csi = c < sv.c - 1 ? c : sv.c - 1;
@@ -392,8 +428,8 @@ topo_visibility_kernel(TopoArgs A)
                         for (int k = 0; k < NCC_KEEP; ++k)
                             if (slot == k)
                                 for (int c = 0; c < 3; ++c) {
-                                    keep_m[k][c] = cm[c];
-                                    keep_s[k][c] = cs[c];
+                                    keep_m[k][c] = (float)cm[c];
+                                    keep_s[k][c] = (float)cs[c];
                                 }
                         for (int c = 0; c < 3; ++c) {
                             sum0[c] += cm[c];
