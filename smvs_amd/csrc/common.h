@@ -205,6 +205,8 @@ struct smvs_ctx {
     size_t topo_mse_cap = 0;
     uint8_t *topo_border = nullptr;   // nodes with > 1 missing neighbour (cut_boundaries)
     size_t topo_border_cap = 0;
+    double *topo_pix = nullptr;       // [H][W][3]: surface depth, d/dx, d/dy per pixel
+    size_t topo_pix_cap = 0;
 
     // grid surgery on the device (surface.hip)
     float *surf_depth = nullptr;       // [H][W] Surface::depth (surface.cc:46-50): the

@@ -65,6 +65,9 @@ struct TopoArgs {
     // that touch none of them
     uint8_t *border_node;
     int only_candidates;
+    // create_subview_surfaces: depth and its pixel derivatives of the surface at
+    // every pixel of a valid patch, [H][W][3] doubles (topo_pixel_surface_kernel)
+    double *pix;
 };
 
 __device__ __forceinline__ void
@@ -254,6 +257,34 @@ group_all(bool ok, int G, int lane, double *red)
     return (b & gmask) == gmask;
 }
 
+// ---- the surface at every pixel of every valid patch: depth w and its pixel
+// derivatives wx, wy.  The visibility kernel needs them per (pixel, neighbour)
+// and, for the NCC samples, per (sample, neighbour): evaluated here ONCE per
+// pixel with the expressions that kernel used per neighbour (patch_eval of
+// topo_math.h: the same bits), 8 x less bicubic arithmetic for 8 neighbours.
+__global__ void __launch_bounds__(256)
+topo_pixel_surface_kernel(TopoArgs A)
+{
+#pragma clang fp contract(off)
+    int const pp = A.ps * A.ps;
+    long long const gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int const p = (int)(gid >> (2 * A.ps_log2));
+    int const k = (int)(gid & (pp - 1));
+    if (p >= A.num_patches || !A.patch_valid[p])
+        return;
+    double n16[16];
+    load_patch_nodes(A, p, n16);
+    int const i = k & (A.ps - 1), j = k >> A.ps_log2;
+    // (x / ps == x * (1 / ps) exactly: ps is a power of two)
+    double const u = (i + 0.5) * A.inv_ps, v = (j + 0.5) * A.inv_ps;
+    int const x = A.start_x + (p % A.npx) * A.ps + i;
+    int const y = A.start_y + (p / A.npx) * A.ps + j;
+    double *out = A.pix + ((size_t)y * A.W + x) * 3;
+    out[0] = smvs_topo::patch_eval(n16, u, v, 0, 0);
+    out[1] = smvs_topo::patch_eval(n16, u, v, 1, 0) * A.inv_ps;
+    out[2] = smvs_topo::patch_eval(n16, u, v, 0, 1) * A.inv_ps;
+}
+
 // ---- visibility of every patch in every neighbour (:472-590), incl.
 // ncc_for_patch (:792-912) ----
 // (192 VGPRs, two waves per SIMD; forcing three or four by launch bounds
@@ -276,8 +307,6 @@ topo_visibility_kernel(TopoArgs A)
     int const s = (int)(gid - (unsigned)p * (unsigned)A.n_subs);
     bool alive = p < A.num_patches && A.patch_valid[p];
     int const pc = alive ? p : 0;
-    double n16[16];
-    load_patch_nodes(A, pc, n16);
     int const px = A.start_x + (pc % A.npx) * ps;
     int const py = A.start_y + (pc / A.npx) * ps;
     const double *M = A.cams->M[s];
@@ -292,20 +321,12 @@ topo_visibility_kernel(TopoArgs A)
     // patch's pixels
     bool visible = true;
     double worst = 0.0;
-    // the patch depth at this lane's pixel: with one pixel per lane
-    // (G == ps^2, i.e. ps <= 16) the NCC samples below take their depth from
-    // the lane that owns the source pixel, through LDS, instead of evaluating
-    // the patch again (the same expression: the same bits)
-    __shared__ double wpix[256];
-    double w_mine = 0.0;
     if (alive)
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
-            // (x / ps == x * (1 / ps) exactly: ps is a power of two)
-            double const u = (i + 0.5) * A.inv_ps, v = (j + 0.5) * A.inv_ps;
-            double const w = smvs_topo::patch_eval(n16, u, v, 0, 0);
-            if (k == gl)
-                w_mine = w;
+            // depth and pixel derivatives of the surface (topo_pixel_surface_kernel)
+            const double *sp = A.pix + ((size_t)(py + j) * A.W + (px + i)) * 3;
+            double const w = sp[0];
             Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
             double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
             if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
@@ -319,8 +340,7 @@ topo_visibility_kernel(TopoArgs A)
                     if (wp.d * 0.95 > zbuf[(size_t)(cy + dy) * zw + (cx + dx)])
                         visible = false;
             // ratio of the squared singular values of the warp Jacobian
-            double const wx = smvs_topo::patch_eval(n16, u, v, 1, 0) * A.inv_ps;
-            double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) * A.inv_ps;
+            double const wx = sp[1], wy = sp[2];
             double jac[4];
             wp.jacobian(M, w, wx, wy, jac);
             double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
@@ -334,11 +354,6 @@ topo_visibility_kernel(TopoArgs A)
             // std::max(worst, ratio): a NaN ratio leaves worst unchanged
             worst = worst < ratio ? ratio : worst;
         }
-    bool const depth_in_lds = A.use_ncc && G == ps * ps;
-    if (depth_in_lds) {
-        wpix[threadIdx.x] = w_mine;
-        __syncthreads();
-    }
     visible = group_all(visible, G, lane, red);
     worst = group_max(worst, G, red);
     alive = alive && visible && !(worst > 8.0);
@@ -364,14 +379,17 @@ topo_visibility_kernel(TopoArgs A)
         float keep_m[NCC_KEEP][3], keep_s[NCC_KEEP][3];
         auto colours = [&](int i, double (&cm)[3], double (&cs)[3], bool check) -> bool {
             NccSample const smp = tpl[i];
+            // the depth of grid sample src is the surface at that pixel; the
+            // corner samples take the corner node's depth (:803-857)
             double depth;
-            if (smp.src >= 0)
-                depth = depth_in_lds ? wpix[(threadIdx.x & ~(G - 1)) + smp.src]
-                    : smvs_topo::patch_eval(n16,
-                        ((smp.src & (ps - 1)) + 0.5) * A.inv_ps,
-                        ((smp.src >> A.ps_log2) + 0.5) * A.inv_ps, 0, 0);
-            else
-                depth = n16[4 * (-1 - smp.src)];
+            if (smp.src >= 0) {
+                depth = A.pix[((size_t)(py + (smp.src >> A.ps_log2)) * A.W
+                    + (px + (smp.src & (ps - 1)))) * 3];
+            } else {
+                int const corner = -1 - smp.src;
+                int const n00 = (pc / A.npx) * A.stride + pc % A.npx;
+                depth = A.nodes[4 * (size_t)(n00 + (corner & 1) + (corner >> 1) * A.stride)];
+            }
             double const sx = (double)(px + smp.dx);
             double const sy = (double)(py + smp.dy);
             Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
@@ -697,6 +715,7 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     A->num_nodes = ctx->num_nodes;
     A->border_node = ctx->topo_border;
     A->only_candidates = 0;
+    A->pix = ctx->topo_pix;
     for (int i = 0; i < 9; ++i)
         A->invproj[i] = 0.0f;
     return SMVS_OK;
@@ -747,6 +766,12 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         }
     }
     size_t const npix = (size_t)ctx->width * ctx->height;
+    if (ctx->topo_pix_cap < npix * 3) {
+        ctx->topo_pix_cap = 0;
+        if ((rc = device_alloc(&ctx->topo_pix, npix * 3)) != SMVS_OK)
+            return rc;
+        ctx->topo_pix_cap = npix * 3;
+    }
     if (sgm_depth != nullptr && ctx->topo_sgm_cap < npix) {
         if ((rc = device_alloc(&ctx->topo_sgm, npix)) != SMVS_OK)
             return rc;
@@ -787,6 +812,11 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
             zh = std::max(zh, ctx->images[1 + s].h + 1);
         }
         hipLaunchKernelGGL(topo_dilate_kernel, dim3((zw + 255) / 256, zh, ctx->n_subs),
+            dim3(256), 0, ctx->stream, A);
+    }
+    {
+        long long const pixels = (long long)ctx->num_patches * ctx->patchsize * ctx->patchsize;
+        hipLaunchKernelGGL(topo_pixel_surface_kernel, dim3((unsigned)((pixels + 255) / 256)),
             dim3(256), 0, ctx->stream, A);
     }
     long long const group = group_size(ctx->patchsize, VIS_WORKGROUP_FROM);
