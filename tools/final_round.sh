@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): everything the round's profiles/ hold.
 # Usage: final_round.sh [round]
-R=${1:-r3}
+R=${1:-r4}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.txt 2>&1
