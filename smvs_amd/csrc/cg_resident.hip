@@ -408,7 +408,12 @@ assemble_rim_block(ResArgs const &A, int mx, int my, int s, double *dst16)
 constexpr int TRACE_ITERS = 12, TRACE_POINTS = 8;
 // after the iteration rows: four prologue stamps of every workgroup
 constexpr int TRACE_BLOCK_BASE = (TRACE_ITERS + 1) * TRACE_POINTS;
-constexpr int TRACE_TOTAL = TRACE_BLOCK_BASE + 4 * RES_MAX_BLOCKS;
+// ... and four stamps of every workgroup in iteration TRACE_SKEW_ITER of the
+// one-exchange solver (start, sums published, totals received, halo collected):
+// how far apart the tiles run
+constexpr int TRACE_SKEW_BASE = TRACE_BLOCK_BASE + 4 * RES_MAX_BLOCKS;
+constexpr int TRACE_SKEW_ITER = 5;
+constexpr int TRACE_TOTAL = TRACE_SKEW_BASE + 4 * RES_MAX_BLOCKS;
 
 __device__ __forceinline__ void
 st_agent(double *p, double v)
@@ -1513,8 +1518,13 @@ cg_resident_kernel(ResArgs A)
         double xbr = 0.0;       // x.(b + r) of the current vectors
         double zr_part = 0.0;   // this node's z.r, formed where z is (end of the last iteration)
         __amdgpu_buffer_rsrc_t const zbuf = pair_buffer(A.zg, (size_t)A.num_nodes * 64);
+        auto skew = [&](int k, int point, int who) {
+            if (A.trace != nullptr && k == TRACE_SKEW_ITER && tid == who)
+                A.trace[TRACE_SKEW_BASE + 4 * blockIdx.x + point] = (long long)wall_clock64();
+        };
         for (int k = 1; alive && k < A.max_iterations; ++k) {
             stamp(k, 0);
+            skew(k, 0, 0);
             double acc[4] = { 0.0, 0.0, 0.0, 0.0 };   // q = H d
             double dself[4];
             tile_product(G, dtile, yl, fb, hd, hu, low, up, mine, acc, dself);
@@ -1560,6 +1570,7 @@ cg_resident_kernel(ResArgs A)
             }
             publish_rim();
             stamp(k, 2);
+            skew(k, 1, 0);
             // Waves 1 and 2 run the two-level all-reduce; wave 0 meanwhile collects
             // the q of the halo nodes into LDS.
             auto fetch_halo = [&](int first, int step) {
@@ -1578,6 +1589,7 @@ cg_resident_kernel(ResArgs A)
                     if (tid < 64) {
                         fetch_halo(tid, 64);
                         stamp(k, 7);
+                        skew(k, 3, 0);
                     }
                 },
                 [&]() {},
@@ -1589,6 +1601,7 @@ cg_resident_kernel(ResArgs A)
             if (!alive)
                 break;
             stamp(k, 3);
+            skew(k, 2, 0);
             double const dq = v8[0], rq = v8[1], qq = v8[2], s1 = v8[3], wq = v8[4],
                 dr = v8[5], rr = v8[6];
             // z.r of the current vectors, summed directly like r.r (d_1 = z_0:
@@ -2189,6 +2202,10 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                 std::fprintf(f, "block %d %lld %lld %lld %lld\n", b,
                     tr[TRACE_BLOCK_BASE + 4 * b], tr[TRACE_BLOCK_BASE + 4 * b + 1],
                     tr[TRACE_BLOCK_BASE + 4 * b + 2], tr[TRACE_BLOCK_BASE + 4 * b + 3]);
+            for (int b = 0; b < num_tiles; ++b)
+                std::fprintf(f, "skew %d %lld %lld %lld %lld\n", b,
+                    tr[TRACE_SKEW_BASE + 4 * b], tr[TRACE_SKEW_BASE + 4 * b + 1],
+                    tr[TRACE_SKEW_BASE + 4 * b + 2], tr[TRACE_SKEW_BASE + 4 * b + 3]);
             std::fclose(f);
         }
     }

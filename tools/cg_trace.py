@@ -30,7 +30,26 @@ for block in open(path).read().split("solve")[1:]:
     lines = block.strip().split("\n")
     blocks = np.array([[int(x) for x in l.split()[1:]] for l in lines if l.startswith("block")],
                       dtype=np.int64)
-    lines = [l for l in lines if not l.startswith("block")]
+    skew = np.array([[int(x) for x in l.split()[1:]] for l in lines if l.startswith("skew")],
+                    dtype=np.int64)
+    lines = [l for l in lines if not l.startswith("block") and not l.startswith("skew")]
+    if len(skew) and skew[:, 1].min() > 0:
+        t0 = skew[:, 1].min()
+        print("  iteration 5 over the %d workgroups, us after the first one started it:" % len(skew))
+        for name, col in (("iteration start", 1), ("sums published", 2), ("totals received", 3),
+                          ("halo collected", 4)):
+            v = (skew[:, col] - t0) / 100.0
+            print("    %-16s min %6.2f  median %6.2f  max %6.2f  (last: workgroup %d)"
+                  % (name, v.min(), np.median(v), v.max(), int(skew[np.argmax(v), 0])))
+        lead = (skew[:, 0] % 16 == 0)
+        for name, m in (("group leaders", lead), ("members", ~lead)):
+            if m.any():
+                print("    %-13s start median %6.2f, sums median %6.2f, totals median %6.2f"
+                      % (name, np.median((skew[m, 1] - t0) / 100.0), np.median((skew[m, 2] - t0) / 100.0),
+                         np.median((skew[m, 3] - t0) / 100.0)))
+        own = (skew[:, 2] - skew[:, 1]) / 100.0
+        print("    start -> sums published inside a workgroup: min %.2f median %.2f max %.2f us"
+              % (own.min(), np.median(own), own.max()))
     if len(blocks):
         # (wall_clock64: one 100 MHz counter for the whole device)
         rel = (blocks[:, 1:] - blocks[:, 1].min()) / 100.0
