@@ -284,7 +284,9 @@ smvs_pinned_alloc(size_t bytes, void **out)
             }
     }
     void *p = nullptr;
-    hipError_t const e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    // (portable: one process may drive several devices -- ViewQueue(N, ...) --
+    // and a pooled buffer outlives the view that allocated it)
+    hipError_t const e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
