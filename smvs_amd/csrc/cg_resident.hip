@@ -40,6 +40,8 @@
 #include <sys/file.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
@@ -76,6 +78,8 @@ struct ResExchange {
     unsigned long long lvl1[2][RES_MAX_BLOCKS][RES_KINDS][2];    // [parity][wg][kind]
     unsigned long long lvl2[2][RES_MAX_GROUPS][RES_KINDS][2];    // [parity][group][kind]
     unsigned timeout;
+    // XCD-aware exchange: slot -> solve tag of the workgroup that took it
+    unsigned claim[RES_MAX_BLOCKS];
 };
 
 struct ResArgs {
@@ -83,7 +87,12 @@ struct ResArgs {
     const double *Pinv;      // [N][16]
     const double *g;         // [N][4]
     double *x, *b;           // [N][4], touched by the owning thread only
-    unsigned long long *zg;  // [N][4][2] z of the rim nodes as tagged granules
+    unsigned long long *zg;  // two-exchange solver: [N][4][2] z of the rim nodes as tagged
+                             // granules; one-exchange solver: [2][N][4][2] q of the rim
+                             // nodes as tagged pairs, double-buffered by iteration parity
+    unsigned long long *zl;  // XCD-aware exchange: [2][blocks][top, bottom, left, right] q of
+                             // a tile's four sides for the neighbours on its own XCD
+                             // (ordinary stores, never leave the XCD's L2)
     ResExchange *ex;
     ResState *state;         // [2] (state[0] is written at the end)
     int *status;
@@ -91,9 +100,16 @@ struct ResArgs {
     int solve_tag;
     int num_nodes, stride, rows;
     int tw, th, tiles_x, num_tiles;
+    // XCD-aware exchange (see grid_allreduce_xcd): 0 off, 1 on, 2 test hook
+    // (workgroups claim each other's slots).  The tiles of an XCD form a
+    // region of region_w x region_h tiles, regions_x regions side by side;
+    // lead_m: which tile of a region sums the XCD; zl_row / zl_col: bytes of a
+    // row / column segment of `zl`
+    int xcd, regions_x, region_w, region_h, lead_m, zl_row, zl_col;
     int max_iterations;
     double q_tolerance, fixed_tolerance;
     long long *trace;        // debug: 100 MHz wall-clock stamps (or nullptr)
+    int trace_wg;            // ... of this workgroup's iterations (SMVS_CG_TRACE_WG)
     int pipelined;           // bit 0: launch-ahead Newton loop (update.hip), bit 1:
                              // report a failure (test hook)
     // fused assembly (the Newton loop): per-patch systems instead of H / g / P
@@ -105,6 +121,10 @@ struct ResArgs {
     double *scalars;
     int npx, npy;
     const double *zeros;     // 16 doubles of +0.0 (a block that does not contribute)
+    // polling cadence of the one-exchange solver (units of s_sleep(8) = 512
+    // cycles ~ 0.25 us): before the halo's first poll, before a group
+    // member's first poll of the group sums, between two polls
+    int wait_halo, wait_member, wait_poll;
 };
 
 // GaussNewtonStep::construct's scatter (gauss_newton_step.cc:88-142) in gather
@@ -405,7 +425,7 @@ assemble_rim_block(ResArgs const &A, int mx, int my, int s, double *dst16)
     }
 }
 
-constexpr int TRACE_ITERS = 12, TRACE_POINTS = 8;
+constexpr int TRACE_ITERS = 12, TRACE_POINTS = 12;
 // after the iteration rows: four prologue stamps of every workgroup
 constexpr int TRACE_BLOCK_BASE = (TRACE_ITERS + 1) * TRACE_POINTS;
 // ... and four stamps of every workgroup in iteration TRACE_SKEW_ITER of the
@@ -413,7 +433,9 @@ constexpr int TRACE_BLOCK_BASE = (TRACE_ITERS + 1) * TRACE_POINTS;
 // how far apart the tiles run
 constexpr int TRACE_SKEW_BASE = TRACE_BLOCK_BASE + 4 * RES_MAX_BLOCKS;
 constexpr int TRACE_SKEW_ITER = 5;
-constexpr int TRACE_TOTAL = TRACE_SKEW_BASE + 4 * RES_MAX_BLOCKS;
+// ... and eight stamps of every wave of workgroup SMVS_CG_TRACE_WG in the same iteration
+constexpr int TRACE_WAVE_BASE = TRACE_SKEW_BASE + 4 * RES_MAX_BLOCKS;
+constexpr int TRACE_TOTAL = TRACE_WAVE_BASE + 8 * 8;
 
 __device__ __forceinline__ void
 st_agent(double *p, double v)
@@ -421,6 +443,20 @@ st_agent(double *p, double v)
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
         (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a
+// release fence at workgroup scope: s_waitcnt vmcnt(0) in front of the
+// s_barrier, so every wave that had published rim values sat at the next
+// barrier until the fabric had acknowledged its write-through stores -- 2 to
+// 2.8 us in EVERY iteration of the one-exchange solver (cg_trace.py, "sweep
+// wave starts"; profiles/r4_cg_barrier.txt).  Nothing in this kernel passes
+// data between the threads of a workgroup through global memory: what
+// crosses workgroups carries its own tag, everything else is LDS.
+__device__ __forceinline__ void
+lds_barrier(void)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // A double that crosses workgroups travels as two 8-byte granules {tag, 32
@@ -445,28 +481,152 @@ ld_agent(const double *p)
     return __longlong_as_double((long long)v);
 }
 
+// Cross-lane sums without the LDS pipe.  __shfl_xor of a double is two
+// ds_bpermute_b32, and the CU has ONE LDS unit for its eight waves: the eight
+// butterflies of an exchange (8 kinds x 6 steps x 2 words x 8 waves = 768
+// bpermutes) kept it busy for ~2.5 us per iteration -- the largest single item
+// of an iteration, found with the per-wave stamps of tools/cg_trace.py
+// (profiles/r4_cg_waves.txt).  gfx950 has what is needed on the VALU:
+// v_permlane32_swap / v_permlane16_swap exchange halves / rows between two
+// registers, DPP row rotations cover the 16 lanes of a row.
+typedef unsigned int uint2_r __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double
+join_words(unsigned lo, unsigned hi)
+{
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// HALF = 32: on return the lower 32 lanes hold x[l] + x[l + 32], the upper 32
+// lanes y[l - 32] + y[l] -- one step of a reduce-scatter over two kinds (with
+// y = x: a butterfly step).  HALF = 16: the same between the even and the odd
+// rows of 16 lanes.  Every pair is summed as (lower lane) + (upper lane).
+template <int HALF>
+__device__ __forceinline__ double
+swap_add(double x, double y)
+{
+    unsigned long long const xb = (unsigned long long)__double_as_longlong(x);
+    unsigned long long const yb = (unsigned long long)__double_as_longlong(y);
+    uint2_r lo, hi;
+    if constexpr (HALF == 32) {
+        lo = __builtin_amdgcn_permlane32_swap((unsigned)xb, (unsigned)yb, false, false);
+        hi = __builtin_amdgcn_permlane32_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32),
+            false, false);
+    } else {
+        lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+        hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32),
+            false, false);
+    }
+    // .x: [x of the lower half | y of the lower half], .y: [x of the upper half |
+    // y of the upper half]
+    return join_words(lo.x, hi.x) + join_words(lo.y, hi.y);
+}
+
+template <int ROR>
+__device__ __forceinline__ double
+row_rotated(double v)
+{
+    unsigned long long const b = (unsigned long long)__double_as_longlong(v);
+    int const lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x120 + ROR, 0xf, 0xf,
+        false);
+    int const hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x120 + ROR, 0xf,
+        0xf, false);
+    return join_words((unsigned)lo, (unsigned)hi);
+}
+
+// Sum over the 16 lanes of a row, every lane gets it (bit-identical in all of
+// them: after the rotation by 8 the values have period 8, so the two lanes of
+// every later pair add the same two numbers).
+__device__ __forceinline__ double
+row_sum(double v)
+{
+    v += row_rotated<8>(v);
+    v += row_rotated<4>(v);
+    v += row_rotated<2>(v);
+    v += row_rotated<1>(v);
+    return v;
+}
+
 // First half of a workgroup sum of K per-thread values: the per-wave sums go
 // to red[K][RES_WAVES]; after the barrier inside, the sum of kind k is
-// red[k][0] + ... + red[k][RES_WAVES - 1] in that order (block_total).
+// red[k][0] + ... + red[k][RES_WAVES - 1] in that order (block_total).  The
+// wave sums are a reduce-scatter: across the halves of the wave a lane keeps
+// half of its kinds, across the rows of a half a quarter; what is left (two
+// kinds of eight) is summed over the row.  Fixed order, the same in every wave
+// and workgroup.
+template <int K>
+__device__ __forceinline__ void
+wave_partials(double const (&v)[K], double *red /*[K][RES_WAVES]*/)
+{
+    constexpr int P = K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : 8;   // kinds, padded
+    static_assert(K <= 8, "block_partials: at most eight kinds");
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        a[i] = i < K ? v[i] : 0.0;
+    // halves of the wave
+    constexpr int N1 = P > 1 ? P / 2 : 1;
+#pragma unroll
+    for (int i = 0; i < N1; ++i)
+        a[i] = swap_add<32>(a[i], P > 1 ? a[i + N1] : a[i]);
+    // rows of a half
+    constexpr int N2 = N1 > 1 ? N1 / 2 : 1;
+#pragma unroll
+    for (int i = 0; i < N2; ++i)
+        a[i] = swap_add<16>(a[i], N1 > 1 ? a[i + N2] : a[i]);
+#pragma unroll
+    for (int i = 0; i < N2; ++i)
+        a[i] = row_sum(a[i]);
+    // which kinds this lane's row holds: bit 5 of the lane chose among the
+    // halves of a[0 .. P), bit 4 among the halves of what was left
+    int const b5 = lane >> 5, b4 = (lane >> 4) & 1;
+    int const first = (P > 1 ? b5 * N1 : 0) + (N1 > 1 ? b4 * N2 : 0);
+    if ((lane & 15) == 0 && (P > 1 || b5 == 0) && (N1 > 1 || b4 == 0)) {
+#pragma unroll
+        for (int i = 0; i < N2; ++i)
+            if (first + i < K)
+                red[(first + i) * RES_WAVES + wave] = a[i];
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void
 block_partials(double const (&v)[K], double *red /*[K][RES_WAVES]*/)
 {
-    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double s = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            s += __shfl_xor(s, off);
-        if (lane == 0)
-            red[k * RES_WAVES + wave] = s;
-    }
-    __syncthreads();
+    wave_partials<K>(v, red);
+    lds_barrier();
     // (no second barrier: the partials are next written by the following
     // block_partials, and every thread passes the caller's barrier behind the
     // sweep first)
 }
+
+// The same without the workgroup barrier: every wave raises its own tag behind
+// its partial sums (LDS serves a wave's requests in order), and only the waves
+// that need the workgroup's sums wait for the eight tags -- the others go on
+// to their stores and polls.  The slots are safe to reuse: whoever reads them
+// does so before the barrier at the end of the exchange, and they are written
+// again only behind it.
+struct PartialTags {
+    volatile unsigned *tag;     // [RES_WAVES]
+    __device__ __forceinline__ void raise(unsigned t) const
+    {
+        if ((threadIdx.x & 63) == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tag[threadIdx.x >> 6] = t;
+        }
+    }
+    // wave-uniform; false after a bounded wait
+    __device__ __forceinline__ bool wait(unsigned t) const
+    {
+        for (unsigned spins = 0; !__all(tag[threadIdx.x & (RES_WAVES - 1)] == t); ++spins) {
+            if (spins > (1u << 22))
+                return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return true;
+    }
+};
 
 __device__ __forceinline__ double
 block_total(const double *red, int k)
@@ -510,7 +670,7 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
 #pragma unroll
         for (int k = 0; k < K; ++k)
             v[k] = block_total(red, k);
-        __syncthreads();   // (the partial sums are free for the next reduction)
+        lds_barrier();   // (the partial sums are free for the next reduction)
         return true;
     }
     // (nothing to drain: everything that crosses workgroups is a granule, the
@@ -583,7 +743,7 @@ grid_allreduce(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
     } else {
         idle();
     }
-    __syncthreads();
+    lds_barrier();
     // The results live apart from the partial sums, so two workgroup barriers
     // per all-reduce are enough (one inside block_partials, this one): results and
     // flags are next written behind the next all-reduce's first barrier, which
@@ -620,6 +780,26 @@ st_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double
     __builtin_amdgcn_raw_buffer_store_b128(w, buf, (int)byte_offset, 0, AUX_SC1);
 }
 
+// The same pair as an ordinary store: it stops in the L2 of the writer's XCD,
+// where an `sc1` load of a workgroup ON THE SAME XCD finds it (0.25 us from
+// store to sight instead of 0.55, and no fabric write: tools/xcd_probe.hip).
+// Workgroups of other XCDs never see it.
+__device__ __forceinline__ void
+st_pair16_xcd_local(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double v)
+{
+    unsigned long long const bits = (unsigned long long)__double_as_longlong(v);
+    uint4_r const w = { (unsigned)bits, tag, (unsigned)(bits >> 32), tag };
+    __builtin_amdgcn_raw_buffer_store_b128(w, buf, (int)byte_offset, 0, 0);
+}
+
+__device__ __forceinline__ unsigned
+xcc_id(void)
+{
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xFu;
+}
+
 __device__ __forceinline__ bool
 ld_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double *v)
 {
@@ -631,23 +811,34 @@ ld_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double
 
 // The four doubles of one node's exchanged vector (64 bytes): four 16-byte
 // loads per poll until all carry `want`; false after a bounded wait.
+__device__ __forceinline__ void
+nap(int units)
+{
+    for (int i = 0; i < units; ++i)
+        __builtin_amdgcn_s_sleep(8);
+}
+
 __device__ __forceinline__ bool
-poll_node_pairs(__amdgpu_buffer_rsrc_t buf, unsigned node, unsigned want,
-    ResExchange *ex, double (&out)[4])
+poll_node_pairs(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned want,
+    ResExchange *ex, double (&out)[4], int gap = 0)
 {
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            ok &= ld_pair16(buf, (node * 4u + (unsigned)q) * 16u, want, &out[q]);
+            ok &= ld_pair16(buf, byte_offset + (unsigned)q * 16u, want, &out[q]);
         if (ok)
             return true;
-        if (spins > (1u << 18)) {
+        if (spins > (1u << 18)
+            || ((spins & 255u) == 255u
+                && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED,
                 __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
+        nap(gap);
         asm volatile("" ::: "memory");   // (the loads are re-issued every round)
     }
 }
@@ -658,7 +849,7 @@ poll_node_pairs(__amdgpu_buffer_rsrc_t buf, unsigned node, unsigned want,
 // bounded wait.
 __device__ __forceinline__ bool
 poll_pairs(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, bool active, unsigned tag,
-    ResExchange *ex, double *value)
+    ResExchange *ex, double *value, int gap = 0, unsigned *rounds = nullptr)
 {
     double got = 0.0;
     bool mine_ok = !active;
@@ -668,6 +859,8 @@ poll_pairs(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, bool active, unsign
             mine_ok = ld_pair16(buf, byte_offset, tag, &got);
         if (__all(mine_ok))
             break;
+        if (rounds != nullptr)
+            *rounds += 1;
         if (spins > (1u << 18)
             || ((spins & 255u) == 255u
                 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
@@ -678,20 +871,79 @@ poll_pairs(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, bool active, unsign
             break;
         }
         __builtin_amdgcn_s_sleep(1);
+        nap(gap);
         asm volatile("" ::: "memory");
     }
     *value = active ? got : 0.0;
+    if (rounds != nullptr)
+        *rounds += 1;
     return good;
 }
 
-// Sum over the 16 lanes of an aligned segment, fixed order, every lane gets it.
+// Sum over the 16 / 32 lanes of an aligned segment, fixed order, every lane gets it.
 __device__ __forceinline__ double
 segment16_sum(double v)
 {
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1)
-        v += __shfl_xor(v, off);
-    return v;
+    return row_sum(v);
+}
+
+__device__ __forceinline__ double
+segment32_sum(double v)
+{
+    return row_sum(swap_add<16>(v, v));
+}
+
+// Who publishes the sums of an exchange.  On gfx9 loads and stores share ONE
+// counter (vmcnt): a wave that has issued a write-through store cannot see the
+// result of a later load before the fabric has acknowledged that store.  The
+// sweeping waves live on their polls, so the workgroup's sums -- and, in a
+// group's first workgroup, the group's sums, which the sweeping waves hand
+// over through LDS -- are stored by the last wave, which never waits for a
+// load.  (The rim's q is published by the owners of the nodes: one wave
+// issuing all ~380 write-through stores of a tile was measured and is far
+// slower, the issue rate of such stores is what counts there.)
+// (the wave of the middle rows of a tile: the fewest rim nodes, so the fewest
+// write-through stores of its own in front of the sums)
+constexpr int RES_SUM_WAVE = 5;
+
+// LDS mailbox between the sweeping waves and the publishing wave of a group's
+// first workgroup: value first, then the tag (LDS serves a wave's requests in
+// order), read in the opposite order.
+struct GroupMailbox {
+    volatile double *value;     // [RES_KINDS]
+    volatile unsigned *tag;     // [RES_KINDS]
+    __device__ __forceinline__ void put(int kind, unsigned t, double v) const
+    {
+        value[kind] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tag[kind] = t;
+    }
+    // (one lane per kind) false after a bounded wait
+    __device__ __forceinline__ bool take(int kind, unsigned t, double *v) const
+    {
+        for (unsigned spins = 0; tag[kind] != t; ++spins) {
+            if (spins > (1u << 22))
+                return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *v = value[kind];
+        return true;
+    }
+};
+
+__device__ __forceinline__ GroupMailbox
+group_mailbox(double *red)
+{
+    double *base = red + RES_KINDS * RES_WAVES + RES_KINDS + (RES_KINDS + 1) / 2;
+    return { base, reinterpret_cast<volatile unsigned *>(base + RES_KINDS) };
+}
+
+__device__ __forceinline__ PartialTags
+partial_tags(double *red)
+{
+    double *base = red + RES_KINDS * RES_WAVES + RES_KINDS + (RES_KINDS + 1) / 2
+        + RES_KINDS + (RES_KINDS + 1) / 2;
+    return { reinterpret_cast<volatile unsigned *>(base) };
 }
 
 // All-reduce of K doubles over the workgroups in two levels.  The flat sweep
@@ -702,21 +954,25 @@ segment16_sum(double v)
 // pairs), publishes the group's sums, and every workgroup sums the <= 16
 // groups: 2 x 16 x K pairs per workgroup and exchange instead of 256 x K, two
 // hops instead of one.  Lane (kind, j) of the sweeping waves 1 .. (K + 3) / 4
-// handles member / group j of one kind; the other waves run `idle`.  Same
-// guarantees as the flat form: fixed summation order (a tree over the members
-// of a group, then a tree over the groups), bit-identical results in every
-// workgroup, slots double-buffered by epoch parity, bounded waits.
-template <int K, typename Idle, typename AfterPublish, typename Mark>
+// handles member / group j of one kind; the other waves run `others(wave)`.
+// Same guarantees as the flat form: fixed summation order (a tree over the
+// members of a group, then a tree over the groups), bit-identical results in
+// every workgroup, slots double-buffered by epoch parity, bounded waits.
+template <int K, typename Others, typename Mark>
 __device__ __forceinline__ bool
 grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
-    double (&v)[K], double *red, int *lds_flag, Idle idle, AfterPublish after_publish,
-    Mark mark)
+    double (&v)[K], double *red, int *lds_flag, Others others, Mark mark,
+    int wait_member = 6, int wait_poll = 0)
 {
     constexpr int SWEEPERS = (K + 3) / 4;
-    static_assert(K <= RES_KINDS && 1 + SWEEPERS <= RES_WAVES, "sweeping waves");
+    static_assert(K <= RES_KINDS && 1 + SWEEPERS <= RES_SUM_WAVE, "sweeping waves");
     unsigned const tag = solve_tag | epoch;
     double *res = red + RES_KINDS * RES_WAVES;
-    block_partials<K>(v, red);
+    GroupMailbox const box = group_mailbox(red);
+    PartialTags const partials = partial_tags(red);
+    wave_partials<K>(v, red);
+    partials.raise(tag);
+    mark(20, -1);
     unsigned const par = epoch & 1u;
     int const b = (int)blockIdx.x;
     __amdgpu_buffer_rsrc_t const xbuf = pair_buffer(ex, sizeof(ResExchange));
@@ -729,62 +985,183 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
             + ((((size_t)par * RES_MAX_GROUPS + (size_t)group) * RES_KINDS + (size_t)kind) * 16));
     };
     int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
-    if (nblocks > 1 && threadIdx.x < K)
-        st_pair16(xbuf, lvl1_at(b, (int)threadIdx.x), tag, block_total(red, (int)threadIdx.x));
-    after_publish();
-    int const wave = (int)(threadIdx.x >> 6) - 1;
-    if (wave >= 0 && wave < SWEEPERS) {
-        int const lane = threadIdx.x & 63;
-        int const kind = 4 * wave + (lane >> 4), j = lane & 15;
+    bool const leads = ngroups > 1 && b % RES_GROUP == 0;
+    int const wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave == RES_SUM_WAVE) {
+        bool handed = partials.wait(tag);
+        mark(21, -1);
+        if (nblocks > 1 && lane < K) {
+            st_pair16(xbuf, lvl1_at(b, lane), tag, block_total(red, lane));
+            if (leads) {
+                double part = 0.0;
+                handed = box.take(lane, tag, &part) && handed;
+                st_pair16(xbuf, lvl2_at(b / RES_GROUP, lane), tag, part);
+            }
+        }
+        if (!__all(handed) && lane == 0)
+            __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        others(wave);
+    } else if (wave >= 1 && wave <= SWEEPERS) {
+        int const kind = 4 * (wave - 1) + (lane >> 4), j = lane & 15;
         bool const kind_ok = kind < K;
         bool ok = true, ok2 = true;
         double total;
+        unsigned rounds1 = 0, rounds2 = 0;
+        mark(8, -1);
         if (nblocks == 1) {
             // a grid of one tile (the coarse scales): nothing to exchange
+            ok = partials.wait(tag);
             total = kind_ok ? block_total(red, kind) : 0.0;
         } else if (ngroups == 1) {
             // a single group: every workgroup sums its <= 16 members itself,
             // one hop instead of two
             ok = poll_pairs(xbuf, lvl1_at(j < nblocks ? j : 0, kind_ok ? kind : 0),
-                kind_ok && j < nblocks, tag, ex, &total);
+                kind_ok && j < nblocks, tag, ex, &total, wait_poll);
             total = segment16_sum(total);
         } else {
-            if (b % RES_GROUP == 0) {
+            if (leads) {
                 // this workgroup sums its group
                 int const member = b + j;
                 double part;
                 ok = poll_pairs(xbuf, lvl1_at(member < nblocks ? member : b,
-                        kind_ok ? kind : 0), kind_ok && member < nblocks, tag, ex, &part);
+                        kind_ok ? kind : 0), kind_ok && member < nblocks, tag, ex, &part,
+                    wait_poll, &rounds1);
                 part = segment16_sum(part);
-                mark(5);
+                mark(5, -1);
                 if (kind_ok && j == 0)
-                    st_pair16(xbuf, lvl2_at(b / RES_GROUP, kind), tag, part);
+                    box.put(kind, tag, part);
             } else {
-                // the group sums cannot be there yet (they are a hop behind):
-                // stay off the fabric for ~1.5 us instead of polling (measured:
-                // -0.2 us per exchange)
-                for (int i = 0; i < 6; ++i)
-                    __builtin_amdgcn_s_sleep(8);
+                // the group sums cannot be there yet (they are a hop behind)
+                nap(wait_member);
             }
+            mark(9, -1);
             ok2 = poll_pairs(xbuf, lvl2_at(j < ngroups ? j : 0, kind_ok ? kind : 0),
-                kind_ok && j < ngroups, tag, ex, &total);
+                kind_ok && j < ngroups, tag, ex, &total, wait_poll, &rounds2);
             total = segment16_sum(total);
         }
-        mark(6);
+        mark(6, -1);
+        mark(10, (long long)(rounds1 * 1000u + rounds2));
         if (kind_ok && j == 0)
             res[kind] = total;
         if (lane == 0) {
             bool flag_ok = ok && ok2;
-            // (a halo wait that gave up raises the same flag)
-            if (wave == 0 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+            // (a wait of another wave that gave up raises the same flag)
+            if (wave == 1 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT) != 0u)
                 flag_ok = false;
-            lds_flag[wave] = flag_ok ? 1 : 0;
+            lds_flag[wave - 1] = flag_ok ? 1 : 0;
         }
     } else {
-        idle();
+        others(wave);
     }
-    __syncthreads();
+    lds_barrier();
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        v[k] = res[k];
+#pragma unroll
+    for (int w = 0; w < SWEEPERS; ++w)
+        ok = ok && lds_flag[w] != 0;
+    return ok;
+}
+
+// The same all-reduce laid along the chip's XCDs.  b is the workgroup's slot
+// (see the kernel: slot % 8 is the XCD it runs on, nblocks a multiple of 8), so
+// the groups of the first level are the XCDs: a member's sums go out as
+// ORDINARY stores that stop in its XCD's L2, where ONE workgroup of the XCD
+// (`leads`: a tile in the middle of the XCD's region, whose CU has no
+// write-through stores of its own queued) reads them with `sc1` loads -- 0.25 us from store to sight instead of
+// 0.55 us through the fabric (tools/xcd_probe.hip, profiles/r4_xcd_probe.txt).
+// Only the eight group sums cross XCDs.  Lane (kind, j) of the sweeping waves
+// 1 .. (K + 1) / 2 handles member / group j of one kind (32 members per XCD at
+// 256 workgroups).  Fixed summation order (a tree over the <= 32 members of an
+// XCD, then a tree over the 8 XCDs), identical in every workgroup.
+// (Measured and dropped: a third hop that hands the totals back inside the
+// XCD, so that only eight workgroups poll through the fabric -- the 31 members
+// polling their XCD's L2 slowed its first workgroup's own polls: 9.7 instead
+// of 9.0 us per iteration.)
+template <int K, typename Others, typename Mark>
+__device__ __forceinline__ bool
+grid_allreduce_xcd(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks, int b,
+    bool leads, double (&v)[K], double *red, int *lds_flag, Others others, Mark mark,
+    int wait_member, int wait_poll)
+{
+    constexpr int SWEEPERS = (K + 1) / 2;
+    static_assert(K <= RES_KINDS && 1 + SWEEPERS <= RES_SUM_WAVE && RES_MAX_BLOCKS <= 8 * 32
+        && RES_MAX_GROUPS >= 8, "sweeping waves");
+    unsigned const tag = solve_tag | epoch;
+    double *res = red + RES_KINDS * RES_WAVES;
+    GroupMailbox const box = group_mailbox(red);
+    PartialTags const partials = partial_tags(red);
+    wave_partials<K>(v, red);
+    partials.raise(tag);
+    mark(20, -1);
+    unsigned const par = epoch & 1u;
+    __amdgpu_buffer_rsrc_t const xbuf = pair_buffer(ex, sizeof(ResExchange));
+    auto lvl1_at = [&](int wg, int kind) {
+        return (unsigned)(offsetof(ResExchange, lvl1)
+            + ((((size_t)par * RES_MAX_BLOCKS + (size_t)wg) * RES_KINDS + (size_t)kind) * 16));
+    };
+    auto lvl2_at = [&](int group, int kind) {
+        return (unsigned)(offsetof(ResExchange, lvl2)
+            + ((((size_t)par * RES_MAX_GROUPS + (size_t)group) * RES_KINDS + (size_t)kind) * 16));
+    };
+    int const xcd = b & 7;
+    int const wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave == RES_SUM_WAVE) {
+        bool handed = partials.wait(tag);
+        mark(21, -1);
+        if (lane < K) {
+            st_pair16_xcd_local(xbuf, lvl1_at(b, lane), tag, block_total(red, lane));
+            if (leads) {
+                double part = 0.0;
+                handed = box.take(lane, tag, &part) && handed;
+                st_pair16(xbuf, lvl2_at(xcd, lane), tag, part);
+            }
+        }
+        if (!__all(handed) && lane == 0)
+            __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        others(wave);
+    } else if (wave >= 1 && wave <= SWEEPERS) {
+        int const kind = 2 * (wave - 1) + (lane >> 5), j = lane & 31;
+        bool const kind_ok = kind < K;
+        bool ok = true, ok2 = true;
+        double total;
+        unsigned rounds1 = 0, rounds2 = 0;
+        mark(8, -1);
+        if (leads) {
+            // this workgroup sums its XCD: slots xcd, xcd + 8, xcd + 16, ...
+            int const member = xcd + 8 * j;
+            bool const active = kind_ok && member < nblocks;
+            double part;
+            ok = poll_pairs(xbuf, lvl1_at(active ? member : b, kind_ok ? kind : 0), active,
+                tag, ex, &part, wait_poll, &rounds1);
+            part = segment32_sum(part);
+            mark(5, -1);
+            if (kind_ok && j == 0)
+                box.put(kind, tag, part);
+        } else {
+            nap(wait_member);
+        }
+        mark(9, -1);
+        ok2 = poll_pairs(xbuf, lvl2_at(j < 8 ? j : 0, kind_ok ? kind : 0), kind_ok && j < 8,
+            tag, ex, &total, wait_poll, &rounds2);
+        total = segment32_sum(total);
+        mark(6, -1);
+        mark(10, (long long)(rounds1 * 1000u + rounds2));
+        if (kind_ok && j == 0)
+            res[kind] = total;
+        if (lane == 0) {
+            bool flag_ok = ok && ok2;
+            if (wave == 1 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                flag_ok = false;
+            lds_flag[wave - 1] = flag_ok ? 1 : 0;
+        }
+    } else {
+        others(wave);
+    }
+    lds_barrier();
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -869,7 +1246,7 @@ tile_product(TileGeom const &G, const double *dtile, double *yl, const double *f
             *dst = (double4_r){ cur.x + t[0], cur.y + t[1], cur.z + t[2],
                 cur.w + t[3] };
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (mine) {
         {
@@ -897,6 +1274,19 @@ tile_product(TileGeom const &G, const double *dtile, double *yl, const double *f
             }
         }
     }
+}
+
+// The symmetric 4 x 4 block of node `li` from its upper triangle in three
+// planes (see resident_lds_layout).
+__device__ __forceinline__ void
+load_symmetric(const double *planes, int tile_nodes, int li, double (&P)[4][4])
+{
+    const double4_r *Pu = reinterpret_cast<const double4_r *>(planes);
+    double4_r const a = Pu[li], b = Pu[tile_nodes + li], c = Pu[2 * tile_nodes + li];
+    P[0][0] = a.x; P[0][1] = a.y; P[0][2] = a.z; P[0][3] = a.w;
+    P[1][0] = a.y; P[1][1] = b.x; P[1][2] = b.y; P[1][3] = b.z;
+    P[2][0] = a.z; P[2][1] = b.y; P[2][2] = b.w; P[2][3] = c.x;
+    P[3][0] = a.w; P[3][1] = b.z; P[3][2] = c.x; P[3][3] = c.y;
 }
 
 // z = P r with the reference's operation order (block_sparse_matrix.h:276-298
@@ -950,7 +1340,7 @@ poll_node_granules(const unsigned long long *src, unsigned want, ResExchange *ex
 // LDS carve (doubles) of the two solver variants; the host sizes the launch
 // with the same function.
 struct ResLds {
-    size_t dtile, yl, Pl, fb, xl, bl, rh, Ph, qh, hinfo, red, total;
+    size_t dtile, yl, Pl, rl, fb, xl, bl, rh, Ph, qh, hinfo, red, total;
 };
 __host__ __device__ __forceinline__ ResLds
 resident_lds_layout(int tw, int th, bool one)
@@ -961,16 +1351,24 @@ resident_lds_layout(int tw, int th, bool one)
     size_t o = 0;
     L.dtile = o; o += (size_t)(tw + 2) * (th + 2) * 4;   // direction tile with halo
     L.yl = o; o += tn * 4;                               // row sums from below
-    L.Pl = o; o += 4 * tn * 4;                           // P, four row planes
+    // P: four row planes (two-exchange solver), or its upper triangle in three
+    // planes {p00 p01 p02 p03} {p11 p12 p13 p22} {p23 p33 - -} (one-exchange
+    // solver: ldl_inverse4 forms P[c1][c2] and P[c2][c1] from the same products
+    // in the same order, so P is symmetric to the bit) -- the 16 KB saved hold
+    // r there, which frees eight registers in a kernel that spills
+    L.Pl = o; o += (one ? 3 : 4) * tn * 4;
+    L.rl = o; o += one ? tn * 4 : 0;                     // r (one-exchange solver)
     L.fb = o; o += (size_t)(3 * tw + 3 * th) * 16;       // rim blocks
     L.xl = o; o += tn * 4;                               // x
     L.bl = o; o += one ? 0 : tn * 4;                     // b (two-exchange solver only)
     L.rh = o; o += one ? ring * 4 : 0;                   // r of the halo nodes
     L.Ph = o; o += one ? ring * 16 : 0;                  // P of the halo nodes
     L.qh = o; o += one ? ring * 4 : 0;                   // q of the halo nodes (one iteration)
-    L.hinfo = o; o += one ? (ring + 1) / 2 : 0;          // node id per halo slot (ints)
+    L.hinfo = o; o += one ? ring : 0;                    // per halo slot: node id, place in zl (ints)
     L.red = o; o += RES_KINDS * RES_WAVES + RES_KINDS;   // partial sums + results
     o += (RES_KINDS + 1) / 2;                            // flags (ints)
+    o += RES_KINDS + (RES_KINDS + 1) / 2;                // group mailbox: values, tags (ints)
+    o += (RES_WAVES + 1) / 2;                            // tags of the waves' partial sums (ints)
     L.total = o;
     return L;
 }
@@ -999,10 +1397,13 @@ resident_lds_layout(int tw, int th, bool one)
 // BEFORE the all-reduce and collected by the wave that does not sweep, while
 // the sweep runs), so it forms the halo's z and d itself, bit-identical with
 // the owner's.
-template <bool FUSED, bool ONE>
+template <bool FUSED, bool ONE, bool XCD, bool TRACE>
 __global__ void __launch_bounds__(RES_THREADS, 2)
 cg_resident_kernel(ResArgs A)
 {
+    // (the stamps of tools/cg_trace.py cost registers in a kernel that has none
+    // to spare: they are compiled into instantiations of their own)
+    bool const tracing = TRACE && A.trace != nullptr;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // launch-ahead Newton loop: the loop ended (or a solve gave up) while this
     // launch was already enqueued -- every workgroup reads the same words
@@ -1014,21 +1415,78 @@ cg_resident_kernel(ResArgs A)
     ResLds const L = resident_lds_layout(tw, th, ONE);
     double *dtile = lds + L.dtile;                        // [LH*LW][4]
     double *yl = lds + L.yl;                              // [tile_nodes][4]
-    double *Pl = lds + L.Pl;                              // [4][tile_nodes][4]
+    double *Pl = lds + L.Pl;                              // [4 | 3][tile_nodes][4]
+    double *rl = lds + L.rl;                              // [tile_nodes][4] (ONE)
     double *fb = lds + L.fb;                              // [3*tw + 3*th][16]
     double *xl = lds + L.xl;                              // [tile_nodes][4]
     double *bl = lds + L.bl;                              // [tile_nodes][4] (!ONE)
     double *rh = lds + L.rh;                              // [ring][4] (ONE)
     double *Ph = lds + L.Ph;                              // [ring][16] (ONE)
     double *qhl = lds + L.qh;                             // [ring][4] (ONE)
-    int *hnode = reinterpret_cast<int *>(lds + L.hinfo);  // [ring] (ONE)
+    int *hnode = reinterpret_cast<int *>(lds + L.hinfo);  // [2][ring] (ONE)
     double *red = lds + L.red;
     int *flag = reinterpret_cast<int *>(red + RES_KINDS * RES_WAVES + RES_KINDS);
 
     int const tid = threadIdx.x;
     int const nblocks = (int)gridDim.x;
     int const tile = (int)blockIdx.x;
-    int const ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    // XCD-aware launch: the tiles of an XCD are a rectangle of region_w x
+    // region_h tiles, so most neighbours of a tile share its XCD (and its L2):
+    // their halo goes through `zl` with ordinary stores; only what crosses a
+    // region's border goes through the fabric.  Workgroups of tiles beyond the
+    // grid own no node and only take part in the all-reduce.
+    constexpr bool xcd_on = ONE && XCD;
+    // The dispatcher deals consecutive workgroups round-robin over the XCDs but
+    // does not start every launch on XCD 0 (tools/xcd_probe.hip, part C: the
+    // start moves with the launches before it).  What holds is that every
+    // aligned group of eight consecutive workgroups covers the eight XCDs, so a
+    // workgroup's place in the exchange is (its group of eight, the XCD it
+    // finds itself on) -- `slot` replaces blockIdx.x everywhere below.  Each
+    // workgroup claims its slot; a slot claimed twice means the placement is
+    // not what this relies on: the solve is given up at once and the host
+    // repeats it (and runs all later ones of this process) with the
+    // device-scope exchange.
+    int slot = tile;
+    if (xcd_on) {
+        unsigned const xcc = A.xcd == 2 ? xcc_id() & 6u : xcc_id();   // (2: test hook)
+        slot = (tile & ~7) | (int)(xcc & 7u);
+        if (tid == 0
+            && __hip_atomic_exchange(&A.ex->claim[slot], (unsigned)A.solve_tag,
+                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.solve_tag) {
+            __hip_atomic_store(A.progress + 6, 1, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&A.ex->timeout, 1u, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    int tx, ty;
+    int const tiles_y = (A.rows + th - 1) / th;
+    // region of a tile, slot of a tile of THIS region
+    int const reg_w = xcd_on ? A.region_w : 1, reg_h = xcd_on ? A.region_h : 1;
+    int const region_x = xcd_on ? (slot & 7) % A.regions_x : 0;
+    int const region_y = xcd_on ? (slot & 7) / A.regions_x : 0;
+    if (xcd_on) {
+        int const m = slot >> 3;
+        tx = region_x * reg_w + m % reg_w;
+        ty = region_y * reg_h + m / reg_w;
+    } else {
+        ty = tile / A.tiles_x;
+        tx = tile - ty * A.tiles_x;
+    }
+    auto tile_exists = [&](int x, int y) {
+        return x >= 0 && x < A.tiles_x && y >= 0 && y < tiles_y;
+    };
+    auto same_xcd = [&](int x, int y) {
+        return xcd_on && tile_exists(x, y) && x / reg_w == region_x && y / reg_h == region_y;
+    };
+    // `zl`: per workgroup the segments top, bottom (zl_row bytes each), left,
+    // right (zl_col): every segment on cache lines of its own
+    unsigned const zl_tile = 2u * (unsigned)A.zl_row + 2u * (unsigned)A.zl_col;
+    auto zl_segment = [&](int x, int y, int side) {
+        int const wg = ((y % reg_h) * reg_w + x % reg_w) * 8 + (slot & 7);
+        return (unsigned)wg * zl_tile + (side < 2 ? (unsigned)side * (unsigned)A.zl_row
+            : 2u * (unsigned)A.zl_row + (unsigned)(side - 2) * (unsigned)A.zl_col);
+    };
     int const lx = tid % tw, ly = tid / tw;
     int const gx = tx * tw + lx, gy = ty * th + ly;
     bool const mine = tid < tile_nodes && gx < A.stride && gy < A.rows;
@@ -1040,6 +1498,28 @@ cg_resident_kernel(ResArgs A)
     // (a grid of one tile has no neighbours: nothing is published)
     bool const rim = nblocks > 1 && mine
         && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
+    // XCD-aware: does a tile of another XCD read this node (-> `zg`, through the
+    // fabric), and which of the tile's side segments in `zl` does a tile of this
+    // XCD read it from (corners: the diagonal neighbours read the ROW segments)
+    bool rim_far = false;
+    unsigned rim_near = 0;   // bit 0 top, 1 bottom, 2 left, 3 right
+    if (xcd_on && rim) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                if ((dx == 0 && dy == 0) || (dx < 0 && lx != 0) || (dx > 0 && lx != tw - 1)
+                    || (dy < 0 && ly != 0) || (dy > 0 && ly != th - 1)
+                    || !tile_exists(tx + dx, ty + dy))
+                    continue;
+                if (!same_xcd(tx + dx, ty + dy))
+                    rim_far = true;
+                else if (dy != 0)
+                    rim_near |= dy < 0 ? 1u : 2u;
+                else
+                    rim_near |= dx < 0 ? 4u : 8u;
+            }
+    }
     size_t const N = (size_t)A.num_nodes;
 
     // halo ring position served by this thread
@@ -1056,17 +1536,29 @@ cg_resident_kernel(ResArgs A)
         hx = LW - 1; hy = tid - 2 * LW - th + 1;
     }
     int halo_node = -1, halo_ix = 0, halo_iy = 0;
-    if (has_halo) {
+    if (has_halo && tile_exists(tx, ty)) {
         halo_ix = tx * tw + hx - 1;
         halo_iy = ty * th + hy - 1;
         if (halo_ix >= 0 && halo_ix < A.stride && halo_iy >= 0 && halo_iy < A.rows)
             halo_node = halo_iy * A.stride + halo_ix;
     }
     int const lhalo = hy * LW + hx;
+    // XCD-aware: where in `zl` the node's q appears (-1: in `zg`)
+    int halo_near = -1;
+    if (xcd_on && halo_node >= 0) {
+        int const dx = hx == 0 ? -1 : hx == LW - 1 ? 1 : 0;
+        int const dy = hy == 0 ? -1 : hy == LH - 1 ? 1 : 0;
+        if (same_xcd(tx + dx, ty + dy)) {
+            // from the row segments where there is a choice (the corners)
+            int const side = dy < 0 ? 1 : dy > 0 ? 0 : dx < 0 ? 3 : 2;
+            int const idx = dy != 0 ? (dx < 0 ? tw - 1 : dx > 0 ? 0 : hx - 1) : hy - 1;
+            halo_near = (int)(zl_segment(tx + dx, ty + dy, side) + (unsigned)idx * 64u);
+        }
+    }
 
-    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+    if (tracing && blockIdx.x == 0 && tid == 0)
         A.trace[0] = (long long)wall_clock64();
-    if (A.trace != nullptr && tid == 0)
+    if (tracing && tid == 0)
         A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 0] = (long long)wall_clock64();
     // tag of the exchanged vectors: the solve id and the iteration that reads them
     unsigned const ztag = (unsigned)A.solve_tag;
@@ -1116,11 +1608,20 @@ cg_resident_kernel(ResArgs A)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 r[k] = -gg[k];
+            if (ONE) {
+                double4_r *Pu = reinterpret_cast<double4_r *>(Pl);
+                Pu[li] = (double4_r){ Pfull[0], Pfull[1], Pfull[2], Pfull[3] };
+                Pu[tile_nodes + li] = (double4_r){ Pfull[5], Pfull[6], Pfull[7], Pfull[10] };
+                Pu[2 * tile_nodes + li] = (double4_r){ Pfull[11], Pfull[15], 0.0, 0.0 };
+                *reinterpret_cast<double4_r *>(rl + (size_t)li * 4)
+                    = (double4_r){ r[0], r[1], r[2], r[3] };
+            } else {
 #pragma unroll
-            for (int row = 0; row < 4; ++row)
-                *reinterpret_cast<double4_r *>(Pl + ((size_t)row * tile_nodes + li) * 4)
-                    = (double4_r){ Pfull[row * 4 + 0], Pfull[row * 4 + 1],
-                        Pfull[row * 4 + 2], Pfull[row * 4 + 3] };
+                for (int row = 0; row < 4; ++row)
+                    *reinterpret_cast<double4_r *>(Pl + ((size_t)row * tile_nodes + li) * 4)
+                        = (double4_r){ Pfull[row * 4 + 0], Pfull[row * 4 + 1],
+                            Pfull[row * 4 + 2], Pfull[row * 4 + 3] };
+            }
             precondition(Pfull, r, z);
             *reinterpret_cast<double4_r *>(xl + (size_t)li * 4)
                 = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
@@ -1155,9 +1656,10 @@ cg_resident_kernel(ResArgs A)
         // registers of the upper blocks are occupied.
         for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
             dtile[i] = 0.0;   // (out-of-grid halo stays zero for the whole solve)
-        __syncthreads();
+        lds_barrier();
         if (has_halo) {
             hnode[tid] = halo_node;
+            hnode[ring + tid] = halo_near;
             // r and P of the halo node, with the operations of its owner
             double Ph16[16], gh[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
@@ -1297,9 +1799,9 @@ cg_resident_kernel(ResArgs A)
             A.g + (size_t)n * 4) : (double4_r){ 0, 0, 0, 0 };
         gnode[0] = gv.x; gnode[1] = gv.y; gnode[2] = gv.z; gnode[3] = gv.w;
     }
-    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+    if (tracing && blockIdx.x == 0 && tid == 0)
         A.trace[2] = (long long)wall_clock64();   // own blocks in registers
-    if (A.trace != nullptr && tid == 0)
+    if (tracing && tid == 0)
         A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 1] = (long long)wall_clock64();
     // `low` holds two bits per lower slot s = 0..3 <-> (dx, dy) = (-1,-1),
     // (0,-1), (1,-1), (-1,0): 0 neighbour outside the grid, 1 neighbour inside
@@ -1359,9 +1861,9 @@ cg_resident_kernel(ResArgs A)
                 assemble_rim_block(A, nx, ny, rs, fb + (size_t)r * 16);
         }
     }
-    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+    if (tracing && blockIdx.x == 0 && tid == 0)
         A.trace[3] = (long long)wall_clock64();   // rim blocks in LDS
-    if (A.trace != nullptr && tid == 0)
+    if (tracing && tid == 0)
         A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 2] = (long long)wall_clock64();
     // upper slots 5..8 <-> (dx, dy) = (1,0), (-1,1), (0,1), (1,1)
 #pragma unroll
@@ -1382,9 +1884,9 @@ cg_resident_kernel(ResArgs A)
             dtile[i] = 0.0;
         init_own();
     }
-    if (A.trace != nullptr && blockIdx.x == 0 && tid == 0)
+    if (tracing && blockIdx.x == 0 && tid == 0)
         A.trace[4] = (long long)wall_clock64();   // P, r, z done
-    if (A.trace != nullptr && tid == 0)
+    if (tracing && tid == 0)
         A.trace[TRACE_BLOCK_BASE + 4 * blockIdx.x + 3] = (long long)wall_clock64();
     st.q0 = -0.0;
     st.iter = 1;
@@ -1394,7 +1896,7 @@ cg_resident_kernel(ResArgs A)
     st.rr = st.tol = st.gnorm = 0.0;
 
     auto stamp = [&](int k, int point) {
-        if (A.trace != nullptr && blockIdx.x == 0 && tid == 0 && k <= TRACE_ITERS)
+        if (tracing && (int)blockIdx.x == A.trace_wg && tid == 0 && k <= TRACE_ITERS)
             A.trace[k * TRACE_POINTS + point] = (long long)wall_clock64();
     };
     if constexpr (!ONE) {
@@ -1430,7 +1932,7 @@ cg_resident_kernel(ResArgs A)
                         zh[2] + beta * old.z, zh[3] + beta * old.w };
                 }
             }
-            __syncthreads();
+            lds_barrier();
             stamp(k, 1);
             double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
             double dself[4];
@@ -1513,48 +2015,105 @@ cg_resident_kernel(ResArgs A)
         }
     } else {
         // ---- one exchange per iteration ----
-        __syncthreads();          // d_1 (own and halo) in the tile
+        lds_barrier();          // d_1 (own and halo) in the tile
         stamp(0, 1);
         double xbr = 0.0;       // x.(b + r) of the current vectors
         double zr_part = 0.0;   // this node's z.r, formed where z is (end of the last iteration)
-        __amdgpu_buffer_rsrc_t const zbuf = pair_buffer(A.zg, (size_t)A.num_nodes * 64);
+        __amdgpu_buffer_rsrc_t const zbuf = pair_buffer(A.zg, (size_t)A.num_nodes * 128);
+        unsigned const zl_plane = (unsigned)nblocks * zl_tile;   // one parity of `zl`
+        __amdgpu_buffer_rsrc_t const lbuf = pair_buffer(A.zl, (size_t)2 * zl_plane);
+        // (both areas are one allocation: one descriptor for the halo's loads)
+        unsigned const zl_base = (unsigned)((A.zl - A.zg) * sizeof(unsigned long long));
+        __amdgpu_buffer_rsrc_t const hbuf = pair_buffer(A.zg, (size_t)zl_base + 2 * zl_plane);
+        // byte offset of a node's four pairs in `zg`: by node id
+        auto zg_at = [&](unsigned par, unsigned node) {
+            return ((par * (unsigned)A.num_nodes + node) * 4u) * 16u;
+        };
+        // ... of this thread's node in the four side segments of its tile in `zl`
+        unsigned const zl_top = zl_segment(tx, ty, 0) + (unsigned)lx * 64u;
+        unsigned const zl_bottom = zl_segment(tx, ty, 1) + (unsigned)lx * 64u;
+        unsigned const zl_left = zl_segment(tx, ty, 2) + (unsigned)ly * 64u;
+        unsigned const zl_right = zl_segment(tx, ty, 3) + (unsigned)ly * 64u;
         auto skew = [&](int k, int point, int who) {
-            if (A.trace != nullptr && k == TRACE_SKEW_ITER && tid == who)
+            if (tracing && k == TRACE_SKEW_ITER && tid == who)
                 A.trace[TRACE_SKEW_BASE + 4 * blockIdx.x + point] = (long long)wall_clock64();
         };
         for (int k = 1; alive && k < A.max_iterations; ++k) {
             stamp(k, 0);
             skew(k, 0, 0);
+            auto sweep_mark = [&](int point, long long value) {
+                if (point >= 16) {
+                    // per-wave stamps of one iteration
+                    if (tracing && (int)blockIdx.x == A.trace_wg
+                        && (tid & 63) == 0 && k == TRACE_SKEW_ITER)
+                        A.trace[TRACE_WAVE_BASE + 8 * (tid >> 6) + point - 16]
+                            = (long long)wall_clock64();
+                    return;
+                }
+                if (tracing && (int)blockIdx.x == A.trace_wg && tid == 64
+                    && k <= TRACE_ITERS)
+                    A.trace[k * TRACE_POINTS + point] = value >= 0 ? value
+                        : (long long)wall_clock64();
+            };
+            sweep_mark(16, -1);
             double acc[4] = { 0.0, 0.0, 0.0, 0.0 };   // q = H d
             double dself[4];
             tile_product(G, dtile, yl, fb, hd, hu, low, up, mine, acc, dself);
             stamp(k, 1);
+            sweep_mark(17, -1);
             // the sums (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
             double v8[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-            // the rim's q for the neighbouring tiles' halo.  It goes out BEFORE
-            // the partial sums although the all-reduce waits for those: a
-            // write-through store takes ~3 us to become visible to a poll on a
-            // busy chip, and issuing the rim later made every exchange later
-            // (measured: 11.5 instead of 9.3 us per iteration)
+            // The rim's q for the neighbouring tiles' halo.  XCD-aware: only what
+            // a tile of another region reads goes through the fabric, the rest
+            // stays in the XCD's L2.
+            unsigned const hpar = (unsigned)k & 1u;
             auto publish_rim = [&]() {
                 if (rim) {
+                    unsigned const t = ztag + (unsigned)k;
+                    if (!xcd_on || rim_far) {
+                        unsigned const at = zg_at(hpar, (unsigned)n);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        st_pair16(zbuf, ((unsigned)n * 4u + (unsigned)q) * 16u,
-                            ztag + (unsigned)k, acc[q]);
+                        for (int q = 0; q < 4; ++q)
+                            st_pair16(zbuf, at + (unsigned)q * 16u, t, acc[q]);
+                    }
+                    if (xcd_on) {
+                        unsigned const places[4] = { zl_top, zl_bottom, zl_left, zl_right };
+#pragma unroll
+                        for (int side = 0; side < 4; ++side)
+                            if ((rim_near >> side) & 1u) {
+                                unsigned const at = hpar * zl_plane + places[side];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    st_pair16_xcd_local(lbuf, at + (unsigned)q * 16u, t,
+                                        acc[q]);
+                            }
+                    }
                 }
             };
+            // (as soon as q is known, in front of the sums although the exchange
+            // waits for those: the write-through stores of a CU drain slowly,
+            // ~380 of them in 3-5 us, and issuing them takes a wave up to 1 us --
+            // behind the sums, the halo arrived 3 us later; here the issue
+            // overlaps the arithmetic of the sums.  Also measured and dropped:
+            // the rim staged in LDS and stored behind the sums by two waves as
+            // whole 64-byte records, four lanes per node -- fewer, fuller
+            // writes, but the halo arrives late: 9.9 instead of 9.1 us.)
+            publish_rim();
+            sweep_mark(19, -1);
             if (mine) {
 #pragma clang fp contract(off)
+                double Pn[4][4];
+                load_symmetric(Pl, tile_nodes, li, Pn);
+                double4_r const rv = *reinterpret_cast<const double4_r *>(
+                    rl + (size_t)li * 4);
+                double const r[4] = { rv.x, rv.y, rv.z, rv.w };
 #pragma unroll
                 for (int row = 0; row < 4; ++row) {
-                    double4_r const p = *reinterpret_cast<const double4_r *>(
-                        Pl + ((size_t)row * tile_nodes + li) * 4);
                     double wi = 0.0;
-                    wi += p.x * acc[0];
-                    wi += p.y * acc[1];
-                    wi += p.z * acc[2];
-                    wi += p.w * acc[3];
+                    wi += Pn[row][0] * acc[0];
+                    wi += Pn[row][1] * acc[1];
+                    wi += Pn[row][2] * acc[2];
+                    wi += Pn[row][3] * acc[3];
                     v8[3] += 2.0 * (wi * r[row]);
                     v8[4] += wi * acc[row];
                 }
@@ -1568,36 +2127,45 @@ cg_resident_kernel(ResArgs A)
                 }
                 v8[7] = zr_part;
             }
-            publish_rim();
+            sweep_mark(18, -1);
             stamp(k, 2);
             skew(k, 1, 0);
-            // Waves 1 and 2 run the two-level all-reduce; wave 0 meanwhile collects
-            // the q of the halo nodes into LDS.
-            auto fetch_halo = [&](int first, int step) {
-                for (int hs = first; hs < ring; hs += step) {
+            // The sweeping waves run the two-level all-reduce; wave 0 meanwhile
+            // collects the q of the halo nodes into LDS.
+            // (Measured and dropped: four adjacent lanes reading the four pairs of
+            // one node, a quarter of the requests per poll round -- the extra
+            // registers cost more than the requests: 174 instead of 176 M
+            // patch-steps/s.)
+            auto fetch_halo = [&]() {
+                if (nblocks > 1)
+                    nap(A.wait_halo);
+                for (int hs = tid; hs < ring; hs += 64) {
                     int const node = hnode[hs];
                     double qv[4] = { 0.0, 0.0, 0.0, 0.0 };
-                    if (node >= 0)
-                        (void)poll_node_pairs(zbuf, (unsigned)node, ztag + (unsigned)k,
-                            A.ex, qv);
+                    if (node >= 0) {
+                        int const near = xcd_on ? hnode[ring + hs] : -1;
+                        (void)poll_node_pairs(hbuf, near >= 0
+                                ? zl_base + hpar * zl_plane + (unsigned)near
+                                : zg_at(hpar, (unsigned)node),
+                            ztag + (unsigned)k, A.ex, qv, A.wait_poll);
+                    }
                     *reinterpret_cast<double4_r *>(qhl + (size_t)hs * 4)
                         = (double4_r){ qv[0], qv[1], qv[2], qv[3] };
                 }
             };
-            alive = grid_allreduce_tree<8>(A.ex, ztag, epoch++, nblocks, v8, red, flag,
-                [&]() {
-                    if (tid < 64) {
-                        fetch_halo(tid, 64);
-                        stamp(k, 7);
-                        skew(k, 3, 0);
-                    }
-                },
-                [&]() {},
-                [&](int point) {
-                    if (A.trace != nullptr && blockIdx.x == 0 && tid == 64
-                        && k <= TRACE_ITERS)
-                        A.trace[k * TRACE_POINTS + point] = (long long)wall_clock64();
-                });
+            auto other_waves = [&](int wave) {
+                if (wave == 0) {
+                    fetch_halo();
+                    stamp(k, 7);
+                    skew(k, 3, 0);
+                }
+            };
+            if constexpr (xcd_on)
+                alive = grid_allreduce_xcd<8>(A.ex, ztag, epoch++, nblocks, slot,
+                    (slot >> 3) == A.lead_m, v8, red, flag, other_waves, sweep_mark, A.wait_member, A.wait_poll);
+            else
+                alive = grid_allreduce_tree<8>(A.ex, ztag, epoch++, nblocks, v8, red, flag,
+                    other_waves, sweep_mark, A.wait_member, A.wait_poll);
             if (!alive)
                 break;
             stamp(k, 3);
@@ -1646,19 +2214,21 @@ cg_resident_kernel(ResArgs A)
                     *xp = (double4_r){ xv.x + alpha * dself[0], xv.y + alpha * dself[1],
                         xv.z + alpha * dself[2], xv.w + alpha * dself[3] };
                     if (!done) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            r[q] = r[q] - alpha * acc[q];
+                        double4_r *rp = reinterpret_cast<double4_r *>(rl + (size_t)li * 4);
+                        double4_r const rv = *rp;
+                        double const r[4] = { rv.x - alpha * acc[0], rv.y - alpha * acc[1],
+                            rv.z - alpha * acc[2], rv.w - alpha * acc[3] };
+                        *rp = (double4_r){ r[0], r[1], r[2], r[3] };
+                        double Pn[4][4];
+                        load_symmetric(Pl, tile_nodes, li, Pn);
                         double zn[4];
 #pragma unroll
                         for (int row = 0; row < 4; ++row) {
-                            double4_r const p = *reinterpret_cast<const double4_r *>(
-                                Pl + ((size_t)row * tile_nodes + li) * 4);
                             double zi = 0.0;
-                            zi += p.x * r[0];
-                            zi += p.y * r[1];
-                            zi += p.z * r[2];
-                            zi += p.w * r[3];
+                            zi += Pn[row][0] * r[0];
+                            zi += Pn[row][1] * r[1];
+                            zi += Pn[row][2] * r[2];
+                            zi += Pn[row][3] * r[3];
                             zn[row] = zi;
                         }
                         {
@@ -1710,7 +2280,7 @@ cg_resident_kernel(ResArgs A)
             st.info = info;
             if (done)
                 break;
-            __syncthreads();      // d_{k+1} in the tile
+            lds_barrier();      // d_{k+1} in the tile
         }
     }
 
@@ -1796,7 +2366,65 @@ choose_tiling(int stride, int rows, int max_tiles, bool one, int *tw_out, int *t
 struct ResidentPlan {
     int tw, th;
     bool one;
+    // launch: workgroups; XCD-aware exchange: regions_x x (8 / regions_x)
+    // regions of region_w x region_h tiles, one per XCD (regions_x = 0: tiles
+    // in row-major order, device-scope exchange everywhere)
+    int blocks, regions_x, region_w, region_h;
 };
+
+// XCD-aware exchange (grid_allreduce_xcd and the region mapping of the tiles):
+// SMVS_CG_XCD=1 turns it on, =2 also makes workgroups claim each other's slots
+// (test of the failover).  Off by default: it keeps two thirds of the rim
+// traffic and the first hop of the all-reduce inside the XCDs' L2s and still
+// measures 1.5 % BEHIND the device-scope exchange on the full grid (174 against
+// 176.5 M patch-steps/s, profiles/r4_cg_exchange.txt) -- what bounds an
+// exchange is the second hop and the skew between the tiles, not the fabric
+// traffic.  Switched off for the rest of the process when a launch finds two
+// workgroups of an aligned group of eight on the same XCD.
+static std::atomic<bool> g_xcd_exchange_off{false};
+
+static int
+xcd_exchange_mode(void)
+{
+    static int const env = [] {
+        const char *e = std::getenv("SMVS_CG_XCD");
+        return e != nullptr ? std::atoi(e) : 0;
+    }();
+    return g_xcd_exchange_off.load(std::memory_order_relaxed) ? 0 : env;
+}
+
+static void
+finish_plan(const smvs_ctx *ctx, int max_tiles, ResidentPlan *plan)
+{
+    int const stride = ctx->node_stride, rows = ctx->num_nodes / stride;
+    int const tiles_x = (stride + plan->tw - 1) / plan->tw;
+    int const tiles_y = (rows + plan->th - 1) / plan->th;
+    plan->blocks = tiles_x * tiles_y;
+    plan->regions_x = plan->region_w = plan->region_h = 0;
+    // two levels only pay on grids of more than one group of the device-scope
+    // tree; eight XCDs on every MI355X partition this runs on
+    if (!plan->one || plan->blocks <= RES_GROUP || xcd_exchange_mode() == 0)
+        return;
+    // the split of the tile grid into 8 regions with the fewest rim nodes on
+    // region borders (what still crosses XCDs), among those that fit the chip
+    long best = -1;
+    for (int rx = 1; rx <= 8; rx *= 2) {
+        int const ry = 8 / rx;
+        int const w = (tiles_x + rx - 1) / rx, h = (tiles_y + ry - 1) / ry;
+        if (8 * w * h > max_tiles)
+            continue;
+        long const crossing = (long)(rx - 1) * tiles_y * plan->th
+            + (long)(ry - 1) * tiles_x * plan->tw;
+        if (best < 0 || crossing < best) {
+            best = crossing;
+            plan->regions_x = rx;
+            plan->region_w = w;
+            plan->region_h = h;
+        }
+    }
+    if (best >= 0)
+        plan->blocks = 8 * plan->region_w * plan->region_h;
+}
 
 static bool
 resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
@@ -1818,6 +2446,7 @@ resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
             plan->tw = tw;
             plan->th = th;
             plan->one = false;
+            finish_plan(ctx, max_tiles, plan);
             return true;
         }
     } else if (ctx->solver_mode == SMVS_SOLVER_RESIDENT_REF) {
@@ -1828,6 +2457,7 @@ resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
     plan->tw = tw;
     plan->th = th;
     plan->one = true;
+    finish_plan(ctx, max_tiles, plan);
     return true;
 }
 
@@ -1997,8 +2627,7 @@ cg_resident_tiles(smvs_ctx *ctx)
     }
     if (!resident_plan(ctx, &plan))
         return 0;
-    int const stride = ctx->node_stride, rows = ctx->num_nodes / stride;
-    return ((stride + plan.tw - 1) / plan.tw) * ((rows + plan.th - 1) / plan.th);
+    return plan.blocks;
 }
 
 // Launches the solver (the caller holds its tiles of the budget and has checked
@@ -2019,9 +2648,15 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         return SMVS_ERR_STATE;
     }
     int const tw = plan.tw, th = plan.th;
-    int const tiles_x = (stride + tw - 1) / tw, tiles_y = (rows + th - 1) / th;
-    int const num_tiles = tiles_x * tiles_y;
+    int const tiles_x = (stride + tw - 1) / tw;
+    int const num_tiles = plan.blocks;   // workgroups of the launch
     bool const one = plan.one;
+    // the side segments of a tile in the XCD-local halo buffer: tw / th nodes
+    // of 64 bytes, each on cache lines of its own; room for the largest tiling
+    // (tw, th <= 128: two planes of 256 tiles of 4 segments of 8 KB)
+    size_t const zl_row = ((size_t)tw * 64 + 127) / 128 * 128;
+    size_t const zl_col = ((size_t)th * 64 + 127) / 128 * 128;
+    size_t const zl_doubles = (size_t)2 * RES_MAX_BLOCKS * 4 * (128 * 64) / sizeof(double);
     size_t const lds_bytes = resident_lds_bytes(tw, th, one);
 
     int rc;
@@ -2032,22 +2667,30 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
             ctx->stream));
     }
+    // (the solver takes grids of at most RES_MAX_BLOCKS tiles of RES_THREADS nodes)
+    size_t const zx_nodes = std::min(ctx->cap_nodes, (size_t)RES_MAX_BLOCKS * RES_THREADS);
     if (ctx->res_zx_cap < (size_t)ctx->num_nodes) {
-        if ((rc = device_alloc(&ctx->res_zx, ctx->cap_nodes * 8)) != SMVS_OK) {
+        // [2][zx_nodes][4][2] words of `zg`, then `zl` at its largest (tw <= 128,
+        // four row segments per workgroup)
+        if ((rc = device_alloc(&ctx->res_zx, zx_nodes * 16 + zl_doubles)) != SMVS_OK) {
             ctx->res_zx_cap = 0;
             return rc;
         }
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0,
-            ctx->cap_nodes * 8 * sizeof(double), ctx->stream));
-        ctx->res_zx_cap = ctx->cap_nodes;
+            (zx_nodes * 16 + zl_doubles) * sizeof(double), ctx->stream));
+        ctx->res_zx_cap = zx_nodes;
     }
     static bool attr_set[16] = { false };
     if (ctx->device < 16 && !attr_set[ctx->device]) {
-        const void *kernels[4] = {
-            reinterpret_cast<const void *>(cg_resident_kernel<false, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<false, true>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, true>) };
+        const void *kernels[8] = {
+            reinterpret_cast<const void *>(cg_resident_kernel<false, false, false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, false, false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<false, true, false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true, false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<false, true, true, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true, true, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true, false, true>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true, true, true>) };
         for (const void *k : kernels)
             SMVS_HIP_CHECK(hipFuncSetAttribute(k,
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2061,6 +2704,16 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.x = ctx->x;
     A.b = ctx->b;
     A.zg = reinterpret_cast<unsigned long long *>(ctx->res_zx);
+    A.zl = reinterpret_cast<unsigned long long *>(ctx->res_zx + ctx->res_zx_cap * 16);
+    A.xcd = plan.regions_x != 0 ? xcd_exchange_mode() : 0;
+    A.regions_x = plan.regions_x;
+    A.region_w = plan.region_w;
+    A.region_h = plan.region_h;
+    // the XCD is summed by a tile in the middle of its region: no neighbour on
+    // another XCD, so no write-through store of its own in front of the sums
+    A.lead_m = (plan.region_h / 2) * plan.region_w + plan.region_w / 2;
+    A.zl_row = (int)zl_row;
+    A.zl_col = (int)zl_col;
     A.ex = reinterpret_cast<ResExchange *>(ctx->res_work);
     A.state = reinterpret_cast<ResState *>(ctx->cg_state);
     A.status = ctx->status;
@@ -2075,7 +2728,7 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
             ctx->stream));
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0,
-            ctx->res_zx_cap * 8 * sizeof(double), ctx->stream));
+            (ctx->res_zx_cap * 16 + zl_doubles) * sizeof(double), ctx->stream));
     }
     A.solve_tag = ctx->cg_solve_id << 16;
     A.num_nodes = ctx->num_nodes;
@@ -2097,33 +2750,80 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.npx = ctx->npx;
     A.npy = ctx->npy;
     A.zeros = ctx->zero_block;
+    {
+        // polling cadence (the measured defaults; SMVS_CG_WAIT="halo,member,poll"
+        // overrides them for experiments): the device-scope exchange gains 1.5 us
+        // per iteration when the halo's polls start 1 us late (they compete with
+        // the write-through stores of the rim), the XCD-aware one does not
+        struct Knobs { int halo = -1, member = 3, poll = 0; };
+        static Knobs const knobs = [] {
+            Knobs k;
+            if (const char *e = std::getenv("SMVS_CG_WAIT"))
+                (void)std::sscanf(e, "%d,%d,%d", &k.halo, &k.member, &k.poll);
+            return k;
+        }();
+        A.wait_halo = knobs.halo >= 0 ? knobs.halo : A.xcd != 0 ? 0 : 4;
+        A.wait_member = knobs.member;
+        A.wait_poll = knobs.poll;
+    }
     A.trace = trace_dev;
+    {
+        static int const wg = [] {
+            const char *e = std::getenv("SMVS_CG_TRACE_WG");
+            return e != nullptr ? std::atoi(e) : 0;
+        }();
+        A.trace_wg = wg;
+    }
     A.pipelined = pipelined ? (test_give_up ? 3 : 1) : 0;
     *solve_tag_out = A.solve_tag;
     *num_tiles_out = num_tiles;
     {
         ScopedKernelTimer timer(ctx, SMVS_K_CG_RESIDENT);
-        if (fused && one)
-            hipLaunchKernelGGL((cg_resident_kernel<true, true>), dim3(num_tiles),
-                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(num_tiles), dim3(RES_THREADS), lds_bytes,
+                ctx->stream, A);
+        };
+        bool const xcd = A.xcd != 0;
+        // (stamps: the fused one-exchange kernels only, what tools/cg_trace.py runs)
+        if (fused && one && trace_dev != nullptr && xcd)
+            launch(cg_resident_kernel<true, true, true, true>);
+        else if (fused && one && trace_dev != nullptr)
+            launch(cg_resident_kernel<true, true, false, true>);
+        else if (fused && one && xcd)
+            launch(cg_resident_kernel<true, true, true, false>);
+        else if (fused && one)
+            launch(cg_resident_kernel<true, true, false, false>);
         else if (fused)
-            hipLaunchKernelGGL((cg_resident_kernel<true, false>), dim3(num_tiles),
-                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+            launch(cg_resident_kernel<true, false, false, false>);
+        else if (one && xcd)
+            launch(cg_resident_kernel<false, true, true, false>);
         else if (one)
-            hipLaunchKernelGGL((cg_resident_kernel<false, true>), dim3(num_tiles),
-                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+            launch(cg_resident_kernel<false, true, false, false>);
         else
-            hipLaunchKernelGGL((cg_resident_kernel<false, false>), dim3(num_tiles),
-                dim3(RES_THREADS), lds_bytes, ctx->stream, A);
+            launch(cg_resident_kernel<false, false, false, false>);
     }
     SMVS_HIP_CHECK(hipGetLastError());
     return SMVS_OK;
 }
 
-size_t
-cg_resident_exchange_bytes(void)
+// A resident solve gave up (the caller has waited for the kernel).  Workgroups
+// that were not all resident: never try again on this context, the streaming
+// kernels take over.  A workgroup on an unexpected XCD: the resident solver
+// stays, the XCD-aware exchange goes for the rest of the process.
+int
+cg_resident_gave_up(smvs_ctx *ctx)
 {
-    return sizeof(ResExchange);
+    SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange), ctx->stream));
+    volatile int *progress = ctx->cg_progress;
+    if (progress[6] != 0) {
+        progress[6] = 0;
+        if (!g_xcd_exchange_off.exchange(true))
+            std::fprintf(stderr, "[smvs_hip] eight consecutive workgroups do not cover the eight "
+                "XCDs: the resident solver exchanges at device scope from now on\n");
+        return SMVS_OK;
+    }
+    ctx->resident_disabled = true;
+    return SMVS_OK;
 }
 
 int
@@ -2202,6 +2902,12 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
                 std::fprintf(f, "block %d %lld %lld %lld %lld\n", b,
                     tr[TRACE_BLOCK_BASE + 4 * b], tr[TRACE_BLOCK_BASE + 4 * b + 1],
                     tr[TRACE_BLOCK_BASE + 4 * b + 2], tr[TRACE_BLOCK_BASE + 4 * b + 3]);
+            for (int w = 0; w < 8; ++w) {
+                std::fprintf(f, "wave %d", w);
+                for (int q = 0; q < 8; ++q)
+                    std::fprintf(f, " %lld", tr[TRACE_WAVE_BASE + 8 * w + q]);
+                std::fprintf(f, "\n");
+            }
             for (int b = 0; b < num_tiles; ++b)
                 std::fprintf(f, "skew %d %lld %lld %lld %lld\n", b,
                     tr[TRACE_SKEW_BASE + 4 * b], tr[TRACE_SKEW_BASE + 4 * b + 1],
@@ -2211,13 +2917,8 @@ cg_resident_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     }
     // (every workgroup has passed its last barrier when the result appears:
     // the kernel is draining and cannot block a barrier kernel started now)
-    if (progress[4] != 0) {
-        // not all workgroups were resident: never try again on this context
-        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
-            ctx->stream));
-        ctx->resident_disabled = true;
-        return SMVS_OK;
-    }
+    if (progress[4] != 0)
+        return cg_resident_gave_up(ctx);
     ctx->last_cg_iterations = progress[3];
     if (num_iterations != nullptr)
         *num_iterations = progress[3];

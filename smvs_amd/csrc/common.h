@@ -466,7 +466,7 @@ struct ScopedTileBudget {
 };
 int cg_resident_enqueue(smvs_ctx *ctx, int max_iterations, double q_tolerance,
     bool test_give_up = false);
-size_t cg_resident_exchange_bytes(void);   // size of ctx->res_work
+int cg_resident_gave_up(smvs_ctx *ctx);   // a resident solve failed: what runs from now on
 
 
 } // namespace smvs_hip

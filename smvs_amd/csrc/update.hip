@@ -1073,10 +1073,8 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             if (solver) {
                 // its workgroups were not all resident: never try again on
                 // this context, the caller goes on with the streaming solver
-                SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0,
-                    cg_resident_exchange_bytes(), ctx->stream));
-                ctx->resident_disabled = true;
-                return SMVS_OK;
+                // (or one of them sat on an unexpected XCD: see there)
+                return cg_resident_gave_up(ctx);
             }
             // the live list outgrew the launch: again, sized for the list
             // length that has come back in the meantime

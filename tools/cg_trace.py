@@ -32,7 +32,16 @@ for block in open(path).read().split("solve")[1:]:
                       dtype=np.int64)
     skew = np.array([[int(x) for x in l.split()[1:]] for l in lines if l.startswith("skew")],
                     dtype=np.int64)
-    lines = [l for l in lines if not l.startswith("block") and not l.startswith("skew")]
+    waves = np.array([[int(x) for x in l.split()[1:]] for l in lines if l.startswith("wave")],
+                     dtype=np.int64)
+    lines = [l for l in lines if not l.startswith(("block", "skew", "wave"))]
+    if len(waves) and waves[:, 1].min() > 0:
+        t0 = waves[:, 1].min()
+        print("  iteration 5, the waves of workgroup %s (us after the first one started the iteration):"
+              % os.environ.get("SMVS_CG_TRACE_WG", "0"))
+        print("    wave   start  product    sums  published  reduced  past the barrier")
+        for w in waves:
+            print("    %4d  " % w[0] + "  ".join("%6.2f" % ((x - t0) / 100.0) for x in w[1:7]))
     if len(skew) and skew[:, 1].min() > 0:
         t0 = skew[:, 1].min()
         print("  iteration 5 over the %d workgroups, us after the first one started it:" % len(skew))
@@ -41,7 +50,7 @@ for block in open(path).read().split("solve")[1:]:
             v = (skew[:, col] - t0) / 100.0
             print("    %-16s min %6.2f  median %6.2f  max %6.2f  (last: workgroup %d)"
                   % (name, v.min(), np.median(v), v.max(), int(skew[np.argmax(v), 0])))
-        lead = (skew[:, 0] % 16 == 0)
+        lead = (skew[:, 0] % 16 == 0)   # (device-scope exchange: the first workgroup of 16)
         for name, m in (("group leaders", lead), ("members", ~lead)):
             if m.any():
                 print("    %-13s start median %6.2f, sums median %6.2f, totals median %6.2f"
@@ -81,6 +90,10 @@ for block in open(path).read().split("solve")[1:]:
             extra = "  [after the sums: group sum %.2f, total %.2f, halo %.2f]" % (
                 (r[5] - r[2]) / 100.0 if r[5] else -1, (r[6] - r[2]) / 100.0 if r[6] else -1,
                 (r[7] - r[2]) / 100.0 if r[7] else -1)
+            if len(r) > 10 and r[8]:
+                extra += "  [sweep wave: starts %.2f, second hop from %.2f, load rounds %d + %d]" % (
+                    (r[8] - r[2]) / 100.0, (r[9] - r[2]) / 100.0 if r[9] else -1,
+                    r[10] // 1000, r[10] % 1000)
             print("  it %2d: " % k + "  ".join("%s %.2f" % (n, v / 100.0) for n, v in zip(names[1:], d))
                   + "  | total %.2f us" % ((r[4] - r[0]) / 100.0) + extra)
             continue
