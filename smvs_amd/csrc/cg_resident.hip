@@ -69,6 +69,7 @@ struct ResState {           // mirrors CgState of cg.hip
 constexpr int RES_KINDS = 8;                 // doubles per all-reduce, at most
 constexpr int RES_GROUP = 16;                                  // workgroups per first-level group
 constexpr int RES_MAX_GROUPS = RES_MAX_BLOCKS / RES_GROUP;
+constexpr int RES_REPLICAS = 16;                               // copies of the group sums
 struct ResExchange {
     // flat all-reduce (two-exchange solver): every workgroup sweeps all of these
     unsigned long long gran[2][2 * RES_KINDS][RES_MAX_BLOCKS];   // [parity][..][wg]
@@ -76,7 +77,11 @@ struct ResExchange {
     // adjacent granules; the first workgroup of a group of RES_GROUP sums its
     // group's partial sums into lvl2, every workgroup sums the groups
     unsigned long long lvl1[2][RES_MAX_BLOCKS][RES_KINDS][2];    // [parity][wg][kind]
-    unsigned long long lvl2[2][RES_MAX_GROUPS][RES_KINDS][2];    // [parity][group][kind]
+    // (RES_REPLICAS copies of the group sums, 2 KB apart: all 256 workgroups
+    // polling the same sixteen cache lines made those lines' memory channel the
+    // clock of the second hop -- a poll round there took as long as the channel
+    // needed for 4,096 line reads, and a group's store queued behind them)
+    unsigned long long lvl2[2][RES_REPLICAS][RES_MAX_GROUPS][RES_KINDS][2];   // [parity][copy][group][kind]
     unsigned timeout;
     // XCD-aware exchange: slot -> solve tag of the workgroup that took it
     unsigned claim[RES_MAX_BLOCKS];
@@ -980,9 +985,10 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
         return (unsigned)(offsetof(ResExchange, lvl1)
             + ((((size_t)par * RES_MAX_BLOCKS + (size_t)wg) * RES_KINDS + (size_t)kind) * 16));
     };
-    auto lvl2_at = [&](int group, int kind) {
+    auto lvl2_at = [&](int copy, int group, int kind) {
         return (unsigned)(offsetof(ResExchange, lvl2)
-            + ((((size_t)par * RES_MAX_GROUPS + (size_t)group) * RES_KINDS + (size_t)kind) * 16));
+            + (((((size_t)par * RES_REPLICAS + (size_t)copy) * RES_MAX_GROUPS + (size_t)group)
+                   * RES_KINDS + (size_t)kind) * 16));
     };
     int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
     bool const leads = ngroups > 1 && b % RES_GROUP == 0;
@@ -990,13 +996,16 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
     if (wave == RES_SUM_WAVE) {
         bool handed = partials.wait(tag);
         mark(21, -1);
-        if (nblocks > 1 && lane < K) {
+        if (nblocks > 1 && lane < K)
             st_pair16(xbuf, lvl1_at(b, lane), tag, block_total(red, lane));
-            if (leads) {
-                double part = 0.0;
-                handed = box.take(lane, tag, &part) && handed;
-                st_pair16(xbuf, lvl2_at(b / RES_GROUP, lane), tag, part);
-            }
+        if (leads) {
+            // lane (copy, kind): eight copies per store instruction
+            static_assert(K == 8, "eight kinds per copy");
+            double part = 0.0;
+            handed = box.take(lane & 7, tag, &part) && handed;
+#pragma unroll
+            for (int c = lane >> 3; c < RES_REPLICAS; c += 8)
+                st_pair16(xbuf, lvl2_at(c, b / RES_GROUP, lane & 7), tag, part);
         }
         if (!__all(handed) && lane == 0)
             __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1035,7 +1044,8 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
                 nap(wait_member);
             }
             mark(9, -1);
-            ok2 = poll_pairs(xbuf, lvl2_at(j < ngroups ? j : 0, kind_ok ? kind : 0),
+            ok2 = poll_pairs(xbuf, lvl2_at(b % RES_REPLICAS, j < ngroups ? j : 0,
+                    kind_ok ? kind : 0),
                 kind_ok && j < ngroups, tag, ex, &total, wait_poll, &rounds2);
             total = segment16_sum(total);
         }
@@ -1102,22 +1112,25 @@ grid_allreduce_xcd(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblo
         return (unsigned)(offsetof(ResExchange, lvl1)
             + ((((size_t)par * RES_MAX_BLOCKS + (size_t)wg) * RES_KINDS + (size_t)kind) * 16));
     };
-    auto lvl2_at = [&](int group, int kind) {
+    auto lvl2_at = [&](int copy, int group, int kind) {
         return (unsigned)(offsetof(ResExchange, lvl2)
-            + ((((size_t)par * RES_MAX_GROUPS + (size_t)group) * RES_KINDS + (size_t)kind) * 16));
+            + (((((size_t)par * RES_REPLICAS + (size_t)copy) * RES_MAX_GROUPS + (size_t)group)
+                   * RES_KINDS + (size_t)kind) * 16));
     };
     int const xcd = b & 7;
     int const wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wave == RES_SUM_WAVE) {
         bool handed = partials.wait(tag);
         mark(21, -1);
-        if (lane < K) {
+        if (lane < K)
             st_pair16_xcd_local(xbuf, lvl1_at(b, lane), tag, block_total(red, lane));
-            if (leads) {
-                double part = 0.0;
-                handed = box.take(lane, tag, &part) && handed;
-                st_pair16(xbuf, lvl2_at(xcd, lane), tag, part);
-            }
+        if (leads) {
+            static_assert(K == 8, "eight kinds per copy");
+            double part = 0.0;
+            handed = box.take(lane & 7, tag, &part) && handed;
+#pragma unroll
+            for (int c = lane >> 3; c < RES_REPLICAS; c += 8)
+                st_pair16(xbuf, lvl2_at(c, xcd, lane & 7), tag, part);
         }
         if (!__all(handed) && lane == 0)
             __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1144,8 +1157,9 @@ grid_allreduce_xcd(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblo
             nap(wait_member);
         }
         mark(9, -1);
-        ok2 = poll_pairs(xbuf, lvl2_at(j < 8 ? j : 0, kind_ok ? kind : 0), kind_ok && j < 8,
-            tag, ex, &total, wait_poll, &rounds2);
+        ok2 = poll_pairs(xbuf, lvl2_at((b >> 3) % RES_REPLICAS, j < 8 ? j : 0,
+                kind_ok ? kind : 0),
+            kind_ok && j < 8, tag, ex, &total, wait_poll, &rounds2);
         total = segment32_sum(total);
         mark(6, -1);
         mark(10, (long long)(rounds1 * 1000u + rounds2));
