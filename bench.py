@@ -57,11 +57,11 @@ FP64_PEAK_TFLOPS = 78.6
 FLOP_PER_PATCH = 0.1081e6
 FLOP_PER_PATCH_SURVEY = 0.50e6
 BYTES_PER_PATCH = 4.2e3
-# The resident PCG reads its input once per solve (1,280 + 128 B per live patch,
+# The resident PCG reads its input once per solve (1,152 + 128 B per live patch,
 # 64 B per node for x and b) and then exchanges per iteration: one two-level
 # all-reduce whose floor is two dependent cross-CU hand-offs at the idle price
 # of MI355X_MICROARCH.md's handoff-1to1 row (0.8-1.1 us each).
-RESIDENT_BYTES_PER_PATCH = 1280 + 128
+RESIDENT_BYTES_PER_PATCH = 144 * 8 + 128    # csrc/common.h PATCH_H_STRIDE doubles + the 16 of g
 RESIDENT_BYTES_PER_NODE = 64
 EXCHANGE_FLOOR_S = 2 * 1.1e-6
 CG_BYTES = {"cg_spmv": 5 * 128 + 2 * 32 + 2 * 32,      # H upper half; z, d_old; Ad, d_new
@@ -342,14 +342,14 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
                peaks_measured=peaks)
     def cg_resident_line():
         # One launch per solve.  Inside the Newton loop the kernel assembles H,
-        # g, P itself from the per-patch systems (1,280 + 128 B per live patch,
+        # g, P itself from the per-patch systems (1,152 + 128 B per live patch,
         # read once) and writes x and b; through smvs_cg_solve it reads the
         # assembled upper half of H, P and g instead.  Either way the matrix
         # then stays in registers.
         ms_k, cnt_k = prof["cg_resident"]
         fused = prof["assemble"][1] == 0
         if fused:
-            bytes_per_launch = (1280 + 128) * patch_steps / max(cnt_k, 1) + 64 * n_nodes
+            bytes_per_launch = RESIDENT_BYTES_PER_PATCH * patch_steps / max(cnt_k, 1) + 64 * n_nodes
         else:
             bytes_per_launch = (5 * 128 + 128 + 32 + 32 + 32) * n_nodes
         avg_s = ms_k * 1e-3 / max(cnt_k, 1)

@@ -202,15 +202,18 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
             // the other node, relative to this one
             int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
             bool const use = pv[q] && act[dy + 1][dx + 1];
-            const double4_r *blk = reinterpret_cast<const double4_r *>(
-                use ? Hl + upper_block(ln, lm) * 16 : A.zeros);
-            double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
             if (lm == ln) {
+                const double4_r *tri = reinterpret_cast<const double4_r *>(
+                    use ? Hl + patch_diag_offset(ln) : A.zeros);
+                double4_r const b0 = tri[0], b1 = tri[1], b2 = tri[2];
                 S.hd[0] += b0.x; S.hd[1] += b0.y; S.hd[2] += b0.z; S.hd[3] += b0.w;
-                S.hd[4] += b1.y; S.hd[5] += b1.z; S.hd[6] += b1.w;
-                S.hd[7] += b2.z; S.hd[8] += b2.w;
-                S.hd[9] += b3.w;
+                S.hd[4] += b1.x; S.hd[5] += b1.y; S.hd[6] += b1.z;
+                S.hd[7] += b1.w; S.hd[8] += b2.x;
+                S.hd[9] += b2.y;
             } else {
+                const double4_r *blk = reinterpret_cast<const double4_r *>(
+                    use ? Hl + patch_upper_offset(ln, lm) : A.zeros);
+                double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
                 int const k = (dy + 1) * 3 + dx + 1 - 5;
                 S.hu[k][0] += b0.x; S.hu[k][1] += b0.y; S.hu[k][2] += b0.z; S.hu[k][3] += b0.w;
                 S.hu[k][4] += b1.x; S.hu[k][5] += b1.y; S.hu[k][6] += b1.z; S.hu[k][7] += b1.w;
@@ -254,14 +257,14 @@ assemble_diagonal(ResArgs const &A, int ix, int iy, double (&hd)[10], double (&g
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int const ln = 3 - q;   // local index of the node in that patch
-        const double4_r *blk = reinterpret_cast<const double4_r *>(pv[q]
-            ? A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE + upper_block(ln, ln) * 16
+        const double4_r *tri = reinterpret_cast<const double4_r *>(pv[q]
+            ? A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE + patch_diag_offset(ln)
             : A.zeros);
-        double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
+        double4_r const b0 = tri[0], b1 = tri[1], b2 = tri[2];
         hd[0] += b0.x; hd[1] += b0.y; hd[2] += b0.z; hd[3] += b0.w;
-        hd[4] += b1.y; hd[5] += b1.z; hd[6] += b1.w;
-        hd[7] += b2.z; hd[8] += b2.w;
-        hd[9] += b3.w;
+        hd[4] += b1.x; hd[5] += b1.y; hd[6] += b1.z;
+        hd[7] += b1.w; hd[8] += b2.x;
+        hd[9] += b2.y;
         double4_r const gv = *reinterpret_cast<const double4_r *>(
             pv[q] ? A.gp + (size_t)pidx[q] * 16 + 4 * ln : A.zeros);
         g[0] += gv.x; g[1] += gv.y; g[2] += gv.z; g[3] += gv.w;
@@ -315,7 +318,7 @@ assemble_upper(ResArgs const &A, int ix, int iy, bool on, double (&hu)[4][16])
             int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
             bool const use = pv[q] && act[dy][dx + 1];
             const double4_r *blk = reinterpret_cast<const double4_r *>(
-                use ? Hl + upper_block(ln, lm) * 16 : A.zeros);
+                use ? Hl + patch_upper_offset(ln, lm) : A.zeros);
             double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
             int const k = (dy + 1) * 3 + dx + 1 - 5;
             hu[k][0] += b0.x; hu[k][1] += b0.y; hu[k][2] += b0.z; hu[k][3] += b0.w;
@@ -357,7 +360,7 @@ assemble_block(ResArgs const &A, int mx, int my, int slot, double *out16)
             uint8_t const fm = A.active[m];
             bool const use = act_row && inside && fp != 0 && fm != 0;
             const double4_r *blk = reinterpret_cast<const double4_r *>(use
-                ? A.Hp + (size_t)p * PATCH_H_STRIDE + upper_block(ln, lm) * 16
+                ? A.Hp + (size_t)p * PATCH_H_STRIDE + patch_upper_offset(ln, lm)
                 : A.zeros);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -409,7 +412,7 @@ assemble_rim_block(ResArgs const &A, int mx, int my, int s, double *dst16)
     for (int e = 0; e < 2; ++e) {
         bool const use = frow != 0 && inside[e] && fp[e] != 0 && fm[e] != 0;
         src[e] = reinterpret_cast<const double4_r *>(use
-            ? A.Hp + (size_t)p[e] * PATCH_H_STRIDE + upper_block(ln[e], lm[e]) * 16
+            ? A.Hp + (size_t)p[e] * PATCH_H_STRIDE + patch_upper_offset(ln[e], lm[e])
             : A.zeros);
     }
     double4_r v0[4], v1[4];

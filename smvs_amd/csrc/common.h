@@ -315,13 +315,30 @@ xcd_band_block(unsigned bid, unsigned nblocks)
     return (bid & 7u) * per + (bid >> 3);
 }
 
-// Per-patch normal equations as stored between the two kernels: the 10 node
-// blocks (bi <= bj) of the upper block triangle, [block][4][4] doubles.
-constexpr int PATCH_H_STRIDE = 160;
+// Per-patch normal equations as stored between the two kernels (144 doubles):
+// the four diagonal node blocks as their UPPER TRIANGLES, 10 entries in 12
+// doubles {h00 h01 h02 h03} {h11 h12 h13 h22} {h23 h33 - -} (the assembly never
+// read the lower triangles: gauss_newton_step.cc:103, 113-119), then the six
+// blocks (bi < bj) of the upper block triangle, [4][4] doubles each.  (Round 3:
+// all ten blocks in full, 160 doubles -- 10 % more to write and to read back.)
+constexpr int PATCH_DIAG_STRIDE = 12;
+constexpr int PATCH_H_STRIDE = 4 * PATCH_DIAG_STRIDE + 6 * 16;
+// index of (i, j), i <= j, in the packed upper triangle of a 4 x 4 (also: of
+// node block (bi, bj) among the ten blocks of the upper block triangle)
 __host__ __device__ __forceinline__ constexpr int
 upper_block(int bi, int bj)
 {
     return bi * 4 - bi * (bi - 1) / 2 + (bj - bi);
+}
+__host__ __device__ __forceinline__ constexpr int
+patch_diag_offset(int b)
+{
+    return b * PATCH_DIAG_STRIDE;
+}
+__host__ __device__ __forceinline__ constexpr int
+patch_upper_offset(int bi, int bj)   // bi < bj
+{
+    return 4 * PATCH_DIAG_STRIDE + (upper_block(bi, bj) - (bi + 1)) * 16;
 }
 
 

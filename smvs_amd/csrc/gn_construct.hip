@@ -901,19 +901,20 @@ gn_patch_kernel(PatchKernelArgs A)
         if (slot_base + q >= live_count)
             continue;
         int const patch = A.live_list[slot_base + q];
-        // Packed store: the 10 node blocks (bi <= bj) of the upper block
-        // triangle, 16 doubles each, row-major (the assembly mirrors the
-        // rest).  v_mfma_f64_4x4x4 leaves element (i, j) of block slot b in
+        // Packed store (common.h, PATCH_H_STRIDE): the upper triangles of the
+        // four diagonal node blocks, then the six blocks (bi < bj) in full,
+        // row-major (the assembly mirrors the rest).  v_mfma_f64_4x4x4 leaves element (i, j) of block slot b in
         // lane 16 i + 4 b + j, i.e. in lane (kg, col) = (i, 4 b + j).
         double *Hout = A.Hp + (size_t)patch * PATCH_H_STRIDE;
         int const bs = col >> 2, jc = col & 3;
-        Hout[upper_block(bs, bs) * 16 + kg * 4 + jc] = acc[q][0];
+        if (kg <= jc)   // (the diagonal blocks: upper triangle only, packed)
+            Hout[patch_diag_offset(bs) + upper_block(kg, jc)] = acc[q][0];
         if (bs >= 1)
-            Hout[upper_block(bs - 1, bs) * 16 + kg * 4 + jc] = acc[q][1];
+            Hout[patch_upper_offset(bs - 1, bs) + kg * 4 + jc] = acc[q][1];
         else   // block (3, 0): the transpose of the stored block (0, 3)
-            Hout[upper_block(0, 3) * 16 + jc * 4 + kg] = acc[q][1];
+            Hout[patch_upper_offset(0, 3) + jc * 4 + kg] = acc[q][1];
         if (bs >= 2)
-            Hout[upper_block(bs - 2, bs) * 16 + kg * 4 + jc] = acc[q][2];
+            Hout[patch_upper_offset(bs - 2, bs) + kg * 4 + jc] = acc[q][2];
         if (lane < 16)
             A.gp[(size_t)patch * 16 + lane] = gv;
     }
@@ -983,11 +984,12 @@ gn_assemble_kernel(AssembleArgs A)
                 // from its upper triangle
                 if (lm < ln)
                     continue;
-                const double *blk = Hl + upper_block(ln, lm) * 16;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    double const v = (lm > ln || r <= c) ? blk[r * 4 + c]
-                        : blk[c * 4 + r];
+                    double const v = lm > ln
+                        ? Hl[patch_upper_offset(ln, lm) + r * 4 + c]
+                        : Hl[patch_diag_offset(ln) + (r <= c ? upper_block(r, c)
+                                                              : upper_block(c, r))];
                     out[slot][c] += v;
                 }
             }
@@ -1375,13 +1377,15 @@ smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp)
             double *dst = Hp + p * 256;
             for (int bi = 0; bi < 4; ++bi)
                 for (int bj = bi; bj < 4; ++bj) {
-                    const double *blk = src + upper_block(bi, bj) * 16;
                     for (int r = 0; r < 4; ++r)
                         for (int c = 0; c < 4; ++c) {
-                            dst[(4 * bi + r) * 16 + 4 * bj + c] = blk[r * 4 + c];
+                            double const v = bj > bi
+                                ? src[patch_upper_offset(bi, bj) + r * 4 + c]
+                                : src[patch_diag_offset(bi) + (r <= c ? upper_block(r, c)
+                                                                      : upper_block(c, r))];
+                            dst[(4 * bi + r) * 16 + 4 * bj + c] = v;
                             if (bj > bi)
-                                dst[(4 * bj + c) * 16 + 4 * bi + r]
-                                    = blk[r * 4 + c];
+                                dst[(4 * bj + c) * 16 + 4 * bi + r] = v;
                         }
                 }
         }

@@ -1203,3 +1203,36 @@ def test_two_processes_share_one_gpu_without_losing_the_resident_solver(hip, tmp
     assert np.array_equal(np.load(str(tmp_path / "nodes0.npy")),
                           np.load(str(tmp_path / "nodes1.npy")))
     assert any(f.startswith("smvs_hip_barrier_") for f in os.listdir(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_xcd_aware_exchange_and_its_failover(hip, tmp_path):
+    """SMVS_CG_XCD=1: the tiles of an XCD form a region, the halo inside a region and
+    the first hop of the all-reduce go through the XCD's L2 with ordinary stores
+    (cg_resident.hip, grid_allreduce_xcd) -- same Newton steps as the device-scope
+    exchange, nodes equal to rounding (the sums associate differently).
+    SMVS_CG_XCD=2: workgroups claim each other's slots, as if the dispatcher had not
+    placed eight consecutive workgroups on eight XCDs: the solve is given up, the
+    process falls back to the device-scope exchange (never to the streaming kernels)
+    and ends with exactly the default's nodes."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    replies, nodes, errs = {}, {}, {}
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, SMVS_LOCK_DIR=str(tmp_path), SMVS_CG_XCD=mode)
+        out = subprocess.run([sys.executable, "-c", _SHARED_GPU_PROBE, root,
+                              str(tmp_path / ("xcd%s.npy" % mode))], env=env,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        replies[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+        nodes[mode] = np.load(str(tmp_path / ("xcd%s.npy" % mode)))
+        errs[mode] = out.stderr
+    if replies["0"]["launches"]["cg_resident"] == 0:
+        pytest.skip("the resident solver does not apply on this device")
+    for mode in ("1", "2"):
+        assert replies[mode]["launches"]["cg_spmv"] == 0, replies[mode]["launches"]
+        assert replies[mode]["steps"] == replies["0"]["steps"]
+    assert "exchanges at device scope from now on" not in errs["1"]
+    assert "exchanges at device scope from now on" in errs["2"]
+    assert np.array_equal(nodes["2"], nodes["0"])
+    np.testing.assert_allclose(nodes["1"], nodes["0"], rtol=1e-6, atol=1e-9)
