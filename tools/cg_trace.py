@@ -6,24 +6,26 @@ for each solve).  Usage: cg_trace.py [out.txt [scale]] -- scale 6 / 5 / 4: the s
 view at a coarse scale (1 / 4 / 16 tiles of the resident solver)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/cg_trace.txt"
+parse_only = len(sys.argv) > 2 and sys.argv[1] == "--parse"   # cg_trace.py --parse raw.txt
+path = sys.argv[2] if parse_only else sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/cg_trace.txt"
 os.environ["SMVS_CG_TRACE"] = path
 os.environ["SMVS_LOOP_TEST"] = "unpipelined"   # the host waits for each solve
-if os.path.exists(path):
-    os.remove(path)
 import numpy as np
-import bench, smvs_amd
-scale = int(sys.argv[2]) if len(sys.argv) > 2 else bench.SCALE
-if scale == bench.SCALE:
-    prob = bench.make_problem(0, False)
-else:
-    from smvs_amd import synth
-    prob = synth.make_problem(bench.W, bench.H, bench.NSUBS, scale, noise=bench.NOISE, seed=2000)
-surf = prob["surf"]
-ctx = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
-ctx.set_views(prob["views"]); ctx.set_surface(surf)
-ctx.run_loop(bench.REG, max_newton_steps=3, reset_active=True)
-ctx.close()
+if not parse_only:
+    if os.path.exists(path):
+        os.remove(path)
+    import bench, smvs_amd
+    scale = int(sys.argv[2]) if len(sys.argv) > 2 else bench.SCALE
+    if scale == bench.SCALE:
+        prob = bench.make_problem(0, False)
+    else:
+        from smvs_amd import synth
+        prob = synth.make_problem(bench.W, bench.H, bench.NSUBS, scale, noise=bench.NOISE, seed=2000)
+    surf = prob["surf"]
+    ctx = smvs_amd.ViewContext(surf["width"], surf["height"], bench.NSUBS)
+    ctx.set_views(prob["views"]); ctx.set_surface(surf)
+    ctx.run_loop(bench.REG, max_newton_steps=3, reset_active=True)
+    ctx.close()
 names2 = ["start", "d+halo", "spmv", "lower", "allreduce A", "update", "allreduce B"]
 names1 = ["start", "product", "P q + sums", "allreduce (+ halo q)", "update"]
 for block in open(path).read().split("solve")[1:]:
@@ -39,9 +41,13 @@ for block in open(path).read().split("solve")[1:]:
         t0 = waves[:, 1].min()
         print("  iteration 5, the waves of workgroup %s (us after the first one started the iteration):"
               % os.environ.get("SMVS_CG_TRACE_WG", "0"))
-        print("    wave   start  product    sums  published  reduced  past the barrier")
+        # stamps 16 .. 21 of the kernel: start, product done, sums formed, rim's stores issued (before the
+        # arithmetic of the sums), partial sums in LDS, (the wave that stores the sums) all eight waves' seen
+        print("    wave   start  product  rim stores issued  sums formed  partial sums in LDS  all partial sums seen")
+        cell = lambda x: "%6.2f" % ((x - t0) / 100.0) if x > 0 else "     -"
         for w in waves:
-            print("    %4d  " % w[0] + "  ".join("%6.2f" % ((x - t0) / 100.0) for x in w[1:7]))
+            print("    %4d  %s  %s  %s            %s       %s               %s"
+                  % (w[0], cell(w[1]), cell(w[2]), cell(w[4]), cell(w[3]), cell(w[5]), cell(w[6])))
     if len(skew) and skew[:, 1].min() > 0:
         t0 = skew[:, 1].min()
         print("  iteration 5 over the %d workgroups, us after the first one started it:" % len(skew))

@@ -19,3 +19,17 @@ timeout 900 bash tools/collect_profiles.sh $R > gpurun_out/${R}_collect.log 2>&1
 tail -3 gpurun_out/${R}_collect.log
 (timeout 600 python tools/fuzz_parity.py 150 0; timeout 900 python tools/fuzz_parity.py 40 1 1) > gpurun_out/${R}_fuzz_parity.txt 2>&1
 grep "^cases\|^worst\|Error\|assert" gpurun_out/${R}_fuzz_parity.txt | tail -8
+# the resident PCG without stamps: slope = one iteration, intercept = the prologue
+(timeout 300 python tools/cg_iteration_cost.py; timeout 300 python tools/cg_iteration_cost.py 3 | tail -1) > gpurun_out/${R}_cg_iteration_cost_now.txt 2>&1
+tail -2 gpurun_out/${R}_cg_iteration_cost_now.txt
+# kernel timeline of one warm optimize(), without and with the SGM initialisation
+ROOT=$(pwd)
+for mode in "" "--sgm"; do
+  tagname=tl${mode#--}
+  (cd /tmp && TMPDIR=/tmp SMVS_HOST_TIMING=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/${R}_$tagname -o run -- python $ROOT/tools/optimize_timeline.py run $mode > $ROOT/gpurun_out/${R}_${tagname}_run.txt 2>&1)
+  trace=$(find gpurun_out/${R}_$tagname -name "*kernel_trace.csv" | head -1)
+  { python tools/optimize_timeline.py report $trace; grep -a "optimize 1\|smvs host" gpurun_out/${R}_${tagname}_run.txt | tail -14; } > gpurun_out/${R}_optimize_timeline_${tagname}.txt 2>&1
+  rm -rf gpurun_out/${R}_$tagname
+  head -3 gpurun_out/${R}_optimize_timeline_${tagname}.txt
+done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
