@@ -9,21 +9,26 @@
 //
 //   * the node grid is cut into <= 256 tiles of <= 512 nodes, one workgroup
 //     (512 threads, one per node) per tile, one workgroup per CU;
-//   * a thread keeps its node's five stored blocks (diagonal + the four upper
-//     neighbours, 80 doubles = 160 VGPRs) in REGISTERS for the whole solve:
-//     the 128 MB register file holds the 83 MB matrix, H is read from HBM once
-//     per solve instead of once per iteration;
+//   * a thread keeps its node's five stored blocks (the diagonal one as its
+//     10 unique entries + the four upper neighbours, 74 doubles = 148 VGPRs)
+//     in REGISTERS for the whole solve: the 128 MB register file holds the
+//     83 MB matrix, H is read from HBM once per solve instead of once per
+//     iteration;
 //   * the product uses the symmetry the storage already exploits: thread m
 //     forms  B d  for its five blocks (its own rows) and  B^T d_m  for its four
 //     upper blocks (the rows of the upper neighbours, handed over through
 //     LDS); rows whose lower neighbour lives in another tile use a copy of
 //     that neighbour's block kept in LDS (the tile's rim, 18 KB);
-//   * per iteration only 32 bytes per rim node cross workgroups (z of the
-//     halo) plus 4 scalars per workgroup (the partial dot products), through
-//     write-through (agent-scope) stores and loads around two grid barriers
-//     (hierarchical counters, MI355X_MICROARCH.md "barrier-xcd"); every
-//     workgroup reduces the partial sums in the same fixed order, so all
-//     derive bit-identical alpha / beta and take the same branch.
+//   * what crosses workgroups is tagged data that is its own flag (16-byte
+//     pairs {32 data bits, tag} x 2, write-through stores, L1-bypassing
+//     loads, no fence): per iteration of the one-exchange solver the q of the
+//     rim nodes for the neighbours' halo and eight partial sums per workgroup
+//     for a two-level all-reduce; every workgroup sums in the same fixed order,
+//     so all derive bit-identical alpha / beta and take the same branch;
+//   * inside a workgroup the waves have roles during an exchange (wave 0 the
+//     halo, waves 1.. the sums, wave 5 the stores of the sums), the cross-lane
+//     sums run on the VALU (v_permlane*_swap, DPP) and the barriers order LDS
+//     only -- each of the three for a measured reason, see there.
 //
 // Numerics: the same operations as the reference except the association of
 // the sums (row sums collect the transposed contributions after the stored
