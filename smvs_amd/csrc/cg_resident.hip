@@ -1678,6 +1678,13 @@ cg_resident_kernel(ResArgs A)
         // registers of the upper blocks are occupied.
         for (int i = tid; i < LH * LW * 4; i += RES_THREADS)
             dtile[i] = 0.0;   // (out-of-grid halo stays zero for the whole solve)
+        // (LDS is not cleared between launches: a word a previous kernel left
+        // where the exchange keeps its tags must not look like one of this
+        // solve's -- tags are never 0)
+        if (tid < RES_KINDS)
+            group_mailbox(red).tag[tid] = 0u;
+        if (tid < RES_WAVES)
+            partial_tags(red).tag[tid] = 0u;
         lds_barrier();
         if (has_halo) {
             hnode[tid] = halo_node;

@@ -298,29 +298,38 @@ surf_expand_apply_kernel(SurfArgs A)
 
 // ---- remove_isolated_patches (surface.cc:887-927) ----
 // The reference deletes in place while it walks the grid column by column, so
-// the walk's order is part of the result.  ONE workgroup replays it as
-// 2 npx + npy - 2 steps of independent cells (surface_math.h): the patch
-// validity lives as bit columns (one-cell border of zeros, rows packed into
-// 32-bit words) in LDS -- or in global memory when the grid is too large for
-// 160 KB -- and thread x handles column x of a step.  Within a step no two
-// threads write the same word (they own different columns) and no thread reads
-// a bit another one writes.  494 us at 478 x 268 patches (0.4 us per step: one
-// LDS round trip and one barrier).  Tried and not kept: 256 threads with two
-// columns each (651 us); several rows of a column per step with the column
-// (ISO_ROWS + 1) rows behind its left neighbour, which needs only
-// ((R + 1) npx + npy) / R steps -- 812 us with R = 8 and 64-bit windows, 522
-// with R = 4 and 32-bit windows: the per-step work then runs into the one
-// CU's ALUs.
+// the walk's order is part of the result: when patch (x, y) is examined, its
+// neighbours (x-1, y-1), (x-1, y), (x-1, y+1), (x, y-1) have been through the
+// walk already (their deletions count), the other four have not (they count
+// as they were).  With del(p) = "the walk deletes p" that is a recurrence on a
+// DAG,
+//     del(p) = valid(p) and  #valid neighbours - #deleted earlier neighbours < 3,
+// whose unique solution a relaxation reaches from any start once every patch
+// has seen final values of its four predecessors.  ONE workgroup relaxes all
+// patches at once, 32 rows of a column per thread and step as bit vectors
+// (one-cell border of zeros, rows packed into 32-bit words, in LDS -- or in
+// global memory when the grid is too large for it): the eight neighbour counts
+// of 32 patches are a bit-sliced adder, ~40 logic operations.  The words are
+// updated in place (a neighbour's word is read either before or after its
+// update, both are states of the relaxation); a sweep in which no word changed
+// read one consistent state and ends the kernel.  The number of sweeps is the
+// length of the longest chain of deletions each caused by the one before --
+// a handful on real surfaces (deletions eat into ragged borders, not along
+// them), bounded by the 2 npx + npy steps of the walk itself.
+// (Rounds 3-4 replayed the walk as a wavefront of 2 npx + npy steps of
+// independent cells, one barrier each: 494 us at 478 x 268 however few
+// patches go; profiles/r4_optimize_timeline_*.txt before / after.)
 __global__ void __launch_bounds__(1024)
 surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
 {
     extern __shared__ unsigned lds_bits[];
-    unsigned *bits = global_bits != nullptr ? global_bits : lds_bits;
     int const npx = A.g.npx, npy = A.g.npy;
     int const cols = npx + 2;
     int const words = cols * wpc;
-    for (int i = threadIdx.x; i < words; i += blockDim.x)
-        bits[i] = 0u;
+    unsigned *orig = global_bits != nullptr ? global_bits : lds_bits;   // [cols][wpc]
+    unsigned *del = orig + words;                                        // [cols][wpc]
+    for (int i = threadIdx.x; i < 2 * words; i += blockDim.x)
+        orig[i] = 0u;
     __syncthreads();
     // column c = x + 1, row r = y + 1; a thread packs 32 rows of one column
     for (int i = threadIdx.x; i < npx * wpc; i += blockDim.x) {
@@ -331,58 +340,68 @@ surf_isolated_kernel(SurfArgs A, unsigned *global_bits, int wpc)
             if (y >= 0 && y < npy && A.patch_valid[(size_t)y * npx + x])
                 word |= 1u << b;
         }
-        bits[(x + 1) * wpc + w] = word;
+        orig[(x + 1) * wpc + w] = word;
     }
     __syncthreads();
-    auto get = [&](int c, int r) -> int {
-        return (int)((bits[c * wpc + (r >> 5)] >> (r & 31)) & 1u);
+    // bit r of the result = bit r - 1 / r + 1 of the column
+    auto from_above = [&](const volatile unsigned *col, int w) -> unsigned {
+        return (col[w] << 1) | (w > 0 ? col[w - 1] >> 31 : 0u);
     };
-    auto count_neighbours = [&](int c, int r) -> int {
-        return get(c - 1, r - 1) + get(c - 1, r) + get(c - 1, r + 1)
-            + get(c, r - 1) + get(c, r + 1)
-            + get(c + 1, r - 1) + get(c + 1, r) + get(c + 1, r + 1);
+    auto from_below = [&](const volatile unsigned *col, int w) -> unsigned {
+        return (col[w] >> 1) | (w + 1 < wpc ? col[w + 1] << 31 : 0u);
     };
-    // Nothing is ever deleted before the first patch (in walk order) that has
-    // fewer than three neighbours to begin with -- a deletion needs an earlier
-    // deletion or such a patch -- so the walk starts at that patch's column,
-    // and does not run at all when there is none (the usual case once the
-    // boundary cuts have settled: 5 us instead of 0.5 ms at 478 x 268).
-    __shared__ int first_column;
-    if (threadIdx.x == 0)
-        first_column = npx;
-    __syncthreads();
-    for (int x = threadIdx.x; x < npx; x += blockDim.x) {
-        bool seed = false;
-        for (int y = 0; y < npy && !seed; ++y)
-            seed = get(x + 1, y + 1) && count_neighbours(x + 1, y + 1) < 3;
-        if (seed)
-            atomicMin(&first_column, x);
-    }
-    __syncthreads();
-    int const x_first = first_column;
-    int const steps = 2 * (npx - 1) + (npy - 1) + 1;   // step(x, y) = 2 x + y
-    for (int t = x_first < npx ? 2 * x_first : steps; t < steps; ++t) {
-        for (int x = threadIdx.x; x < npx; x += blockDim.x) {
-            int const y = t - 2 * x;
-            if (y < 0 || y >= npy)
+    int const max_sweeps = 2 * npx + npy + 2;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        bool changed = false;
+        for (int i = threadIdx.x; i < npx * wpc; i += blockDim.x) {
+            int const c = 1 + i / wpc, w = i % wpc;
+            unsigned const mine = orig[c * wpc + w];
+            if (mine == 0u)
                 continue;
-            int const c = x + 1, r = y + 1;
-            if (!get(c, r))
-                continue;
-            int const neighbours = get(c - 1, r - 1) + get(c - 1, r) + get(c - 1, r + 1)
-                + get(c, r - 1) + get(c, r + 1)
-                + get(c + 1, r - 1) + get(c + 1, r) + get(c + 1, r + 1);
-            if (neighbours < 3)
-                bits[c * wpc + (r >> 5)] &= ~(1u << (r & 31));
+            const volatile unsigned *Lo = orig + (c - 1) * wpc, *Ld = del + (c - 1) * wpc;
+            const volatile unsigned *Mo = orig + c * wpc, *Md = del + c * wpc;
+            const volatile unsigned *Ro = orig + (c + 1) * wpc;
+            // the left column and the cell above as the walk left them ...
+            unsigned const l_above = from_above(Lo, w) & ~from_above(Ld, w);
+            unsigned const l_same = Lo[w] & ~Ld[w];
+            unsigned const l_below = from_below(Lo, w) & ~from_below(Ld, w);
+            unsigned const m_above = from_above(Mo, w) & ~from_above(Md, w);
+            // ... the cell below and the right column as they were
+            unsigned const m_below = from_below(Mo, w);
+            unsigned const r_above = from_above(Ro, w), r_same = Ro[w],
+                           r_below = from_below(Ro, w);
+            // 32 sums of eight bits: ones s0, twos s1, fours s2, eights s3
+            unsigned const sa = l_above ^ l_same ^ l_below;
+            unsigned const ca = (l_above & l_same) | (l_below & (l_above ^ l_same));
+            unsigned const sb = m_above ^ m_below ^ r_above;
+            unsigned const cb = (m_above & m_below) | (r_above & (m_above ^ m_below));
+            unsigned const sc = r_same ^ r_below, cc = r_same & r_below;
+            unsigned const s0 = sa ^ sb ^ sc;
+            unsigned const cd = (sa & sb) | (sc & (sa ^ sb));
+            unsigned const ts = ca ^ cb ^ cc;
+            unsigned const tc = (ca & cb) | (cc & (ca ^ cb));
+            unsigned const s1 = ts ^ cd, u = ts & cd;
+            unsigned const s2 = tc ^ u, s3 = tc & u;
+            unsigned const three_or_more = s3 | s2 | (s1 & s0);
+            unsigned const now = mine & ~three_or_more;
+            if (now != del[c * wpc + w]) {
+                del[c * wpc + w] = now;
+                changed = true;
+            }
         }
-        __syncthreads();
+        if (!__syncthreads_or(changed ? 1 : 0))
+            break;
     }
     int removed = 0;
     for (int p = threadIdx.x; p < npx * npy; p += blockDim.x) {
         int const x = p % npx, y = p / npx;
-        uint8_t const now = (uint8_t)get(x + 1, y + 1);
-        removed += (A.patch_valid[p] != 0 && now == 0) ? 1 : 0;
-        A.patch_valid[p] = now;
+        int const c = x + 1, r = y + 1;
+        unsigned const gone = (del[c * wpc + (r >> 5)] >> (r & 31)) & 1u;
+        if (gone != 0u) {
+            // (del is a subset of the valid patches)
+            A.patch_valid[p] = 0;
+            removed += 1;
+        }
     }
     for (int off = 32; off > 0; off >>= 1)
         removed += __shfl_xor(removed, off);
@@ -767,7 +786,8 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
     SurfArgs A;
     fill_surf_args(ctx, &A);
     int const wpc = (A.g.npy + 2 + 31) / 32;
-    size_t const bytes = (size_t)(A.g.npx + 2) * wpc * sizeof(unsigned);
+    // (the patches as they are and the deletions, one bit each)
+    size_t const bytes = 2 * (size_t)(A.g.npx + 2) * wpc * sizeof(unsigned);
     unsigned *global_bits = nullptr;
     size_t lds = bytes;
     if (bytes > (size_t)150 * 1024) {
@@ -789,8 +809,6 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
         attr_set[ctx->device] = true;
     }
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_SURF_CHANGED, 0, sizeof(int), ctx->stream));
-    // (one column per thread: with 256 threads and two columns each the walk
-    // took 651 instead of 494 us at 478 x 268, one row per step)
     hipLaunchKernelGGL(surf_isolated_kernel, dim3(1), dim3(1024), lds, ctx->stream, A,
         global_bits, wpc);
     launch_remove_nodes(ctx, A);
