@@ -172,7 +172,9 @@ int smvs_gn_construct(smvs_ctx *ctx, double regularization,
 int smvs_gn_download(smvs_ctx *ctx, double *H9, double *g, double *P);
 /* per-patch 16x16 systems and 16-gradients before assembly
  * (sub_hessian / sub_gradient, gauss_newton_step.cc:61-62); entries of
- * patches that were not evaluated are unspecified. */
+ * patches that were not evaluated are unspecified.  The device keeps the
+ * upper triangle (the part the assembly reads, gauss_newton_step.cc:103,
+ * 113-119); the lower one comes back as its mirror. */
 int smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp);
 /* Overwrite the assembled system (solver tests on arbitrary systems). */
 int smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
