@@ -2456,7 +2456,34 @@ finish_plan(const smvs_ctx *ctx, int max_tiles, ResidentPlan *plan)
 }
 
 static bool
+compute_resident_plan(const smvs_ctx *ctx, ResidentPlan *plan);
+
+// (once per grid: a Newton step asks for the plan, a loop three more times)
+static bool
 resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
+{
+    smvs_ctx::ResidentPlanMemo &m = ctx->res_plan;
+    int const xcd_mode = xcd_exchange_mode();
+    if (m.stride != ctx->node_stride || m.nodes != ctx->num_nodes
+        || m.solver_mode != (int)ctx->solver_mode || m.xcd_mode != xcd_mode
+        || m.cus != ctx->resident_cus) {
+        ResidentPlan p = {};
+        m.ok = compute_resident_plan(ctx, &p);
+        m.stride = ctx->node_stride;
+        m.nodes = ctx->num_nodes;
+        m.solver_mode = (int)ctx->solver_mode;
+        m.xcd_mode = xcd_mode;
+        m.cus = ctx->resident_cus;
+        m.tw = p.tw; m.th = p.th; m.one = p.one ? 1 : 0; m.blocks = p.blocks;
+        m.regions_x = p.regions_x; m.region_w = p.region_w; m.region_h = p.region_h;
+    }
+    plan->tw = m.tw; plan->th = m.th; plan->one = m.one != 0; plan->blocks = m.blocks;
+    plan->regions_x = m.regions_x; plan->region_w = m.region_w; plan->region_h = m.region_h;
+    return m.ok;
+}
+
+static bool
+compute_resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
 {
     int const stride = ctx->node_stride;
     int const rows = ctx->num_nodes / stride;

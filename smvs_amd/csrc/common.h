@@ -175,6 +175,14 @@ struct smvs_ctx {
     double *res_work = nullptr;     // partial sums + barrier words
     double *res_zx = nullptr;       // [cap_nodes][4] z exchanged between workgroups
     size_t res_zx_cap = 0;
+    // the resident solver's tiling of the current grid (cg_resident.hip,
+    // resident_plan: ~1,000 candidate shapes), kept while its inputs stay
+    struct ResidentPlanMemo {
+        int stride = -1, nodes = -1, solver_mode = -1, xcd_mode = -1, cus = -1;
+        bool ok = false;
+        int tw = 0, th = 0, one = 0, blocks = 0, regions_x = 0, region_w = 0, region_h = 0;
+    };
+    mutable ResidentPlanMemo res_plan;
     int resident_cus = 0, resident_lds = 0;
     bool resident_disabled = false;
     int solver_mode = 0;            // smvs_solver_mode (smvs_ctx_set_solver)
