@@ -64,7 +64,7 @@ struct CgArgs {
     uint16_t *mask;          // bit s: stencil slot s of the node is in the matrix
     double *x, *r, *z, *Ad, *b;
     double *dbuf[2];
-    double *partials;      // [4][CG_MAX_BLOCKS]
+    double *partials;      // [2][CG_PARTIAL_ROWS][CG_MAX_BLOCKS]: high words, low words
     CgState *state;        // [2]
     int *status;
     int *progress;         // pinned host memory, see cg_solve_launch
@@ -96,46 +96,114 @@ publish_progress(CgArgs const &A, int done, int info, int iter)
         __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The dot products: every product is rounded to double as in the reference
+// (sse_vector.cc:215-262), and the SUM of the rounded products is exact --
+// accumulated in twice the working precision (TwoSum: the exact error of
+// every addition collected in a second double, combined across lanes, waves
+// and blocks in the same arithmetic).  The value every block derives is the
+// correctly rounded sum of the reference's own products: it no longer depends
+// on how the elements are dealt to threads and blocks, and it differs from the
+// reference's sequential sum by that sum's own accumulated rounding only.
+// Why: the termination tests of a long solve on an ill-conditioned system are
+// discrete decisions that amplify a 1-ulp change of a dot product into a
+// different iteration count; a plain tree sum over 512-thread blocks ended a
+// 68-iteration solve of the fuzz sweep after 61 (tests/test_gpu_parity.py,
+// FUZZ_OUTLIERS).  tools/cg_association.py runs the reference's recurrence on
+// the CPU with its dot products summed in seven associations
+// (profiles/r5_cg_association.txt): none but the reference's own order is
+// guaranteed to reproduce its count on such systems (spread -7 .. +6 on
+// solves of 50-100 iterations), and the exact sum of the rounded products is
+// the one that stays within one iteration on all seven.  The streaming
+// kernels are bound by memory latency, the extra arithmetic is free.
+struct DD {
+    double hi, lo;
+};
+
+// s += a * b, the product rounded once
+__device__ __forceinline__ void
+dd_fma(DD &s, double a, double b)
+{
+#pragma clang fp contract(off)
+    double const p = a * b;
+    double const t = s.hi + p;
+    double const zz = t - s.hi;
+    double const te = (s.hi - (t - zz)) + (p - zz);
+    s.hi = t;
+    s.lo += te;
+}
+
+// (TwoSum's error term is the exact error of the rounded sum, whichever
+// operand comes first: dd_add is commutative to the bit, so a butterfly leaves
+// the same value in every lane)
+__device__ __forceinline__ DD
+dd_add(DD a, DD b)
+{
+#pragma clang fp contract(off)
+    double const t = a.hi + b.hi;
+    double const zz = t - a.hi;
+    double const te = (a.hi - (t - zz)) + (b.hi - zz);
+    DD r;
+    r.hi = t;
+    r.lo = (a.lo + b.lo) + te;
+    return r;
+}
+
+__device__ __forceinline__ DD
+dd_shfl_xor(DD v, int off)
+{
+    DD r;
+    r.hi = __shfl_xor(v.hi, off);
+    r.lo = __shfl_xor(v.lo, off);
+    return r;
+}
+
+// rows of the partial buffer: the high words in rows 0 .. CG_PARTIAL_ROWS - 1,
+// the low words CG_PARTIAL_ROWS rows behind
+constexpr int CG_PARTIAL_ROWS = 6;
+
 // Sum NV arrays of `nb` (<= CG_THREADS) per-block partials in a fixed order;
 // every thread of every block gets the same values.  The loads are split
 // from the reduction so that a kernel can request them together with its
 // other operands and pay one memory round trip instead of two.
 template <int NV>
 __device__ __forceinline__ void
-load_partials(const double *partials, int nb, double (&mine)[NV])
+load_partials(const double *partials, int nb, DD (&mine)[NV])
 {
 #pragma unroll
     // branch-free and unmasked (reduce_loaded masks): the loads stay
     // countable for s_waitcnt and nothing waits for them here
-    for (int k = 0; k < NV; ++k)
-        mine[k] = partials[(size_t)k * CG_MAX_BLOCKS
-            + min((int)threadIdx.x, nb - 1)];
+    for (int k = 0; k < NV; ++k) {
+        size_t const at = (size_t)k * CG_MAX_BLOCKS + min((int)threadIdx.x, nb - 1);
+        mine[k].hi = partials[at];
+        mine[k].lo = partials[at + (size_t)CG_PARTIAL_ROWS * CG_MAX_BLOCKS];
+    }
 }
 
 template <int NV>
 __device__ __forceinline__ void
-reduce_loaded(double (&mine)[NV], int nb, double (&out)[NV])
+reduce_loaded(DD (&mine)[NV], int nb, double (&out)[NV])
 {
-    __shared__ double red[NV][CG_THREADS / 64];
+    __shared__ DD red[NV][CG_THREADS / 64];
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double s = 0.0;
-        s += (int)threadIdx.x < nb ? mine[k] : 0.0;
+        DD s = { 0.0, 0.0 };
+        if ((int)threadIdx.x < nb)
+            s = mine[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
-            s += __shfl_xor(s, off);
+            s = dd_add(s, dd_shfl_xor(s, off));
         if (lane == 0)
             red[k][wave] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double s = 0.0;
+        DD s = red[k][0];
 #pragma unroll
-        for (int wv = 0; wv < CG_THREADS / 64; ++wv)
-            s += red[k][wv];
-        out[k] = s;
+        for (int wv = 1; wv < CG_THREADS / 64; ++wv)
+            s = dd_add(s, red[k][wv]);
+        out[k] = s.hi + s.lo;
     }
     __syncthreads();
 }
@@ -144,7 +212,7 @@ template <int NV>
 __device__ __forceinline__ void
 reduce_partials(const double *partials, int nb, double (&out)[NV])
 {
-    double mine[NV];
+    DD mine[NV];
     load_partials<NV>(partials, nb, mine);
     reduce_loaded<NV>(mine, nb, out);
 }
@@ -152,16 +220,16 @@ reduce_partials(const double *partials, int nb, double (&out)[NV])
 // Block-level sum of per-thread values -> partials[k][blockIdx.x]
 template <int NV>
 __device__ __forceinline__ void
-store_partials(double (&v)[NV], double *partials)
+store_partials(DD (&v)[NV], double *partials)
 {
-    __shared__ double red[NV][CG_THREADS / 64];
+    __shared__ DD red[NV][CG_THREADS / 64];
     int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double s = v[k];
+        DD s = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
-            s += __shfl_xor(s, off);
+            s = dd_add(s, dd_shfl_xor(s, off));
         if (lane == 0)
             red[k][wave] = s;
     }
@@ -169,11 +237,13 @@ store_partials(double (&v)[NV], double *partials)
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            double s = 0.0;
+            DD s = red[k][0];
 #pragma unroll
-            for (int wv = 0; wv < CG_THREADS / 64; ++wv)
-                s += red[k][wv];
-            partials[(size_t)k * CG_MAX_BLOCKS + blockIdx.x] = s;
+            for (int wv = 1; wv < CG_THREADS / 64; ++wv)
+                s = dd_add(s, red[k][wv]);
+            size_t const at = (size_t)k * CG_MAX_BLOCKS + blockIdx.x;
+            partials[at] = s.hi;
+            partials[at + (size_t)CG_PARTIAL_ROWS * CG_MAX_BLOCKS] = s.lo;
         }
     }
 }
@@ -183,7 +253,7 @@ __global__ void __launch_bounds__(CG_THREADS)
 cg_init_kernel(CgArgs A)
 {
     int const items = A.num_nodes * 4;
-    double v[2] = { 0.0, 0.0 };
+    DD v[2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
     for (int gid = blockIdx.x * CG_THREADS + threadIdx.x; gid < items;
          gid += gridDim.x * CG_THREADS) {
         int const n = gid >> 2, row = gid & 3;
@@ -206,8 +276,8 @@ cg_init_kernel(CgArgs A)
         }
         A.z[gid] = zi;
         A.dbuf[1][gid] = zi;
-        v[0] += zi * bi;
-        v[1] += gi * gi;
+        dd_fma(v[0], zi, bi);
+        dd_fma(v[1], gi, gi);
         if (row == 0) {
             // Inactive nodes have no row and no column in the reference's
             // matrix (gauss_newton_step.cc:91-105): their b, r, z, d and x
@@ -325,7 +395,7 @@ cg_spmv_kernel(CgArgs A, int nb)
     int n_next = tile_node(tile + per_xcd_blocks, grid_next);
     unsigned const raw_cur = A.mask[n_cur], raw_next = A.mask[n_next];
     // (A_1 reduces the two sums of the init kernel: z.r and g.g)
-    double mine[3];
+    DD mine[3];
     load_partials<3>(A.partials + (first ? 4 : 1) * CG_MAX_BLOCKS, nb, mine);
     // A launch after convergence is a no-op.  It takes no early exit here (a
     // branch would serialise the state load ahead of everything else): its
@@ -438,7 +508,7 @@ cg_spmv_kernel(CgArgs A, int nb)
         // initial state: x = 0, r = b = -g, z = P r, d = z
         // (conjugate_gradient.h:86-118)
         double v[2];
-        double init[2] = { mine[0], mine[1] };
+        DD init[2] = { mine[0], mine[1] };
         reduce_loaded<2>(init, nb, v);
         prev.rr = v[0];
         prev.q0 = -0.0;  // -1.0 * x.(b + r) with x = 0
@@ -462,7 +532,7 @@ cg_spmv_kernel(CgArgs A, int nb)
             return;
     }
 
-    double v[1] = { 0.0 };
+    DD v[1] = { { 0.0, 0.0 } };
     bool first_tile = true;
     for (; tile < band_end; tile += per_xcd_blocks) {
         if (!first_tile) {
@@ -511,7 +581,7 @@ cg_spmv_kernel(CgArgs A, int nb)
             Ad[gid] = acc;
             if (!first)
                 d_new[gid] = d_own;
-            v[0] += d_own * acc;
+            dd_fma(v[0], d_own, acc);
         }
     }
     store_partials<1>(v, A.partials);
@@ -558,7 +628,8 @@ cg_update_kernel(CgArgs A, int nb)
     // (rounds beyond the grid are redirected like idle ones: no branches
     // between the requests)
     constexpr int PRE = 2;
-    double mine[1], dad[1];
+    DD mine[1];
+    double dad[1];
     load_partials<1>(A.partials, nb, mine);
     Item pre[PRE];
 #pragma unroll
@@ -568,7 +639,7 @@ cg_update_kernel(CgArgs A, int nb)
         return;
     reduce_loaded<1>(mine, nb, dad);
     double const alpha = st.rr / dad[0];
-    double v[3] = { 0.0, 0.0, 0.0 };
+    DD v[3] = { { 0.0, 0.0 }, { 0.0, 0.0 }, { 0.0, 0.0 } };
     auto process = [&](int round, Item const &item) {
         int const gid = (round * gridDim.x + blockIdx.x) * CG_THREADS
             + threadIdx.x;
@@ -599,9 +670,15 @@ cg_update_kernel(CgArgs A, int nb)
                 zi += item.P.w * rn[3];
             }
             A.z[gid] = zi;
-            v[0] += ri * ri;
-            v[1] += xi * (item.b + ri);
-            v[2] += zi * ri;
+            double tmp;
+            {
+                // conjugate_gradient.h:176-178: tmp = b + r, rounded, then x . tmp
+#pragma clang fp contract(off)
+                tmp = item.b + ri;
+            }
+            dd_fma(v[0], ri, ri);
+            dd_fma(v[1], xi, tmp);
+            dd_fma(v[2], zi, ri);
         }
     };
 #pragma unroll

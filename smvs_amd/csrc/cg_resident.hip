@@ -88,8 +88,18 @@ struct ResExchange {
     // needed for 4,096 line reads, and a group's store queued behind them)
     unsigned long long lvl2[2][RES_REPLICAS][RES_MAX_GROUPS][RES_KINDS][2];   // [parity][copy][group][kind]
     unsigned timeout;
-    // XCD-aware exchange: slot -> solve tag of the workgroup that took it
-    unsigned claim[RES_MAX_BLOCKS];
+    // compacted solve: solve tag | 1 (the tile has an active node) or | 2 (it has
+    // none: its workgroup has left), written once per solve by every workgroup
+    unsigned live[RES_MAX_BLOCKS];
+};
+
+// Who takes part in an exchange (the compacted solve, see the kernel): the
+// first LIVE workgroup of a group sums the group, members and groups without an
+// active node are not waited for -- their sums are exactly +0.0, so leaving
+// them out of the tree changes no bit of any total.
+struct LiveSet {
+    bool leads;         // this workgroup sums its group (wave-uniform)
+    unsigned bits;      // lane (kind, j): bit 0 member j of its group is live, bit 1 group j is
 };
 
 struct ResArgs {
@@ -100,9 +110,6 @@ struct ResArgs {
     unsigned long long *zg;  // two-exchange solver: [N][4][2] z of the rim nodes as tagged
                              // granules; one-exchange solver: [2][N][4][2] q of the rim
                              // nodes as tagged pairs, double-buffered by iteration parity
-    unsigned long long *zl;  // XCD-aware exchange: [2][blocks][top, bottom, left, right] q of
-                             // a tile's four sides for the neighbours on its own XCD
-                             // (ordinary stores, never leave the XCD's L2)
     ResExchange *ex;
     ResState *state;         // [2] (state[0] is written at the end)
     int *status;
@@ -110,12 +117,6 @@ struct ResArgs {
     int solve_tag;
     int num_nodes, stride, rows;
     int tw, th, tiles_x, num_tiles;
-    // XCD-aware exchange (see grid_allreduce_xcd): 0 off, 1 on, 2 test hook
-    // (workgroups claim each other's slots).  The tiles of an XCD form a
-    // region of region_w x region_h tiles, regions_x regions side by side;
-    // lead_m: which tile of a region sums the XCD; zl_row / zl_col: bytes of a
-    // row / column segment of `zl`
-    int xcd, regions_x, region_w, region_h, lead_m, zl_row, zl_col;
     int max_iterations;
     double q_tolerance, fixed_tolerance;
     long long *trace;        // debug: 100 MHz wall-clock stamps (or nullptr)
@@ -123,8 +124,9 @@ struct ResArgs {
     int pipelined;           // bit 0: launch-ahead Newton loop (update.hip), bit 1:
                              // report a failure (test hook)
     // fused assembly (the Newton loop): per-patch systems instead of H / g / P
-    const double *Hp;        // [P][10][16]
-    const double *gp;        // [P][16]
+    const double *Hp;        // the packed per-patch systems, 36 quads per patch ...
+    const double *gp;        // ... and gradients, 4 quads per patch, laid out as
+    PatchLayout layout;      // this says (common.h)
     const uint8_t *patch_valid;
     const uint8_t *active;
     uint8_t *active_next;    // cleared for the node update of this step
@@ -135,6 +137,7 @@ struct ResArgs {
     // cycles ~ 0.25 us): before the halo's first poll, before a group
     // member's first poll of the group sums, between two polls
     int wait_halo, wait_member, wait_poll;
+    int compact;             // leave out what has no active node (SMVS_CG_COMPACT, default 1)
 };
 
 // GaussNewtonStep::construct's scatter (gauss_newton_step.cc:88-142) in gather
@@ -147,6 +150,32 @@ struct NodeSystem {
     double hu[4][16];   // slots 5..8
     double g[4];
 };
+
+// `count` consecutive quads of patch p's record from element `e0` (a multiple
+// of 4) on, or -- unconditionally, so that the loads of a thread stay
+// independent of its flags -- the same number of loads from the block of zeros.
+struct QuadSource {
+    const double4_r *base;
+    unsigned step;
+    __device__ __forceinline__ double4_r operator[](int i) const { return base[(size_t)i * step]; }
+};
+__device__ __forceinline__ QuadSource
+patch_quads(ResArgs const &A, int p, int e0, bool use)
+{
+    const double4_r *Hq = reinterpret_cast<const double4_r *>(A.Hp);
+    QuadSource q;
+    q.base = use ? Hq + ((size_t)(e0 >> 2) * A.layout.hq + (size_t)p * A.layout.hp)
+        : reinterpret_cast<const double4_r *>(A.zeros);
+    q.step = use ? A.layout.hq : 0u;
+    return q;
+}
+__device__ __forceinline__ double4_r
+patch_gradient(ResArgs const &A, int p, int ln, bool use)
+{
+    const double4_r *gq = reinterpret_cast<const double4_r *>(A.gp);
+    return *(use ? gq + ((size_t)ln * A.layout.gq + (size_t)p * A.layout.gp)
+        : reinterpret_cast<const double4_r *>(A.zeros));
+}
 
 // The loads below are unconditional: a block that does not contribute (patch
 // outside the grid / invalid, other node inactive) is read from a block of
@@ -199,7 +228,6 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int const ln = 3 - q;   // local index of the node in that patch
-        const double *Hl = A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE;
 #pragma unroll
         for (int lm = 0; lm < 4; ++lm) {
             if (lm < ln)
@@ -208,16 +236,14 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
             int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
             bool const use = pv[q] && act[dy + 1][dx + 1];
             if (lm == ln) {
-                const double4_r *tri = reinterpret_cast<const double4_r *>(
-                    use ? Hl + patch_diag_offset(ln) : A.zeros);
+                QuadSource const tri = patch_quads(A, pidx[q], patch_diag_offset(ln), use);
                 double4_r const b0 = tri[0], b1 = tri[1], b2 = tri[2];
                 S.hd[0] += b0.x; S.hd[1] += b0.y; S.hd[2] += b0.z; S.hd[3] += b0.w;
                 S.hd[4] += b1.x; S.hd[5] += b1.y; S.hd[6] += b1.z;
                 S.hd[7] += b1.w; S.hd[8] += b2.x;
                 S.hd[9] += b2.y;
             } else {
-                const double4_r *blk = reinterpret_cast<const double4_r *>(
-                    use ? Hl + patch_upper_offset(ln, lm) : A.zeros);
+                QuadSource const blk = patch_quads(A, pidx[q], patch_upper_offset(ln, lm), use);
                 double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
                 int const k = (dy + 1) * 3 + dx + 1 - 5;
                 S.hu[k][0] += b0.x; S.hu[k][1] += b0.y; S.hu[k][2] += b0.z; S.hu[k][3] += b0.w;
@@ -226,8 +252,7 @@ assemble_node(ResArgs const &A, int ix, int iy, bool on, NodeSystem &S)
                 S.hu[k][12] += b3.x; S.hu[k][13] += b3.y; S.hu[k][14] += b3.z; S.hu[k][15] += b3.w;
             }
         }
-        double4_r const gv = *reinterpret_cast<const double4_r *>(
-            pv[q] ? A.gp + (size_t)pidx[q] * 16 + 4 * ln : A.zeros);
+        double4_r const gv = patch_gradient(A, pidx[q], ln, pv[q]);
         S.g[0] += gv.x; S.g[1] += gv.y; S.g[2] += gv.z; S.g[3] += gv.w;
     }
 }
@@ -262,16 +287,13 @@ assemble_diagonal(ResArgs const &A, int ix, int iy, double (&hd)[10], double (&g
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int const ln = 3 - q;   // local index of the node in that patch
-        const double4_r *tri = reinterpret_cast<const double4_r *>(pv[q]
-            ? A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE + patch_diag_offset(ln)
-            : A.zeros);
+        QuadSource const tri = patch_quads(A, pidx[q], patch_diag_offset(ln), pv[q]);
         double4_r const b0 = tri[0], b1 = tri[1], b2 = tri[2];
         hd[0] += b0.x; hd[1] += b0.y; hd[2] += b0.z; hd[3] += b0.w;
         hd[4] += b1.x; hd[5] += b1.y; hd[6] += b1.z;
         hd[7] += b1.w; hd[8] += b2.x;
         hd[9] += b2.y;
-        double4_r const gv = *reinterpret_cast<const double4_r *>(
-            pv[q] ? A.gp + (size_t)pidx[q] * 16 + 4 * ln : A.zeros);
+        double4_r const gv = patch_gradient(A, pidx[q], ln, pv[q]);
         g[0] += gv.x; g[1] += gv.y; g[2] += gv.z; g[3] += gv.w;
     }
 }
@@ -315,15 +337,13 @@ assemble_upper(ResArgs const &A, int ix, int iy, bool on, double (&hu)[4][16])
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int const ln = 3 - q;   // local index of the node in that patch
-        const double *Hl = A.Hp + (size_t)pidx[q] * PATCH_H_STRIDE;
 #pragma unroll
         for (int lm = 0; lm < 4; ++lm) {
             if (lm <= ln)
                 continue;
             int const dx = (lm & 1) - (ln & 1), dy = (lm >> 1) - (ln >> 1);
             bool const use = pv[q] && act[dy][dx + 1];
-            const double4_r *blk = reinterpret_cast<const double4_r *>(
-                use ? Hl + patch_upper_offset(ln, lm) : A.zeros);
+            QuadSource const blk = patch_quads(A, pidx[q], patch_upper_offset(ln, lm), use);
             double4_r const b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
             int const k = (dy + 1) * 3 + dx + 1 - 5;
             hu[k][0] += b0.x; hu[k][1] += b0.y; hu[k][2] += b0.z; hu[k][3] += b0.w;
@@ -364,9 +384,7 @@ assemble_block(ResArgs const &A, int mx, int my, int slot, double *out16)
             uint8_t const fp = A.patch_valid[p];
             uint8_t const fm = A.active[m];
             bool const use = act_row && inside && fp != 0 && fm != 0;
-            const double4_r *blk = reinterpret_cast<const double4_r *>(use
-                ? A.Hp + (size_t)p * PATCH_H_STRIDE + patch_upper_offset(ln, lm)
-                : A.zeros);
+            QuadSource const blk = patch_quads(A, p, patch_upper_offset(ln, lm), use);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 double4_r const v = blk[i];
@@ -397,7 +415,7 @@ assemble_rim_block(ResArgs const &A, int mx, int my, int s, double *dst16)
     bool const two = s == 1 || s == 3;
     int const mrow = my * A.stride + mx;
     uint8_t const frow = A.active[mrow];
-    const double4_r *src[2];
+    QuadSource src[2];
     uint8_t fp[2], fm[2];
     bool inside[2];
     int p[2];
@@ -416,9 +434,8 @@ assemble_rim_block(ResArgs const &A, int mx, int my, int s, double *dst16)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         bool const use = frow != 0 && inside[e] && fp[e] != 0 && fm[e] != 0;
-        src[e] = reinterpret_cast<const double4_r *>(use
-            ? A.Hp + (size_t)p[e] * PATCH_H_STRIDE + patch_upper_offset(ln[e], lm[e])
-            : A.zeros);
+        // (ln, lm depend on s at run time here: the offset is computed, not folded)
+        src[e] = patch_quads(A, p[e], patch_upper_offset(ln[e], lm[e]), use);
     }
     double4_r v0[4], v1[4];
 #pragma unroll
@@ -793,26 +810,6 @@ st_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double
     __builtin_amdgcn_raw_buffer_store_b128(w, buf, (int)byte_offset, 0, AUX_SC1);
 }
 
-// The same pair as an ordinary store: it stops in the L2 of the writer's XCD,
-// where an `sc1` load of a workgroup ON THE SAME XCD finds it (0.25 us from
-// store to sight instead of 0.55, and no fabric write: tools/xcd_probe.hip).
-// Workgroups of other XCDs never see it.
-__device__ __forceinline__ void
-st_pair16_xcd_local(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double v)
-{
-    unsigned long long const bits = (unsigned long long)__double_as_longlong(v);
-    uint4_r const w = { (unsigned)bits, tag, (unsigned)(bits >> 32), tag };
-    __builtin_amdgcn_raw_buffer_store_b128(w, buf, (int)byte_offset, 0, 0);
-}
-
-__device__ __forceinline__ unsigned
-xcc_id(void)
-{
-    unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    return x & 0xFu;
-}
-
 __device__ __forceinline__ bool
 ld_pair16(__amdgpu_buffer_rsrc_t buf, unsigned byte_offset, unsigned tag, double *v)
 {
@@ -974,7 +971,7 @@ partial_tags(double *red)
 template <int K, typename Others, typename Mark>
 __device__ __forceinline__ bool
 grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks,
-    double (&v)[K], double *red, int *lds_flag, Others others, Mark mark,
+    LiveSet const live, double (&v)[K], double *red, int *lds_flag, Others others, Mark mark,
     int wait_member = 6, int wait_poll = 0)
 {
     constexpr int SWEEPERS = (K + 3) / 4;
@@ -999,7 +996,8 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
                    * RES_KINDS + (size_t)kind) * 16));
     };
     int const ngroups = (nblocks + RES_GROUP - 1) / RES_GROUP;
-    bool const leads = ngroups > 1 && b % RES_GROUP == 0;
+    bool const leads = live.leads;
+    bool const member_live = (live.bits & 1u) != 0u, group_live = (live.bits & 2u) != 0u;
     int const wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wave == RES_SUM_WAVE) {
         bool handed = partials.wait(tag);
@@ -1033,16 +1031,16 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
             // a single group: every workgroup sums its <= 16 members itself,
             // one hop instead of two
             ok = poll_pairs(xbuf, lvl1_at(j < nblocks ? j : 0, kind_ok ? kind : 0),
-                kind_ok && j < nblocks, tag, ex, &total, wait_poll);
+                kind_ok && j < nblocks && member_live, tag, ex, &total, wait_poll);
             total = segment16_sum(total);
         } else {
             if (leads) {
                 // this workgroup sums its group
-                int const member = b + j;
+                int const member = b - b % RES_GROUP + j;
                 double part;
                 ok = poll_pairs(xbuf, lvl1_at(member < nblocks ? member : b,
-                        kind_ok ? kind : 0), kind_ok && member < nblocks, tag, ex, &part,
-                    wait_poll, &rounds1);
+                        kind_ok ? kind : 0), kind_ok && member < nblocks && member_live, tag,
+                    ex, &part, wait_poll, &rounds1);
                 part = segment16_sum(part);
                 mark(5, -1);
                 if (kind_ok && j == 0)
@@ -1054,7 +1052,7 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
             mark(9, -1);
             ok2 = poll_pairs(xbuf, lvl2_at(b % RES_REPLICAS, j < ngroups ? j : 0,
                     kind_ok ? kind : 0),
-                kind_ok && j < ngroups, tag, ex, &total, wait_poll, &rounds2);
+                kind_ok && j < ngroups && group_live, tag, ex, &total, wait_poll, &rounds2);
             total = segment16_sum(total);
         }
         mark(6, -1);
@@ -1064,117 +1062,6 @@ grid_allreduce_tree(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nbl
         if (lane == 0) {
             bool flag_ok = ok && ok2;
             // (a wait of another wave that gave up raises the same flag)
-            if (wave == 1 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT) != 0u)
-                flag_ok = false;
-            lds_flag[wave - 1] = flag_ok ? 1 : 0;
-        }
-    } else {
-        others(wave);
-    }
-    lds_barrier();
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        v[k] = res[k];
-#pragma unroll
-    for (int w = 0; w < SWEEPERS; ++w)
-        ok = ok && lds_flag[w] != 0;
-    return ok;
-}
-
-// The same all-reduce laid along the chip's XCDs.  b is the workgroup's slot
-// (see the kernel: slot % 8 is the XCD it runs on, nblocks a multiple of 8), so
-// the groups of the first level are the XCDs: a member's sums go out as
-// ORDINARY stores that stop in its XCD's L2, where ONE workgroup of the XCD
-// (`leads`: a tile in the middle of the XCD's region, whose CU has no
-// write-through stores of its own queued) reads them with `sc1` loads -- 0.25 us from store to sight instead of
-// 0.55 us through the fabric (tools/xcd_probe.hip, profiles/r4_xcd_probe.txt).
-// Only the eight group sums cross XCDs.  Lane (kind, j) of the sweeping waves
-// 1 .. (K + 1) / 2 handles member / group j of one kind (32 members per XCD at
-// 256 workgroups).  Fixed summation order (a tree over the <= 32 members of an
-// XCD, then a tree over the 8 XCDs), identical in every workgroup.
-// (Measured and dropped: a third hop that hands the totals back inside the
-// XCD, so that only eight workgroups poll through the fabric -- the 31 members
-// polling their XCD's L2 slowed its first workgroup's own polls: 9.7 instead
-// of 9.0 us per iteration.)
-template <int K, typename Others, typename Mark>
-__device__ __forceinline__ bool
-grid_allreduce_xcd(ResExchange *ex, unsigned solve_tag, unsigned epoch, int nblocks, int b,
-    bool leads, double (&v)[K], double *red, int *lds_flag, Others others, Mark mark,
-    int wait_member, int wait_poll)
-{
-    constexpr int SWEEPERS = (K + 1) / 2;
-    static_assert(K <= RES_KINDS && 1 + SWEEPERS <= RES_SUM_WAVE && RES_MAX_BLOCKS <= 8 * 32
-        && RES_MAX_GROUPS >= 8, "sweeping waves");
-    unsigned const tag = solve_tag | epoch;
-    double *res = red + RES_KINDS * RES_WAVES;
-    GroupMailbox const box = group_mailbox(red);
-    PartialTags const partials = partial_tags(red);
-    wave_partials<K>(v, red);
-    partials.raise(tag);
-    mark(20, -1);
-    unsigned const par = epoch & 1u;
-    __amdgpu_buffer_rsrc_t const xbuf = pair_buffer(ex, sizeof(ResExchange));
-    auto lvl1_at = [&](int wg, int kind) {
-        return (unsigned)(offsetof(ResExchange, lvl1)
-            + ((((size_t)par * RES_MAX_BLOCKS + (size_t)wg) * RES_KINDS + (size_t)kind) * 16));
-    };
-    auto lvl2_at = [&](int copy, int group, int kind) {
-        return (unsigned)(offsetof(ResExchange, lvl2)
-            + (((((size_t)par * RES_REPLICAS + (size_t)copy) * RES_MAX_GROUPS + (size_t)group)
-                   * RES_KINDS + (size_t)kind) * 16));
-    };
-    int const xcd = b & 7;
-    int const wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wave == RES_SUM_WAVE) {
-        bool handed = partials.wait(tag);
-        mark(21, -1);
-        if (lane < K)
-            st_pair16_xcd_local(xbuf, lvl1_at(b, lane), tag, block_total(red, lane));
-        if (leads) {
-            static_assert(K == 8, "eight kinds per copy");
-            double part = 0.0;
-            handed = box.take(lane & 7, tag, &part) && handed;
-#pragma unroll
-            for (int c = lane >> 3; c < RES_REPLICAS; c += 8)
-                st_pair16(xbuf, lvl2_at(c, xcd, lane & 7), tag, part);
-        }
-        if (!__all(handed) && lane == 0)
-            __hip_atomic_store(&ex->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        others(wave);
-    } else if (wave >= 1 && wave <= SWEEPERS) {
-        int const kind = 2 * (wave - 1) + (lane >> 5), j = lane & 31;
-        bool const kind_ok = kind < K;
-        bool ok = true, ok2 = true;
-        double total;
-        unsigned rounds1 = 0, rounds2 = 0;
-        mark(8, -1);
-        if (leads) {
-            // this workgroup sums its XCD: slots xcd, xcd + 8, xcd + 16, ...
-            int const member = xcd + 8 * j;
-            bool const active = kind_ok && member < nblocks;
-            double part;
-            ok = poll_pairs(xbuf, lvl1_at(active ? member : b, kind_ok ? kind : 0), active,
-                tag, ex, &part, wait_poll, &rounds1);
-            part = segment32_sum(part);
-            mark(5, -1);
-            if (kind_ok && j == 0)
-                box.put(kind, tag, part);
-        } else {
-            nap(wait_member);
-        }
-        mark(9, -1);
-        ok2 = poll_pairs(xbuf, lvl2_at((b >> 3) % RES_REPLICAS, j < 8 ? j : 0,
-                kind_ok ? kind : 0),
-            kind_ok && j < 8, tag, ex, &total, wait_poll, &rounds2);
-        total = segment32_sum(total);
-        mark(6, -1);
-        mark(10, (long long)(rounds1 * 1000u + rounds2));
-        if (kind_ok && j == 0)
-            res[kind] = total;
-        if (lane == 0) {
-            bool flag_ok = ok && ok2;
             if (wave == 1 && __hip_atomic_load(&ex->timeout, __ATOMIC_RELAXED,
                     __HIP_MEMORY_SCOPE_AGENT) != 0u)
                 flag_ok = false;
@@ -1362,7 +1249,7 @@ poll_node_granules(const unsigned long long *src, unsigned want, ResExchange *ex
 // LDS carve (doubles) of the two solver variants; the host sizes the launch
 // with the same function.
 struct ResLds {
-    size_t dtile, yl, Pl, rl, fb, xl, bl, rh, Ph, qh, hinfo, red, total;
+    size_t dtile, yl, Pl, rl, fb, xl, bl, rh, Ph, qh, hinfo, red, live, total;
 };
 __host__ __device__ __forceinline__ ResLds
 resident_lds_layout(int tw, int th, bool one)
@@ -1386,11 +1273,12 @@ resident_lds_layout(int tw, int th, bool one)
     L.rh = o; o += one ? ring * 4 : 0;                   // r of the halo nodes
     L.Ph = o; o += one ? ring * 16 : 0;                  // P of the halo nodes
     L.qh = o; o += one ? ring * 4 : 0;                   // q of the halo nodes (one iteration)
-    L.hinfo = o; o += one ? ring : 0;                    // per halo slot: node id, place in zl (ints)
+    L.hinfo = o; o += one ? (ring + 1) / 2 : 0;          // per halo slot: node id (ints)
     L.red = o; o += RES_KINDS * RES_WAVES + RES_KINDS;   // partial sums + results
     o += (RES_KINDS + 1) / 2;                            // flags (ints)
     o += RES_KINDS + (RES_KINDS + 1) / 2;                // group mailbox: values, tags (ints)
     o += (RES_WAVES + 1) / 2;                            // tags of the waves' partial sums (ints)
+    L.live = o; o += RES_MAX_BLOCKS / 64;                // which tiles have an active node (bits)
     L.total = o;
     return L;
 }
@@ -1419,7 +1307,7 @@ resident_lds_layout(int tw, int th, bool one)
 // BEFORE the all-reduce and collected by the wave that does not sweep, while
 // the sweep runs), so it forms the halo's z and d itself, bit-identical with
 // the owner's.
-template <bool FUSED, bool ONE, bool XCD, bool TRACE>
+template <bool FUSED, bool ONE, bool TRACE>
 __global__ void __launch_bounds__(RES_THREADS, 2)
 cg_resident_kernel(ResArgs A)
 {
@@ -1445,69 +1333,18 @@ cg_resident_kernel(ResArgs A)
     double *rh = lds + L.rh;                              // [ring][4] (ONE)
     double *Ph = lds + L.Ph;                              // [ring][16] (ONE)
     double *qhl = lds + L.qh;                             // [ring][4] (ONE)
-    int *hnode = reinterpret_cast<int *>(lds + L.hinfo);  // [2][ring] (ONE)
+    int *hnode = reinterpret_cast<int *>(lds + L.hinfo);  // [ring] (ONE)
     double *red = lds + L.red;
     int *flag = reinterpret_cast<int *>(red + RES_KINDS * RES_WAVES + RES_KINDS);
 
     int const tid = threadIdx.x;
     int const nblocks = (int)gridDim.x;
     int const tile = (int)blockIdx.x;
-    // XCD-aware launch: the tiles of an XCD are a rectangle of region_w x
-    // region_h tiles, so most neighbours of a tile share its XCD (and its L2):
-    // their halo goes through `zl` with ordinary stores; only what crosses a
-    // region's border goes through the fabric.  Workgroups of tiles beyond the
-    // grid own no node and only take part in the all-reduce.
-    constexpr bool xcd_on = ONE && XCD;
-    // The dispatcher deals consecutive workgroups round-robin over the XCDs but
-    // does not start every launch on XCD 0 (tools/xcd_probe.hip, part C: the
-    // start moves with the launches before it).  What holds is that every
-    // aligned group of eight consecutive workgroups covers the eight XCDs, so a
-    // workgroup's place in the exchange is (its group of eight, the XCD it
-    // finds itself on) -- `slot` replaces blockIdx.x everywhere below.  Each
-    // workgroup claims its slot; a slot claimed twice means the placement is
-    // not what this relies on: the solve is given up at once and the host
-    // repeats it (and runs all later ones of this process) with the
-    // device-scope exchange.
-    int slot = tile;
-    if (xcd_on) {
-        unsigned const xcc = A.xcd == 2 ? xcc_id() & 6u : xcc_id();   // (2: test hook)
-        slot = (tile & ~7) | (int)(xcc & 7u);
-        if (tid == 0
-            && __hip_atomic_exchange(&A.ex->claim[slot], (unsigned)A.solve_tag,
-                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.solve_tag) {
-            __hip_atomic_store(A.progress + 6, 1, __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&A.ex->timeout, 1u, __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    int tx, ty;
     int const tiles_y = (A.rows + th - 1) / th;
-    // region of a tile, slot of a tile of THIS region
-    int const reg_w = xcd_on ? A.region_w : 1, reg_h = xcd_on ? A.region_h : 1;
-    int const region_x = xcd_on ? (slot & 7) % A.regions_x : 0;
-    int const region_y = xcd_on ? (slot & 7) / A.regions_x : 0;
-    if (xcd_on) {
-        int const m = slot >> 3;
-        tx = region_x * reg_w + m % reg_w;
-        ty = region_y * reg_h + m / reg_w;
-    } else {
-        ty = tile / A.tiles_x;
-        tx = tile - ty * A.tiles_x;
-    }
+    int const ty = tile / A.tiles_x;
+    int const tx = tile - ty * A.tiles_x;
     auto tile_exists = [&](int x, int y) {
         return x >= 0 && x < A.tiles_x && y >= 0 && y < tiles_y;
-    };
-    auto same_xcd = [&](int x, int y) {
-        return xcd_on && tile_exists(x, y) && x / reg_w == region_x && y / reg_h == region_y;
-    };
-    // `zl`: per workgroup the segments top, bottom (zl_row bytes each), left,
-    // right (zl_col): every segment on cache lines of its own
-    unsigned const zl_tile = 2u * (unsigned)A.zl_row + 2u * (unsigned)A.zl_col;
-    auto zl_segment = [&](int x, int y, int side) {
-        int const wg = ((y % reg_h) * reg_w + x % reg_w) * 8 + (slot & 7);
-        return (unsigned)wg * zl_tile + (side < 2 ? (unsigned)side * (unsigned)A.zl_row
-            : 2u * (unsigned)A.zl_row + (unsigned)(side - 2) * (unsigned)A.zl_col);
     };
     int const lx = tid % tw, ly = tid / tw;
     int const gx = tx * tw + lx, gy = ty * th + ly;
@@ -1518,30 +1355,87 @@ cg_resident_kernel(ResArgs A)
     TileGeom const G = { tw, th, LW, lx, ly, li, lcore };
     // the exchanged vector of a rim node is read by the neighbouring tiles
     // (a grid of one tile has no neighbours: nothing is published)
-    bool const rim = nblocks > 1 && mine
-        && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
-    // XCD-aware: does a tile of another XCD read this node (-> `zg`, through the
-    // fabric), and which of the tile's side segments in `zl` does a tile of this
-    // XCD read it from (corners: the diagonal neighbours read the ROW segments)
-    bool rim_far = false;
-    unsigned rim_near = 0;   // bit 0 top, 1 bottom, 2 left, 3 right
-    if (xcd_on && rim) {
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                if ((dx == 0 && dy == 0) || (dx < 0 && lx != 0) || (dx > 0 && lx != tw - 1)
-                    || (dy < 0 && ly != 0) || (dy > 0 && ly != th - 1)
-                    || !tile_exists(tx + dx, ty + dy))
-                    continue;
-                if (!same_xcd(tx + dx, ty + dy))
-                    rim_far = true;
-                else if (dy != 0)
-                    rim_near |= dy < 0 ? 1u : 2u;
-                else
-                    rim_near |= dx < 0 ? 4u : 8u;
+    // ---- the compacted solve (fused one-exchange kernel) ----
+    // The reference's system holds the active nodes only
+    // (gauss_newton_step.cc:73-79, 91-105).  Here the rows of an inactive node
+    // are zero, and so are its r, z, d, q and its terms of every sum -- exactly:
+    //   * an inactive rim node publishes nothing and nobody polls for it (the
+    //     neighbour takes q = 0, what the owner would have sent);
+    //   * a tile without an active node says so in `ex->live` and LEAVES before
+    //     it assembles anything: its CU is free, the all-reduce neither waits for
+    //     it nor reads its slots (the first live member of a group sums it).
+    // Both leave every total, every iterate and the iteration count bit-identical
+    // (SMVS_CG_COMPACT=0 runs the full grid; tests/test_gpu_parity.py compares).
+    bool compact = FUSED && ONE && !TRACE && nblocks > 1 && A.compact != 0;
+    unsigned long long *livemap = reinterpret_cast<unsigned long long *>(lds + L.live);
+    unsigned const live_tag = (unsigned)A.solve_tag;
+    // every thread of the first RES_MAX_BLOCKS polls one tile's word; false after
+    // a bounded wait.  On return the map is in LDS.
+    auto gather_live_map = [&]() -> bool {
+        bool ok = true;
+        if (tid < RES_MAX_BLOCKS) {
+            bool const need = tid < nblocks;
+            unsigned w = 0u;
+            for (unsigned spins = 0; need; ++spins) {
+                w = __hip_atomic_load(&A.ex->live[tid], __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                if ((w & 0xFFFF0000u) == live_tag && (w & 3u) != 0u)
+                    break;
+                if (spins > (1u << 18)) {
+                    __hip_atomic_store(&A.ex->timeout, 1u, __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    w = 0u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
+            unsigned long long const m = __ballot(need && (w & 1u) != 0u);
+            if ((tid & 63) == 0)
+                livemap[tid >> 6] = m;
+        }
+        return __syncthreads_and(ok ? 1 : 0) != 0;
+    };
+    auto tile_live = [&](int t) {
+        return ((livemap[t >> 6] >> (t & 63)) & 1ull) != 0ull;
+    };
+    bool node_on = true;        // FUSED: the thread's node is active
+    if (compact) {
+        node_on = mine && A.active[n] != 0;
+        int const any = __syncthreads_or(node_on ? 1 : 0);
+        if (tid == 0)
+            __hip_atomic_store(&A.ex->live[tile], live_tag | (any ? 1u : 2u), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+        if (!any) {
+            // what the prologue and the end of the solve do for the tile's nodes:
+            // clear the flags of the step's node update, delta = 0, b = -g
+            if (mine) {
+                A.active_next[n] = 0;
+                *reinterpret_cast<double4_r *>(A.x + (size_t)n * 4)
+                    = (double4_r){ 0.0, 0.0, 0.0, 0.0 };
+                *reinterpret_cast<double4_r *>(A.b + (size_t)n * 4)
+                    = (double4_r){ -0.0, -0.0, -0.0, -0.0 };
+            }
+            if (tile == 0 && tid == 0) {
+                A.status[I_ACTIVE_PATCHES] = A.status[I_LIVE_PATCHES];
+                A.status[I_NUM_ACTIVE] = 0;
+                A.scalars[S_SUMDIFF] = 0.0;
+                A.scalars[S_COUNT_DIFF] = 0.0;
+            }
+            bool const got = gather_live_map();
+            bool any_live = false;
+            for (int w = 0; w < RES_MAX_BLOCKS / 64; ++w)
+                any_live = any_live || livemap[w] != 0ull;
+            if (!got || any_live)
+                return;
+            // no tile has an active node: a system of zeros, which the full grid
+            // runs the way it always has (every workgroup is here and stays)
+            compact = false;
+            node_on = true;
+        }
     }
+    bool const rim = nblocks > 1 && mine && (!compact || node_on)
+        && (lx == 0 || lx == tw - 1 || ly == 0 || ly == th - 1);
     size_t const N = (size_t)A.num_nodes;
 
     // halo ring position served by this thread
@@ -1565,19 +1459,6 @@ cg_resident_kernel(ResArgs A)
             halo_node = halo_iy * A.stride + halo_ix;
     }
     int const lhalo = hy * LW + hx;
-    // XCD-aware: where in `zl` the node's q appears (-1: in `zg`)
-    int halo_near = -1;
-    if (xcd_on && halo_node >= 0) {
-        int const dx = hx == 0 ? -1 : hx == LW - 1 ? 1 : 0;
-        int const dy = hy == 0 ? -1 : hy == LH - 1 ? 1 : 0;
-        if (same_xcd(tx + dx, ty + dy)) {
-            // from the row segments where there is a choice (the corners)
-            int const side = dy < 0 ? 1 : dy > 0 ? 0 : dx < 0 ? 3 : 2;
-            int const idx = dy != 0 ? (dx < 0 ? tw - 1 : dx > 0 ? 0 : hx - 1) : hy - 1;
-            halo_near = (int)(zl_segment(tx + dx, ty + dy, side) + (unsigned)idx * 64u);
-        }
-    }
-
     if (tracing && blockIdx.x == 0 && tid == 0)
         A.trace[0] = (long long)wall_clock64();
     if (tracing && tid == 0)
@@ -1687,8 +1568,8 @@ cg_resident_kernel(ResArgs A)
             partial_tags(red).tag[tid] = 0u;
         lds_barrier();
         if (has_halo) {
-            hnode[tid] = halo_node;
-            hnode[ring + tid] = halo_near;
+            // (compacted: nobody publishes an inactive node's q -- it is zero)
+            hnode[tid] = halo_node >= 0 && compact && A.active[halo_node] == 0 ? -1 : halo_node;
             // r and P of the halo node, with the operations of its owner
             double Ph16[16], gh[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
@@ -1906,6 +1787,8 @@ cg_resident_kernel(ResArgs A)
     }
     unsigned epoch = 1;
     bool alive = true;
+    int reporter = 0;       // the workgroup that writes the result (compacted: the first live one)
+    bool report_all = false;
     ResState st;
     if constexpr (!ONE) {
         // zero the direction tile (out-of-grid halo stays zero for the whole solve)
@@ -2046,23 +1929,41 @@ cg_resident_kernel(ResArgs A)
         // ---- one exchange per iteration ----
         lds_barrier();          // d_1 (own and halo) in the tile
         stamp(0, 1);
+        // who takes part in the exchanges: everybody, or (compacted) the tiles
+        // with an active node -- their words have been out since they started
+        LiveSet live;
+        int const ngroups_all = (nblocks + RES_GROUP - 1) / RES_GROUP;
+        live.leads = ngroups_all > 1 && tile % RES_GROUP == 0;
+        live.bits = 3u;
+        if (compact) {
+            // (a map that did not arrive: the solve is given up, and since nobody
+            // knows who the first live tile is, every workgroup says so)
+            if (!gather_live_map())
+                alive = false, report_all = true;
+            int const member0 = tile - tile % RES_GROUP, j = tid & 15;
+            auto group_live = [&](int g) {
+                return ((livemap[(g * RES_GROUP) >> 6] >> ((g * RES_GROUP) & 63)) & 0xFFFFull)
+                    != 0ull;
+            };
+            unsigned const mine16 = (unsigned)((livemap[member0 >> 6] >> (member0 & 63))
+                & 0xFFFFull);
+            live.leads = ngroups_all > 1 && mine16 != 0u
+                && (int)__builtin_ctz(mine16) == tile - member0;
+            live.bits = (member0 + j < nblocks && tile_live(member0 + j) ? 1u : 0u)
+                | (j < ngroups_all && group_live(j) ? 2u : 0u);
+            // the first live tile reports the result
+            reporter = 0;
+            for (int w = RES_MAX_BLOCKS / 64 - 1; w >= 0; --w)
+                if (livemap[w] != 0ull)
+                    reporter = 64 * w + (int)__builtin_ctzll(livemap[w]);
+        }
         double xbr = 0.0;       // x.(b + r) of the current vectors
         double zr_part = 0.0;   // this node's z.r, formed where z is (end of the last iteration)
         __amdgpu_buffer_rsrc_t const zbuf = pair_buffer(A.zg, (size_t)A.num_nodes * 128);
-        unsigned const zl_plane = (unsigned)nblocks * zl_tile;   // one parity of `zl`
-        __amdgpu_buffer_rsrc_t const lbuf = pair_buffer(A.zl, (size_t)2 * zl_plane);
-        // (both areas are one allocation: one descriptor for the halo's loads)
-        unsigned const zl_base = (unsigned)((A.zl - A.zg) * sizeof(unsigned long long));
-        __amdgpu_buffer_rsrc_t const hbuf = pair_buffer(A.zg, (size_t)zl_base + 2 * zl_plane);
         // byte offset of a node's four pairs in `zg`: by node id
         auto zg_at = [&](unsigned par, unsigned node) {
             return ((par * (unsigned)A.num_nodes + node) * 4u) * 16u;
         };
-        // ... of this thread's node in the four side segments of its tile in `zl`
-        unsigned const zl_top = zl_segment(tx, ty, 0) + (unsigned)lx * 64u;
-        unsigned const zl_bottom = zl_segment(tx, ty, 1) + (unsigned)lx * 64u;
-        unsigned const zl_left = zl_segment(tx, ty, 2) + (unsigned)ly * 64u;
-        unsigned const zl_right = zl_segment(tx, ty, 3) + (unsigned)ly * 64u;
         auto skew = [&](int k, int point, int who) {
             if (tracing && k == TRACE_SKEW_ITER && tid == who)
                 A.trace[TRACE_SKEW_BASE + 4 * blockIdx.x + point] = (long long)wall_clock64();
@@ -2092,31 +1993,15 @@ cg_resident_kernel(ResArgs A)
             sweep_mark(17, -1);
             // the sums (z.q + w.r is taken as 2 w.r: P is symmetric, z.q = r.(P q))
             double v8[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-            // The rim's q for the neighbouring tiles' halo.  XCD-aware: only what
-            // a tile of another region reads goes through the fabric, the rest
-            // stays in the XCD's L2.
+            // The rim's q for the neighbouring tiles' halo.
             unsigned const hpar = (unsigned)k & 1u;
             auto publish_rim = [&]() {
                 if (rim) {
                     unsigned const t = ztag + (unsigned)k;
-                    if (!xcd_on || rim_far) {
-                        unsigned const at = zg_at(hpar, (unsigned)n);
+                    unsigned const at = zg_at(hpar, (unsigned)n);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            st_pair16(zbuf, at + (unsigned)q * 16u, t, acc[q]);
-                    }
-                    if (xcd_on) {
-                        unsigned const places[4] = { zl_top, zl_bottom, zl_left, zl_right };
-#pragma unroll
-                        for (int side = 0; side < 4; ++side)
-                            if ((rim_near >> side) & 1u) {
-                                unsigned const at = hpar * zl_plane + places[side];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    st_pair16_xcd_local(lbuf, at + (unsigned)q * 16u, t,
-                                        acc[q]);
-                            }
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        st_pair16(zbuf, at + (unsigned)q * 16u, t, acc[q]);
                 }
             };
             // (as soon as q is known, in front of the sums although the exchange
@@ -2171,13 +2056,9 @@ cg_resident_kernel(ResArgs A)
                 for (int hs = tid; hs < ring; hs += 64) {
                     int const node = hnode[hs];
                     double qv[4] = { 0.0, 0.0, 0.0, 0.0 };
-                    if (node >= 0) {
-                        int const near = xcd_on ? hnode[ring + hs] : -1;
-                        (void)poll_node_pairs(hbuf, near >= 0
-                                ? zl_base + hpar * zl_plane + (unsigned)near
-                                : zg_at(hpar, (unsigned)node),
+                    if (node >= 0)
+                        (void)poll_node_pairs(zbuf, zg_at(hpar, (unsigned)node),
                             ztag + (unsigned)k, A.ex, qv, A.wait_poll);
-                    }
                     *reinterpret_cast<double4_r *>(qhl + (size_t)hs * 4)
                         = (double4_r){ qv[0], qv[1], qv[2], qv[3] };
                 }
@@ -2189,12 +2070,8 @@ cg_resident_kernel(ResArgs A)
                     skew(k, 3, 0);
                 }
             };
-            if constexpr (xcd_on)
-                alive = grid_allreduce_xcd<8>(A.ex, ztag, epoch++, nblocks, slot,
-                    (slot >> 3) == A.lead_m, v8, red, flag, other_waves, sweep_mark, A.wait_member, A.wait_poll);
-            else
-                alive = grid_allreduce_tree<8>(A.ex, ztag, epoch++, nblocks, v8, red, flag,
-                    other_waves, sweep_mark, A.wait_member, A.wait_poll);
+            alive = grid_allreduce_tree<8>(A.ex, ztag, epoch++, nblocks, live, v8, red, flag,
+                other_waves, sweep_mark, A.wait_member, A.wait_poll);
             if (!alive)
                 break;
             stamp(k, 3);
@@ -2321,7 +2198,7 @@ cg_resident_kernel(ResArgs A)
             *reinterpret_cast<double4_r *>(A.b + (size_t)n * 4)
                 = *reinterpret_cast<const double4_r *>(bl + (size_t)li * 4);
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if ((tile == reporter || report_all) && tid == 0) {
         // (a halo wait of any workgroup that gave up raised the exchange's flag)
         bool const late_timeout = __hip_atomic_load(&A.ex->timeout, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -2395,32 +2272,8 @@ choose_tiling(int stride, int rows, int max_tiles, bool one, int *tw_out, int *t
 struct ResidentPlan {
     int tw, th;
     bool one;
-    // launch: workgroups; XCD-aware exchange: regions_x x (8 / regions_x)
-    // regions of region_w x region_h tiles, one per XCD (regions_x = 0: tiles
-    // in row-major order, device-scope exchange everywhere)
-    int blocks, regions_x, region_w, region_h;
+    int blocks;     // workgroups of the launch = tiles, row-major
 };
-
-// XCD-aware exchange (grid_allreduce_xcd and the region mapping of the tiles):
-// SMVS_CG_XCD=1 turns it on, =2 also makes workgroups claim each other's slots
-// (test of the failover).  Off by default: it keeps two thirds of the rim
-// traffic and the first hop of the all-reduce inside the XCDs' L2s and still
-// measures 1.5 % BEHIND the device-scope exchange on the full grid (174 against
-// 176.5 M patch-steps/s, profiles/r4_cg_exchange.txt) -- what bounds an
-// exchange is the second hop and the skew between the tiles, not the fabric
-// traffic.  Switched off for the rest of the process when a launch finds two
-// workgroups of an aligned group of eight on the same XCD.
-static std::atomic<bool> g_xcd_exchange_off{false};
-
-static int
-xcd_exchange_mode(void)
-{
-    static int const env = [] {
-        const char *e = std::getenv("SMVS_CG_XCD");
-        return e != nullptr ? std::atoi(e) : 0;
-    }();
-    return g_xcd_exchange_off.load(std::memory_order_relaxed) ? 0 : env;
-}
 
 static void
 finish_plan(const smvs_ctx *ctx, int max_tiles, ResidentPlan *plan)
@@ -2429,30 +2282,6 @@ finish_plan(const smvs_ctx *ctx, int max_tiles, ResidentPlan *plan)
     int const tiles_x = (stride + plan->tw - 1) / plan->tw;
     int const tiles_y = (rows + plan->th - 1) / plan->th;
     plan->blocks = tiles_x * tiles_y;
-    plan->regions_x = plan->region_w = plan->region_h = 0;
-    // two levels only pay on grids of more than one group of the device-scope
-    // tree; eight XCDs on every MI355X partition this runs on
-    if (!plan->one || plan->blocks <= RES_GROUP || xcd_exchange_mode() == 0)
-        return;
-    // the split of the tile grid into 8 regions with the fewest rim nodes on
-    // region borders (what still crosses XCDs), among those that fit the chip
-    long best = -1;
-    for (int rx = 1; rx <= 8; rx *= 2) {
-        int const ry = 8 / rx;
-        int const w = (tiles_x + rx - 1) / rx, h = (tiles_y + ry - 1) / ry;
-        if (8 * w * h > max_tiles)
-            continue;
-        long const crossing = (long)(rx - 1) * tiles_y * plan->th
-            + (long)(ry - 1) * tiles_x * plan->tw;
-        if (best < 0 || crossing < best) {
-            best = crossing;
-            plan->regions_x = rx;
-            plan->region_w = w;
-            plan->region_h = h;
-        }
-    }
-    if (best >= 0)
-        plan->blocks = 8 * plan->region_w * plan->region_h;
 }
 
 static bool
@@ -2463,22 +2292,17 @@ static bool
 resident_plan(const smvs_ctx *ctx, ResidentPlan *plan)
 {
     smvs_ctx::ResidentPlanMemo &m = ctx->res_plan;
-    int const xcd_mode = xcd_exchange_mode();
     if (m.stride != ctx->node_stride || m.nodes != ctx->num_nodes
-        || m.solver_mode != (int)ctx->solver_mode || m.xcd_mode != xcd_mode
-        || m.cus != ctx->resident_cus) {
+        || m.solver_mode != (int)ctx->solver_mode || m.cus != ctx->resident_cus) {
         ResidentPlan p = {};
         m.ok = compute_resident_plan(ctx, &p);
         m.stride = ctx->node_stride;
         m.nodes = ctx->num_nodes;
         m.solver_mode = (int)ctx->solver_mode;
-        m.xcd_mode = xcd_mode;
         m.cus = ctx->resident_cus;
         m.tw = p.tw; m.th = p.th; m.one = p.one ? 1 : 0; m.blocks = p.blocks;
-        m.regions_x = p.regions_x; m.region_w = p.region_w; m.region_h = p.region_h;
     }
     plan->tw = m.tw; plan->th = m.th; plan->one = m.one != 0; plan->blocks = m.blocks;
-    plan->regions_x = m.regions_x; plan->region_w = m.region_w; plan->region_h = m.region_h;
     return m.ok;
 }
 
@@ -2707,14 +2531,6 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     int const tiles_x = (stride + tw - 1) / tw;
     int const num_tiles = plan.blocks;   // workgroups of the launch
     bool const one = plan.one;
-    // the side segments of a tile in the XCD-local halo buffer: tw / th nodes
-    // of 64 bytes, each on cache lines of its own; room for the largest tiling
-    // (tw, th <= 128: two planes of 256 tiles of 4 segments of 8 KB)
-    size_t const zl_row = ((size_t)tw * 64 + 127) / 128 * 128;
-    size_t const zl_col = ((size_t)th * 64 + 127) / 128 * 128;
-    // (only with the XCD-aware exchange switched on: 16 MB per context otherwise idle)
-    size_t const zl_doubles = xcd_exchange_mode() != 0
-        ? (size_t)2 * RES_MAX_BLOCKS * 4 * (128 * 64) / sizeof(double) : 16;
     size_t const lds_bytes = resident_lds_bytes(tw, th, one);
 
     int rc;
@@ -2728,31 +2544,25 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     // (the solver takes grids of at most RES_MAX_BLOCKS tiles of RES_THREADS nodes)
     size_t const zx_nodes = std::min(ctx->cap_nodes, (size_t)RES_MAX_BLOCKS * RES_THREADS);
     if (ctx->res_zx_cap < (size_t)ctx->num_nodes) {
-        // [2][zx_nodes][4][2] words of `zg`, then `zl` at its largest (tw <= 128,
-        // four row segments per workgroup)
-        if ((rc = device_alloc(&ctx->res_zx, zx_nodes * 16 + zl_doubles)) != SMVS_OK) {
+        // [2][zx_nodes][4][2] words of `zg`
+        if ((rc = device_alloc(&ctx->res_zx, zx_nodes * 16)) != SMVS_OK) {
             ctx->res_zx_cap = 0;
             return rc;
         }
-        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0,
-            (zx_nodes * 16 + zl_doubles) * sizeof(double), ctx->stream));
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0, zx_nodes * 16 * sizeof(double),
+            ctx->stream));
         ctx->res_zx_cap = zx_nodes;
     }
-    static bool attr_set[16] = { false };
-    if (ctx->device < 16 && !attr_set[ctx->device]) {
-        const void *kernels[8] = {
-            reinterpret_cast<const void *>(cg_resident_kernel<false, false, false, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, false, false, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<false, true, false, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, true, false, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<false, true, true, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, true, true, false>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, true, false, true>),
-            reinterpret_cast<const void *>(cg_resident_kernel<true, true, true, true>) };
+    {
+        const void *kernels[5] = {
+            reinterpret_cast<const void *>(cg_resident_kernel<false, false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, false, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<false, true, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true, false>),
+            reinterpret_cast<const void *>(cg_resident_kernel<true, true, true>) };
         for (const void *k : kernels)
-            SMVS_HIP_CHECK(hipFuncSetAttribute(k,
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[ctx->device] = true;
+            if ((rc = allow_dynamic_lds(ctx->device, k, lds_bytes)) != SMVS_OK)
+                return rc;
     }
 
     ResArgs A;
@@ -2762,16 +2572,6 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.x = ctx->x;
     A.b = ctx->b;
     A.zg = reinterpret_cast<unsigned long long *>(ctx->res_zx);
-    A.zl = reinterpret_cast<unsigned long long *>(ctx->res_zx + ctx->res_zx_cap * 16);
-    A.xcd = plan.regions_x != 0 ? xcd_exchange_mode() : 0;
-    A.regions_x = plan.regions_x;
-    A.region_w = plan.region_w;
-    A.region_h = plan.region_h;
-    // the XCD is summed by a tile in the middle of its region: no neighbour on
-    // another XCD, so no write-through store of its own in front of the sums
-    A.lead_m = (plan.region_h / 2) * plan.region_w + plan.region_w / 2;
-    A.zl_row = (int)zl_row;
-    A.zl_col = (int)zl_col;
     A.ex = reinterpret_cast<ResExchange *>(ctx->res_work);
     A.state = reinterpret_cast<ResState *>(ctx->cg_state);
     A.status = ctx->status;
@@ -2786,7 +2586,7 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange),
             ctx->stream));
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_zx, 0,
-            (ctx->res_zx_cap * 16 + zl_doubles) * sizeof(double), ctx->stream));
+            ctx->res_zx_cap * 16 * sizeof(double), ctx->stream));
     }
     A.solve_tag = ctx->cg_solve_id << 16;
     A.num_nodes = ctx->num_nodes;
@@ -2801,6 +2601,7 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.fixed_tolerance = error_tolerance;
     A.Hp = ctx->Hp;
     A.gp = ctx->gp;
+    A.layout = patch_layout(ctx);
     A.patch_valid = ctx->patch_valid;
     A.active = ctx->active;
     A.active_next = ctx->active_next;
@@ -2810,9 +2611,9 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
     A.zeros = ctx->zero_block;
     {
         // polling cadence (the measured defaults; SMVS_CG_WAIT="halo,member,poll"
-        // overrides them for experiments): the device-scope exchange gains 1.5 us
-        // per iteration when the halo's polls start 1 us late (they compete with
-        // the write-through stores of the rim), the XCD-aware one does not
+        // overrides them for experiments): the exchange gains 1.5 us per iteration
+        // when the halo's polls start 1 us late (they compete with the
+        // write-through stores of the rim)
         struct Knobs { int halo = -1, member = 3, poll = 0; };
         static Knobs const knobs = [] {
             Knobs k;
@@ -2822,9 +2623,16 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         }();
         // (the full grid only: at 64 tiles the wait changes nothing, 6.95 against
         // 6.86 us per iteration, at 16 tiles it costs 0.5 us)
-        A.wait_halo = knobs.halo >= 0 ? knobs.halo : A.xcd != 0 || num_tiles <= 64 ? 0 : 4;
+        A.wait_halo = knobs.halo >= 0 ? knobs.halo : num_tiles <= 64 ? 0 : 4;
         A.wait_member = knobs.member;
         A.wait_poll = knobs.poll;
+    }
+    {
+        static int const compact = [] {
+            const char *e = std::getenv("SMVS_CG_COMPACT");
+            return e != nullptr && e[0] == '0' ? 0 : 1;
+        }();
+        A.compact = compact;
     }
     A.trace = trace_dev;
     {
@@ -2843,45 +2651,29 @@ resident_enqueue(smvs_ctx *ctx, int max_iterations, double error_tolerance,
             hipLaunchKernelGGL(kernel, dim3(num_tiles), dim3(RES_THREADS), lds_bytes,
                 ctx->stream, A);
         };
-        bool const xcd = A.xcd != 0;
-        // (stamps: the fused one-exchange kernels only, what tools/cg_trace.py runs)
-        if (fused && one && trace_dev != nullptr && xcd)
-            launch(cg_resident_kernel<true, true, true, true>);
-        else if (fused && one && trace_dev != nullptr)
-            launch(cg_resident_kernel<true, true, false, true>);
-        else if (fused && one && xcd)
-            launch(cg_resident_kernel<true, true, true, false>);
+        // (stamps: the fused one-exchange kernel only, what tools/cg_trace.py runs)
+        if (fused && one && trace_dev != nullptr)
+            launch(cg_resident_kernel<true, true, true>);
         else if (fused && one)
-            launch(cg_resident_kernel<true, true, false, false>);
+            launch(cg_resident_kernel<true, true, false>);
         else if (fused)
-            launch(cg_resident_kernel<true, false, false, false>);
-        else if (one && xcd)
-            launch(cg_resident_kernel<false, true, true, false>);
+            launch(cg_resident_kernel<true, false, false>);
         else if (one)
-            launch(cg_resident_kernel<false, true, false, false>);
+            launch(cg_resident_kernel<false, true, false>);
         else
-            launch(cg_resident_kernel<false, false, false, false>);
+            launch(cg_resident_kernel<false, false, false>);
     }
     SMVS_HIP_CHECK(hipGetLastError());
     return SMVS_OK;
 }
 
-// A resident solve gave up (the caller has waited for the kernel).  Workgroups
-// that were not all resident: never try again on this context, the streaming
-// kernels take over.  A workgroup on an unexpected XCD: the resident solver
-// stays, the XCD-aware exchange goes for the rest of the process.
+// A resident solve gave up (the caller has waited for the kernel): its
+// workgroups were not all resident.  Never try again on this context, the
+// streaming kernels take over.
 int
 cg_resident_gave_up(smvs_ctx *ctx)
 {
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->res_work, 0, sizeof(ResExchange), ctx->stream));
-    volatile int *progress = ctx->cg_progress;
-    if (progress[6] != 0) {
-        progress[6] = 0;
-        if (!g_xcd_exchange_off.exchange(true))
-            std::fprintf(stderr, "[smvs_hip] eight consecutive workgroups do not cover the eight "
-                "XCDs: the resident solver exchanges at device scope from now on\n");
-        return SMVS_OK;
-    }
     ctx->resident_disabled = true;
     return SMVS_OK;
 }

@@ -145,7 +145,7 @@ struct smvs_ctx {
     // CG vectors, [N][4] each
     double *x = nullptr, *r = nullptr, *z = nullptr, *Ad = nullptr,
         *d = nullptr, *d2 = nullptr, *b = nullptr;
-    double *partials = nullptr;     // [4][1024] per-block reduction partials
+    double *partials = nullptr;     // [2][6][512] per-block reduction partials of cg.hip (high, low words)
     void *cg_state = nullptr;       // CgState[2] (cg.hip)
     int last_cg_iterations = 0;     // sizes the first chunk of the next solve
     bool cg_use_active = false;     // system built by gn_construct: skip inactive nodes
@@ -178,9 +178,9 @@ struct smvs_ctx {
     // the resident solver's tiling of the current grid (cg_resident.hip,
     // resident_plan: ~1,000 candidate shapes), kept while its inputs stay
     struct ResidentPlanMemo {
-        int stride = -1, nodes = -1, solver_mode = -1, xcd_mode = -1, cus = -1;
+        int stride = -1, nodes = -1, solver_mode = -1, cus = -1;
         bool ok = false;
-        int tw = 0, th = 0, one = 0, blocks = 0, regions_x = 0, region_w = 0, region_h = 0;
+        int tw = 0, th = 0, one = 0, blocks = 0;
     };
     mutable ResidentPlanMemo res_plan;
     int resident_cus = 0, resident_lds = 0;
@@ -265,6 +265,12 @@ int device_malloc(void **ptr, size_t bytes);
 // Returns what the pools hold idle to the driver; -> objects freed.
 int release_idle_device_memory(void);
 
+// Launches with more than 64 KB of dynamic LDS need
+// hipFuncAttributeMaxDynamicSharedMemorySize raised for the kernel on the
+// device: done once per (device, kernel) and size reached, under a mutex, for
+// any device index.  Returns SMVS_ERR_HIP when the device cannot grant it.
+int allow_dynamic_lds(int device, const void *kernel, size_t bytes);
+
 template <typename T>
 int device_alloc(T **ptr, size_t count)
 {
@@ -348,6 +354,34 @@ patch_upper_offset(int bi, int bj)   // bi < bj
 {
     return 4 * PATCH_DIAG_STRIDE + (upper_block(bi, bj) - (bi + 1)) * 16;
 }
+
+// Where the 36 quads (4 doubles = 32 bytes) of a patch's packed system and the
+// 4 quads of its gradient live in HBM.  Two strides, in quads, per buffer:
+// quad j of patch p sits at quad index j * quad_stride + p * patch_stride.
+//   planar (default since round 5): quad_stride = P rounded up to 4,
+//     patch_stride = 1 -- 36 (4) planes of one quad per patch.  The consumer is
+//     the resident solver's prologue, whose thread for node n reads the same
+//     quad of patches p, p + 1, ... in neighbouring lanes: one contiguous
+//     32 bytes x 64 lanes per load instead of 64 lines 1,152 bytes apart (the
+//     prologue was bound by the address rate of its texture unit: 2.7 TB/s);
+//   patch-major (SMVS_HP_LAYOUT=aos, rounds 1-4): quad_stride = 1,
+//     patch_stride = 36 (4).
+// The values are the same either way; tests run both.
+struct PatchLayout {
+    unsigned hq, hp;    // Hp: quad stride, patch stride
+    unsigned gq, gp;    // gp
+};
+__host__ __device__ __forceinline__ size_t
+patch_h_at(PatchLayout const &L, size_t patch, int element)     // index in doubles
+{
+    return ((size_t)(element >> 2) * L.hq + patch * L.hp) * 4 + (size_t)(element & 3);
+}
+__host__ __device__ __forceinline__ size_t
+patch_g_at(PatchLayout const &L, size_t patch, int element)
+{
+    return ((size_t)(element >> 2) * L.gq + patch * L.gp) * 4 + (size_t)(element & 3);
+}
+PatchLayout patch_layout(const smvs_ctx *ctx);
 
 
 // lib/ldl_decomposition.h:43-92 for a 4x4 block, same operation order.

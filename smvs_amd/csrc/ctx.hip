@@ -1,9 +1,30 @@
 // Context management, plane / surface uploads, profiling.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <cmath>
 
 namespace smvs_hip {
+
+PatchLayout
+patch_layout(const smvs_ctx *ctx)
+{
+    static bool const aos = [] {
+        const char *e = std::getenv("SMVS_HP_LAYOUT");
+        return e != nullptr && e[0] == 'a';
+    }();
+    PatchLayout L;
+    if (aos) {
+        L.hq = 1; L.hp = PATCH_H_STRIDE / 4;
+        L.gq = 1; L.gp = 4;
+    } else {
+        unsigned const plane = ((unsigned)ctx->num_patches + 3u) & ~3u;
+        L.hq = plane; L.hp = 1;
+        L.gq = plane; L.gp = 1;
+    }
+    return L;
+}
 
 static thread_local char g_error[512] = "";
 
@@ -268,7 +289,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || (rc = device_alloc(&ctx->status, I_NUM)) != SMVS_OK
         || (rc = device_alloc(&ctx->lighting, 16)) != SMVS_OK
         || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK
-        || (rc = device_alloc(&ctx->partials, 4 * 1024)) != SMVS_OK
+        || (rc = device_alloc(&ctx->partials, 2 * 6 * 512)) != SMVS_OK
         || (rc = device_alloc(&ctx->step_counter, 2)) != SMVS_OK
         || (rc = device_alloc(&ctx->zero_block, 16)) != SMVS_OK
         || (rc = device_alloc(reinterpret_cast<char **>(&ctx->cg_state), 256)) != SMVS_OK) {
@@ -644,8 +665,10 @@ smvs_hip::ctx_ensure_grid(smvs_ctx *ctx, int scale, int npx, int npy, int start_
         if ((rc = device_alloc(&ctx->patch_valid, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->live_list, cap)) != SMVS_OK
             || (rc = device_alloc(&ctx->patch_vis, cap)) != SMVS_OK
-            || (rc = device_alloc(&ctx->Hp, cap * 256)) != SMVS_OK
-            || (rc = device_alloc(&ctx->gp, cap * 16)) != SMVS_OK)
+            // (36 and 4 quads of 4 doubles per patch, in planes of the patch
+            // count rounded up to a multiple of four: PatchLayout, common.h)
+            || (rc = device_alloc(&ctx->Hp, (cap + 4) * PATCH_H_STRIDE)) != SMVS_OK
+            || (rc = device_alloc(&ctx->gp, (cap + 4) * 16)) != SMVS_OK)
             return rc;
         ctx->cap_patches = cap;
     }

@@ -43,6 +43,7 @@ struct PatchKernelArgs {
     const double *lighting;      // [16] or nullptr
     double *Hp;
     double *gp;
+    PatchLayout layout;          // of Hp / gp (common.h)
     int W, H;
     int npx, npy, stride;
     int ps, start_x, start_y;
@@ -905,18 +906,19 @@ gn_patch_kernel(PatchKernelArgs A)
         // four diagonal node blocks, then the six blocks (bi < bj) in full,
         // row-major (the assembly mirrors the rest).  v_mfma_f64_4x4x4 leaves element (i, j) of block slot b in
         // lane 16 i + 4 b + j, i.e. in lane (kg, col) = (i, 4 b + j).
-        double *Hout = A.Hp + (size_t)patch * PATCH_H_STRIDE;
+        // (where element e of the packed record goes: PatchLayout, common.h)
+        auto at = [&](int e) { return patch_h_at(A.layout, (size_t)patch, e); };
         int const bs = col >> 2, jc = col & 3;
         if (kg <= jc)   // (the diagonal blocks: upper triangle only, packed)
-            Hout[patch_diag_offset(bs) + upper_block(kg, jc)] = acc[q][0];
+            A.Hp[at(patch_diag_offset(bs) + upper_block(kg, jc))] = acc[q][0];
         if (bs >= 1)
-            Hout[patch_upper_offset(bs - 1, bs) + kg * 4 + jc] = acc[q][1];
+            A.Hp[at(patch_upper_offset(bs - 1, bs) + kg * 4 + jc)] = acc[q][1];
         else   // block (3, 0): the transpose of the stored block (0, 3)
-            Hout[patch_upper_offset(0, 3) + jc * 4 + kg] = acc[q][1];
+            A.Hp[at(patch_upper_offset(0, 3) + jc * 4 + kg)] = acc[q][1];
         if (bs >= 2)
-            Hout[patch_upper_offset(bs - 2, bs) + kg * 4 + jc] = acc[q][2];
+            A.Hp[at(patch_upper_offset(bs - 2, bs) + kg * 4 + jc)] = acc[q][2];
         if (lane < 16)
-            A.gp[(size_t)patch * 16 + lane] = gv;
+            A.gp[patch_g_at(A.layout, (size_t)patch, lane)] = gv;
     }
 }
 
@@ -930,6 +932,7 @@ gn_patch_kernel(PatchKernelArgs A)
 struct AssembleArgs {
     const double *Hp;
     const double *gp;
+    PatchLayout layout;
     const uint8_t *patch_valid;
     const uint8_t *active;
     double *H9;     // [5][N][16]: slots 4..8 of the block stencil
@@ -969,7 +972,7 @@ gn_assemble_kernel(AssembleArgs A)
             int const p = pyq * A.npx + pxq;
             if (!A.patch_valid[p])
                 continue;
-            const double *Hl = A.Hp + (size_t)p * PATCH_H_STRIDE;
+            auto Hl = [&](int e) { return A.Hp[patch_h_at(A.layout, (size_t)p, e)]; };
             int const n00 = pyq * A.stride + pxq;
 #pragma unroll
             for (int lm = 0; lm < 4; ++lm) {
@@ -987,13 +990,13 @@ gn_assemble_kernel(AssembleArgs A)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     double const v = lm > ln
-                        ? Hl[patch_upper_offset(ln, lm) + r * 4 + c]
-                        : Hl[patch_diag_offset(ln) + (r <= c ? upper_block(r, c)
-                                                              : upper_block(c, r))];
+                        ? Hl(patch_upper_offset(ln, lm) + r * 4 + c)
+                        : Hl(patch_diag_offset(ln) + (r <= c ? upper_block(r, c)
+                                                              : upper_block(c, r)));
                     out[slot][c] += v;
                 }
             }
-            gout += A.gp[(size_t)p * 16 + 4 * ln + r];
+            gout += A.gp[patch_g_at(A.layout, (size_t)p, 4 * ln + r)];
         }
     }
 
@@ -1148,6 +1151,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     A.lighting = ctx->lighting;
     A.Hp = ctx->Hp;
     A.gp = ctx->gp;
+    A.layout = patch_layout(ctx);
     A.W = ctx->width;
     A.H = ctx->height;
     A.npx = ctx->npx;
@@ -1219,6 +1223,7 @@ gn_assemble_launch(smvs_ctx *ctx)
     AssembleArgs B;
     B.Hp = ctx->Hp;
     B.gp = ctx->gp;
+    B.layout = patch_layout(ctx);
     B.patch_valid = ctx->patch_valid;
     B.active = ctx->active;
     B.status = ctx->status;
@@ -1359,30 +1364,41 @@ smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp)
     }
     SMVS_HIP_CHECK(hipSetDevice(ctx->device));
     size_t const P = (size_t)ctx->num_patches;
-    std::vector<double> packed;
+    PatchLayout const L = patch_layout(ctx);
+    // (the buffers as they lie on the device: the record of the last patch
+    // ends where its last element does, in either layout)
+    size_t const h_doubles = P == 0 ? 0 : patch_h_at(L, P - 1, PATCH_H_STRIDE - 1) + 1;
+    size_t const g_doubles = P == 0 ? 0 : patch_g_at(L, P - 1, 15) + 1;
+    std::vector<double> packed, gpacked;
     if (Hp != nullptr) {
-        packed.resize(P * PATCH_H_STRIDE);
+        packed.resize(h_doubles);
         SMVS_HIP_CHECK(hipMemcpyAsync(packed.data(), ctx->Hp,
             packed.size() * sizeof(double), hipMemcpyDeviceToHost,
             ctx->stream));
     }
-    if (gp != nullptr)
-        SMVS_HIP_CHECK(hipMemcpyAsync(gp, ctx->gp, P * 16 * sizeof(double),
+    if (gp != nullptr) {
+        gpacked.resize(g_doubles);
+        SMVS_HIP_CHECK(hipMemcpyAsync(gpacked.data(), ctx->gp, g_doubles * sizeof(double),
             hipMemcpyDeviceToHost, ctx->stream));
+    }
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (gp != nullptr)
+        for (size_t p = 0; p < P; ++p)
+            for (int e = 0; e < 16; ++e)
+                gp[p * 16 + e] = gpacked[patch_g_at(L, p, e)];
     if (Hp != nullptr) {
         // unpack the upper block triangle; blocks below it are the mirror
         for (size_t p = 0; p < P; ++p) {
-            const double *src = packed.data() + p * PATCH_H_STRIDE;
+            auto src = [&](int e) { return packed[patch_h_at(L, p, e)]; };
             double *dst = Hp + p * 256;
             for (int bi = 0; bi < 4; ++bi)
                 for (int bj = bi; bj < 4; ++bj) {
                     for (int r = 0; r < 4; ++r)
                         for (int c = 0; c < 4; ++c) {
                             double const v = bj > bi
-                                ? src[patch_upper_offset(bi, bj) + r * 4 + c]
-                                : src[patch_diag_offset(bi) + (r <= c ? upper_block(r, c)
-                                                                      : upper_block(c, r))];
+                                ? src(patch_upper_offset(bi, bj) + r * 4 + c)
+                                : src(patch_diag_offset(bi) + (r <= c ? upper_block(r, c)
+                                                                      : upper_block(c, r)));
                             dst[(4 * bi + r) * 16 + 4 * bj + c] = v;
                             if (bj > bi)
                                 dst[(4 * bj + c) * 16 + 4 * bi + r] = v;

@@ -274,11 +274,13 @@ depth_key(float d)
 // Surface::remove_isolated_patches, lib/surface.cc:887-927, deletes in place
 // while it walks the grid column by column, so a deletion changes the counts
 // of the patches visited after it.  Cell (x, y) reads the visited state of
-// (x-1, y-1..y+1) and (x, y-1) and the unvisited state of the rest.  A
-// schedule in which column x runs at least one row plus a step behind column
-// x - 1 reproduces the sequential walk exactly; csrc/surface.hip's kernel
-// (one thread per column, ISO_ROWS rows per step) and the host mirror's
-// transposed walk are the two users.
+// (x-1, y-1..y+1) and (x, y-1) and the unvisited state of the rest: a
+// recurrence on a DAG, del(p) = valid(p) and (valid neighbours - deleted
+// earlier neighbours < 3), whose unique solution a relaxation reaches from any
+// start.  csrc/surface.hip's kernel relaxes all patches at once on bit columns
+// (32 rows per word, the neighbour counts by a bit-sliced adder; pinned by
+// tests/test_isolated_relaxation_cpu.py); the host mirror walks like the
+// reference (csrc/host/surface.cc).
 
 } // namespace smvs_surf
 

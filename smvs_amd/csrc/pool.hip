@@ -14,9 +14,36 @@
 // smvs_release_workspaces() or process exit.
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace smvs_hip {
+
+int
+allow_dynamic_lds(int device, const void *kernel, size_t bytes)
+{
+    // what a launch gets without asking
+    if (bytes <= (size_t)64 * 1024)
+        return SMVS_OK;
+    static std::mutex mutex;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    std::lock_guard<std::mutex> guard(mutex);
+    size_t &have = granted[std::make_pair(device, kernel)];
+    if (bytes <= have)
+        return SMVS_OK;
+    // (the attribute belongs to the current device: the callers have set it)
+    hipError_t const err = hipFuncSetAttribute(kernel,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("allow_dynamic_lds: %zu bytes of LDS refused on device %d: %s", bytes,
+            device, hipGetErrorString(err));
+        return SMVS_ERR_HIP;
+    }
+    have = bytes;
+    return SMVS_OK;
+}
 
 namespace {
 constexpr int MAX_DEVICES = 16;

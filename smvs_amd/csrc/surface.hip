@@ -790,7 +790,13 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
     size_t const bytes = 2 * (size_t)(A.g.npx + 2) * wpc * sizeof(unsigned);
     unsigned *global_bits = nullptr;
     size_t lds = bytes;
-    if (bytes > (size_t)150 * 1024) {
+    // The bit columns live in LDS when they fit (the kernel's static
+    // __shared__ word counts against the CU's 160 KB too) and the device grants
+    // that much dynamic LDS for this launch -- asked for per launch, only as
+    // much as the grid needs; otherwise in global memory.
+    if (bytes > (size_t)150 * 1024
+        || allow_dynamic_lds(ctx->device,
+               reinterpret_cast<const void *>(surf_isolated_kernel), bytes) != SMVS_OK) {
         if (ctx->surf_bits_cap < bytes) {
             ctx->surf_bits_cap = 0;
             if ((rc = device_alloc(&ctx->surf_bits, bytes / sizeof(unsigned))) != SMVS_OK)
@@ -799,14 +805,6 @@ smvs_surface_remove_isolated_patches(smvs_ctx *ctx, int *num_valid_patches)
         }
         global_bits = ctx->surf_bits;
         lds = 0;
-    }
-    static bool attr_set[16] = { false };
-    if (ctx->device < 16 && !attr_set[ctx->device]) {
-        SMVS_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(surf_isolated_kernel),
-            // (the kernel's static __shared__ word counts against the 160 KB too)
-            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr_set[ctx->device] = true;
     }
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_SURF_CHANGED, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(surf_isolated_kernel, dim3(1), dim3(1024), lds, ctx->stream, A,

@@ -1073,7 +1073,6 @@ run_steps_pipelined(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
             if (solver) {
                 // its workgroups were not all resident: never try again on
                 // this context, the caller goes on with the streaming solver
-                // (or one of them sat on an unexpected XCD: see there)
                 return cg_resident_gave_up(ctx);
             }
             // the live list outgrew the launch: again, sized for the list

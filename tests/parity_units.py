@@ -1,0 +1,92 @@
+"""What a whole-optimize() parity test asserts about the batch log: the units the
+bench metric counts (BASELINE.json: Gauss-Newton iterations x active patches),
+not only the control flow.
+
+Per batch (one run_newton_iterations call, lib/depth_optimizer.cc:219-304):
+
+  * scale, iteration, Newton steps and valid patches   -- identical;
+  * active patch-steps (sum over the steps of the patches with an active node,
+    gauss_newton_step.cc:73-79)                        -- identical;
+  * CG iterations (conjugate_gradient.h:123-198)       -- within `cg_bound`.
+
+The written bound on the CG iterations of a batch: the solver's termination
+tests are discrete decisions on sums whose association differs between a
+sequential CPU loop and a tree over wavefronts (the reference's own SSE and
+scalar branches end solves of a 1920x1080 optimize() 16 iterations apart over
+the last batches), so a solve may end one iteration apart
+from the oracle's: bound = one per Newton step of the batch.  On grids of more
+than one tile no difference has been observed in any sweep
+(profiles/r4_fuzz_parity.txt: 40 / 40) and the full-size tests demand zero
+there unless the caller passes a measured exception.
+
+When every batch agrees exactly the caller demands the north-star depth
+tolerance (1e-4 relative L2); the table is written next to the other GPU
+evidence (gpurun_out/, copied to profiles/ at the end of a round)."""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def grid_nodes(width, height, scale):
+    """Nodes of the surface at a scale (lib/surface.cc:28-37)."""
+    ps = 1 << scale
+    npx = (width - 2) // ps - 1
+    npy = (height - 2) // ps - 1
+    return (npx + 1) * (npy + 1)
+
+
+def one_tile(width, height, scale):
+    """The resident solver runs such a grid in ONE workgroup in the reference's
+    operation order (csrc/cg_resident.hip, resident_plan)."""
+    return grid_nodes(width, height, scale) <= 512
+
+
+def control_flow(log):
+    return [(e["scale"], e["iter"], e["newton_steps"], e["valid_patches"]) for e in log]
+
+
+def table(got, want, width, height):
+    rows = ["scale iter | steps dev/orc | valid patches dev/orc | active patch-steps dev/orc"
+            " | CG iterations dev/orc | bound"]
+    for a, b in zip(got, want):
+        rows.append("%5d %4d | %5d / %-5d | %9d / %-9d | %10d / %-10d | %6d / %-6d | %d"
+                    % (a["scale"], a["iter"], a["newton_steps"], b["newton_steps"],
+                       a["valid_patches"], b["valid_patches"], a["active_patch_steps"],
+                       b["active_patch_steps"], a["cg_iterations"], b["cg_iterations"],
+                       cg_bound(b, width, height)))
+    rows.append("totals: active patch-steps %d / %d, CG iterations %d / %d"
+                % (sum(e["active_patch_steps"] for e in got),
+                   sum(e["active_patch_steps"] for e in want),
+                   sum(e["cg_iterations"] for e in got),
+                   sum(e["cg_iterations"] for e in want)))
+    return "\n".join(rows)
+
+
+def cg_bound(entry, width, height, multi_tile_bound=0):
+    if one_tile(width, height, entry["scale"]):
+        return entry["newton_steps"]
+    return multi_tile_bound * entry["newton_steps"]
+
+
+def assert_same_units(got, want, width, height, tag, multi_tile_bound=0):
+    """got / want: batch logs of host.optimize / oracle.optimize.  Returns True
+    when every batch agrees in every unit exactly."""
+    text = table(got, want, width, height)
+    print("%s\n%s" % (tag, text))
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r5_units_%s.txt" % tag), "w") as f:
+            f.write("# %s: batch log of DepthOptimizer::optimize, device (C++ host + HIP) / oracle\n%s\n"
+                    % (tag, text))
+    except OSError:
+        pass
+    assert control_flow(got) == control_flow(want), text
+    assert len(got) == len(want)
+    exact = True
+    for a, b in zip(got, want):
+        assert a["active_patch_steps"] == b["active_patch_steps"], text
+        diff = abs(a["cg_iterations"] - b["cg_iterations"])
+        assert diff <= cg_bound(b, width, height, multi_tile_bound), text
+        exact = exact and diff == 0
+    return exact

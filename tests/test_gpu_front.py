@@ -35,9 +35,7 @@ def oracle_threads(oracle):
     oracle.lib().orc_set_threads(1)
 
 
-def _same_control_flow(a, b):
-    key = lambda e: (e["scale"], e["iter"], e["newton_steps"], e["valid_patches"])
-    return [key(e) for e in a] == [key(e) for e in b]
+from parity_units import assert_same_units  # noqa: E402  (tests/parity_units.py)
 
 
 # ------------------------------------------------------------ a19: SGM front
@@ -166,9 +164,11 @@ def test_full_size_optimize_with_sgm_matches_oracle(hip, oracle, oracle_threads)
     (960x540 x 128 planes, 8 paths, two neighbours, L/R check, merge) feeding
     DepthOptimizer::optimize down to scale 2.  C++ host + HIP against the
     oracle running its own SGM front end and optimiser on the same images:
-    the merged SGM depth is bit-identical, the batch log (scale, iteration,
-    Newton steps, valid patches) identical, the valid pixels identical and the
-    depth within 1e-4 relative L2."""
+    the merged SGM depth is bit-identical, the batch log identical in the
+    units the bench metric counts (scale, iteration, Newton steps, valid
+    patches, ACTIVE PATCH-STEPS per batch exactly; CG iterations per batch
+    within the written bound of tests/parity_units.py), the valid pixels
+    identical and the depth within 1e-4 relative L2."""
     from smvs_amd import host
     inputs = _full_size_inputs()
     sgm = host.sgm_depth(inputs, sgm_scale=1)
@@ -180,7 +180,7 @@ def test_full_size_optimize_with_sgm_matches_oracle(hip, oracle, oracle_threads)
     want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
                            sgm_depth=oracle.sgm_depth_for_view(inputs, sgm_scale=1,
                                                                roundtrip=True))
-    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert_same_units(got["log"], want["log"], 1920, 1080, "configs2_sgm_1920x1080")
     assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
     assert (want["depth"] > 0).mean() > 0.5
     assert _rel(got["depth"], want["depth"]) <= 1e-4
@@ -196,8 +196,10 @@ def test_full_size_optimize_basic_matches_oracle(hip, oracle, oracle_threads):
     test, expand), shading off, scales init .. 2, five iterations per scale.
     C++ host + HIP against the oracle's optimize(): identical batch log (scale,
     iteration, Newton steps, valid patches), identical valid pixels, depth
-    within 1e-4 relative L2; the per-batch active patch-steps and CG iteration
-    totals are printed side by side (they are the units of the bench value)."""
+    within 1e-4 relative L2; the per-batch ACTIVE PATCH-STEPS -- the unit of the
+    bench value -- are asserted equal and the CG iterations per batch within
+    the written bound (tests/parity_units.py); the table goes to
+    gpurun_out/r5_units_configs1_basic_1920x1080.txt."""
     from smvs_amd import host
     import bench
     inputs = _full_size_inputs()
@@ -205,12 +207,7 @@ def test_full_size_optimize_basic_matches_oracle(hip, oracle, oracle_threads):
                         min_scale=bench.SCALE)
     want = oracle.optimize(inputs, regularization=bench.REG, num_iterations=5,
                            min_scale=bench.SCALE)
-    for a, b in zip(got["log"], want["log"]):
-        print("scale %d iter %d: steps %d / %d, valid %d / %d, CG %s / %s"
-              % (a["scale"], a["iter"], a["newton_steps"], b["newton_steps"],
-                 a["valid_patches"], b["valid_patches"], a.get("cg_iterations"),
-                 b.get("cg_iterations")))
-    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert_same_units(got["log"], want["log"], 1920, 1080, "configs1_basic_1920x1080")
     assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
     assert (want["depth"] > 0).mean() > 0.2
     print("configs[1] whole optimize: depth rel. L2 %.2e" % _rel(got["depth"], want["depth"]))
@@ -233,10 +230,41 @@ def test_full_size_optimize_shading_aware_matches_oracle(hip, oracle, oracle_thr
                         use_shading=True)
     want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
                            use_shading=True)
-    assert _same_control_flow(got["log"], want["log"]), (got["log"], want["log"])
+    assert_same_units(got["log"], want["log"], 1920, 1080, "configs3_shading_1920x1080")
     assert got["lighting"] is not None and want["lighting"] is not None
     assert _rel(got["lighting"], want["lighting"]) < 1e-3
     assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
+
+
+def test_full_size_view_of_config5_sgm_and_shading_matches_oracle(hip, oracle, oracle_threads):
+    """BASELINE.json configs[4]'s per-view task at its real size on one rank
+    (app/smvsrecon.cc:693-720): 1920x1080, 1 + 8 views, the SGM initialisation
+    (960x540 x 128 planes, two neighbours, L/R check, merge, bilateral
+    upsample) AND -S (GlobalLighting SH fit per view + shading residual)
+    together, down to scale 2.  C++ host + HIP against the oracle's own SGM
+    front end and optimiser: SGM depth bit-identical, batch log identical in
+    the metric's units (tests/parity_units.py), lighting to 1e-3, valid pixels
+    identical, depth within 1e-4 relative L2.  (The 64-view / 8-GPU sharding
+    of configs[4] repeats this task per view: test_shard_cpu.py,
+    test_config5_whole_pipeline_round_robin.)"""
+    from smvs_amd import host
+    rng = np.random.default_rng(4242)
+    lighting = np.zeros(16); lighting[0] = 0.85
+    lighting[1:4] = rng.uniform(-0.2, 0.2, 3)
+    inputs = _full_size_inputs(lighting)
+    sgm = host.sgm_depth(inputs, sgm_scale=1)
+    got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                        use_shading=True, sgm_depth=sgm)
+    sgm_o = oracle.sgm_depth_for_view(inputs, sgm_scale=1, roundtrip=True)
+    assert np.array_equal(got["sgm_roundtrip"], sgm_o)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                           use_shading=True, sgm_depth=sgm_o)
+    assert_same_units(got["log"], want["log"], 1920, 1080, "configs4_view_sgm_shading_1920x1080")
+    assert got["lighting"] is not None and want["lighting"] is not None
+    assert _rel(got["lighting"], want["lighting"]) < 1e-3
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert (want["depth"] > 0).mean() > 0.5
     assert _rel(got["depth"], want["depth"]) <= 1e-4
 
 
@@ -318,7 +346,7 @@ def test_config5_whole_pipeline_round_robin(hip, oracle, oracle_threads):
         assert np.array_equal(got["sgm_roundtrip"], sgm_o), view
         want = oracle.optimize(inputs, regularization=0.01, num_iterations=3,
                                min_scale=2, use_shading=True, sgm_depth=sgm_o)
-        assert _same_control_flow(got["log"], want["log"]), (view, got["log"], want["log"])
+        assert_same_units(got["log"], want["log"], w, h, "config5_round_robin_view%d" % view)
         assert got["lighting"] is not None and want["lighting"] is not None
         assert _rel(got["lighting"], want["lighting"]) < 1e-3
         assert np.array_equal(got["depth"] > 0, want["depth"] > 0)

@@ -125,7 +125,9 @@ def test_device_surface_from_an_initial_depth_map(host, oracle, init_scale):
 def test_device_surface_full_size_script(host, oracle):
     """The grids of the bench workload: 1920x1080 from a depth map at scale 4,
     subdivided twice to scale 2 (479 x 269 nodes) with the fill and the
-    isolated-patch walk (1,222 steps) in between."""
+    isolated-patch walk (1,222 steps) in between -- against the host mirror
+    (bit-identical) AND against the oracle's restatement of lib/surface.cc
+    (validity identical, nodes to 1e-12 after the subdivisions)."""
     from smvs_amd import synth
     scene = synth.pipeline_inputs("sphere", 1920, 1080, 1, flen=1.2)
     truth = np.asarray(scene["truth"], dtype=np.float32).copy()
@@ -136,6 +138,9 @@ def test_device_surface_full_size_script(host, oracle):
     got = host.surface_script(scene, 4, ops, init_depth=truth, delete_every=7, device=0)
     mirror = host.surface_script(scene, 4, ops, init_depth=truth, delete_every=7)
     _same(got, mirror, exact=True)
+    want = oracle.surface_script(scene, 4, ops, init_depth=truth, delete_every=7)
+    _same(got, want, exact=False)
+    assert int(want["patch_valid"].sum()) < want["patch_valid"].size   # deletions happened
     assert (got["scale"], got["npx"], got["npy"]) == (2, 478, 268)
     assert got["valid_patches"] == int(mirror["patch_valid"].sum()) > 10000
 

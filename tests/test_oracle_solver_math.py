@@ -170,3 +170,23 @@ def test_pcg_solves_the_system_and_stops_like_a_textbook_pcg(oracle, active_frac
     assert np.linalg.norm(x_ref - x_tb) <= 1e-10 * np.linalg.norm(x_tb)
     # and it is a useful step: most of the way to the solution
     assert np.linalg.norm(x_ref - x_direct) < 0.2 * np.linalg.norm(x_direct)
+
+
+def test_cg_iteration_count_and_the_association_of_the_dot_products():
+    """tools/cg_association.py on two small fuzz outliers: the numpy transcription
+    of ConjugateGradient::solve with the reference's sequential dot product ends
+    where the oracle's C solve ends (the transcription is the same recurrence),
+    and so does the variant whose dot products are the EXACT sum of the rounded
+    products -- what the streaming solver (csrc/cg.hip) computes with TwoSum
+    accumulators.  (All seven outliers and six other associations:
+    profiles/r5_cg_association.txt.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools"))
+    import cg_association as ca
+    for case in (1, 3):
+        nodes, want, got = ca.first_solve(case, (("seq", ca.dot_seq), ("sumx", ca.dot_sumx)))
+        assert want > 20 and nodes > 90
+        assert got["seq"] == want
+        assert got["sumx"] == want

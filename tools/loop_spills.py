@@ -9,7 +9,7 @@ out = os.path.join(tempfile.gettempdir(), "cg_resident.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S",
                        "--cuda-device-only", src, "-o", out] + sys.argv[1:], stderr=subprocess.DEVNULL)
 s = open(out).read()
-for name in ("ILb1ELb1ELb0ELb0E", "ILb1ELb1ELb1ELb0E", "ILb1ELb1ELb0ELb1E", "ILb1ELb0ELb0ELb0E"):
+for name in ("ILb1ELb1ELb0E", "ILb1ELb1ELb1E", "ILb1ELb0ELb0E"):
     full = "_ZN8smvs_hip18cg_resident_kernel%sEEvNS_7ResArgsE" % name
     a = s.index(full + ":")
     body = s[a:s.index(".Lfunc_end", a)].split("\n")
