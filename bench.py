@@ -736,12 +736,23 @@ def main():
     dist = None
     if smvs_amd.device_count() < 1:
         raise RuntimeError("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (SMVS_DEVICE_MAP: logical -> physical devices, csrc/common.h; the library
+    # maps its own device indices, torch gets the physical one.  With
+    # SMVS_BENCH_DIST_BACKEND=gloo the ranks may then share a GPU -- the
+    # rehearsal of the multi-rank path on a one-GPU box, tests/test_gpu_front.py;
+    # RCCL itself refuses two ranks on one device)
+    dev_map = [int(x) for x in os.environ.get("SMVS_DEVICE_MAP", "").split(",") if x.strip()]
+    torch_index = dev_map[local_rank] if local_rank < len(dev_map) else local_rank
+    backend = os.environ.get("SMVS_BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(torch_index)
+    device = torch.device("cuda", torch_index)
     if world > 1:
         import torch.distributed as dist
         with shard.quiet_stdout():   # (RCCL's version banner)
-            dist.init_process_group("nccl", device_id=device)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
             dist.barrier()
 
     surf = prob["surf"]
@@ -830,7 +841,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         # whole-job aggregate: units summed over ranks, time = max over ranks
-        dev = device if dist is not None else None
+        dev = device if dist is not None and backend == "nccl" else None
         units, secs = shard.aggregate_throughput(patch_steps, elapsed, dist, dev)
         its, _ = shard.aggregate_throughput(cg_its, 0.0, dist, dev)
         repeats.append((units / secs, secs, units, its))
@@ -864,6 +875,32 @@ def main():
         except Exception as e:
             rccl_round = dict(error=repr(e))
 
+    # world > 1: what RCCL itself says about the job -- a native communicator over
+    # all ranks (include/smvs_rccl.h), ncclCommCount, and one all-reduce of a
+    # known pattern through the lighting buffer (rank r contributes (r + 1) x
+    # pattern: the total is world (world + 1) / 2 x pattern only if every rank's
+    # buffer was summed).  After the timed region: a failure here is reported,
+    # never a reason to lose the headline.
+    rccl_proof = None
+    # (not in the one-GPU rehearsal over gloo: RCCL refuses ranks that share a device)
+    if world > 1 and backend == "nccl" and os.environ.get("SMVS_BENCH_NO_RCCL_PROOF", "") == "":
+        try:
+            proof_comm = native if native is not None else shard.NativeComm(local_rank, dist)
+            n_seen, r_seen = proof_comm.ranks()
+            rccl_proof = dict(n_ranks_seen_by_rccl=int(n_seen), rank_seen_by_rccl=int(r_seen))
+            pattern = np.arange(1.0, 273.0)
+            ctx.light_upload((rank + 1) * pattern[:256], (rank + 1) * pattern[256:])
+            proof_comm.allreduce_lighting([ctx])
+            A_sum, b_sum = ctx.light_download()
+            total = 0.5 * world * (world + 1)
+            rccl_proof["allreduce_summed_every_rank"] = bool(
+                np.array_equal(A_sum.reshape(-1), total * pattern[:256])
+                and np.array_equal(b_sum, total * pattern[256:]))
+            if proof_comm is not native:
+                proof_comm.close()
+        except Exception as e:
+            rccl_proof = dict(rccl_proof or {}, error=repr(e))
+
     # The distributed job ends here: contexts, communicator and process group
     # go away, the other ranks exit.  What follows runs on rank 0 alone, the
     # multi-GPU part in fresh child processes (it cannot take the headline
@@ -890,6 +927,8 @@ def main():
         secondary = {}
         if rccl_round is not None:
             secondary["rccl_lighting_round"] = rccl_round
+        if rccl_proof is not None:
+            secondary["rccl"] = rccl_proof
         if not args.no_multi_gpu_views and not args.no_secondary:
             try:
                 smvs_amd._capi.load().smvs_release_workspaces()
@@ -946,6 +985,9 @@ def main():
                        "ms_per_step_max": 1e3 * repeats[0][1] / args.steps},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
+        if isinstance(rccl_proof, dict) and "n_ranks_seen_by_rccl" in rccl_proof:
+            # (top level: the ranks RCCL counted, not the ranks the launcher claims)
+            out["n_ranks_seen_by_rccl"] = rccl_proof["n_ranks_seen_by_rccl"]
         # BASELINE.md's own timed region (all Newton loops of all scales of one
         # optimize() of the same scene) beside the headline's scale-2 replay
         if isinstance(secondary, dict) and isinstance(secondary.get("optimize"), dict) \

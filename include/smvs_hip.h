@@ -271,6 +271,10 @@ int smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev);
 /* Reads the context's 272-double buffer back (after the caller's collective
  * has summed it in place over the views that share their lighting). */
 int smvs_light_download(smvs_ctx *ctx, double *A256, double *b16);
+/* The other direction: puts normal equations into the context's buffer -- sums
+ * a caller has kept (a lock-step round continued later), or a known pattern
+ * (bench.py checks the RCCL all-reduce of smvs_rccl.h with one). */
+int smvs_light_upload(smvs_ctx *ctx, const double *A256, const double *b16);
 
 /* ------------------------------------------------------------------ */
 /* SGM                                                                */

@@ -31,6 +31,10 @@ int smvs_comm_unique_id(void *id128);
 int smvs_comm_create(int device, int rank, int world, const void *id128,
     smvs_comm **out);
 int smvs_comm_destroy(smvs_comm *comm);
+/* What RCCL itself says about the communicator: ncclCommCount and
+ * ncclCommUserRank -- the evidence a multi-GPU run records that N ranks really
+ * joined (bench.py: "n_ranks_seen_by_rccl"). */
+int smvs_comm_ranks(smvs_comm *comm, int *num_ranks, int *this_rank);
 
 /* A (16 x 16) and b (16) of LightOptimizer::fit_lighting_to_image
  * (light_optimizer.cc:32-49) as smvs_light_accumulate_dev left them in the

@@ -104,17 +104,14 @@ publish_progress(CgArgs const &A, int done, int info, int iter)
 // correctly rounded sum of the reference's own products: it no longer depends
 // on how the elements are dealt to threads and blocks, and it differs from the
 // reference's sequential sum by that sum's own accumulated rounding only.
-// Why: the termination tests of a long solve on an ill-conditioned system are
-// discrete decisions that amplify a 1-ulp change of a dot product into a
-// different iteration count; a plain tree sum over 512-thread blocks ended a
-// 68-iteration solve of the fuzz sweep after 61 (tests/test_gpu_parity.py,
-// FUZZ_OUTLIERS).  tools/cg_association.py runs the reference's recurrence on
-// the CPU with its dot products summed in seven associations
-// (profiles/r5_cg_association.txt): none but the reference's own order is
-// guaranteed to reproduce its count on such systems (spread -7 .. +6 on
-// solves of 50-100 iterations), and the exact sum of the rounded products is
-// the one that stays within one iteration on all seven.  The streaming
-// kernels are bound by memory latency, the extra arithmetic is free.
+// Why: the block partition is a property of the launch (grid size, XCD bands),
+// and the sums should not be.  What it does NOT buy is the oracle's iteration
+// count on the ill-conditioned systems of the fuzz sweep: there the count flips
+// between two exits (68 / 61 iterations) when g moves by 1e-12 -- in the
+// oracle's own solve too (tools/cg_association.py, profiles/r5_cg_association.txt,
+// tests/test_oracle_solver_math.py) -- and the device's g is 1e-12 from the
+// oracle's.  The streaming kernels are bound by memory latency, the extra
+// arithmetic is free.
 struct DD {
     double hi, lo;
 };
@@ -158,8 +155,10 @@ dd_shfl_xor(DD v, int off)
 }
 
 // rows of the partial buffer: the high words in rows 0 .. CG_PARTIAL_ROWS - 1,
-// the low words CG_PARTIAL_ROWS rows behind
-constexpr int CG_PARTIAL_ROWS = 6;
+// the low words CG_PARTIAL_ROWS rows behind.  Rows in use: 0 (d.Ad), 1-3 (r.r,
+// x.(b + r), z.r), 4-5 (the init kernel's z.r, g.g); A_1 loads three rows from
+// row 4 on (branch-free: it reads row 6 and ignores it), so eight rows.
+constexpr int CG_PARTIAL_ROWS = 8;
 
 // Sum NV arrays of `nb` (<= CG_THREADS) per-block partials in a fixed order;
 // every thread of every block gets the same values.  The loads are split
@@ -861,7 +860,7 @@ smvs_cg_solve(smvs_ctx *ctx, int max_iterations, double error_tolerance,
         set_error("smvs_cg_solve: no system constructed");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     return cg_solve_launch(ctx, max_iterations, error_tolerance, q_tolerance,
         num_iterations, info);
 }
@@ -874,7 +873,7 @@ smvs_cg_download_x(smvs_ctx *ctx, double *x)
         set_error("smvs_cg_download_x: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     SMVS_HIP_CHECK(hipMemcpyAsync(x, ctx->x,
         (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyDeviceToHost,
         ctx->stream));
@@ -890,7 +889,7 @@ smvs_cg_upload_x(smvs_ctx *ctx, const double *x)
         set_error("smvs_cg_upload_x: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->x, x,
         (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyHostToDevice,
         ctx->stream));

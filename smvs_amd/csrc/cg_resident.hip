@@ -2361,7 +2361,7 @@ cg_resident_applies(smvs_ctx *ctx, int max_iterations)
         return false;
     if (ctx->resident_cus == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess)
+        if (hipGetDeviceProperties(&prop, physical_device(ctx->device)) != hipSuccess)
             return false;
         ctx->resident_cus = prop.multiProcessorCount;
     }
@@ -2384,6 +2384,8 @@ DeviceTileBudget::bind(int device)
     bound = true;
     hipDeviceProp_t prop;
     capacity = RES_MAX_BLOCKS;
+    // (`device` is the PHYSICAL device here: logical devices mapped onto one
+    // GPU share its CUs, cg_resident_budget)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess
         && prop.multiProcessorCount < capacity)
         capacity = prop.multiProcessorCount;
@@ -2413,33 +2415,35 @@ DeviceTileBudget::bind(int device)
             "push it into the streaming kernels\n", path.c_str(), std::strerror(errno));
 }
 
-void
-DeviceTileBudget::lock_file(void)
+// The advisory file lock that makes PROCESSES sharing a GPU take turns with
+// their barrier kernels.  Taken by the head of this process's line WITHOUT the
+// budget's mutex held (it may sleep for as long as another process's loops
+// run); kept while loops of this process follow each other, but for at most
+// FILE_HOLD at a stretch: after that the next acquirer lets the loops in flight
+// drain, returns the lock -- a process waiting on it gets its turn -- and takes
+// it again (a drain every 100 ms costs the single process ~1 %).  A lock somebody holds for 20 s is not one of ours (or is stuck):
+// go on without it for a while -- the worst case is a resident solve that times
+// out into the streaming kernels, not a hang.
+static constexpr auto FILE_HOLD = std::chrono::milliseconds(100);
+static constexpr auto FILE_GIVE_UP = std::chrono::seconds(20);
+static constexpr auto FILE_RETRY_AFTER = std::chrono::seconds(60);
+
+bool
+DeviceTileBudget::take_file_lock(void)
 {
-    // (caller holds the mutex; the first holder of this process takes the
-    // file lock, the last one returns it)
-    if (fd < 0)
-        return;
-    // A Newton loop holds the lock for milliseconds.  Somebody who holds it
-    // for 20 s is not one of ours (or is stuck): go on without the file lock --
-    // the worst case is a resident solve that times out into the streaming
-    // kernels, not a hang.
+    // (no mutex held: the caller is the only thread of this process in here)
     auto const t0 = std::chrono::steady_clock::now();
-    file_locked = false;
     for (long spin = 0;; ++spin) {
-        if (::flock(fd, LOCK_EX | LOCK_NB) == 0) {
-            file_locked = true;
-            return;
-        }
+        if (::flock(fd, LOCK_EX | LOCK_NB) == 0)
+            return true;
         if (errno != EWOULDBLOCK && errno != EINTR)
-            return;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-            static bool warned = false;
-            if (!warned)
+            return false;
+        if (std::chrono::steady_clock::now() - t0 > FILE_GIVE_UP) {
+            static std::atomic<bool> warned{false};
+            if (!warned.exchange(true))
                 std::fprintf(stderr, "[smvs_hip] barrier lock file busy for 20 s: "
                     "continuing without it\n");
-            warned = true;
-            return;
+            return false;
         }
         if (spin < 64)
             std::this_thread::yield();
@@ -2467,10 +2471,28 @@ DeviceTileBudget::acquire(int device, int tiles)
     // in arrival order; the head of the line waits for its tiles, the others
     // wait for the head
     turn.wait(guard, [&] { return serving == ticket && used + tiles <= capacity; });
+    auto const now = std::chrono::steady_clock::now();
+    if (fd >= 0 && now >= no_file_until) {
+        if (file_locked && now - file_since > FILE_HOLD) {
+            // this process has had the GPU's barrier kernels to itself long
+            // enough: let its loops in flight end (nobody passes the head of the
+            // line meanwhile) and hand the lock back before taking it again
+            turn.wait(guard, [&] { return holders == 0; });
+            unlock_file();
+        }
+        if (!file_locked) {
+            guard.unlock();
+            bool const got = take_file_lock();
+            guard.lock();
+            file_locked = got;
+            file_since = std::chrono::steady_clock::now();
+            if (!got)
+                no_file_until = file_since + FILE_RETRY_AFTER;
+        }
+    }
     used += tiles;
     serving += 1;
-    if (holders++ == 0)
-        lock_file();
+    holders += 1;
     guard.unlock();
     turn.notify_all();   // (the next in line may fit beside this one)
 }
@@ -2484,7 +2506,7 @@ DeviceTileBudget::release(int tiles)
             tiles = capacity;
         used -= tiles;
         if (--holders == 0)
-            unlock_file();
+            unlock_file();      // (non-blocking)
     }
     turn.notify_all();
 }
@@ -2492,7 +2514,7 @@ DeviceTileBudget::release(int tiles)
 DeviceTileBudget &
 cg_resident_budget(int device)
 {
-    return g_resident_budget[device & 15];
+    return g_resident_budget[physical_device(device) & 15];
 }
 
 int
@@ -2501,7 +2523,7 @@ cg_resident_tiles(smvs_ctx *ctx)
     ResidentPlan plan;
     if (ctx->resident_cus == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess)
+        if (hipGetDeviceProperties(&prop, physical_device(ctx->device)) != hipSuccess)
             return 0;
         ctx->resident_cus = prop.multiProcessorCount;
     }

@@ -5,6 +5,7 @@
 #include "host/topo_math.h"
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <condition_variable>
@@ -145,7 +146,7 @@ struct smvs_ctx {
     // CG vectors, [N][4] each
     double *x = nullptr, *r = nullptr, *z = nullptr, *Ad = nullptr,
         *d = nullptr, *d2 = nullptr, *b = nullptr;
-    double *partials = nullptr;     // [2][6][512] per-block reduction partials of cg.hip (high, low words)
+    double *partials = nullptr;     // [2][8][512] per-block reduction partials of cg.hip (high, low words)
     void *cg_state = nullptr;       // CgState[2] (cg.hip)
     int last_cg_iterations = 0;     // sizes the first chunk of the next solve
     bool cg_use_active = false;     // system built by gn_construct: skip inactive nodes
@@ -264,6 +265,22 @@ int ctx_ensure_grid(smvs_ctx *ctx, int scale, int npx, int npy, int start_x, int
 int device_malloc(void **ptr, size_t bytes);
 // Returns what the pools hold idle to the driver; -> objects freed.
 int release_idle_device_memory(void);
+
+// Logical -> physical devices.  Every device index of the C ABI (and
+// smvs_ctx::device, Workspace::device, the per-device pools) is a LOGICAL
+// device; SMVS_DEVICE_MAP="0,0,1" makes logical device i the HIP device
+// map[i] (identity without it).  A node's GPUs can be renumbered or shared
+// that way, and the multi-device code -- ViewQueue(num_devices > 1), its
+// per-device context / workspace / pinned pools -- can run on a box with one
+// GPU (tests/test_gpu_front.py).  What must be shared by logical devices on
+// one GPU is keyed by the physical one: the tile budget of the barrier kernels.
+int logical_device_count(void);          // -1: HIP error
+int physical_device(int logical);        // (the caller has checked the range)
+inline hipError_t
+set_device(int logical)
+{
+    return hipSetDevice(physical_device(logical));
+}
 
 // Launches with more than 64 KB of dynamic LDS need
 // hipFuncAttributeMaxDynamicSharedMemorySize raised for the kernel on the
@@ -490,16 +507,18 @@ bool cg_resident_applies(smvs_ctx *ctx, int max_iterations);
 // Requests are served in arrival order, so a large request is not starved by
 // a stream of small ones.  Across PROCESSES that share the GPU the budget
 // cannot be shared; there an advisory lock on a file named after the device's
-// PCI bus id still makes the processes take turns (held while any loop of this
-// process holds tiles): two such kernels of two processes started together
-// could each hold half of the CUs and wait for the other half for ever.
+// PCI bus id still makes the processes take turns: two such kernels of two
+// processes started together could each hold half of the CUs and wait for the
+// other half for ever.  The file lock is taken without the mutex held, kept
+// while loops of this process follow each other, and handed back after 100 ms at
+// the latest so that a process waiting for it gets its turn (cg_resident.hip).
 class DeviceTileBudget {
 public:
     void acquire(int device, int tiles);
     void release(int tiles);
 private:
     void bind(int device);      // capacity, lock file: once
-    void lock_file(void);
+    bool take_file_lock(void);
     void unlock_file(void);
     std::mutex mutex;
     std::condition_variable turn;
@@ -507,6 +526,7 @@ private:
     unsigned long long next_ticket = 0, serving = 0;
     int fd = -1;
     bool bound = false, file_locked = false;
+    std::chrono::steady_clock::time_point file_since{}, no_file_until{};
 };
 DeviceTileBudget &cg_resident_budget(int device);
 // workgroups (= tiles = CUs) the resident solver launches for this context's
@@ -517,7 +537,7 @@ struct ScopedTileBudget {
     int tiles;
     ScopedTileBudget(int device, int tiles_) : budget(cg_resident_budget(device)), tiles(tiles_)
     {
-        budget.acquire(device, tiles);
+        budget.acquire(physical_device(device), tiles);
     }
     ~ScopedTileBudget() { budget.release(tiles); }
     ScopedTileBudget(ScopedTileBudget const &) = delete;

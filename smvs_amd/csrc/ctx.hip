@@ -198,10 +198,9 @@ smvs_last_error(void)
 extern "C" int
 smvs_device_count(void)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess)
-        return 0;
-    return n;
+    // (logical devices: SMVS_DEVICE_MAP, common.h)
+    int const n = logical_device_count();
+    return n < 0 ? 0 : n;
 }
 
 // A context is a few hundred MB of device buffers (the per-patch systems, H,
@@ -264,10 +263,9 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
     SMVS_REQUIRE(width > 4 && height > 4, "image too small");
     SMVS_REQUIRE(n_subs >= 1 && n_subs <= SMVS_MAX_SUBS,
         "n_subs must be in [1, SMVS_MAX_SUBS]");
-    int count = 0;
-    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
+    int const count = logical_device_count();
     SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
-    SMVS_HIP_CHECK(hipSetDevice(device));
+    SMVS_HIP_CHECK(set_device(device));
 
     smvs_ctx *ctx = new smvs_ctx();
     ctx->device = device;
@@ -289,7 +287,7 @@ smvs_ctx_create(int device, int width, int height, int n_subs, smvs_ctx **out)
         || (rc = device_alloc(&ctx->status, I_NUM)) != SMVS_OK
         || (rc = device_alloc(&ctx->lighting, 16)) != SMVS_OK
         || (rc = device_alloc(&ctx->lightAb, 272)) != SMVS_OK
-        || (rc = device_alloc(&ctx->partials, 2 * 6 * 512)) != SMVS_OK
+        || (rc = device_alloc(&ctx->partials, 2 * 8 * 512)) != SMVS_OK
         || (rc = device_alloc(&ctx->step_counter, 2)) != SMVS_OK
         || (rc = device_alloc(&ctx->zero_block, 16)) != SMVS_OK
         || (rc = device_alloc(reinterpret_cast<char **>(&ctx->cg_state), 256)) != SMVS_OK) {
@@ -325,16 +323,17 @@ smvs_ctx_destroy(smvs_ctx *ctx)
     if (ctx == nullptr)
         return SMVS_OK;
     // park it for the next view of this geometry
-    (void)hipSetDevice(ctx->device);
+    (void)set_device(ctx->device);
     if (ctx->stream != nullptr && hipStreamSynchronize(ctx->stream) == hipSuccess) {
         ctx_reset_for_reuse(ctx);
-        // The pool is bounded by count AND by what it leaves of the device:
-        // parked contexts are keyed on their exact geometry, so a scene of
-        // mixed image sizes would otherwise pin one idle context (~0.9 GB at
-        // 1920x1080 x 8) per size.  While less than a quarter of the device is
-        // free, the contexts parked longest go back to the driver.
+        // The pool is bounded by count.  What it holds goes back to the driver
+        // when an allocation of this library runs out of memory (device_malloc
+        // releases the parked contexts and the idle workspaces and tries again)
+        // -- not by looking at the device's free memory: with several processes
+        // on one GPU, or this process's own live contexts filling it, that rule
+        // (round 4) drained the pool on every destroy and every view paid its
+        // ~40 allocations again.
         std::vector<smvs_ctx *> evict;
-        int const device = ctx->device;   // (once parked, ctx may be taken or evicted)
         {
             std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
             g_ctx_pool.push_back(ctx);
@@ -343,24 +342,8 @@ smvs_ctx_destroy(smvs_ctx *ctx)
                 g_ctx_pool.erase(g_ctx_pool.begin());
             }
         }
-        for (;;) {
-            for (smvs_ctx *c : evict)
-                (void)ctx_free(c);
-            evict.clear();
-            size_t free_b = 0, total_b = 0;
-            (void)hipSetDevice(device);
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= total_b / 4)
-                break;
-            std::lock_guard<std::mutex> guard(g_ctx_pool_mutex);
-            for (size_t i = 0; i < g_ctx_pool.size(); ++i)
-                if (g_ctx_pool[i]->device == device) {
-                    evict.push_back(g_ctx_pool[i]);
-                    g_ctx_pool.erase(g_ctx_pool.begin() + (long)i);
-                    break;
-                }
-            if (evict.empty())
-                break;
-        }
+        for (smvs_ctx *c : evict)
+            (void)ctx_free(c);
         return SMVS_OK;
     }
     return ctx_free(ctx);
@@ -390,7 +373,7 @@ ctx_free(smvs_ctx *ctx)
 {
     if (ctx == nullptr)
         return SMVS_OK;
-    (void)hipSetDevice(ctx->device);
+    (void)set_device(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = { ctx->main_grad, ctx->main_shading, ctx->main_shading_grad,
@@ -462,7 +445,7 @@ extern "C" int
 smvs_ctx_synchronize(smvs_ctx *ctx)
 {
     SMVS_REQUIRE(ctx != nullptr, "null context");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SMVS_OK;
 }
@@ -482,7 +465,7 @@ smvs_ctx_set_cameras(smvs_ctx *ctx, const double *Mi, const double *ti,
     float flen, float inv_flen)
 {
     SMVS_REQUIRE(ctx && Mi && ti, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     DeviceCameras cams;
     memset(&cams, 0, sizeof(cams));
     for (int s = 0; s < ctx->n_subs; ++s) {
@@ -511,7 +494,7 @@ smvs_ctx_upload_main(smvs_ctx *ctx, const float *grad2, const float *shading1,
     SMVS_REQUIRE(ctx && grad2, "null argument");
     SMVS_REQUIRE((shading1 == nullptr) == (shading_grad2 == nullptr),
         "shading image and shading gradients come together");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->main_grad, grad2, npix * sizeof(float2),
         hipMemcpyHostToDevice, ctx->stream));
@@ -540,7 +523,7 @@ smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
     SMVS_REQUIRE(ctx && grad2 && hess3, "null argument");
     SMVS_REQUIRE(sub >= 0 && sub < ctx->n_subs, "sub view index out of range");
     SMVS_REQUIRE(width > 1 && height > 1, "bad sub view size");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     SubPlanes &sp = ctx->subs[sub];
     size_t const npix = (size_t)width * height;
     int rc;
@@ -627,7 +610,7 @@ smvs_hip::ctx_ensure_grid(smvs_ctx *ctx, int scale, int npx, int npy, int start_
     SMVS_REQUIRE(start_x >= 0 && start_y >= 0
         && start_x + npx * ps <= ctx->width && start_y + npy * ps <= ctx->height,
         "patch grid does not fit the image");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
 
     size_t const N = (size_t)(npx + 1) * (npy + 1);
     size_t const P = (size_t)npx * npy;
@@ -748,7 +731,7 @@ smvs_ctx_set_active(smvs_ctx *ctx, const uint8_t *active)
         set_error("smvs_ctx_set_active: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     // a system built for another active set no longer matches the flags
     ctx->cg_use_active = false;
     if (active == nullptr) {
@@ -772,7 +755,7 @@ smvs_get_active(smvs_ctx *ctx, uint8_t *active, int *num_active)
         set_error("smvs_get_active: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     std::vector<uint8_t> tmp(ctx->num_nodes);
     SMVS_HIP_CHECK(hipMemcpyAsync(tmp.data(), ctx->active, ctx->num_nodes,
         hipMemcpyDeviceToHost, ctx->stream));
@@ -796,7 +779,7 @@ smvs_get_nodes(smvs_ctx *ctx, double *nodes)
         set_error("smvs_get_nodes: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     return ctx_download(ctx, nodes, ctx->nodes,
         (size_t)ctx->num_nodes * 4 * sizeof(double));
 }
@@ -809,7 +792,7 @@ smvs_set_nodes(smvs_ctx *ctx, const double *nodes)
         set_error("smvs_set_nodes: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes, nodes,
         (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyHostToDevice,
         ctx->stream));
@@ -825,7 +808,7 @@ smvs_ctx_save_nodes(smvs_ctx *ctx)
         set_error("smvs_ctx_save_nodes: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const n = (size_t)ctx->num_nodes * 4;
     if (ctx->nodes_saved_cap < n) {
         if (ctx->nodes_saved != nullptr)
@@ -855,7 +838,7 @@ smvs_ctx_restore_nodes(smvs_ctx *ctx)
         set_error("smvs_ctx_restore_nodes: no saved nodes for this surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     SMVS_HIP_CHECK(hipMemcpyAsync(ctx->nodes, ctx->nodes_saved,
         (size_t)ctx->num_nodes * 4 * sizeof(double), hipMemcpyDeviceToDevice,
         ctx->stream));

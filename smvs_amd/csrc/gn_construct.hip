@@ -1263,7 +1263,7 @@ smvs_gn_construct(smvs_ctx *ctx, double regularization,
         set_error("smvs_gn_construct: cameras and surface must be set first");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     if (lighting16 != nullptr)
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->lighting, lighting16,
             16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1287,7 +1287,7 @@ smvs_gn_download(smvs_ctx *ctx, double *H9, double *g, double *P)
         set_error("smvs_gn_download: no system constructed");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const N = (size_t)ctx->num_nodes;
     if (H9 != nullptr) {
         std::vector<double> tmp(N * 5 * 16);
@@ -1333,7 +1333,7 @@ smvs_gn_upload(smvs_ctx *ctx, const double *H9, const double *g,
         set_error("smvs_gn_upload: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const N = (size_t)ctx->num_nodes;
     // the system must be symmetric: the upper slots are taken
     std::vector<double> tmp(N * 5 * 16);
@@ -1362,7 +1362,7 @@ smvs_gn_download_patch_systems(smvs_ctx *ctx, double *Hp, double *gp)
         set_error("smvs_gn_download_patch_systems: no system constructed");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const P = (size_t)ctx->num_patches;
     PatchLayout const L = patch_layout(ctx);
     // (the buffers as they lie on the device: the record of the last patch

@@ -84,6 +84,15 @@ parse_ihdr(unsigned char const* d, std::string const& path)
     if (h.width <= 0 || h.height <= 0 || d[10] != 0 || d[11] != 0 || h.interlace > 1
         || h.samples() == 0)
         throw std::runtime_error("bad PNG header: " + path);
+    // The header is untrusted input: bound the dimensions before anything is
+    // allocated or any pass size is computed from them (2^20 pixels a side and
+    // 2^30 samples -- far beyond any camera image -- keep every product below
+    // in range and a forged header from asking for gigabytes).
+    constexpr int MAX_SIDE = 1 << 20;
+    constexpr long long MAX_SAMPLES = 1ll << 30;
+    if (h.width > MAX_SIDE || h.height > MAX_SIDE
+        || (long long)h.width * h.height * h.samples() > MAX_SAMPLES)
+        throw std::runtime_error("PNG dimensions out of range: " + path);
     return h;
 }
 

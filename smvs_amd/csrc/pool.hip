@@ -14,11 +14,67 @@
 // smvs_release_workspaces() or process exit.
 #include "common.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
 
 namespace smvs_hip {
+
+namespace {
+std::vector<int> const &
+device_map(void)
+{
+    static std::vector<int> const map = [] {
+        std::vector<int> m;
+        const char *e = std::getenv("SMVS_DEVICE_MAP");
+        if (e == nullptr || e[0] == 0)
+            return m;
+        int physical = 0;
+        if (hipGetDeviceCount(&physical) != hipSuccess)
+            physical = 0;
+        for (const char *c = e; *c != 0;) {
+            char *end = nullptr;
+            long const v = std::strtol(c, &end, 10);
+            if (end == c)
+                break;
+            if (v < 0 || v >= physical) {
+                std::fprintf(stderr, "[smvs_hip] SMVS_DEVICE_MAP=%s names device %ld, "
+                    "%d visible: the map is ignored\n", e, v, physical);
+                m.clear();
+                return m;
+            }
+            m.push_back((int)v);
+            c = *end == ',' ? end + 1 : end;
+            if (*end != ',' && *end != 0)
+                break;
+        }
+        return m;
+    }();
+    return map;
+}
+}
+
+int
+logical_device_count(void)
+{
+    std::vector<int> const &m = device_map();
+    if (!m.empty())
+        return (int)m.size();
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return -1;
+    return n;
+}
+
+int
+physical_device(int logical)
+{
+    std::vector<int> const &m = device_map();
+    if (m.empty() || logical < 0 || logical >= (int)m.size())
+        return logical;
+    return m[(size_t)logical];
+}
 
 int
 allow_dynamic_lds(int device, const void *kernel, size_t bytes)
@@ -29,7 +85,7 @@ allow_dynamic_lds(int device, const void *kernel, size_t bytes)
     static std::mutex mutex;
     static std::map<std::pair<int, const void *>, size_t> granted;
     std::lock_guard<std::mutex> guard(mutex);
-    size_t &have = granted[std::make_pair(device, kernel)];
+    size_t &have = granted[std::make_pair(physical_device(device), kernel)];
     if (bytes <= have)
         return SMVS_OK;
     // (the attribute belongs to the current device: the callers have set it)
@@ -207,14 +263,13 @@ Workspace::download(void *dst_host, const void *src_dev, size_t bytes)
 Workspace *
 workspace_acquire(int device)
 {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count
-        || device >= MAX_DEVICES) {
+    int const count = logical_device_count();
+    if (device < 0 || device >= count || device >= MAX_DEVICES) {
         set_error("workspace_acquire: no such HIP device (%d)", device);
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) {
-        set_error("hipSetDevice(%d) failed", device);
+    if (set_device(device) != hipSuccess) {
+        set_error("set_device(%d) failed", device);
         return nullptr;
     }
     {
@@ -250,7 +305,7 @@ workspace_release(Workspace *w)
 static void
 workspace_destroy(Workspace *w)
 {
-    (void)hipSetDevice(w->device);
+    (void)set_device(w->device);
     if (w->stream != nullptr)
         (void)hipStreamSynchronize(w->stream);
     for (auto &b : w->dev)

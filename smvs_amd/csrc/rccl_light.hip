@@ -74,10 +74,9 @@ smvs_comm_create(int device, int rank, int world, const void *id128,
 {
     SMVS_REQUIRE(out != nullptr && id128 != nullptr, "null argument");
     SMVS_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
-    int count = 0;
-    SMVS_HIP_CHECK(hipGetDeviceCount(&count));
+    int const count = logical_device_count();
     SMVS_REQUIRE(device >= 0 && device < count, "no such HIP device");
-    SMVS_HIP_CHECK(hipSetDevice(device));
+    SMVS_HIP_CHECK(set_device(device));
     smvs_comm *c = new smvs_comm();
     c->device = device;
     c->rank = rank;
@@ -105,7 +104,7 @@ smvs_comm_destroy(smvs_comm *c)
 {
     if (c == nullptr)
         return SMVS_OK;
-    (void)hipSetDevice(c->device);
+    (void)set_device(c->device);
     if (c->stream != nullptr)
         (void)hipStreamSynchronize(c->stream);
     if (c->comm != nullptr)
@@ -115,6 +114,20 @@ smvs_comm_destroy(smvs_comm *c)
     if (c->stream != nullptr)
         (void)hipStreamDestroy(c->stream);
     delete c;
+    return SMVS_OK;
+}
+
+extern "C" int
+smvs_comm_ranks(smvs_comm *c, int *num_ranks, int *this_rank)
+{
+    SMVS_REQUIRE(c != nullptr && c->comm != nullptr, "null communicator");
+    int count = 0, rank = -1;
+    SMVS_NCCL_CHECK(ncclCommCount(c->comm, &count));
+    SMVS_NCCL_CHECK(ncclCommUserRank(c->comm, &rank));
+    if (num_ranks != nullptr)
+        *num_ranks = count;
+    if (this_rank != nullptr)
+        *this_rank = rank;
     return SMVS_OK;
 }
 
@@ -130,7 +143,7 @@ smvs_light_allreduce(smvs_comm *comm, smvs_ctx *const *ctxs, int n)
             "the contexts live on the communicator's device");
         bufs.p[k] = ctxs[k]->lightAb;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctxs[0]->device));
+    SMVS_HIP_CHECK(set_device(ctxs[0]->device));
     // the buffers were left by smvs_light_accumulate_dev, which returns with
     // the contexts' streams idle
     hipStream_t const stream = comm != nullptr ? comm->stream : ctxs[0]->stream;

@@ -281,7 +281,7 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
     if (view == -1)
         SMVS_REQUIRE(width == ctx->width && height == ctx->height,
             "main image size differs from the context");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     smvs_ctx::ViewImage &vi = ctx->images[view + 1];
     size_t const n = (size_t)width * height * channels;
     int rc;
@@ -328,7 +328,7 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
             set_error("smvs_ctx_set_scale: view %d has no image", v - 1);
             return SMVS_ERR_STATE;
         }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     // stereo_view.cc:29-31; the weights use the host's expf like the reference
     double const sigma_d = 0.12 * std::pow(2.0, scale) + 0.2;
     float const sigma = (float)sigma_d;
@@ -415,7 +415,7 @@ smvs_ctx_download_planes(smvs_ctx *ctx, int view, float *grad2, float *hess3)
 {
     SMVS_REQUIRE(ctx && grad2, "null argument");
     SMVS_REQUIRE(view >= -1 && view < ctx->n_subs, "view index out of range");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     if (view == -1) {
         SMVS_REQUIRE(hess3 == nullptr, "the main view keeps no Hessian plane");
         SMVS_HIP_CHECK(hipMemcpyAsync(grad2, ctx->main_grad,
@@ -455,7 +455,7 @@ smvs_ctx_upload_shading(smvs_ctx *ctx, const float *shading1,
     const float *shading_grad2)
 {
     SMVS_REQUIRE(ctx && shading1 && shading_grad2, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
     int rc;
     if (ctx->main_shading == nullptr) {

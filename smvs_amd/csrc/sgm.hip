@@ -1477,7 +1477,7 @@ smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
         set_error("smvs_ctx_sgm_init_depth: main image size differs from the context");
         return SMVS_ERR_INVALID;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     int rc;
     size_t const n = (size_t)ctx->width * ctx->height;
     size_t const n_low = (size_t)dm_w * dm_h;

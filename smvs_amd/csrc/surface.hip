@@ -595,7 +595,7 @@ require_surface(smvs_ctx *ctx, const char *who)
             "smvs_ctx_set_surface)", who);
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     return SMVS_OK;
 }
 
@@ -614,7 +614,7 @@ smvs_surface_create(smvs_ctx *ctx, int scale, const float *depth,
     SMVS_REQUIRE(n_points >= 0 && (n_points == 0 || (point_pixel && point_depth)),
         "bad point list");
     SMVS_REQUIRE(scale >= 0 && scale <= 10, "scale out of range");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     Grid const g = smvs_surf::grid_for_scale(ctx->width, ctx->height, scale);
     SMVS_REQUIRE(g.npx >= 1 && g.npy >= 1, "image too small for this scale");
     size_t const npix = (size_t)ctx->width * ctx->height;

@@ -730,7 +730,7 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
     uint32_t *patch_vis_out)
 {
     SMVS_REQUIRE(ctx != nullptr, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     if ((ctx->image_ok & 1u) != 0u
         && (ctx->images[0].w != ctx->width || ctx->images[0].h != ctx->height)) {
         set_error("smvs_topology_subviews: main image size differs from the context");
@@ -875,7 +875,7 @@ extern "C" int
 smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
 {
     SMVS_REQUIRE(ctx && mse_out, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     TopoArgs A;
     int rc = prepare_patch_mse(ctx, &A, "smvs_topology_patch_mse");
     if (rc == SMVS_OK)
@@ -893,7 +893,7 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     uint8_t *patch_valid_out, uint8_t *node_valid_out, int *total_deleted)
 {
     SMVS_REQUIRE(ctx && inv_calibration9, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     TopoArgs A;
     int const rc = prepare_patch_mse(ctx, &A, "smvs_topology_cut_boundaries");
     if (rc != SMVS_OK)

@@ -769,7 +769,7 @@ smvs_update_and_reactivate(smvs_ctx *ctx, double threshold,
         set_error("smvs_update_and_reactivate: no surface / cameras");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     int rc = reactivate_launch(ctx, threshold, full_optimization);
     if (rc != SMVS_OK)
         return rc;
@@ -1132,7 +1132,7 @@ smvs_gn_run_loop(smvs_ctx *ctx, const smvs_gn_loop_params *prm,
     // (finish_step_kernel packs the list length and the active-node count
     // into 24 bits each of one atomic; larger surfaces use two atomics per
     // workgroup, FinishArgs::wide)
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     memset(stats, 0, sizeof(*stats));
     int rc;
     if (prm->use_lighting)
@@ -1204,7 +1204,7 @@ smvs_get_depth_map(smvs_ctx *ctx, float *depth)
         set_error("smvs_get_depth_map: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
     int rc = ensure_map_scratch(ctx);
     if (rc != SMVS_OK)
@@ -1230,7 +1230,7 @@ smvs_get_normal_map(smvs_ctx *ctx, float *normals)
         set_error("smvs_get_normal_map: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const n = (size_t)ctx->width * ctx->height * 3;
     int rc = ensure_map_scratch(ctx);
     if (rc != SMVS_OK)
@@ -1257,7 +1257,7 @@ smvs_get_maps(smvs_ctx *ctx, const float *inv_calibration9, float *depth, float 
         set_error("smvs_get_maps: no surface");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
     // depth behind the normals in one scratch buffer of W*H*4 floats
     if (ctx->map_scratch_floats < npix * 4) {
@@ -1294,7 +1294,7 @@ smvs_light_accumulate_dev(smvs_ctx *ctx, double **Ab272_dev)
         set_error("smvs_light_accumulate: needs a surface and a shading image");
         return SMVS_ERR_STATE;
     }
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     size_t const npix = (size_t)ctx->width * ctx->height;
     int rc = ensure_map_scratch(ctx);
     if (rc != SMVS_OK)
@@ -1345,10 +1345,23 @@ smvs_light_accumulate(smvs_ctx *ctx, double *A256, double *b16)
 }
 
 extern "C" int
+smvs_light_upload(smvs_ctx *ctx, const double *A256, const double *b16)
+{
+    SMVS_REQUIRE(ctx && A256 && b16, "null argument");
+    SMVS_HIP_CHECK(set_device(ctx->device));
+    double host[272];
+    memcpy(host, A256, 256 * sizeof(double));
+    memcpy(host + 256, b16, 16 * sizeof(double));
+    SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SMVS_HIP_CHECK(hipMemcpy(ctx->lightAb, host, sizeof(host), hipMemcpyHostToDevice));
+    return SMVS_OK;
+}
+
+extern "C" int
 smvs_light_download(smvs_ctx *ctx, double *A256, double *b16)
 {
     SMVS_REQUIRE(ctx && A256 && b16, "null argument");
-    SMVS_HIP_CHECK(hipSetDevice(ctx->device));
+    SMVS_HIP_CHECK(set_device(ctx->device));
     double host[272];
     SMVS_HIP_CHECK(hipMemcpy(host, ctx->lightAb, sizeof(host),
         hipMemcpyDeviceToHost));

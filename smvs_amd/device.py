@@ -296,6 +296,10 @@ class ViewContext:
         check(self.lib.smvs_light_accumulate_dev(self.handle, C.byref(ptr)))
         return ptr.value
 
+    def light_upload(self, A, b):
+        A = _f64(A).reshape(16, 16); b = _f64(b).reshape(16)
+        check(self.lib.smvs_light_upload(self.handle, _p(A, _dp), _p(b, _dp)))
+
     def light_download(self):
         A = np.zeros((16, 16)); b = np.zeros(16)
         check(self.lib.smvs_light_download(self.handle, _p(A, _dp), _p(b, _dp)))

@@ -220,11 +220,12 @@ def reconstruct_scene(scene_dir, view_ids=None, image_embedding="undistorted",
                       regularization=1.0, output_scale=2, use_shading=False, use_sgm=True,
                       force_recon=False, force_sgm=False, sgm_range=(0.0, 0.0), sgm_scale=1,
                       num_neighbors=6, min_neighbors=3, first_device=0, num_devices=1,
-                      views_in_flight=2, input_scale=0, max_pixels=1700000, details=False):
+                      views_in_flight=2, input_scale=-1, max_pixels=1700000, details=False):
     """smvsrecon's scene-level run (app/smvsrecon.cc:400-745) through
     smvs_amd::reconstruct_scene: returns (reconstructed ids, skipped, seconds)
-    [, input scale used if `details`].  input_scale < 0: smvsrecon's automatic
-    choice from max_pixels (:477-500); > 0: the views are read from the
+    [, input scale used if `details`].  input_scale < 0 (the default, as
+    app/smvsrecon.cc:44): smvsrecon's automatic choice from max_pixels
+    (:477-500); 0: full resolution; > 0: the views are read from the
     embedding undist-L<input_scale>, created with rescale_half_size_gaussian
     where missing (:621-650), and the outputs are named smvs-B<input_scale>."""
     lib = load()

@@ -160,6 +160,15 @@ class NativeComm:
         arr = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
         _capi.check(self.lib.smvs_light_allreduce(self.handle, arr, len(ctxs)))
 
+    def ranks(self):
+        """(ranks in the communicator, this rank) as RCCL reports them
+        (ncclCommCount, ncclCommUserRank)."""
+        import ctypes as C
+        from . import _capi
+        n, r = C.c_int(0), C.c_int(-1)
+        _capi.check(self.lib.smvs_comm_ranks(self.handle, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def close(self):
         if self.handle:
             self.lib.smvs_comm_destroy(self.handle)

@@ -31,14 +31,15 @@ def test_rccl_library_exports_its_header():
     text = open(os.path.join(_capi.HERE, "..", "include", "smvs_rccl.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     syms = sorted(set(re.findall(r"\b(smvs_[a-z_0-9]+)\s*\(", text)))
-    assert syms == ["smvs_comm_create", "smvs_comm_destroy", "smvs_comm_unique_id",
-                    "smvs_light_allreduce"]
+    assert syms == ["smvs_comm_create", "smvs_comm_destroy", "smvs_comm_ranks",
+                    "smvs_comm_unique_id", "smvs_light_allreduce"]
     lib = C.CDLL(path)
     assert not [s for s in syms if not hasattr(lib, s)]
     # argument errors are status codes
     assert lib.smvs_comm_unique_id(None) == -1
     assert lib.smvs_light_allreduce(None, None, 0) == -1
     assert lib.smvs_comm_destroy(None) == 0
+    assert lib.smvs_comm_ranks(None, None, None) == -1
 
 
 def test_product_package_does_not_import_oracle():

@@ -447,14 +447,95 @@ def test_native_rccl_lighting_allreduce_world_1(hip, oracle):
         refs.append(oracle.light_accumulate(orc.normal_map(), prob["views"]["shading"]))
     comm = shard.NativeComm(0, None)
     assert (comm.rank, comm.world) == (0, 1)
+    assert comm.ranks() == (1, 0)          # ncclCommCount, ncclCommUserRank
     comm.allreduce_lighting(ctxs)
     A_sum = sum(r[0] for r in refs); b_sum = sum(r[1] for r in refs)
     for c in ctxs:
         A, b = c.light_download()
         assert _rel(A, A_sum) < 1e-10 and _rel(b, b_sum) < 1e-10
+    # smvs_light_upload: the pattern bench.py --gpus N sends through the
+    # all-reduce to prove that every rank's buffer was summed
+    pattern = np.arange(1.0, 273.0)
+    ctxs[0].light_upload(3.0 * pattern[:256], 3.0 * pattern[256:])
+    comm.allreduce_lighting(ctxs[:1])
+    A, b = ctxs[0].light_download()
+    assert np.array_equal(A.reshape(-1), 3.0 * pattern[:256])
+    assert np.array_equal(b, 3.0 * pattern[256:])
     comm.close()
     for c in ctxs:
         c.close()
+
+
+_DEVICE_MAP_PROBE = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime, see conftest.py)
+sys.path.insert(0, sys.argv[1])
+import smvs_amd
+from smvs_amd import synth, host
+inputs = synth.pipeline_inputs("sphere", 384, 256, 3, flen=1.2)
+many = host.optimize_views(inputs, 5, regularization=0.01, num_iterations=3, min_scale=2,
+                           sgm_scale=1, num_devices=int(sys.argv[3]), views_in_flight=2,
+                           keep_job=3)
+np.save(sys.argv[2], many["depth"])
+strip = lambda log: [{k: v for k, v in e.items() if k != "loop_seconds"} for e in log]
+print(json.dumps(dict(devices=smvs_amd.device_count(), logs=[strip(l) for l in many["logs"]])))
+"""
+
+
+def test_device_map_runs_the_multi_device_code_on_one_gpu(hip, tmp_path):
+    """SMVS_DEVICE_MAP=0,0 (csrc/common.h): two LOGICAL devices on the one GPU
+    of this box, so that ViewQueue(num_devices = 2, views_in_flight = 2) --
+    workers bound to different devices, per-device context / workspace / pinned
+    pools, the tile budget shared by the logical devices of one GPU -- runs in
+    the one-GPU suite (app/smvsrecon.cc:658-733 is the unit being
+    parallelised).  Every job has the batch log and the kept job the depth map,
+    bit for bit, of the same queue on one logical device.  (What this cannot
+    rehearse: two physical GPUs, and RCCL across ranks -- the scaling curve
+    stays unmeasured by the builder)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    replies, maps = [], []
+    for tag, env_extra, ndev in (("one", {}, 1), ("two", {"SMVS_DEVICE_MAP": "0,0"}, 2)):
+        env = dict(os.environ, SMVS_LOCK_DIR=str(tmp_path), **env_extra)
+        out = str(tmp_path / (tag + ".npy"))
+        res = subprocess.run([sys.executable, "-c", _DEVICE_MAP_PROBE, root, out, str(ndev)],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        replies.append(json.loads(res.stdout.strip().splitlines()[-1]))
+        maps.append(np.load(out))
+    assert replies[1]["devices"] == 2 and replies[0]["devices"] >= 1
+    assert len(replies[1]["logs"]) == 5
+    for log in replies[1]["logs"]:
+        assert log == replies[0]["logs"][0]
+    assert np.array_equal(maps[0], maps[1]) and (maps[0] > 0).mean() > 0.2
+
+
+def test_bench_two_ranks_on_the_logical_devices_of_one_gpu(hip, tmp_path):
+    """`bench.py --gpus 2` rehearsed on ONE GPU: SMVS_DEVICE_MAP=0,0 and the
+    gloo backend for the launcher's barrier (RCCL refuses two ranks on one
+    device).  Exercises what the driver's multi-GPU run does and the one-GPU
+    bench does not: the self-spawn under torch.distributed.run, two ranks whose
+    Newton loops take turns on the GPU through the cross-process lock file, the
+    barrier-bracketed timing with max over ranks and summed units, then whole
+    views as two processes and as one ViewQueue(2, in_flight).  The numbers mean
+    nothing (two ranks share a GPU); the JSON contract and the code paths do."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMVS_DEVICE_MAP="0,0", SMVS_BENCH_DIST_BACKEND="gloo",
+               SMVS_LOCK_DIR=str(tmp_path))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--small", "--steps",
+           "4", "--warmup", "1", "--repeats", "2", "--views-per-rank", "3"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    v = out["secondary"]["views_per_s"]
+    for mode in ("one_process_per_gpu", "one_process_view_queue", "single_gpu_reference"):
+        assert "error" not in v[mode], v[mode]
+    assert v["one_process_per_gpu"]["views"] == 6
+    assert v["one_process_view_queue"]["views"] == 6
+    assert any(f.startswith("smvs_hip_barrier_") for f in os.listdir(str(tmp_path)))
 
 
 def test_reconstruct_scene_end_to_end(hip, oracle, oracle_threads, tmp_path):
@@ -737,6 +818,9 @@ def test_bench_two_gpus_reports_whole_views(hip):
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.strip().startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0
+    # what RCCL itself counted, and that the all-reduce summed both ranks
+    assert out["n_ranks_seen_by_rccl"] == 2
+    assert out["secondary"]["rccl"]["allreduce_summed_every_rank"] is True
     v = out["secondary"]["views_per_s"]
     for mode in ("one_process_per_gpu", "one_process_view_queue", "single_gpu_reference"):
         assert "error" not in v[mode], v[mode]

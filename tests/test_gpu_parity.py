@@ -1099,24 +1099,27 @@ FUZZ_OUTLIERS = [
 @pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("case", range(len(FUZZ_OUTLIERS)))
 def test_fuzz_outliers_keep_the_control_flow(hip, oracle, case, solver):
-    """On these systems a long solve may end an iteration apart from the
-    oracle's (its termination test is a discrete decision on sums whose
-    association differs from the sequential chain of the reference; the
-    reference's own SSE and scalar branches do the same to each other,
-    DESIGN.md section 5).  What holds, and is asserted for EVERY solver -- the
-    streaming fallback included, whose dot products are summed in twice the
-    working precision since round 5 (csrc/cg.hip, Dot2; tools/cg_association.py
-    shows on the CPU that exact dot products end every one of these solves
-    within one iteration of the reference's sequential sums, where a plain
-    tree over 512-thread blocks ended outlier 6 after 61 instead of 68): the
-    number of Newton steps is the oracle's and the CG iteration total is within
-    2 per solve.  When the totals agree, the whole control flow (active patches
-    per step, final active set) is identical and the depth is within the
-    north-star 1e-4.  When a solve ended apart, x differs at the solver's own
-    1e-3 tolerance: the depth bound is then 5e-4 (measured: 1.5e-4 on outlier
-    2) and a re-activation decision at the 0.15 px threshold may flip (2 of 270
-    active patch-steps on outlier 0), so the active-patch total is then
-    asserted to 2 % only."""
+    """On these systems the iteration count of a long solve is not a function
+    of the system alone: the oracle's OWN C solve ends outlier 6 after 68 or
+    after 61 iterations depending on a 1e-12 relative perturbation of g, outlier
+    3 after 50, 51 or 54 (tests/test_oracle_solver_math.py,
+    test_oracle_iteration_count_flips_under_input_noise;
+    profiles/r5_cg_association.txt) -- the convergence test zeta < 1e-3 comes
+    within rounding of triggering seven iterations before it finally does.  The
+    device's g and H agree with the oracle's to 1e-12 / 1e-10, not to the bit, so
+    no solver can be held to the oracle's count here, whatever the association
+    of its sums (round 5 gave the streaming solver exact sums of the rounded
+    products, csrc/cg.hip: outlier 6 still ends after 61, the other mode).
+    What holds, and is asserted for every solver: the number of Newton steps
+    is the oracle's and the CG iteration total is within the spread the oracle
+    shows against itself: 2 per solve or 12 %, whichever is larger (measured:
+    resident solvers 0-2, streaming 0-7 of 68).  When the totals agree, the
+    whole control flow (active patches per step, final active set) is
+    identical and the depth is within the north-star 1e-4.  When a solve ended
+    apart, x differs at the solver's own 1e-3 tolerance: the depth bound is then
+    5e-4 (measured: 2.6e-4 at most) and a re-activation decision at the 0.15 px
+    threshold may flip (2 of 270 active patch-steps on outlier 0), so the
+    active-patch total is then asserted to 2 % only."""
     from smvs_amd import synth
     c = FUZZ_OUTLIERS[case]
     prob = synth.make_problem(c["w"], c["h"], c["n_subs"], c["scale"], shading=True,
@@ -1141,9 +1144,7 @@ def test_fuzz_outliers_keep_the_control_flow(hip, oracle, case, solver):
     print("fuzz outlier %d [%s]: steps %d, CG iterations oracle %d device %d, depth %.2e"
           % (case, solver, steps, its, stats["linear_iterations"], ed))
     assert stats["newton_steps"] == steps
-    # every solver ends within 2 iterations per solve of the oracle (measured
-    # over all seven: 0 or 1) -- no exception for the streaming fallback
-    slack = 2 * steps
+    slack = max(2 * steps, int(np.ceil(0.12 * its)))
     assert abs(stats["linear_iterations"] - its) <= slack
     if stats["linear_iterations"] == its:
         assert (stats["active_patch_steps"], stats["final_active_nodes"]) == (psteps, n_act)

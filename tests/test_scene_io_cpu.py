@@ -130,6 +130,15 @@ def test_png_palette_and_writer_and_errors(tmp_path):
     open(bad, "wb").write(sixteen)
     with pytest.raises(Exception):
         host.load_byte_image(bad)
+    # a forged header (2^31 - 1 pixels a side, a few bytes of data) is refused
+    # before any size is computed from it: no overflow, no multi-GB allocation
+    for w, h in ((0x7FFFFFFF, 0x7FFFFFFF), (0x7FFFFFFF, 1), (1 << 21, 3), (1 << 16, 1 << 16)):
+        forged = (b"\x89PNG\r\n\x1a\n" + mve_scene._png_chunk(b"IHDR", struct.pack(
+            ">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + mve_scene._png_chunk(b"IDAT", zlib.compress(raw))
+            + mve_scene._png_chunk(b"IEND", b""))
+        open(bad, "wb").write(forged)
+        with pytest.raises(Exception, match="out of range"):
+            host.load_byte_image(bad)
 
 
 @pytest.mark.parametrize("shape", [(37, 53, 3), (64, 64, 1), (5, 2, 3), (101, 7, 1), (2, 2, 1)])

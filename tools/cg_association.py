@@ -20,7 +20,11 @@ Result (profiles/r5_cg_association.txt): on these systems the count is sensitive
 some solve 2 .. 7 iterations apart (outlier 6: 61 instead of 68 with blocked sums, the
 very number the streaming solver produced on the GPU in round 4; outlier 0: 107 instead
 of 101 with the correctly rounded dot product).  The exact sum of the rounded products
-(sumx) is the one that stays within ONE iteration on all seven (six identical).
+(sumx) is the one that stays within ONE iteration on all seven (six identical) ON THE
+ORACLE'S OWN SYSTEM.  Part 1 of the output shows why that does not carry over to the
+device: the oracle's own solve flips between the same two exits (68 / 61, 50 / 54, ...)
+when g moves by 1e-12 relative, which is how far the device's construction is from the
+oracle's.  The bound of tests/test_gpu_parity.py (FUZZ_OUTLIERS) is that spread.
 """
 import math
 import os
@@ -145,9 +149,33 @@ DOTS = (("seq", dot_seq), ("sumx", dot_sumx), ("pairx", dot_pairx), ("exact", do
         ("pair", dot_pair), ("blk64", make_blocked(64)),
         ("blk256", make_blocked(256)), ("blk512", make_blocked(512)))
 
+def input_noise(case, trials=12, rel=1e-12, seed=1):
+    """The oracle's own C solve of the outlier's first system with g perturbed by
+    `rel` (relative, Gaussian) -- the level at which the device's g agrees with the
+    oracle's.  Returns the iteration counts (the first one unperturbed)."""
+    c = FUZZ_OUTLIERS[case]
+    prob = synth.make_problem(c["w"], c["h"], c["n_subs"], c["scale"], shading=True,
+                              noise=c["noise"], seed=c["seed"])
+    surf, lighting, light_reg = prob["surf"], prob["lighting"], c.get("light_reg", 0.5)
+    orc = oracle.OracleProblem(surf, prob["views"])
+    ref = orc.gn_construct(surf["node_valid"].copy(), 0.01, light_reg, lighting)
+    rng = np.random.default_rng(seed)
+    counts = []
+    for k in range(trials):
+        g = ref["g"] * (1.0 + (0.0 if k == 0 else rel) * rng.standard_normal(ref["g"].shape))
+        _, it, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -g, 200,
+                                0.01 * np.linalg.norm(g), 1e-3)
+        counts.append(it)
+    return counts
+
+
 if __name__ == "__main__":
-    print("# tools/cg_association.py: iterations of the first solve of each fuzz outlier, the "
-          "reference's PCG with its dot products summed in different associations")
+    print("# tools/cg_association.py, part 1: the ORACLE's own solve (C, sequential sums) of the first "
+          "system of each fuzz outlier with g perturbed by 1e-12 relative -- the count is not a "
+          "function of the system alone")
+    for ci in range(len(FUZZ_OUTLIERS)):
+        print("outlier %d: %s" % (ci, " ".join("%3d" % c for c in input_noise(ci))), flush=True)
+    print("# part 2: the reference's recurrence with its dot products summed in different associations")
     for ci in range(len(FUZZ_OUTLIERS)):
         nodes, itr, res = first_solve(ci, DOTS)
         print("outlier %d: %4d nodes, oracle (C) %3d | %s" % (ci, nodes, itr, "  ".join(
