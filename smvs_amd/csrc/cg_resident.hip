@@ -1394,7 +1394,19 @@ cg_resident_kernel(ResArgs A)
             if ((tid & 63) == 0)
                 livemap[tid >> 6] = m;
         }
-        return __syncthreads_and(ok ? 1 : 0) != 0;
+        // (workgroup-wide AND through the flag words of the all-reduce, which
+        // are free outside an exchange -- __syncthreads_and would bring static
+        // LDS into a kernel whose dynamic LDS is sized to the CU's 160 KB)
+        bool const wave_ok = __all(ok);
+        if ((tid & 63) == 0)
+            flag[tid >> 6] = wave_ok ? 1 : 0;
+        lds_barrier();
+        bool all_ok = true;
+#pragma unroll
+        for (int wv = 0; wv < RES_WAVES; ++wv)
+            all_ok = all_ok && flag[wv] != 0;
+        lds_barrier();
+        return all_ok;
     };
     auto tile_live = [&](int t) {
         return ((livemap[t >> 6] >> (t & 63)) & 1ull) != 0ull;
@@ -1402,7 +1414,15 @@ cg_resident_kernel(ResArgs A)
     bool node_on = true;        // FUSED: the thread's node is active
     if (compact) {
         node_on = mine && A.active[n] != 0;
-        int const any = __syncthreads_or(node_on ? 1 : 0);
+        bool const wave_any = __any(node_on);
+        if ((tid & 63) == 0)
+            flag[tid >> 6] = wave_any ? 1 : 0;
+        lds_barrier();
+        bool any = false;
+#pragma unroll
+        for (int wv = 0; wv < RES_WAVES; ++wv)
+            any = any || flag[wv] != 0;
+        lds_barrier();
         if (tid == 0)
             __hip_atomic_store(&A.ex->live[tile], live_tag | (any ? 1u : 2u), __ATOMIC_RELAXED,
                 __HIP_MEMORY_SCOPE_AGENT);

@@ -20,6 +20,37 @@ BlockStencilMatrix::num_non_zero(void) const
     return count;
 }
 
+ConjugateGradient::Vector
+BlockStencilMatrix::multiply(ConjugateGradient::Vector const& x) const
+{
+    if (x.size() != 4 * num_nodes || blocks.size() != num_nodes * 9 * 16
+        || node_stride == 0)
+        throw std::invalid_argument("Incompatible dimensions");
+    ConjugateGradient::Vector ret(4 * num_nodes, 0.0);
+    long const N = (long)num_nodes, stride = (long)node_stride;
+    for (long r = 0; r < N; ++r) {
+        long const rx = r % stride;
+        // the block columns of row r in ascending node id = ascending slot
+        for (int s = 0; s < 9; ++s) {
+            int const dx = s % 3 - 1, dy = s / 3 - 1;
+            long const i = r + dy * stride + dx;
+            if (rx + dx < 0 || rx + dx >= stride || i < 0 || i >= N)
+                continue;
+            double const* v = blocks.data() + ((std::size_t)r * 9 + s) * 16;
+            bool any = false;
+            for (int e = 0; e < 16; ++e)
+                any = any || v[e] != 0.0;
+            if (!any)
+                continue;   // (the reference holds no such block)
+            int block_id = 0;
+            for (int br = 0; br < 4; ++br)
+                for (int bc = 0; bc < 4; ++bc)
+                    ret[4 * r + br] += v[block_id++] * x[4 * i + bc];
+        }
+    }
+    return ret;
+}
+
 ConjugateGradient::ConjugateGradient(Options const& options, int device)
     : opts(options), device(device)
 {

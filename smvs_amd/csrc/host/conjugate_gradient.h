@@ -42,13 +42,18 @@ public:
         ReturnInfo info = CG_INVALID_INPUT;
     };
 
-    // :44-50.  The reference's solver only calls multiply(); the device solver
-    // needs the matrix itself, so the one Functor it accepts is
-    // BlockStencilMatrix (what GaussNewtonStep::construct produces).
+    // :44-50, the reference's interface member for member.  The reference's
+    // solver only calls multiply(); the device solver needs the matrix itself,
+    // so solve() accepts the one Functor whose matrix it can see:
+    // BlockStencilMatrix (what GaussNewtonStep::construct produces) -- any
+    // other Functor is refused with std::invalid_argument, not silently solved
+    // on the host.  multiply() is there for the callers that use the operator
+    // outside solve() (residual checks: H x - b).
     class Functor
     {
     public:
         virtual ~Functor(void) {}
+        virtual Vector multiply(Vector const& x) const = 0;
         virtual std::size_t input_size(void) const = 0;
         virtual std::size_t output_size(void) const = 0;
     };
@@ -83,6 +88,11 @@ public:
     std::size_t num_nodes = 0, node_stride = 0;
     std::vector<double> blocks;
 
+    // BlockSparseMatrix<4>::multiply (block_sparse_matrix.h:276-298) on the
+    // host: per output row the products in the reference's order (ascending
+    // block column, then column inside the block, one multiplication and one
+    // addition each); std::invalid_argument on a size mismatch (:279-280)
+    ConjugateGradient::Vector multiply(ConjugateGradient::Vector const& x) const;
     std::size_t input_size(void) const { return 4 * num_nodes; }
     std::size_t output_size(void) const { return 4 * num_nodes; }
     std::size_t num_non_zero(void) const;   // block_sparse_matrix.h:70 (entries)

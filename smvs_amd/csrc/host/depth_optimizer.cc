@@ -1,5 +1,7 @@
 // Host mirror of lib/depth_optimizer.cc driving the HIP hot path.
 #include "depth_optimizer.h"
+
+#include <iostream>
 #include "topo_math.h"
 #include <string>
 #include <map>
@@ -418,10 +420,31 @@ DepthOptimizer::optimize(void)
         ScopedHostTimer timer("create_initial_surface");
         this->create_initial_surface();
     }
+    // Options::debug_lvl (lib/depth_optimizer.h:36): level 1 and above print
+    // what the reference prints per scale and per iteration (:58-60, 84-86,
+    // 92-94, 112-113, 132-134, 185-187, 306-316), fed from the batch log and
+    // the device's kernel timers; the images the reference writes at levels 2
+    // and 3 (smvs-initial, smvs-shaded, reprojections) are not produced.
+    auto const scale_start = [this](int scale) {
+        if (opts.debug_lvl > 0)
+            std::cout << "########### Scale " << scale << " ###########" << std::endl;
+        return std::chrono::steady_clock::now();
+    };
+    auto const scale_end = [this](std::chrono::steady_clock::time_point t0) {
+        if (opts.debug_lvl > 0)
+            std::cout << "Scale " << current_scale() << " took "
+                << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()
+                << "s" << std::endl;
+    };
+    if (opts.debug_lvl > 0)
+        check(smvs_profile_enable(ctx, 1), "smvs_profile_enable");
+    auto scale_timer = scale_start(current_scale());
     this->set_scale_everywhere(current_scale());
     this->run_newton_iterations(opts.num_iterations);
+    scale_end(scale_timer);
 
     while (current_scale() > opts.min_scale && current_scale() > 0) {
+        scale_timer = scale_start(current_scale() - 1);
         {
             ScopedHostTimer timer("subdivide_patches");
             if (device_surface) {
@@ -441,10 +464,13 @@ DepthOptimizer::optimize(void)
                 surface->fill_patches_from_depth();
         }
         if (opts.use_shading && current_scale() < 4) {
+            if (opts.debug_lvl > 0)
+                std::cout << "######## with Lighting ########" << std::endl;
             ScopedHostTimer timer("fit_lighting");
             this->fit_lighting();
         }
         this->run_newton_iterations(opts.num_iterations);
+        scale_end(scale_timer);
     }
     {
         // get_depth() + get_normals() (:150-160) in one pass over the surface
@@ -512,6 +538,9 @@ DepthOptimizer::run_newton_iterations(int num_iters)
     for (int iter = 0; iter < num_iters; ++iter) {
         int const num_valid_patches = device_surface ? valid_patches
             : surface->count_valid_patches();
+        if (opts.debug_lvl > 0 && iter == 0)
+            std::cout << "Surface Status - Valid patches: " << num_valid_patches
+                << std::endl;
         if (iter == 0) {
             {
                 ScopedHostTimer timer("create_subview_surfaces");
@@ -542,6 +571,8 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         double loop_seconds = 0.0;
         {
             ScopedHostTimer timer("device Newton loop");
+            if (opts.debug_lvl > 0)
+                check(smvs_profile_reset(ctx), "smvs_profile_reset");
             auto const t0 = std::chrono::steady_clock::now();
             check(smvs_gn_run_loop(ctx, &prm, &stats), "smvs_gn_run_loop");
             loop_seconds = std::chrono::duration<double>(
@@ -557,6 +588,30 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         log.push_back({ current_scale(), iter, stats.newton_steps,
             num_valid_patches, stats.linear_iterations, stats.active_patch_steps,
             loop_seconds });
+        if (opts.debug_lvl > 0) {
+            // lib/depth_optimizer.cc:306-316.  Construction = the patch kernel
+            // (+ the assembly kernel when the streaming solver runs), solver =
+            // the resident solve (its assembly prologue inside) or the streaming
+            // kernels: HIP-event times of the loop's launches.
+            double ms[SMVS_K_COUNT] = { 0.0 };
+            long long launches[SMVS_K_COUNT] = { 0 };
+            check(smvs_profile_get(ctx, ms, launches), "smvs_profile_get");
+            double const steps = (double)stats.newton_steps;
+            double const build = ms[SMVS_K_PATCH] + ms[SMVS_K_ASSEMBLE];
+            double const solve = ms[SMVS_K_CG_RESIDENT] + ms[SMVS_K_CG_SPMV]
+                + ms[SMVS_K_CG_UPDATE] + ms[SMVS_K_CG_INIT];
+            std::cout << "### Finished iteration: " << iter << std::endl;
+            std::cout << "Number of Newton steps: " << stats.newton_steps << std::endl;
+            std::cout << "Avg construction time: " << build / steps << "ms" << std::endl;
+            std::cout << "Avg solver time: " << solve / steps << "ms" << std::endl;
+            // (integer division, as the reference's std::size_t counters)
+            std::cout << "Avg solver iterations: "
+                << (stats.newton_steps > 0 ? stats.linear_iterations / stats.newton_steps : 0)
+                << std::endl;
+            if (opts.debug_lvl > 1)
+                std::cout << "Active patch-steps: " << stats.active_patch_steps
+                    << ", device loop " << 1e3 * loop_seconds << " ms" << std::endl;
+        }
         this->dump_state(iter, "newton");
 
         if (finished)

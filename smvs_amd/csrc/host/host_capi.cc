@@ -94,6 +94,10 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
         opts.full_optimization = o->full_optimization != 0;
         opts.device = o->device;
         opts.solver = o->solver;
+        // (the test harness sets Options::debug_lvl through the environment:
+        // smvs_host_options is mirrored field for field by smvs_amd/host.py)
+        if (const char *lvl = std::getenv("SMVS_DEBUG_LVL"))
+            opts.debug_lvl = std::atoi(lvl);
         DepthOptimizer optimizer(main_view, subs, bundle, opts);
         optimizer.optimize();
         size_t const npix = (size_t)main_in->width * main_in->height;
@@ -855,6 +859,29 @@ smvs_host_rescale_half_size_gaussian(const uint8_t *pixels, int width, int heigh
         ByteImage::Ptr half = rescale_half_size_gaussian(img);
         std::memcpy(out, half->begin(),
             (std::size_t)half->width() * half->height() * half->channels());
+        return 0;
+    } catch (std::exception const& e) {
+        g_host_error = e.what();
+        return -1;
+    }
+}
+
+extern "C" int
+smvs_host_block_multiply(int num_nodes, int node_stride, const double *blocks9,
+    const double *x, double *y)
+{
+    try {
+        if (num_nodes < 1 || node_stride < 1 || blocks9 == nullptr || x == nullptr
+            || y == nullptr)
+            throw std::invalid_argument("smvs_host_block_multiply: bad argument");
+        BlockStencilMatrix A;
+        A.num_nodes = (std::size_t)num_nodes;
+        A.node_stride = (std::size_t)node_stride;
+        A.blocks.assign(blocks9, blocks9 + (std::size_t)num_nodes * 9 * 16);
+        ConjugateGradient::Functor const& op = A;      // (through the interface)
+        ConjugateGradient::Vector const r = op.multiply(
+            ConjugateGradient::Vector(x, x + 4 * (std::size_t)num_nodes));
+        std::copy(r.begin(), r.end(), y);
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();

@@ -212,6 +212,12 @@ int smvs_host_select_neighbors(const smvs_host_view *views, int n_views,
     const smvs_host_bundle *bundle, int view, int num_neighbors, int *out,
     int *n_out);
 
+/* smvs_amd::BlockStencilMatrix::multiply (BlockSparseMatrix<4>::multiply,
+ * lib/block_sparse_matrix.h:276-298) on the host, no device involved:
+ * y = A x for the block stencil blocks9[num_nodes][9][16]. */
+int smvs_host_block_multiply(int num_nodes, int node_stride, const double *blocks9,
+    const double *x, double *y);
+
 #ifdef __cplusplus
 }
 #endif

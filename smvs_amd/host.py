@@ -491,3 +491,21 @@ def sgm_image(inputs, view_index=0, halvings=1):
                                C.byref(w), C.byref(h)) != 0:
         raise _capi.SmvsError(-1, lib.smvs_host_last_error().decode())
     return out[:w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def block_multiply(H9, node_stride, x):
+    """smvs_amd::BlockStencilMatrix::multiply (BlockSparseMatrix<4>::multiply,
+    lib/block_sparse_matrix.h:276-298) on the host: y = A x for the block
+    stencil H9 [N][9][16].  No device involved."""
+    lib = load()
+    H9 = np.ascontiguousarray(H9, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    n = x.size // 4
+    y = np.zeros(4 * n)
+    dp = C.POINTER(C.c_double)
+    rc = lib.smvs_host_block_multiply(C.c_int(n), C.c_int(node_stride),
+                                      H9.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                                      y.ctypes.data_as(dp))
+    if rc != 0:
+        raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
+    return y

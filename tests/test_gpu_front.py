@@ -466,6 +466,56 @@ def test_native_rccl_lighting_allreduce_world_1(hip, oracle):
         c.close()
 
 
+_DEBUG_PROBE = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime, see conftest.py)
+sys.path.insert(0, sys.argv[1])
+from smvs_amd import synth, host
+inputs = synth.pipeline_inputs("sphere", 384, 256, 3, flen=1.2)
+out = host.optimize(inputs, regularization=0.01, num_iterations=3, min_scale=2,
+                    use_shading=True)
+sys.stdout.flush()
+print("LOG " + json.dumps([[e["scale"], e["iter"], e["newton_steps"], e["valid_patches"],
+                            e["cg_iterations"]] for e in out["log"]]))
+"""
+
+
+def test_debug_lvl_prints_the_reference_report(hip):
+    """DepthOptimizer::Options::debug_lvl = 1 (lib/depth_optimizer.cc:58-60,
+    84-86, 92-94, 112-113, 132-134, 185-187, 306-316): the per-scale banner and
+    time, the valid patches of a scale's first batch, and per batch the number
+    of Newton steps and the average solver iterations -- the same numbers as
+    get_log(), in the reference's wording."""
+    import json, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMVS_DEBUG_LVL="1")
+    res = subprocess.run([sys.executable, "-c", _DEBUG_PROBE, root], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    text = res.stdout
+    log = json.loads([l for l in text.splitlines() if l.startswith("LOG ")][-1][4:])
+    scales = [int(m) for m in re.findall(r"#{11} Scale (\d+) #{11}", text)]
+    assert scales == sorted({e[0] for e in log}, reverse=True) and scales[-1] == 2
+    assert [int(m) for m in re.findall(r"Scale (\d+) took [0-9.e+-]+s", text)] == scales
+    assert text.count("######## with Lighting ########") == sum(1 for k in scales[1:] if k < 4)
+    assert [int(m) for m in re.findall(r"### Finished iteration: (\d+)", text)] \
+        == [e[1] for e in log]
+    assert [int(m) for m in re.findall(r"Number of Newton steps: (\d+)", text)] \
+        == [e[2] for e in log]
+    assert [int(m) for m in re.findall(r"Surface Status - Valid patches: (\d+)", text)] \
+        == [e[3] for e in log if e[1] == 0]
+    assert [int(m) for m in re.findall(r"Avg solver iterations: (\d+)", text)] \
+        == [e[4] // e[2] if e[2] else 0 for e in log]
+    times = re.findall(r"Avg construction time: ([0-9.e+-]+)ms", text)
+    assert len(times) == len(log) and all(float(t) > 0 for t in times)
+    # ... and nothing is printed without it
+    res0 = subprocess.run([sys.executable, "-c", _DEBUG_PROBE, root],
+                          env={k: v for k, v in os.environ.items() if k != "SMVS_DEBUG_LVL"},
+                          capture_output=True, text=True, timeout=900)
+    assert res0.returncode == 0 and "Scale" not in res0.stdout
+
+
 _DEVICE_MAP_PROBE = r"""
 import json, sys
 import numpy as np
