@@ -402,7 +402,10 @@ int smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
  * reference's double arithmetic in its operation order.  Every call leaves the
  * number of valid (non-null) patches in *num_valid_patches (may be NULL) --
  * the one quantity the optimiser's outer loop needs (:339-356) -- and resets
- * the visibility masks when the grid changed. */
+ * the visibility masks when the grid changed.  A call that is asked for no
+ * count (every output pointer NULL) only ENQUEUES its kernels on the
+ * context's stream and returns without waiting for the device: the sequence
+ * between two Newton batches costs one synchronisation, with its last call. */
 typedef struct {
     int scale, patchsize;      /* patchsize = 2^scale */
     int npx, npy;              /* patches; nodes = (npx + 1) * (npy + 1) */

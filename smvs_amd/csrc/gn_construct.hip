@@ -56,7 +56,6 @@ struct PatchKernelArgs {
     int use_lighting;
     int *status;
     int check_stop;   // leave at once when status[I_STOP] / [I_STEP_ABORT] is set
-    int warm;         // coarse scales: request every neighbour's texels up front
 };
 
 // 1 / x to ~1 ulp: hardware estimate (2^-26 or better) + two Newton steps.
@@ -335,55 +334,10 @@ col_functions(int col, int *ex, int *ey)
 // ---------------------------------------------------------------------------
 // `nb` points at this lane's column of the per-neighbour scratch in LDS:
 // value k of neighbour slot c lives at nb[(c * 5 + k) * 64].
-//
-// STAGED (the one-patch-per-wave kernel of scales >= 4): the cameras and plane
-// descriptors of the neighbours come from `camtab` in LDS, CAM_DOUBLES doubles
-// per neighbour {M[9], t[3], width | height, grad, hess}.  In that kernel the
-// compiler reads them with VECTOR loads (its chunk loop stores to LDS through
-// generic pointers in between, so it cannot prove them unmodified): a memory
-// round trip per neighbour in front of the texel requests, eight in a row.
-constexpr int CAM_DOUBLES = 15;
-
-struct NeighbourCamera {
-    double M[9], t[3];
-    SubPlanes sp;
-};
-
-template <bool STAGED>
-__device__ __forceinline__ NeighbourCamera
-neighbour_camera(PatchKernelArgs const &A, const double *camtab, int j)
-{
-    NeighbourCamera c;
-    if constexpr (STAGED) {
-        const double *src = camtab + j * CAM_DOUBLES;
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-            c.M[i] = src[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            c.t[i] = src[9 + i];
-        long long const wh = __double_as_longlong(src[12]);
-        c.sp.width = (int)(wh & 0xFFFFFFFFll);
-        c.sp.height = (int)(wh >> 32);
-        c.sp.grad = reinterpret_cast<float2 *>(__double_as_longlong(src[13]));
-        c.sp.hess = reinterpret_cast<float4 *>(__double_as_longlong(src[14]));
-    } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-            c.M[i] = A.cams->M[j][i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            c.t[i] = A.cams->t[j][i];
-        c.sp = A.subs[j];
-    }
-    return c;
-}
-
-template <bool STAGED>
 __device__ __forceinline__ void
 pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
-    const double *camtab, double *nb, double const theta[16], int px, int py, int sx,
-    int sy, uint32_t vis, double M6[21], double v6[6])
+    double *nb, double const theta[16], int px, int py, int sx, int sy,
+    uint32_t vis, double M6[21], double v6[6])
 {
 #pragma unroll
     for (int i = 0; i < 21; ++i)
@@ -426,73 +380,7 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         }
     }
 
-    float2 gm = A.main_grad[(size_t)py * A.W + px];
-
-    // ---- coarse scales: all neighbours' texels requested at once ----
-    // At scales >= 4 the reference samples every 2nd / 4th pixel of a patch of
-    // 16 .. 64 pixels a side on FULL-resolution planes
-    // (gauss_newton_step.cc:157-161, stereo_view.cc:24-60): every lane's taps
-    // sit on cache lines of their own, cold in every cache, and a Newton step
-    // touches 150-200 MB of them with a few hundred to a few thousand waves.
-    // The neighbour loop below keeps ONE neighbour's requests in flight per
-    // lane, so a wave waits for eight memory latencies in a row (78 us for a
-    // wave of 64 samples, of which 9 us are arithmetic).  Here the first tap of
-    // both rows of both planes of EVERY neighbour is requested before anything
-    // waits: one latency for all of them, and the loop then finds its lines in
-    // the L2.  The values are summed into a number nobody reads.
-    if (A.warm) {
-        typedef const __attribute__((address_space(1))) float *gf_ptr;
-        float acc = 0.0f;
-        for (int j0 = 0; j0 < A.n_subs; j0 += 8) {
-            // first every address (the camera loads of a neighbour wait for
-            // whatever was requested before them: loads return in order) ...
-            gf_ptr grad[8], hess[8];
-            unsigned o0[8], o1[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                // (uniform index for the loads of the camera; lanes that do not
-                // see the neighbour read its first texel)
-                int const j = min(j0 + jj, A.n_subs - 1);
-                bool const on = j0 + jj < A.n_subs && ((vis >> j) & 1u);
-                NeighbourCamera const cam = neighbour_camera<STAGED>(A, camtab, j);
-                SubPlanes const sp = cam.sp;
-                double proj0, proj1;
-                {
-#pragma clang fp contract(off)
-                    double const u = (double)px + 0.5, vv = (double)py + 0.5;
-                    double const p = cam.M[0] * u + cam.M[1] * vv + cam.M[2];
-                    double const q = cam.M[3] * u + cam.M[4] * vv + cam.M[5];
-                    double const r = cam.M[6] * u + cam.M[7] * vv + cam.M[8];
-                    double const a = w * p + cam.t[0];
-                    double const b = w * q + cam.t[1];
-                    double const d = w * r + cam.t[2];
-                    double const inv_d = fast_rcp(d);
-                    proj0 = a * inv_d - 0.5;
-                    proj1 = b * inv_d - 0.5;
-                }
-                Taps const tp = make_taps((float)proj0, (float)proj1, sp.width, sp.height);
-                o0[jj] = on ? 2u * tp.o00 : 0u;
-                o1[jj] = on ? 2u * tp.o01 : 0u;
-                grad[jj] = (gf_ptr)sp.grad;
-                hess[jj] = (gf_ptr)sp.hess;
-            }
-            // ... then every request, nothing in between that waits
-            float v[8][4];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                v[jj][0] = grad[jj][o0[jj]];
-                v[jj][1] = grad[jj][o1[jj]];
-                v[jj][2] = hess[jj][2u * o0[jj]];
-                v[jj][3] = hess[jj][2u * o1[jj]];
-            }
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                acc += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
-        }
-        // (ties the sum to a value the loop below uses, so the requests are
-        // neither dropped nor sunk behind it; no instruction is generated)
-        asm("" : "+v"(gm.x) : "v"(acc));
-    }
+    float2 const gm = A.main_grad[(size_t)py * A.W + px];
     double const gm0 = gm.x, gm1 = gm.y;
 
     // ---- neighbours (gauss_newton_step.cc:175-208) ----
@@ -561,15 +449,14 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
         // (copied up front: after the LDS stores below the compiler could
         // no longer prove the cameras unmodified and would re-read them with
         // vector loads)
-        NeighbourCamera const cam = neighbour_camera<STAGED>(A, camtab, j);
         double M[9], t[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i)
-            M[i] = cam.M[i];
+            M[i] = A.cams->M[j][i];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            t[i] = cam.t[i];
-        SubPlanes const sp = cam.sp;
+            t[i] = A.cams->t[j][i];
+        SubPlanes const sp = A.subs[j];
         double p, q, r, a, b, d, proj0, proj1, inv_d;
         {
             // correspondence.cc:36-51 in the reference's operation order (no
@@ -856,28 +743,6 @@ gn_patch_kernel(PatchKernelArgs A)
         int const row = i / 12, e = i - row * 12;
         tabs[i] = A.hermite_tab[(size_t)(row * A.sampling) * 12 + e];
     }
-    // one patch per wave (scales >= 4): the neighbours' cameras and plane
-    // descriptors into LDS, once (see pixel_system)
-    constexpr bool STAGED = PPW == 1;
-    double *camtab = tabs + A.spr * 12;
-    if (STAGED) {
-        for (int i = lane; i < A.n_subs * CAM_DOUBLES; i += 64) {
-            int const j = i / CAM_DOUBLES, e = i - j * CAM_DOUBLES;
-            double v;
-            if (e < 9)
-                v = A.cams->M[j][e];
-            else if (e < 12)
-                v = A.cams->t[j][e - 9];
-            else if (e == 12)
-                v = __longlong_as_double(((long long)A.subs[j].height << 32)
-                    | (long long)(unsigned)A.subs[j].width);
-            else if (e == 13)
-                v = __longlong_as_double(reinterpret_cast<long long>(A.subs[j].grad));
-            else
-                v = __longlong_as_double(reinterpret_cast<long long>(A.subs[j].hess));
-            camtab[i] = v;
-        }
-    }
 
     // the patch this lane works for in phase 1
     int const q1 = lane / SLOTS;
@@ -931,8 +796,8 @@ gn_patch_kernel(PatchKernelArgs A)
             int const si = c * SLOTS + sidx;
             if (live && si < A.P) {
                 int const sy = si / A.spr, sx = si - sy * A.spr;
-                pixel_system<STAGED>(A, tabs, camtab, Msh + lane, theta,
-                    pox + sx * A.sampling, poy + sy * A.sampling, sx, sy, vis, M6, v6);
+                pixel_system(A, tabs, Msh + lane, theta, pox + sx * A.sampling,
+                    poy + sy * A.sampling, sx, sy, vis, M6, v6);
             } else {
 #pragma unroll
                 for (int i = 0; i < 21; ++i)
@@ -1311,22 +1176,10 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     A.use_lighting = use_lighting ? 1 : 0;
     A.status = ctx->status;
     A.check_stop = check_stop ? 1 : 0;
-    {
-        // SMVS_PATCH_WARM=<scale>: from which scale on (default 4: where a
-        // wave's samples are 2 .. 4 pixels apart on patches of >= 16 pixels;
-        // 99 switches it off)
-        static int const from_scale = [] {
-            const char *e = std::getenv("SMVS_PATCH_WARM");
-            return e != nullptr ? std::atoi(e) : 4;
-        }();
-        A.warm = ctx->scale >= from_scale ? 1 : 0;
-    }
 
     int const scratch_rows = 5 * (ctx->n_subs - 1) > 27 ? 5 * (ctx->n_subs - 1) : 27;
+    size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12) * sizeof(double);
     bool const four = A.P <= 16;
-    // (the one-patch-per-wave kernel also keeps the neighbours' cameras there)
-    size_t const lds = (size_t)(scratch_rows * 64 + A.spr * 12
-        + (four ? 0 : ctx->n_subs * 15)) * sizeof(double);
     int const ppw = four ? 4 : 1;
     // grid = the live list when the host knows its length (read back after the
     // previous step of the same Newton loop), otherwise every patch (the

@@ -448,7 +448,8 @@ DepthOptimizer::optimize(void)
         {
             ScopedHostTimer timer("subdivide_patches");
             if (device_surface) {
-                check(smvs_surface_subdivide(ctx, &valid_patches),
+                // (fill_patches_from_depth below reports the valid patches)
+                check(smvs_surface_subdivide(ctx, nullptr),
                     "smvs_surface_subdivide");
                 check(smvs_surface_info(ctx, &geom, nullptr), "smvs_surface_info");
             } else
@@ -625,7 +626,7 @@ DepthOptimizer::run_newton_iterations(int num_iters)
             {
                 ScopedHostTimer timer("expand");
                 if (device_surface)
-                    check(smvs_surface_expand(ctx, nullptr, &valid_patches),
+                    check(smvs_surface_expand(ctx, nullptr, nullptr),
                         "smvs_surface_expand");
                 else
                     surface->expand();
@@ -698,7 +699,9 @@ DepthOptimizer::create_subview_surfaces(void)
         // (use_sgm: the filtered SGM map is resident, create_initial_surface)
         check(smvs_topology_subviews(ctx, nullptr, opts.use_sgm ? 0 : 1, nullptr),
             "smvs_topology_subviews");
-        check(smvs_surface_delete_unseen_patches(ctx, nullptr, &valid_patches),
+        // (no count asked for, so no synchronisation: the batch's last
+        // operation reports the valid patches, run_newton_iterations)
+        check(smvs_surface_delete_unseen_patches(ctx, nullptr, nullptr),
             "smvs_surface_delete_unseen_patches");
         return;
     }

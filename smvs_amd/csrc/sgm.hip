@@ -22,6 +22,8 @@
 // read-modify-writes S once.
 #include "common.h"
 
+#include <utility>
+
 #include <mutex>
 
 #include <cmath>
@@ -145,6 +147,167 @@ warp_kernel(WarpArgs A)
             for (int k = 0; k < 4 && dd + k < nd; ++k)
                 A.warped[o + k] = src[k];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same cost volume with TWO planes per lane in the two 16-bit halves of a
+// register and the census window kept in registers (round 5).
+//
+// cost_tiled_kernel below spends 3 vector instructions and one LDS byte read
+// per census bit and plane (63 x 3 x 66 M: the ~410 us it takes).  Two
+// observations:
+//   * the Hamming distance needs no census word: with the main view's bit m_k
+//     (the same for every plane of a pixel, so it lives in scalar registers)
+//         popcount(census_warped ^ census_main) = sum_k [thr < v_k] ^ m_k
+//                                               = popcount(m) + sum_k s_k [thr < v_k],
+//     s_k = +1 where m_k = 0 and -1 where m_k = 1.  Per bit and PAIR of planes:
+//     a saturating packed subtraction (v_k - thr, zero unless thr < v_k), a
+//     packed minimum with 1, a packed multiply-add with the scalar s_k --
+//     three instructions for two planes instead of three for one;
+//   * the 9 x 7 windows of neighbouring pixels share eight of their nine
+//     columns: a wave that walks a row keeps the window in 63 registers and
+//     reads the ONE new column per pixel, 7 LDS reads instead of 63.
+// Same tile, same bits (tests/test_gpu_parity.py, test_sgm_bit_exact: cost
+// volume array_equal with the oracle); plane counts that are not a multiple
+// of four keep the kernel below.
+constexpr int CP_W = 16, CP_H = 8, CP_D = 128;
+
+// (written as instructions: from `min(sub_sat(v, thr), 1)` on a 2 x u16 vector
+// type the compiler builds compares and selects per half, five instructions
+// where these are two)
+__device__ __forceinline__ uint32_t
+pk_sub_sat_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t
+pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * s + c per half, s in a scalar register
+__device__ __forceinline__ uint32_t
+pk_mad_u16(uint32_t a, uint32_t s, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t
+pk_mad_u16_vvv(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// f(integral_constant<0>), f(integral_constant<1>), ... in order
+template <typename F, int... I>
+__device__ __forceinline__ void
+for_each_index(F &f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>()), ...);
+}
+
+__global__ void __launch_bounds__(256)
+cost_packed_kernel(const uint8_t *__restrict__ warped,
+    const unsigned long long *__restrict__ main_census, int w, int h, int D,
+    uint8_t *__restrict__ cost)
+{
+    constexpr int TW = CP_W + 8;
+    __shared__ uint8_t tile[(CP_H + 6) * TW * CP_D];
+    int const tiles_x = (w + CP_W - 1) / CP_W;
+    int const x0 = (blockIdx.x % tiles_x) * CP_W;
+    int const y0 = (blockIdx.x / tiles_x) * CP_H;
+    int const dbase = blockIdx.y * CP_D;
+    int const tid = threadIdx.x;
+
+    // stage: 4 planes (one u32) per thread and position (D is a multiple of 4)
+    for (int idx = tid; idx < (CP_H + 6) * TW * (CP_D / 4); idx += 256) {
+        int const pos = idx / (CP_D / 4), q = idx - pos * (CP_D / 4);
+        int const ty = pos / TW, tx = pos - ty * TW;
+        int const gx = x0 - 4 + tx, gy = y0 - 3 + ty;
+        int const d4 = dbase + 4 * q;
+        uint32_t v = 0;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h && d4 < D)
+            v = *reinterpret_cast<const uint32_t *>(warped + ((size_t)gy * w + gx) * D + d4);
+        *reinterpret_cast<uint32_t *>(tile + (size_t)pos * CP_D + 4 * q) = v;
+    }
+    __syncthreads();
+
+    int const lane = tid & 63, wave = tid >> 6;
+    int const d0 = dbase + 2 * lane;            // this lane's planes: d0, d0 + 1
+    uint32_t const one = 0x00010001u, c255 = 0x00FF00FFu;
+    for (int py = wave; py < CP_H; py += 4) {
+        int const y = y0 + py;
+        if (y >= h)
+            break;
+        // column c of the tile, rows py .. py + 6: this lane's two planes, one
+        // per 16-bit half
+        auto load_column = [&](int c, uint32_t (&col)[7]) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                uint32_t const raw = *reinterpret_cast<const uint16_t *>(
+                    tile + ((py + j) * TW + c) * CP_D + 2 * lane);
+                col[j] = (raw & 0xFFu) | ((raw & 0xFF00u) << 8);
+            }
+        };
+        uint32_t win[9][7];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            load_column(i, win[i]);
+        // one pixel of the row; PX is a template argument so that every index
+        // into the window is a constant and the window stays in registers (a
+        // `#pragma unroll` of a loop this long is only partly honoured, and the
+        // window then lives in scratch)
+        auto pixel = [&](auto px_tag) {
+            constexpr int px = decltype(px_tag)::value;
+            int const x = x0 + px;
+            if (x < w) {
+                uint32_t const thr = win[(px + 4) % 9][3];
+                unsigned long long const mc = main_census[(size_t)y * w + x];
+                // the address is wave-uniform: the bits go to scalar registers
+                uint32_t const mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mc >> 32));
+                uint32_t const mlo = __builtin_amdgcn_readfirstlane((uint32_t)mc);
+                uint32_t const pc = (uint32_t)(__popc(mhi) + __popc(mlo));
+                uint32_t c = pc | (pc << 16);
+                if (x >= 4 && x < w - 5 && y >= 3 && y < h - 4) {
+                    uint32_t cnt = 0u;
+                    // sgm_stereo.cc:139-145: i outer, j inner, MSB first: bit k
+                    // of the census is bit 62 - k of the 64-bit word
+#pragma unroll
+                    for (int k = 0; k < 63; ++k) {
+                        int const i = k / 7, j = k - 7 * i;
+                        if (i == 4 && j == 3)
+                            continue;   // the centre: thr < thr never holds
+                        uint32_t const v = win[(px + i) % 9][j];
+                        uint32_t const lt = pk_min_u16(pk_sub_sat_u16(v, thr), one);
+                        int const bit = 62 - k;
+                        bool const m = ((bit >= 32 ? mhi >> (bit - 32) : mlo >> bit) & 1u) != 0u;
+                        cnt = pk_mad_u16(lt, m ? 0xFFFFFFFFu : 0x00010001u, cnt);
+                    }
+                    // (mod 2^16 per half; the true value is 0 .. 63)
+                    c = pk_mad_u16_vvv(cnt, one, c);
+                }
+                // a plane that was not warped here (thr = 0) costs 255:
+                // c = (c - 255) * [thr > 0] + 255 per half
+                uint32_t const warped_here = pk_min_u16(thr, one);
+                uint32_t const cm = pk_mad_u16_vvv(c255, 0xFFFFFFFFu, c);     // c - 255
+                c = pk_mad_u16_vvv(cm, warped_here, c255);
+                if (d0 < D)
+                    *reinterpret_cast<uint16_t *>(cost + ((size_t)y * w + x) * D + d0)
+                        = (uint16_t)((c & 0xFFu) | ((c >> 8) & 0xFF00u));
+            }
+            // the column that leaves makes room for the one that enters
+            if constexpr (px + 1 < CP_W)
+                load_column(px + 9, win[px % 9]);
+        };
+        for_each_index(pixel, std::make_integer_sequence<int, CP_W>());
     }
 }
 
@@ -1082,10 +1245,20 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     {
         SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_COST);
         int const tiles = ((w + CT_W - 1) / CT_W) * ((h + CT_H - 1) / CT_H);
-        hipLaunchKernelGGL(cost_tiled_kernel,
-            dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
-            B.warped, B.census, w, h,
-            num_steps, B.cost);
+        // (SMVS_SGM_COST=tiled: the one-plane-per-lane kernel for every plane count)
+        static bool const force_tiled = [] {
+            const char *e = std::getenv("SMVS_SGM_COST");
+            return e != nullptr && e[0] == 't';
+        }();
+        if ((num_steps & 3) == 0 && !force_tiled)
+            hipLaunchKernelGGL(cost_packed_kernel,
+                dim3(tiles, (num_steps + CP_D - 1) / CP_D), dim3(256), 0, stream,
+                B.warped, B.census, w, h, num_steps, B.cost);
+        else
+            hipLaunchKernelGGL(cost_tiled_kernel,
+                dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,
+                B.warped, B.census, w, h,
+                num_steps, B.cost);
     }
     SMVS_HIP_CHECK(hipGetLastError());
 

@@ -563,10 +563,17 @@ launch_fill_from_depth(smvs_ctx *ctx, SurfArgs const &A)
     return SMVS_OK;
 }
 
-// valid patches (and the "changed" word) to the host: one synchronisation
+// valid patches (and the "changed" word) to the host: one synchronisation --
+// or none when the caller asks for neither.  The operations themselves never
+// need the host: DepthOptimizer enqueues the sequence between two Newton
+// batches (cuts, expand, subview surfaces, isolated patches) and asks for the
+// number of valid patches once, with the last of them
+// (lib/depth_optimizer.cc:339-356 is all that reads it).
 static int
 read_counts(smvs_ctx *ctx, SurfArgs const &A, int *valid, int *changed)
 {
+    if (valid == nullptr && changed == nullptr)
+        return SMVS_OK;
     SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_SURF_VALID, 0, sizeof(int),
         ctx->stream));
     int const blocks = (int)std::min<size_t>(blocks_for((size_t)A.num_patches), 512);
