@@ -882,41 +882,68 @@ def main():
     # buffer was summed).  After the timed region: a failure here is reported,
     # never a reason to lose the headline.
     rccl_proof = None
+    proof_hung = False
     # (not in the one-GPU rehearsal over gloo: RCCL refuses ranks that share a device)
     if world > 1 and backend == "nccl" and os.environ.get("SMVS_BENCH_NO_RCCL_PROOF", "") == "":
-        try:
-            proof_comm = native if native is not None else shard.NativeComm(local_rank, dist)
-            n_seen, r_seen = proof_comm.ranks()
-            rccl_proof = dict(n_ranks_seen_by_rccl=int(n_seen), rank_seen_by_rccl=int(r_seen))
-            pattern = np.arange(1.0, 273.0)
-            ctx.light_upload((rank + 1) * pattern[:256], (rank + 1) * pattern[256:])
-            proof_comm.allreduce_lighting([ctx])
-            A_sum, b_sum = ctx.light_download()
-            total = 0.5 * world * (world + 1)
-            rccl_proof["allreduce_summed_every_rank"] = bool(
-                np.array_equal(A_sum.reshape(-1), total * pattern[:256])
-                and np.array_equal(b_sum, total * pattern[256:]))
-            if proof_comm is not native:
-                proof_comm.close()
-        except Exception as e:
-            rccl_proof = dict(rccl_proof or {}, error=repr(e))
+        import threading
+        box = {}
+
+        def prove():
+            try:
+                comm = native if native is not None else shard.NativeComm(local_rank, dist)
+                n_seen, r_seen = comm.ranks()
+                box.update(n_ranks_seen_by_rccl=int(n_seen), rank_seen_by_rccl=int(r_seen))
+                pattern = np.arange(1.0, 273.0)
+                ctx.light_upload((rank + 1) * pattern[:256], (rank + 1) * pattern[256:])
+                comm.allreduce_lighting([ctx])
+                A_sum, b_sum = ctx.light_download()
+                total = 0.5 * world * (world + 1)
+                box["allreduce_summed_every_rank"] = bool(
+                    np.array_equal(A_sum.reshape(-1), total * pattern[:256])
+                    and np.array_equal(b_sum, total * pattern[256:]))
+                if comm is not native:
+                    comm.close()
+            except Exception as e:
+                box["error"] = repr(e)
+
+        # in a thread with a deadline: a communicator that never forms must not
+        # take the headline with it (the measurement is finished at this point)
+        worker = threading.Thread(target=prove, daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get("SMVS_BENCH_RCCL_PROOF_TIMEOUT", "90")))
+        proof_hung = worker.is_alive()
+        rccl_proof = dict(box)
+        if proof_hung:
+            rccl_proof["error"] = "no answer from RCCL within the deadline"
 
     # The distributed job ends here: contexts, communicator and process group
     # go away, the other ranks exit.  What follows runs on rank 0 alone, the
     # multi-GPU part in fresh child processes (it cannot take the headline
     # with it).
     with shard.quiet_stdout():
-        if native is not None:
-            native.close()
-            native = None
-        for c in ctxs:
-            c.close()
+        if not proof_hung:
+            if native is not None:
+                native.close()
+                native = None
+            for c in ctxs:
+                c.close()
         ctxs = []
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        if dist is not None and not proof_hung:
+            # (with a deadline as well: a rank whose RCCL check failed differently
+            # from the others must not wait here for ranks that have left)
+            import threading
+
+            def leave():
+                dist.barrier()
+                dist.destroy_process_group()
+            leaver = threading.Thread(target=leave, daemon=True)
+            leaver.start()
+            leaver.join(120.0 if rccl_proof is not None and "error" in rccl_proof else None)
+            proof_hung = leaver.is_alive()
             dist = None
     if rank != 0:
+        if proof_hung:
+            os._exit(0)     # (a thread is stuck inside RCCL: no orderly exit)
         return
 
     # The GPU phase comes first (what the driver's samplers watch at the start
@@ -1001,6 +1028,8 @@ def main():
         shard.flush_c_stdio()   # (whatever a C library still holds goes out first)
         print(json.dumps(out))
         sys.stdout.flush()
+        if proof_hung:
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ HOST_DIR = os.path.join(CSRC, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libsmvs_host.so")
 HOST_SOURCES = ["camera.cc", "stereo_view.cc", "surface.cc", "sgm_stereo.cc",
                 "depth_optimizer.cc", "view_selection.cc", "view_queue.cc", "conjugate_gradient.cc",
-                "gauss_newton_step.cc", "scene_io.cc", "png_io.cc", "pinned_images.cc", "host_capi.cc"]
+                "gauss_newton_step.cc", "scene_io.cc", "png_io.cc", "jpeg_io.cc", "pinned_images.cc", "host_capi.cc"]
 
 
 def _host_stale():

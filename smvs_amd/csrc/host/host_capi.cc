@@ -1,5 +1,6 @@
 #include "host_capi.h"
 #include "png_io.h"
+#include "jpeg_io.h"
 
 #include <algorithm>
 #include <cstring>
@@ -812,8 +813,12 @@ smvs_host_load_byte_image(const char *path, int *whc, uint8_t *pixels, size_t ca
         if (path == nullptr || whc == nullptr)
             throw std::invalid_argument("smvs_host_load_byte_image: bad argument");
         std::string const p = path;
-        ByteImage::Ptr img = p.size() > 4 && p.substr(p.size() - 4) == ".png"
-            ? load_png_u8(p) : load_mvei_u8(p);
+        auto ends_with = [&](char const* ext) {
+            std::size_t const n = std::strlen(ext);
+            return p.size() > n && p.compare(p.size() - n, n, ext) == 0;
+        };
+        ByteImage::Ptr img = ends_with(".png") ? load_png_u8(p)
+            : (ends_with(".jpg") || ends_with(".jpeg")) ? load_jpeg_u8(p) : load_mvei_u8(p);
         whc[0] = img->width();
         whc[1] = img->height();
         whc[2] = img->channels();

@@ -15,6 +15,7 @@
 
 #include "depth_optimizer.h"
 #include "png_io.h"
+#include "jpeg_io.h"
 #include "sgm_stereo.h"
 #include "stereo_view.h"
 #include "view_queue.h"
@@ -183,15 +184,20 @@ bool
 SceneView::has_image(std::string const& embedding) const
 {
     return present && (file_exists(directory + "/" + embedding + ".mvei")
-        || file_exists(directory + "/" + embedding + ".png"));
+        || file_exists(directory + "/" + embedding + ".png")
+        || file_exists(directory + "/" + embedding + ".jpg"));
 }
 
 std::string
 SceneView::image_path(std::string const& embedding) const
 {
+    // (.mvei, then .png, then .jpg -- makescene keeps a camera's JPEG as
+    // original.jpg, smvsrecon --image=original reads it, app/smvsrecon.cc:41, 156)
     std::string const base = directory + "/" + embedding;
     if (!file_exists(base + ".mvei") && file_exists(base + ".png"))
         return base + ".png";
+    if (!file_exists(base + ".mvei") && file_exists(base + ".jpg"))
+        return base + ".jpg";
     return base + ".mvei";
 }
 
@@ -201,10 +207,8 @@ SceneView::load_byte_image(std::string const& embedding) const
     std::string const path = image_path(embedding);
     if (path.size() > 4 && path.substr(path.size() - 4) == ".png")
         return load_png_u8(path);
-    if (!file_exists(path) && file_exists(directory + "/" + embedding + ".jpg"))
-        throw std::runtime_error("embedding " + embedding + " of " + directory
-            + " exists only as JPEG, which is not decoded here: convert it to PNG "
-            "or .mvei");
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".jpg")
+        return load_jpeg_u8(path);
     return load_mvei_u8(path);
 }
 
@@ -214,6 +218,8 @@ SceneView::image_size(std::string const& embedding, int* whc) const
     std::string const path = image_path(embedding);
     if (path.size() > 4 && path.substr(path.size() - 4) == ".png")
         return png_header(path, whc);
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".jpg")
+        return jpeg_header(path, whc);
     int whct[4] = { 0, 0, 0, 0 };
     if (!mvei_header(path, whct))
         return false;

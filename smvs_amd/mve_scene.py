@@ -160,6 +160,10 @@ def write_view(scene_dir, view_id, cam, image_u8, embedding="undistorted", conta
         f.write("[view]\nid = %d\nname = %04d\n" % (view_id, view_id))
     if container == "png":      # what makescene leaves: <embedding>.png
         save_png(os.path.join(d, embedding + ".png"), np.asarray(image_u8, dtype=np.uint8))
+    elif container == "jpg":    # ... and original.jpg, the camera's own file
+        from PIL import Image   # (test helper: Pillow is the independent codec of the tests)
+        Image.fromarray(np.asarray(image_u8, dtype=np.uint8)).save(
+            os.path.join(d, embedding + ".jpg"), format="JPEG", quality=95, subsampling=2)
     else:
         save_mvei(os.path.join(d, embedding + ".mvei"), np.asarray(image_u8, dtype=np.uint8))
     return d

@@ -168,7 +168,8 @@ def test_rescale_half_size_gaussian_matches_oracle(oracle, shape):
 def test_scene_with_png_embeddings_is_read(tmp_path):
     """What makescene leaves in a view directory: undistorted.png.  The scene
     reader reports its size from the IHDR chunk; a view that holds both
-    containers prefers the .mvei; a .jpg alone does not count as an image."""
+    containers prefers the .mvei; a file called .jpg that is no JPEG does not
+    count as an image."""
     from smvs_amd import host
     inputs = synth.pipeline_inputs("plane", 96, 64, 2, n_features=20)
     d = str(tmp_path)
@@ -183,3 +184,90 @@ def test_scene_with_png_embeddings_is_read(tmp_path):
               os.path.join(d, "views", "view_0001.mve", "undistorted.jpg"))
     info = host.scene_info(d)
     assert info["width"].tolist() == [96, 0, 96]
+
+
+def _jpeg_test_image(h, w, c, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([127 + 100 * np.sin(xx / (7.0 + k)) * np.cos(yy / (5.0 + 2 * k))
+                  for k in range(c)], -1) + rng.normal(0, 12, (h, w, c))
+    a = np.clip(a, 0, 255).astype(np.uint8)
+    return a if c > 1 else a[:, :, 0]
+
+
+def test_jpeg_decoder_matches_libjpeg(tmp_path):
+    """csrc/host/jpeg_io.cc against Pillow's decoder (libjpeg-turbo with
+    libjpeg's default parameters: islow IDCT, fancy upsampling -- what
+    mve::image::load_jpg_file uses [MVE-unverified M32]) -- BIT-identical on
+    4:4:4 / 4:2:2 / 4:2:0 / 4:1:1 and grey images, qualities 30 .. 95, standard
+    and optimised Huffman tables, restart intervals, RGB stored without a colour
+    transform, sizes from 1 x 1 to several MCUs that are no multiple of 8 or 16."""
+    PIL = pytest.importorskip("PIL.Image")
+    from smvs_amd import host
+    p = str(tmp_path / "t.jpg")
+    checked = 0
+
+    def check(a, **kw):
+        nonlocal checked
+        PIL.fromarray(a).save(p, format="JPEG", **kw)
+        want = np.array(PIL.open(p))
+        got = host.load_byte_image(p)
+        assert got.shape == want.shape, (a.shape, kw)
+        assert np.array_equal(got, want), (a.shape, kw, int(np.abs(got.astype(int) - want).max()))
+        checked += 1
+
+    for i, (h, w) in enumerate(((33, 47), (64, 64), (17, 9), (120, 200), (8, 8), (1, 1), (2, 35))):
+        for sub in (0, 1, 2):
+            for q, opt in ((30, False), (75, True), (95, False)):
+                check(_jpeg_test_image(h, w, 3, 10 * i + sub), quality=q, subsampling=sub,
+                      optimize=opt)
+        check(_jpeg_test_image(h, w, 1, i), quality=80)
+    a = _jpeg_test_image(100, 130, 3, 99)
+    check(a, quality=85, subsampling="4:1:1")
+    check(a, quality=80, restart_marker_blocks=3)
+    check(a, quality=80, restart_marker_rows=1, subsampling=2)
+    check(a, quality=80, restart_marker_blocks=1, subsampling=1)
+    check(a, quality=90, keep_rgb=True)
+    assert checked >= 70
+
+
+def test_jpeg_decoder_refuses_what_it_does_not_decode(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    from smvs_amd import host
+    a = _jpeg_test_image(40, 52, 3, 5)
+    p = str(tmp_path / "t.jpg")
+    PIL.fromarray(a).save(p, format="JPEG", quality=90, progressive=True)
+    with pytest.raises(Exception, match="progressive"):
+        host.load_byte_image(p)
+    PIL.fromarray(a).save(p, format="JPEG", quality=90)
+    data = open(p, "rb").read()
+    open(p, "wb").write(data[: len(data) // 2])                  # truncated
+    with pytest.raises(Exception, match="truncated"):
+        host.load_byte_image(p)
+    # a forged frame header (65535 x 65535 x 3) is refused before anything is allocated
+    sof = data.index(b"\xff\xc0")
+    forged = bytearray(data)
+    forged[sof + 5: sof + 9] = b"\xff\xff\xff\xff"
+    open(p, "wb").write(bytes(forged))
+    with pytest.raises(Exception, match="out of range"):
+        host.load_byte_image(p)
+    open(p, "wb").write(b"not a jpeg at all")
+    with pytest.raises(Exception):
+        host.load_byte_image(p)
+
+
+def test_scene_with_jpeg_embeddings_is_read(tmp_path):
+    """smvsrecon --image=original (app/smvsrecon.cc:41, 156): the embedding
+    makescene keeps as original.jpg.  The scene reader reports its size from the
+    frame header and loads the pixels libjpeg would."""
+    PIL = pytest.importorskip("PIL.Image")
+    from smvs_amd import host
+    inputs = synth.pipeline_inputs("plane", 96, 64, 2, n_features=20)
+    d = str(tmp_path)
+    mve_scene.write_scene(d, inputs, embedding="original", container="jpg")
+    info = host.scene_info(d, "original")
+    assert info["present"].tolist() == [1, 1, 1]
+    assert info["width"].tolist() == [96, 96, 96] and info["height"].tolist() == [64, 64, 64]
+    v0 = os.path.join(d, "views", "view_0000.mve", "original.jpg")
+    got = host.load_byte_image(v0)
+    assert np.array_equal(got.reshape(np.array(PIL.open(v0)).shape), np.array(PIL.open(v0)))
