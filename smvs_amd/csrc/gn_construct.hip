@@ -697,23 +697,38 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
 }
 
 // ---------------------------------------------------------------------------
-// The patch kernel: one wavefront per block.
+// The patch kernel: one wavefront per block -- or, WAVES > 1, one wavefront per
+// CHUNK of a patch.
 //   PPW patches per wave (4 when a patch has <= 16 sampled pixels, else 1),
 //   SLOTS = 64 / PPW pixel slots per patch and chunk.
+//   WAVES (round 5, PPW == 1 only): a patch of more than 64 samples (scale 6:
+//   16 x 16) was four chunks walked by ONE wave one after the other, and a
+//   coarse step has a few hundred patches: 375 waves on 1,024 SIMDs, each
+//   running four dependent chains of ~20 us (projection -> taps -> IRLS, eight
+//   neighbours in a row).  With WAVES = 4 every chunk has its own wave (its own
+//   LDS scratch); the four partial systems are added in chunk order through
+//   LDS and wave 0 stores the patch.  Same sums chunk by chunk, associated
+//   ((c0 + c1) + c2) + c3 instead of pixel by pixel across the chunks.
 // ---------------------------------------------------------------------------
-template <int PPW>
-__global__ void __launch_bounds__(64, 2)
+//   ONE_CHUNK (PPW == 1, WAVES == 1): the patch has at most 64 samples (scales 4
+//   and 5): no loop over chunks, so the accumulators are only live in phase 2
+//   (the generic form carries them around the loop: 256 VGPRs and scratch).
+template <int PPW, int WAVES, bool ONE_CHUNK>
+__global__ void __launch_bounds__(64 * WAVES, 2)
 gn_patch_kernel(PatchKernelArgs A)
 {
+    static_assert(WAVES == 1 || PPW == 1, "chunks are split over waves for whole-wave patches only");
+    static_assert(!ONE_CHUNK || (PPW == 1 && WAVES == 1), "ONE_CHUNK is a variant of <1, 1>");
     constexpr int SLOTS = 64 / PPW;
     extern __shared__ double lds[];
+    int const wave = WAVES == 1 ? 0 : (int)(threadIdx.x >> 6);
     // [27][64] pixel systems, aliased with the [5 * n_subs][64] neighbour
-    // scratch of phase 1 (dead once M6 is formed)
-    double *Msh = lds;
+    // scratch of phase 1 (dead once M6 is formed); one region per wave
     int const scratch_rows = max(27, 5 * (A.n_subs - 1));
-    double *tabs = lds + scratch_rows * 64;  // [spr][12] sampled coordinates
+    double *Msh = lds + (size_t)wave * scratch_rows * 64;
+    double *tabs = lds + (size_t)WAVES * scratch_rows * 64;  // [spr][12] sampled coordinates
 
-    int const lane = threadIdx.x;
+    int const lane = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     // a pipelined Newton loop enqueues steps before it knows whether the loop
     // goes on (update.hip): once it has ended they do nothing
     if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
@@ -730,7 +745,7 @@ gn_patch_kernel(PatchKernelArgs A)
         // the pipelined loop sized this launch before the list existed and
         // the list came out longer: the whole step is abandoned (every
         // workgroup takes this branch) and the host enqueues it again
-        if (blockIdx.x == 0 && lane == 0)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
             A.status[I_STEP_ABORT] = ABORT_GRID;
         return;
     }
@@ -739,7 +754,7 @@ gn_patch_kernel(PatchKernelArgs A)
         return;
     int const slot_base = (int)wv * PPW;
 
-    for (int i = lane; i < A.spr * 12; i += 64) {
+    for (int i = (int)threadIdx.x; i < A.spr * 12; i += 64 * WAVES) {
         int const row = i / 12, e = i - row * 12;
         tabs[i] = A.hermite_tab[(size_t)(row * A.sampling) * 12 + e];
     }
@@ -787,8 +802,12 @@ gn_patch_kernel(PatchKernelArgs A)
     double gacc[PPW];
     // PPW == 4 means P <= 16 = SLOTS: a single chunk, so the accumulators are
     // only live in phase 2
-    int const chunks = PPW == 4 ? 1 : (A.P + SLOTS - 1) / SLOTS;
-    for (int c = 0; c < chunks; ++c) {
+    int const chunks = PPW == 4 || ONE_CHUNK ? 1 : (A.P + SLOTS - 1) / SLOTS;
+    // (WAVES > 1: wave w runs chunk w -- the host launches chunks == WAVES --
+    // and every wave passes the barriers below exactly once)
+    int const c_first = WAVES == 1 ? 0 : wave;
+    int const c_last = WAVES == 1 ? chunks : wave + 1;
+    for (int c = c_first; c < c_last; ++c) {
         __syncthreads();
         // ---- phase 1 ----
         {
@@ -817,7 +836,7 @@ gn_patch_kernel(PatchKernelArgs A)
                 Msh[(21 + i) * 64 + lane] = v6[i];
         }
         __syncthreads();
-        if (c == 0) {
+        if (c == c_first) {
 #pragma unroll
             for (int q = 0; q < PPW; ++q) {
                 acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
@@ -890,6 +909,26 @@ gn_patch_kernel(PatchKernelArgs A)
                 acc[q][0] = a0; acc[q][1] = a1; acc[q][2] = a2;
                 gacc[q] = gsum;
             }
+        }
+    }
+
+    if constexpr (WAVES > 1) {
+        // the chunks' partial systems, added in chunk order by wave 0
+        __syncthreads();            // (every wave is done with its scratch)
+        Msh[0 * 64 + lane] = acc[0][0];
+        Msh[1 * 64 + lane] = acc[0][1];
+        Msh[2 * 64 + lane] = acc[0][2];
+        Msh[3 * 64 + lane] = gacc[0];
+        __syncthreads();
+        if (wave != 0)
+            return;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            const double *part = lds + (size_t)w * scratch_rows * 64;
+            acc[0][0] += part[0 * 64 + lane];
+            acc[0][1] += part[1 * 64 + lane];
+            acc[0][2] += part[2 * 64 + lane];
+            gacc[0] += part[3 * 64 + lane];
         }
     }
 
@@ -1197,11 +1236,28 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
     unsigned const blocks = ((live_blocks + 7u) >> 3) << 3;
     if (blocks > 0) {
         ScopedKernelTimer timer(ctx, SMVS_K_PATCH);
+        // (SMVS_PATCH_SPLIT=0: a patch's chunks one after the other in one wave,
+        // rounds 1-4)
+        static bool const split_off = [] {
+            const char *e = std::getenv("SMVS_PATCH_SPLIT");
+            return e != nullptr && e[0] == '0';
+        }();
+        int const chunks = four ? 1 : (A.P + 63) / 64;
+        size_t const lds4 = (size_t)(4 * scratch_rows * 64 + A.spr * 12) * sizeof(double);
         if (four)
-            hipLaunchKernelGGL((gn_patch_kernel<4>), dim3(blocks), dim3(64), lds,
+            hipLaunchKernelGGL((gn_patch_kernel<4, 1, false>), dim3(blocks), dim3(64), lds,
+                ctx->stream, A);
+        else if (chunks == 4 && !split_off
+            && allow_dynamic_lds(ctx->device,
+                   reinterpret_cast<const void *>(gn_patch_kernel<1, 4, false>), lds4) == SMVS_OK)
+            // a wave per chunk (scale 6: 16 x 16 samples per patch)
+            hipLaunchKernelGGL((gn_patch_kernel<1, 4, false>), dim3(blocks), dim3(256), lds4,
+                ctx->stream, A);
+        else if (chunks == 1 && !split_off)
+            hipLaunchKernelGGL((gn_patch_kernel<1, 1, true>), dim3(blocks), dim3(64), lds,
                 ctx->stream, A);
         else
-            hipLaunchKernelGGL((gn_patch_kernel<1>), dim3(blocks), dim3(64), lds,
+            hipLaunchKernelGGL((gn_patch_kernel<1, 1, false>), dim3(blocks), dim3(64), lds,
                 ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());

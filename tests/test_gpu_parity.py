@@ -41,9 +41,12 @@ def _setup(hip, oracle, width, height, n_subs, scale, shading=False, noise=0.004
 @pytest.mark.parametrize("scale,size,n_subs", [(2, (192, 128), 3),
                                                 (3, (256, 192), 4),
                                                 (4, (320, 256), 2),
-                                                (5, (512, 384), 8)])
+                                                (5, (512, 384), 8),
+                                                (6, (704, 512), 5)])
 def test_patch_systems_match_oracle(hip, oracle, scale, size, n_subs):
-    """per-patch 16x16 J^T W J and 16-gradient (gauss_newton_step.cc:145-518)."""
+    """per-patch 16x16 J^T W J and 16-gradient (gauss_newton_step.cc:145-518);
+    scales 2 / 3: four patches per wave, 4 / 5: one patch per wave, 6: 256
+    samples per patch, four chunks on four waves of a workgroup."""
     prob, ctx, orc = _setup(hip, oracle, size[0], size[1], n_subs, scale)
     reg = 0.01
     ctx.gn_construct(reg)
@@ -1300,3 +1303,41 @@ def test_compacted_solve_is_bit_identical_and_matches_oracle(hip, oracle, tmp_pa
     ctx.set_nodes(nodes["default"])
     assert _rel(ctx.depth_map(), orc.depth_map()) <= 1e-5
     ctx.close()
+
+
+def test_patch_chunks_on_four_waves_equal_one_wave(hip, tmp_path):
+    """Scale 6 (16 x 16 samples per patch): the four chunks of a patch on four
+    waves of a workgroup (gn_patch_kernel<1, 4>, the default) against one wave
+    walking them one after the other (SMVS_PATCH_SPLIT=0, rounds 1-4): the same
+    per-chunk sums, added ((c0 + c1) + c2) + c3 instead of pixel by pixel --
+    1e-13 relative on every patch system, the same number of Newton steps."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401
+sys.path.insert(0, sys.argv[1])
+import smvs_amd
+from smvs_amd import synth
+prob = synth.make_problem(704, 512, 5, 6, noise=0.01)
+ctx = smvs_amd.ViewContext(704, 512, 5)
+ctx.set_views(prob["views"]); ctx.set_surface(prob["surf"])
+ctx.gn_construct(0.01)
+Hp, gp = ctx.gn_patch_systems()
+np.save(sys.argv[2], np.concatenate([Hp.reshape(len(Hp), -1), gp.reshape(len(gp), -1)], 1))
+stats = ctx.run_loop(0.01, max_newton_steps=4)
+print(json.dumps({k: int(v) for k, v in stats.items()}))
+"""
+    out, stats = {}, {}
+    for tag, extra in (("split", {}), ("serial", {"SMVS_PATCH_SPLIT": "0"})):
+        env = dict(os.environ, **extra)
+        res = subprocess.run([sys.executable, "-c", probe, root, str(tmp_path / (tag + ".npy"))],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        stats[tag] = json.loads(res.stdout.strip().splitlines()[-1])
+        out[tag] = np.load(str(tmp_path / (tag + ".npy")))
+    assert out["split"].shape == out["serial"].shape and np.abs(out["serial"]).max() > 0
+    scale = np.abs(out["serial"]).max(axis=1, keepdims=True) + 1e-300
+    assert np.max(np.abs(out["split"] - out["serial"]) / scale) < 1e-13
+    assert stats["split"]["newton_steps"] == stats["serial"]["newton_steps"] >= 1
