@@ -706,9 +706,10 @@ pixel_system(PatchKernelArgs const &A, const double *tabs /*LDS [spr][12]*/,
 //   coarse step has a few hundred patches: 375 waves on 1,024 SIMDs, each
 //   running four dependent chains of ~20 us (projection -> taps -> IRLS, eight
 //   neighbours in a row).  With WAVES = 4 every chunk has its own wave (its own
-//   LDS scratch); the four partial systems are added in chunk order through
-//   LDS and wave 0 stores the patch.  Same sums chunk by chunk, associated
-//   ((c0 + c1) + c2) + c3 instead of pixel by pixel across the chunks.
+//   LDS scratch) for phase 1; phase 2 -- the accumulation on the matrix cores,
+//   a few microseconds per chunk -- is taken in turns in chunk order with the
+//   accumulators handed on through LDS, so the patch system is bit-identical
+//   with the one-wave form; the last wave stores it.
 // ---------------------------------------------------------------------------
 //   ONE_CHUNK (PPW == 1, WAVES == 1): the patch has at most 64 samples (scales 4
 //   and 5): no loop over chunks, so the accumulators are only live in phase 2
@@ -727,6 +728,7 @@ gn_patch_kernel(PatchKernelArgs A)
     int const scratch_rows = max(27, 5 * (A.n_subs - 1));
     double *Msh = lds + (size_t)wave * scratch_rows * 64;
     double *tabs = lds + (size_t)WAVES * scratch_rows * 64;  // [spr][12] sampled coordinates
+    double *hand = tabs + A.spr * 12;     // WAVES > 1: [4][64] accumulators from wave to wave
 
     int const lane = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     // a pipelined Newton loop enqueues steps before it knows whether the loop
@@ -836,12 +838,29 @@ gn_patch_kernel(PatchKernelArgs A)
                 Msh[(21 + i) * 64 + lane] = v6[i];
         }
         __syncthreads();
-        if (c == c_first) {
+        // WAVES > 1: the waves take turns at phase 2 in chunk order and hand the
+        // accumulators on through LDS, so that the matrix-core accumulation runs
+        // through the chunks exactly as in one wave -- the patch system has the
+        // same bits (a reordered sum moved three of 121,524 patches of a
+        // 1920 x 1080 optimize() across a validity decision five scales later).
+        // Phase 1, the long dependent chain, is what runs side by side.
+#pragma unroll 1
+        for (int turn = 0; turn < WAVES; ++turn) {
+        if (WAVES > 1 && wave != turn) {
+            __syncthreads();
+            continue;
+        }
+        if (WAVES == 1 ? c == c_first : turn == 0) {
 #pragma unroll
             for (int q = 0; q < PPW; ++q) {
                 acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
                 gacc[q] = 0.0;
             }
+        } else if (WAVES > 1) {
+            acc[0][0] = hand[0 * 64 + lane];
+            acc[0][1] = hand[1 * 64 + lane];
+            acc[0][2] = hand[2 * 64 + lane];
+            gacc[0] = hand[3 * 64 + lane];
         }
         // ---- phase 2: H += sum_pix D6^T (M6 D6) on the matrix cores ----
         // With PPW == 4 and 4 x 4 samples per patch, pixel slot
@@ -910,27 +929,21 @@ gn_patch_kernel(PatchKernelArgs A)
                 gacc[q] = gsum;
             }
         }
+        if (WAVES > 1) {
+            if (turn + 1 < WAVES) {
+                hand[0 * 64 + lane] = acc[0][0];
+                hand[1 * 64 + lane] = acc[0][1];
+                hand[2 * 64 + lane] = acc[0][2];
+                hand[3 * 64 + lane] = gacc[0];
+            }
+            __syncthreads();
+        }
+        }   // turns
     }
 
-    if constexpr (WAVES > 1) {
-        // the chunks' partial systems, added in chunk order by wave 0
-        __syncthreads();            // (every wave is done with its scratch)
-        Msh[0 * 64 + lane] = acc[0][0];
-        Msh[1 * 64 + lane] = acc[0][1];
-        Msh[2 * 64 + lane] = acc[0][2];
-        Msh[3 * 64 + lane] = gacc[0];
-        __syncthreads();
-        if (wave != 0)
-            return;
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            const double *part = lds + (size_t)w * scratch_rows * 64;
-            acc[0][0] += part[0 * 64 + lane];
-            acc[0][1] += part[1 * 64 + lane];
-            acc[0][2] += part[2 * 64 + lane];
-            gacc[0] += part[3 * 64 + lane];
-        }
-    }
+    // (the wave of the last chunk holds the patch system)
+    if (WAVES > 1 && wave != WAVES - 1)
+        return;
 
     // ---- phase 3: store the per-patch systems ----
 #pragma unroll
@@ -1243,7 +1256,7 @@ gn_construct_launch(smvs_ctx *ctx, double reg, double light_reg,
             return e != nullptr && e[0] == '0';
         }();
         int const chunks = four ? 1 : (A.P + 63) / 64;
-        size_t const lds4 = (size_t)(4 * scratch_rows * 64 + A.spr * 12) * sizeof(double);
+        size_t const lds4 = (size_t)(4 * scratch_rows * 64 + A.spr * 12 + 4 * 64) * sizeof(double);
         if (four)
             hipLaunchKernelGGL((gn_patch_kernel<4, 1, false>), dim3(blocks), dim3(64), lds,
                 ctx->stream, A);
