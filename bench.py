@@ -279,7 +279,8 @@ def roofline(ctx, prob, steps, ms_per_step, lighting=None, with_peaks=True):
     # their own rocprofv3 passes, tools/collect_profiles.sh): a committed
     # measurement of this command on an earlier box, NOT taken in this run
     traffic = traffic_source = None
-    for tf in ("traffic_r4.json", "traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
+    for tf in ("traffic_r5.json", "traffic_r4.json", "traffic_r3.json", "traffic_r2.json",
+               "traffic_r1.json"):
         tfile = os.path.join(ROOT, "profiles", tf)
         if os.path.exists(tfile):
             with open(tfile) as f:

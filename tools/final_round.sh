@@ -1,11 +1,17 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): everything the round's profiles/ hold.
 # Usage: final_round.sh [round]
-R=${1:-r4}
+R=${1:-r5}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.txt 2>&1
 tail -3 gpurun_out/${R}_pytest_gpu.txt
+# the counter passes first: the bench line below reads the traffic they measure
+timeout 900 bash tools/collect_profiles.sh $R > gpurun_out/${R}_collect.log 2>&1
+tail -3 gpurun_out/${R}_collect.log
+cp gpurun_out/prof_${R}/summary/traffic_${R}.json profiles/ 2>/dev/null
+# the batch logs of the whole-optimize() parity tests, device / oracle, one table
+cat gpurun_out/r5_units_configs*.txt gpurun_out/r5_units_sphere_960x540.txt gpurun_out/r5_units_sgm_shading_384x256.txt gpurun_out/r5_units_config5_round_robin_view*.txt > gpurun_out/${R}_parity_units.txt 2>/dev/null
 timeout 600 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 python - <<PY
 import json
@@ -15,8 +21,6 @@ print({k: v for k, v in d["secondary"]["views_per_s"]["per_gpu"].items()} if "vi
 PY
 timeout 300 python bench.py --workload optimize > gpurun_out/${R}_bench_optimize.json 2>> gpurun_out/${R}_bench_default.err
 cat gpurun_out/${R}_bench_optimize.json | cut -c1-300
-timeout 900 bash tools/collect_profiles.sh $R > gpurun_out/${R}_collect.log 2>&1
-tail -3 gpurun_out/${R}_collect.log
 (timeout 600 python tools/fuzz_parity.py 150 0; timeout 900 python tools/fuzz_parity.py 40 1 1) > gpurun_out/${R}_fuzz_parity.txt 2>&1
 grep "^cases\|^worst\|Error\|assert" gpurun_out/${R}_fuzz_parity.txt | tail -8
 # the resident PCG without stamps: slope = one iteration, intercept = the prologue
