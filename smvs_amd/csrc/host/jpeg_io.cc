@@ -11,9 +11,13 @@
 // methods) on 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1 / grey images, optimised Huffman
 // tables, restart intervals, sizes that are no multiple of the MCU.
 //
-// Supported: SOF0 / SOF1 (sequential, Huffman, 8 bits), one or three
-// components, sampling factors 1 .. 4.  Refused with a reason: progressive,
-// arithmetic-coded, lossless and 12-bit files, CMYK / YCCK.
+// Supported: SOF0 / SOF1 (sequential) and SOF2 (progressive: spectral
+// selection and successive approximation, jdphuff.c), Huffman, 8 bits, one or
+// three components, sampling factors 1 .. 4, interleaved and non-interleaved
+// scans.  Every scan decodes into the frame's coefficient arrays; the inverse
+// DCT runs once at the end (for a complete progressive file libjpeg's block
+// smoothing is inactive, so the pixels are again libjpeg's).  Refused with a
+// reason: arithmetic-coded, lossless and 12-bit files, CMYK / YCCK.
 #include "jpeg_io.h"
 
 #include <array>
@@ -68,7 +72,16 @@ struct Component {
     int width_blocks = 0, height_blocks = 0;   // padded to whole MCUs
     int down_w = 0, down_h = 0;         // downsampled_width / _height
     std::vector<unsigned char> plane;   // [height_blocks * 8][width_blocks * 8]
+    std::vector<int16_t> coefs;         // [height_blocks][width_blocks][64], natural order
+    uint16_t q[64];                     // its quantisation table, natural order, latched
+    bool q_latched = false;             //   at the component's first scan (jdinput.c)
     int pred = 0;
+};
+
+struct Scan {
+    int ns = 0;
+    Component* comp[4] = { nullptr, nullptr, nullptr, nullptr };
+    int ss = 0, se = 63, ah = 0, al = 0;
 };
 
 struct Decoder {
@@ -83,6 +96,8 @@ struct Decoder {
     int restart_interval = 0;
     bool saw_jfif = false, saw_adobe = false;
     int adobe_transform = 0;
+    bool have_frame = false, progressive = false;
+    int eobrun = 0;
     // bit reader
     uint32_t bitbuf = 0;
     int bits = 0;
@@ -323,20 +338,20 @@ extend(int v, int s)   // HUFF_EXTEND
     return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
 }
 
+// ---- one block of a scan into the component's coefficient array ----
+// (coefficients in natural order, not yet dequantised)
+
+// sequential: DC difference and the AC run lengths of the whole block (jdhuff.c)
 void
-decode_block(Decoder& d, Component& c, int bx, int by)
+block_sequential(Decoder& d, Component& c, int16_t* coef)
 {
     HuffTable const& dct = d.dc[c.td];
     HuffTable const& act = d.ac[c.ta];
-    int coef[64];
-    std::memset(coef, 0, sizeof(coef));
     int const s = decode_symbol(d, dct);
     if (s > 15)
         d.fail("corrupt entropy-coded data (DC size)");
-    int const diff = s ? extend(get_bits(d, s), s) : 0;
-    c.pred += diff;
-    const uint16_t* q = d.quant[c.tq];
-    coef[0] = c.pred * q[0];
+    c.pred += s ? extend(get_bits(d, s), s) : 0;
+    coef[0] = (int16_t)c.pred;
     for (int k = 1; k < 64;) {
         int const rs = decode_symbol(d, act);
         int const r = rs >> 4, sz = rs & 15;
@@ -349,30 +364,126 @@ decode_block(Decoder& d, Component& c, int bx, int by)
         k += r;
         if (k > 63)
             d.fail("corrupt entropy-coded data (run past the block)");
-        coef[ZIGZAG[k]] = extend(get_bits(d, sz), sz) * q[k];
+        coef[ZIGZAG[k]] = (int16_t)extend(get_bits(d, sz), sz);
         k += 1;
     }
-    std::size_t const stride = (std::size_t)c.width_blocks * 8;
-    idct_islow(coef, c.plane.data() + (std::size_t)by * 8 * stride + (std::size_t)bx * 8,
-        stride);
+}
+
+// progressive, jdphuff.c: decode_mcu_DC_first / _DC_refine / _AC_first / _AC_refine
+void
+block_dc_first(Decoder& d, Component& c, int16_t* coef, int al)
+{
+    int const s = decode_symbol(d, d.dc[c.td]);
+    if (s > 15)
+        d.fail("corrupt entropy-coded data (DC size)");
+    c.pred += s ? extend(get_bits(d, s), s) : 0;
+    coef[0] = (int16_t)(c.pred * (1 << al));
 }
 
 void
-parse_tables_and_frame(Decoder& d)
+block_dc_refine(Decoder& d, int16_t* coef, int al)
 {
-    if (d.u8() != 0xFF || d.u8() != 0xD8)
-        d.fail("not a JPEG file (no SOI)");
-    bool have_frame = false;
+    if (get_bits(d, 1))
+        coef[0] = (int16_t)(coef[0] | (1 << al));
+}
+
+void
+block_ac_first(Decoder& d, Component& c, int16_t* coef, Scan const& sc)
+{
+    if (d.eobrun > 0) {
+        d.eobrun -= 1;
+        return;
+    }
+    HuffTable const& act = d.ac[c.ta];
+    for (int k = sc.ss; k <= sc.se; ++k) {
+        int const rs = decode_symbol(d, act);
+        int const r = rs >> 4, sz = rs & 15;
+        if (sz != 0) {
+            k += r;
+            if (k > 63)
+                d.fail("corrupt entropy-coded data (run past the block)");
+            coef[ZIGZAG[k]] = (int16_t)(extend(get_bits(d, sz), sz) * (1 << sc.al));
+        } else if (r == 15) {
+            k += 15;            // ZRL
+        } else {
+            d.eobrun = 1 << r;  // EOBr
+            if (r)
+                d.eobrun += get_bits(d, r);
+            d.eobrun -= 1;      // (this band is one of them)
+            break;
+        }
+    }
+}
+
+void
+block_ac_refine(Decoder& d, Component& c, int16_t* coef, Scan const& sc)
+{
+    int const p1 = 1 << sc.al, m1 = -(1 << sc.al);
+    HuffTable const& act = d.ac[c.ta];
+    auto correct = [&](int16_t* v) {
+        // a correction bit for a coefficient that is already non-zero
+        if (get_bits(d, 1) && (*v & p1) == 0)
+            *v = (int16_t)(*v >= 0 ? *v + p1 : *v + m1);
+    };
+    int k = sc.ss;
+    if (d.eobrun == 0) {
+        for (; k <= sc.se; ++k) {
+            int const rs = decode_symbol(d, act);
+            int r = rs >> 4, sz = rs & 15;
+            int value = 0;
+            if (sz != 0) {
+                if (sz != 1)
+                    d.fail("corrupt entropy-coded data (refinement size)");
+                value = get_bits(d, 1) ? p1 : m1;
+            } else if (r != 15) {
+                d.eobrun = 1 << r;
+                if (r)
+                    d.eobrun += get_bits(d, r);
+                break;          // (the rest of the band is handled below)
+            }
+            // skip r zero coefficients, correcting the non-zero ones on the way
+            for (; k <= sc.se; ++k) {
+                int16_t* v = coef + ZIGZAG[k];
+                if (*v != 0)
+                    correct(v);
+                else if (--r < 0)
+                    break;
+            }
+            if (value != 0) {
+                if (k > 63)
+                    d.fail("corrupt entropy-coded data (run past the block)");
+                coef[ZIGZAG[k]] = (int16_t)value;
+            }
+        }
+    }
+    if (d.eobrun > 0) {
+        for (; k <= sc.se; ++k) {
+            int16_t* v = coef + ZIGZAG[k];
+            if (*v != 0)
+                correct(v);
+        }
+        d.eobrun -= 1;
+    }
+}
+
+// Tables and headers up to the next scan (true) or the end of the image (false).
+bool
+next_scan(Decoder& d, Scan* sc)
+{
     for (;;) {
+        // (between segments: fill bytes and, after a scan, whatever the entropy
+        // decoder left unread in front of the marker)
         int b = d.u8();
         if (b != 0xFF)
-            d.fail("marker expected");
+            continue;
         while ((b = d.u8()) == 0xFF) {}
         int const marker = b;
-        if (marker == 0xD9)
-            d.fail("no image data (EOI)");
-        if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7))
+        if (marker == 0x00 || marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7))
             continue;
+        if (marker == 0xD8)
+            continue;           // SOI
+        if (marker == 0xD9)
+            return false;       // EOI
         int const len = d.u16();
         if (len < 2 || d.pos + (std::size_t)len - 2 > d.data.size())
             d.fail("bad segment length");
@@ -383,8 +494,8 @@ parse_tables_and_frame(Decoder& d)
                 int const prec = pq >> 4, id = pq & 15;
                 if (id > 3)
                     d.fail("bad quantisation table id");
-                for (int i = 0; i < 64; ++i)
-                    d.quant[id][i] = (uint16_t)(prec ? d.u16() : d.u8());   // zigzag order
+                for (int i = 0; i < 64; ++i)    // (stored in zigzag order)
+                    d.quant[id][ZIGZAG[i]] = (uint16_t)(prec ? d.u16() : d.u8());
                 d.quant_present[id] = true;
             }
         } else if (marker == 0xC4) {    // DHT
@@ -416,9 +527,10 @@ parse_tables_and_frame(Decoder& d)
                 d.saw_adobe = true;
                 d.adobe_transform = d.data[d.pos + 11];
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {   // SOF0 / SOF1
-            if (have_frame)
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {   // SOF0 / 1 / 2
+            if (d.have_frame)
                 d.fail("two frame headers");
+            d.progressive = marker == 0xC2;
             int const precision = d.u8();
             d.height = d.u16();
             d.width = d.u16();
@@ -443,41 +555,129 @@ parse_tables_and_frame(Decoder& d)
                 if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3)
                     d.fail("bad component description");
             }
-            have_frame = true;
-        } else if (marker == 0xC2) {
-            d.fail("progressive JPEG is not supported (convert the embedding to baseline "
-                "JPEG, PNG or .mvei)");
+            d.have_frame = true;
         } else if ((marker >= 0xC3 && marker <= 0xCF) && marker != 0xC4 && marker != 0xC8
             && marker != 0xCC) {
             d.fail("lossless / hierarchical / arithmetic-coded JPEG is not supported");
         } else if (marker == 0xCC) {
             d.fail("arithmetic-coded JPEG is not supported");
         } else if (marker == 0xDA) {    // SOS
-            if (!have_frame)
+            if (!d.have_frame)
                 d.fail("scan before the frame header");
-            int const ns = d.u8();
-            if (ns != (int)d.comps.size())
-                d.fail("non-interleaved scans of a sequential JPEG are not supported");
-            for (int i = 0; i < ns; ++i) {
+            sc->ns = d.u8();
+            if (sc->ns < 1 || sc->ns > (int)d.comps.size())
+                d.fail("bad number of components in a scan");
+            for (int i = 0; i < sc->ns; ++i) {
                 int const id = d.u8();
                 int const tables = d.u8();
                 Component* c = nullptr;
                 for (Component& k : d.comps)
                     if (k.id == id)
                         c = &k;
-                if (c == nullptr || c != &d.comps[(std::size_t)i])
+                if (c == nullptr || (i > 0 && c <= sc->comp[i - 1]))
                     d.fail("scan components out of order");
                 c->td = tables >> 4;
                 c->ta = tables & 15;
-                if (c->td > 3 || c->ta > 3 || !d.dc[c->td].present || !d.ac[c->ta].present
+                if (c->td > 3 || c->ta > 3)
+                    d.fail("bad Huffman table selector");
+                sc->comp[i] = c;
+            }
+            sc->ss = d.u8();
+            sc->se = d.u8();
+            int const a = d.u8();
+            sc->ah = a >> 4;
+            sc->al = a & 15;
+            if (!d.progressive) {
+                // B.2.3: a sequential scan covers the whole block
+                sc->ss = 0; sc->se = 63; sc->ah = 0; sc->al = 0;
+            } else if (sc->ss > sc->se || sc->se > 63 || sc->ah > 13 || sc->al > 13
+                || (sc->ss == 0 && sc->se != 0) || (sc->ss > 0 && sc->ns != 1)) {
+                d.fail("bad progression parameters");
+            }
+            for (int i = 0; i < sc->ns; ++i) {
+                Component* c = sc->comp[i];
+                bool const need_dc = sc->ss == 0 && sc->ah == 0;
+                bool const need_ac = sc->se > 0;
+                if ((need_dc && !d.dc[c->td].present) || (need_ac && !d.ac[c->ta].present)
                     || !d.quant_present[c->tq])
                     d.fail("scan refers to a table that was not defined");
+                if (!c->q_latched) {
+                    std::memcpy(c->q, d.quant[c->tq], sizeof(c->q));
+                    c->q_latched = true;
+                }
             }
-            d.pos = end;   // (Ss, Se, Ah/Al of a sequential scan: 0, 63, 0)
-            return;
+            d.pos = end;
+            return true;
         }
         d.pos = end;
     }
+}
+
+// The entropy-coded data of one scan (A.2.3 / B.2.3 for the MCU order).
+void
+decode_scan(Decoder& d, Scan const& sc, int mcux, int mcuy)
+{
+    bool const interleaved = sc.ns > 1;
+    int const nx = interleaved ? mcux : (sc.comp[0]->down_w + 7) / 8;
+    int const ny = interleaved ? mcuy : (sc.comp[0]->down_h + 7) / 8;
+    d.bits = 0;
+    d.bitbuf = 0;
+    d.hit_marker = false;
+    d.eobrun = 0;
+    for (int i = 0; i < sc.ns; ++i)
+        sc.comp[i]->pred = 0;
+    int restarts_left = d.restart_interval;
+    int next_rst = 0;
+    for (int my = 0; my < ny; ++my)
+        for (int mx = 0; mx < nx; ++mx) {
+            if (d.restart_interval > 0 && restarts_left == 0) {
+                // byte-align, expect RSTn
+                d.bits = 0;
+                d.bitbuf = 0;
+                d.hit_marker = false;
+                while (d.pos + 1 < d.data.size()
+                    && !(d.data[d.pos] == 0xFF && d.data[d.pos + 1] >= 0xD0
+                        && d.data[d.pos + 1] <= 0xD7)) {
+                    if (d.data[d.pos] == 0xFF && d.data[d.pos + 1] != 0x00
+                        && d.data[d.pos + 1] != 0xFF)
+                        d.fail("restart marker expected");
+                    d.pos += 1;
+                }
+                if (d.pos + 1 >= d.data.size() || d.data[d.pos + 1] != 0xD0 + next_rst)
+                    d.fail("restart markers out of sequence");
+                d.pos += 2;
+                next_rst = (next_rst + 1) & 7;
+                restarts_left = d.restart_interval;
+                d.eobrun = 0;
+                for (int i = 0; i < sc.ns; ++i)
+                    sc.comp[i]->pred = 0;
+            }
+            for (int i = 0; i < sc.ns; ++i) {
+                Component& c = *sc.comp[i];
+                int const bh = interleaved ? c.h : 1, bv = interleaved ? c.v : 1;
+                for (int by = 0; by < bv; ++by)
+                    for (int bx = 0; bx < bh; ++bx) {
+                        int16_t* coef = c.coefs.data()
+                            + ((std::size_t)(my * bv + by) * c.width_blocks + (mx * bh + bx)) * 64;
+                        if (!d.progressive)
+                            block_sequential(d, c, coef);
+                        else if (sc.ss == 0 && sc.ah == 0)
+                            block_dc_first(d, c, coef, sc.al);
+                        else if (sc.ss == 0)
+                            block_dc_refine(d, coef, sc.al);
+                        else if (sc.ah == 0)
+                            block_ac_first(d, c, coef, sc);
+                        else
+                            block_ac_refine(d, c, coef, sc);
+                    }
+            }
+            if (d.restart_interval > 0)
+                restarts_left -= 1;
+        }
+    // (the bits of the last byte are padding; the next marker follows)
+    d.bits = 0;
+    d.bitbuf = 0;
+    d.hit_marker = false;
 }
 
 // ---- chroma upsampling (jdsample.c) of one component to full resolution ----
@@ -580,7 +780,11 @@ decode(std::string const& path, bool header_only, int* whc)
     Decoder d;
     d.path = path;
     d.data = read_file(path);
-    parse_tables_and_frame(d);
+    if (d.u8() != 0xFF || d.u8() != 0xD8)
+        d.fail("not a JPEG file (no SOI)");
+    Scan sc;
+    if (!next_scan(d, &sc))
+        d.fail("no image data (EOI)");
     int const n = (int)d.comps.size();
     if (whc != nullptr) {
         whc[0] = d.width;
@@ -605,49 +809,30 @@ decode(std::string const& path, bool header_only, int* whc)
         // jdmaster.c: downsampled_width = ceil(image_width * h_samp / max_h_samp)
         c.down_w = (int)(((long)d.width * c.h + hmax - 1) / hmax);
         c.down_h = (int)(((long)d.height * c.v + vmax - 1) / vmax);
-        c.plane.assign((std::size_t)c.width_blocks * 8 * c.height_blocks * 8, 0);
+        c.coefs.assign((std::size_t)c.width_blocks * c.height_blocks * 64, 0);
     }
-    // (a single-component scan is not interleaved: its MCU is one block and
-    // the block rows / columns are those of the component itself, B.2.3)
-    bool const single = n == 1;
-    int const scan_mcux = single ? (d.comps[0].down_w + 7) / 8 : mcux;
-    int const scan_mcuy = single ? (d.comps[0].down_h + 7) / 8 : mcuy;
-    int restarts_left = d.restart_interval;
-    int next_rst = 0;
-    for (int my = 0; my < scan_mcuy; ++my)
-        for (int mx = 0; mx < scan_mcux; ++mx) {
-            if (d.restart_interval > 0 && restarts_left == 0) {
-                // byte-align, expect RSTn
-                d.bits = 0;
-                d.bitbuf = 0;
-                d.hit_marker = false;
-                // (skip fill bytes before the marker)
-                while (d.pos + 1 < d.data.size()
-                    && !(d.data[d.pos] == 0xFF && d.data[d.pos + 1] >= 0xD0
-                        && d.data[d.pos + 1] <= 0xD7)) {
-                    if (d.data[d.pos] == 0xFF && d.data[d.pos + 1] != 0x00
-                        && d.data[d.pos + 1] != 0xFF)
-                        d.fail("restart marker expected");
-                    d.pos += 1;
-                }
-                if (d.pos + 1 >= d.data.size()
-                    || d.data[d.pos + 1] != 0xD0 + next_rst)
-                    d.fail("restart markers out of sequence");
-                d.pos += 2;
-                next_rst = (next_rst + 1) & 7;
-                restarts_left = d.restart_interval;
-                for (Component& c : d.comps)
-                    c.pred = 0;
+    // every scan of the frame (one for most sequential files, about ten for a
+    // progressive one), then the inverse DCT of what has arrived
+    do {
+        decode_scan(d, sc, mcux, mcuy);
+    } while (next_scan(d, &sc));
+    for (Component& c : d.comps) {
+        if (!c.q_latched)
+            d.fail("a component of the frame is in no scan");
+        std::size_t const stride = (std::size_t)c.width_blocks * 8;
+        c.plane.assign(stride * c.height_blocks * 8, 0);
+        for (int by = 0; by < c.height_blocks; ++by)
+            for (int bx = 0; bx < c.width_blocks; ++bx) {
+                const int16_t* src = c.coefs.data()
+                    + ((std::size_t)by * c.width_blocks + bx) * 64;
+                int coef[64];
+                for (int i = 0; i < 64; ++i)
+                    coef[i] = (int)src[i] * c.q[i];
+                idct_islow(coef, c.plane.data() + (std::size_t)by * 8 * stride
+                    + (std::size_t)bx * 8, stride);
             }
-            for (Component& c : d.comps) {
-                int const bh = single ? 1 : c.h, bv = single ? 1 : c.v;
-                for (int by = 0; by < bv; ++by)
-                    for (int bx = 0; bx < bh; ++bx)
-                        decode_block(d, c, mx * bh + bx, my * bv + by);
-            }
-            if (d.restart_interval > 0)
-                restarts_left -= 1;
-        }
+        std::vector<int16_t>().swap(c.coefs);
+    }
 
     // colour space (jdapimin.c, default_decompress_parms)
     bool ycc = false;
