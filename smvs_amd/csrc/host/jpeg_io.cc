@@ -1,4 +1,4 @@
-// Baseline JPEG decoder for the byte-image embeddings of an MVE view
+// JPEG decoder (sequential and progressive) for the byte-image embeddings of an MVE view
 // ("original.jpg": smvsrecon --image=original, app/smvsrecon.cc:41, 156;
 // makescene keeps the camera's JPEG as the `original` embedding).  The
 // reference reads them through mve::image::load_jpg_file, i.e. libjpeg with its
@@ -8,8 +8,9 @@
 // (jdcolor.c).  This file restates those published algorithms so that the
 // pixels are the ones libjpeg produces: tests/test_scene_io_cpu.py compares
 // with Pillow's decoder (libjpeg-turbo, bit-identical to libjpeg for these
-// methods) on 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1 / grey images, optimised Huffman
-// tables, restart intervals, sizes that are no multiple of the MCU.
+// methods) on 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1 / grey images, sequential and
+// progressive, optimised Huffman tables, restart intervals, sizes that are no
+// multiple of the MCU.
 //
 // Supported: SOF0 / SOF1 (sequential) and SOF2 (progressive: spectral
 // selection and successive approximation, jdphuff.c), Huffman, 8 bits, one or

@@ -1,6 +1,6 @@
-// JPEG byte-image embeddings of an MVE view (csrc/host/jpeg_io.cc): baseline /
-// extended sequential Huffman JPEG, 8 bits, grey or three components, decoded
-// the way libjpeg decodes with its default parameters (what
+// JPEG byte-image embeddings of an MVE view (csrc/host/jpeg_io.cc): sequential
+// and progressive Huffman JPEG, 8 bits, grey or three components, decoded the
+// way libjpeg decodes with its default parameters (what
 // mve::image::load_jpg_file uses).
 #pragma once
 
@@ -11,7 +11,7 @@
 namespace smvs_amd {
 
 // Throws std::runtime_error with the reason for files it does not decode
-// (progressive, arithmetic-coded, 12-bit, CMYK) and for corrupt data.
+// (arithmetic-coded, lossless, 12-bit, CMYK) and for corrupt data.
 ByteImage::Ptr load_jpeg_u8(std::string const& path);
 // width, height, channels without decoding the image data
 bool jpeg_header(std::string const& path, int* whc);
