@@ -325,7 +325,7 @@ topo_visibility_kernel(TopoArgs A)
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
             // depth and pixel derivatives of the surface (topo_pixel_surface_kernel)
-            const double *sp = A.pix + ((size_t)(py + j) * A.W + (px + i)) * 3;
+            const double *sp = A.pix + ((unsigned)(py + j) * (unsigned)A.W + (unsigned)(px + i)) * 3u;
             double const w = sp[0];
             Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
             double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
@@ -337,7 +337,7 @@ topo_visibility_kernel(TopoArgs A)
             int const cx = (int)qx, cy = (int)qy;
             for (int dx = -1; dx < 2; ++dx)
                 for (int dy = -1; dy < 2; ++dy)
-                    if (wp.d * 0.95 > zbuf[(size_t)(cy + dy) * zw + (cx + dx)])
+                    if (wp.d * 0.95 > zbuf[(unsigned)(cy + dy) * (unsigned)zw + (unsigned)(cx + dx)])
                         visible = false;
             // ratio of the squared singular values of the warp Jacobian
             double const wx = sp[1], wy = sp[2];
@@ -383,8 +383,10 @@ topo_visibility_kernel(TopoArgs A)
             // corner samples take the corner node's depth (:803-857)
             double depth;
             if (smp.src >= 0) {
-                depth = A.pix[((size_t)(py + (smp.src >> A.ps_log2)) * A.W
-                    + (px + (smp.src & (ps - 1)))) * 3];
+                // (32-bit offsets: the host checks that the planes have fewer than
+                // 2^31 elements; 64-bit multiply-adds run at a quarter of the rate)
+                depth = A.pix[((unsigned)(py + (smp.src >> A.ps_log2)) * (unsigned)A.W
+                    + (unsigned)(px + (smp.src & (ps - 1)))) * 3u];
             } else {
                 int const corner = -1 - smp.src;
                 int const n00 = (pc / A.npx) * A.stride + pc % A.npx;
@@ -402,7 +404,7 @@ topo_visibility_kernel(TopoArgs A)
                 // ones; per channel the arithmetic is linear_at's
                 // (topo_math.h), term for term
                 float3_r const m3 = *reinterpret_cast<const float3_r *>(mv.image
-                    + ((size_t)(py + smp.dy) * mv.w + (px + smp.dx)) * 3);
+                    + ((unsigned)(py + smp.dy) * (unsigned)mv.w + (unsigned)(px + smp.dx)) * 3u);
                 cm[0] = m3.x; cm[1] = m3.y; cm[2] = m3.z;
                 float x = (float)qx, y = (float)qy;
                 x = x < 0.0f ? 0.0f : (x > (float)(sv.w - 1) ? (float)(sv.w - 1) : x);
@@ -414,10 +416,11 @@ topo_visibility_kernel(TopoArgs A)
                 float const w3 = y - (float)fy, w2 = 1.0f - w3;
                 float const k00 = w0 * w2, k10 = w1 * w2, k01 = w0 * w3, k11 = w1 * w3;
                 const float *img = sv.image;
-                float3_r const v00 = *reinterpret_cast<const float3_r *>(img + ((long)fy * sv.w + fx) * 3);
-                float3_r const v10 = *reinterpret_cast<const float3_r *>(img + ((long)fy * sv.w + fx1) * 3);
-                float3_r const v01 = *reinterpret_cast<const float3_r *>(img + ((long)fy1 * sv.w + fx) * 3);
-                float3_r const v11 = *reinterpret_cast<const float3_r *>(img + ((long)fy1 * sv.w + fx1) * 3);
+                unsigned const row0 = (unsigned)fy * (unsigned)sv.w, row1 = (unsigned)fy1 * (unsigned)sv.w;
+                float3_r const v00 = *reinterpret_cast<const float3_r *>(img + (row0 + (unsigned)fx) * 3u);
+                float3_r const v10 = *reinterpret_cast<const float3_r *>(img + (row0 + (unsigned)fx1) * 3u);
+                float3_r const v01 = *reinterpret_cast<const float3_r *>(img + (row1 + (unsigned)fx) * 3u);
+                float3_r const v11 = *reinterpret_cast<const float3_r *>(img + (row1 + (unsigned)fx1) * 3u);
                 cs[0] = v00.x * k00 + v10.x * k10 + v01.x * k01 + v11.x * k11;
                 cs[1] = v00.y * k00 + v10.y * k10 + v01.y * k01 + v11.y * k11;
                 cs[2] = v00.z * k00 + v10.z * k10 + v01.z * k01 + v11.z * k11;
@@ -438,10 +441,11 @@ topo_visibility_kernel(TopoArgs A)
                 for (int i = gl; i < n; i += G, ++slot) {
                     double cm[3], cs[3];
                     if (pass == 0) {
-                        if (!colours(i, cm, cs, true)) {
-                            inside = false;
-                            break;
-                        }
+                        // (no early exit when a sample falls outside: the taps are
+                        // clamped into the image, the sums of such a patch are never
+                        // used (ncc = -1), and a loop without an exit lets the loads
+                        // of the next sample start under the arithmetic of this one)
+                        inside = colours(i, cm, cs, true) && inside;
 #pragma unroll
                         for (int k = 0; k < NCC_KEEP; ++k)
                             if (slot == k)
@@ -736,6 +740,16 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         set_error("smvs_topology_subviews: main image size differs from the context");
         return SMVS_ERR_INVALID;
     }
+    // (the kernels index the per-pixel planes and the float images with 32-bit offsets)
+    if ((size_t)ctx->width * ctx->height * 3 >= ((size_t)1 << 31)) {
+        set_error("smvs_topology_subviews: images of 2^31 / 3 pixels and more are not supported");
+        return SMVS_ERR_INVALID;
+    }
+    for (int j = 0; j <= ctx->n_subs; ++j)
+        if ((size_t)ctx->images[j].w * ctx->images[j].h * 3 >= ((size_t)1 << 31)) {
+            set_error("smvs_topology_subviews: images of 2^31 / 3 pixels and more are not supported");
+            return SMVS_ERR_INVALID;
+        }
     int rc;
     // the 32 sample templates of ncc_for_patch for this patch size
     if (ctx->topo_ncc_ps != ctx->patchsize && ctx->has_surface) {
