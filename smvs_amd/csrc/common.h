@@ -64,6 +64,8 @@ enum {
     I_NUM_ACTIVE,    // active nodes after re-activation
     I_ACTIVE_PATCHES,
     I_TOPO_DELETED,  // patches deleted by one cut_boundaries pass
+    I_TOPO_CANDIDATES,   // (behind I_TOPO_DELETED: one memset clears both) patches
+                         // the mse kernel evaluates (topology.hip)
     I_LIVE_PATCHES,  // entries of the compacted live-patch list
     I_NUM_INITIAL,   // active nodes at the start of the Newton loop (finish_step_kernel, begin)
     I_STOP,          // pipelined Newton loop: the loop has ended, enqueued steps do nothing
@@ -214,6 +216,8 @@ struct smvs_ctx {
     size_t topo_mse_cap = 0;
     uint8_t *topo_border = nullptr;   // nodes with > 1 missing neighbour (cut_boundaries)
     size_t topo_border_cap = 0;
+    int *topo_mse_list = nullptr;     // patches whose error is evaluated (topology.hip)
+    size_t topo_mse_list_cap = 0;
     double *topo_pix = nullptr;       // [H][W][3]: surface depth, d/dx, d/dy per pixel
     size_t topo_pix_cap = 0;
 

@@ -407,6 +407,8 @@ ctx_free(smvs_ctx *ctx)
         (void)hipFree(ctx->topo_mse);
     if (ctx->topo_border)
         (void)hipFree(ctx->topo_border);
+    if (ctx->topo_mse_list)
+        (void)hipFree(ctx->topo_mse_list);
     if (ctx->topo_pix)
         (void)hipFree(ctx->topo_pix);
     if (ctx->blur_tmp[0])

@@ -16,7 +16,10 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include "host/topo_math.h"
 
 #include <vector>
@@ -28,6 +31,97 @@ using smvs_topo::Warp;
 
 // three packed floats (4-byte aligned): one global_load_dwordx3
 struct __attribute__((packed, aligned(4))) float3_r { float x, y, z; };
+
+// Several quotients over one denominator.  a / d as the compiler expands it is
+// v_div_scale (twice), v_rcp_f64, two Newton steps on the reciprocal, the
+// quotient a * r, ONE residual correction (v_div_fmas) and v_div_fixup: thirteen
+// instructions, five of which depend only on d.  For a denominator well inside
+// the normal range the scaling steps are the identity, so the same quotient --
+// bit for bit, it is the same sequence of roundings -- comes from the shared
+// refined reciprocal in three instructions plus the fix-up (zero, infinite and
+// NaN numerators).  Any other denominator (zero, NaN, 1e-70 ...) is `plain ==
+// false`: the caller divides.  The warp of a pixel divides ten times by d and
+// d * d (Correspondence, topo_math.h): the visibility kernel issues a vector
+// instruction every cycle it can, and a seventh of them were these.
+struct SharedDivisor {
+    double d, inv;
+    bool plain;
+    __device__ __forceinline__ explicit SharedDivisor(double d_, bool allow = true) : d(d_)
+    {
+        double const m = fabs(d_);
+        plain = allow && m > 1e-70 && m < 1e70;   // (false for NaN)
+        double r = __builtin_amdgcn_rcp(d_);
+        r = __builtin_fma(__builtin_fma(-d_, r, 1.0), r, r);
+        inv = __builtin_fma(__builtin_fma(-d_, r, 1.0), r, r);
+    }
+    // a / d, `plain` denominators only (no branch: straight-line callers)
+    __device__ __forceinline__ double under(double a) const
+    {
+        double const q = a * inv;
+        double const rem = __builtin_fma(-q, d, a);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(rem, inv, q), d, a);
+    }
+    // a / d for any denominator
+    __device__ __forceinline__ double quotient(double a) const
+    {
+        return plain ? under(a) : a / d;
+    }
+};
+
+// Warp::x, Warp::y and Warp::jacobian (topo_math.h; lib/correspondence.cc:20-51,
+// 88-100): SHARED = the reciprocals of d and d * d computed once (only when
+// plain()), otherwise the divisions of topo_math.h.  The same operations in
+// the same order, every quotient the one the division gives.
+template <bool SHARED>
+struct WarpQuotients {
+    SharedDivisor by_d, by_d2;
+    __device__ __forceinline__ explicit WarpQuotients(Warp const &wp, bool allow = true)
+        : by_d(wp.d, allow), by_d2(wp.d * wp.d, allow) {}
+    __device__ __forceinline__ bool plain(void) const { return by_d.plain && by_d2.plain; }
+    __device__ __forceinline__ double x(Warp const &wp) const
+    {
+        return SHARED ? by_d.under(wp.a) : wp.x();
+    }
+    __device__ __forceinline__ double y(Warp const &wp) const
+    {
+        return SHARED ? by_d.under(wp.b) : wp.y();
+    }
+    __device__ __forceinline__ void
+    jacobian(Warp const &wp, const double *M, double w, double wx, double wy,
+        double *jac) const
+    {
+#pragma clang fp contract(off)
+        if (!SHARED) {
+            wp.jacobian(M, w, wx, wy, jac);
+            return;
+        }
+        jac[0] = by_d.under(wx * wp.p + w * M[0]) - by_d2.under(wp.a * (wx * wp.r + w * M[6]));
+        jac[2] = by_d.under(wy * wp.p + w * M[1]) - by_d2.under(wp.a * (wy * wp.r + w * M[7]));
+        jac[1] = by_d.under(wx * wp.q + w * M[3]) - by_d2.under(wp.b * (wx * wp.r + w * M[6]));
+        jac[3] = by_d.under(wy * wp.q + w * M[4]) - by_d2.under(wp.b * (wy * wp.r + w * M[7]));
+    }
+};
+
+// linear_at (topo_math.h) on both channels of a gradient plane: the taps once,
+// four 8-byte loads, per channel linear_at's arithmetic term for term.
+__device__ __forceinline__ void
+linear_at_pair(const float2 *data, int w, int h, float x, float y, float *c0, float *c1)
+{
+#pragma clang fp contract(off)
+    x = x < 0.0f ? 0.0f : (x > (float)(w - 1) ? (float)(w - 1) : x);
+    y = y < 0.0f ? 0.0f : (y > (float)(h - 1) ? (float)(h - 1) : y);
+    int const fx = (int)x, fy = (int)y;
+    int const fx1 = fx + 1 < w - 1 ? fx + 1 : w - 1;
+    int const fy1 = fy + 1 < h - 1 ? fy + 1 : h - 1;
+    float const w1 = x - (float)fx, w0 = 1.0f - w1;
+    float const w3 = y - (float)fy, w2 = 1.0f - w3;
+    float2 const v00 = data[(long)fy * w + fx];
+    float2 const v10 = data[(long)fy * w + fx1];
+    float2 const v01 = data[(long)fy1 * w + fx];
+    float2 const v11 = data[(long)fy1 * w + fx1];
+    *c0 = v00.x * (w0 * w2) + v10.x * (w1 * w2) + v01.x * (w0 * w3) + v11.x * (w1 * w3);
+    *c1 = v00.y * (w0 * w2) + v10.y * (w1 * w2) + v01.y * (w0 * w3) + v11.y * (w1 * w3);
+}
 
 struct TopoView {
     int w, h, c;
@@ -65,9 +159,14 @@ struct TopoArgs {
     // that touch none of them
     uint8_t *border_node;
     int only_candidates;
+    int *mse_list;      // patches topo_mse_kernel evaluates
+    int *mse_count;     // status word: entries of mse_list
     // create_subview_surfaces: depth and its pixel derivatives of the surface at
     // every pixel of a valid patch, [H][W][3] doubles (topo_pixel_surface_kernel)
     double *pix;
+    // SMVS_TOPO_DIVIDE=exact: every quotient by the division itself
+    // (SharedDivisor; the test that both give the same bits)
+    int exact_divisions;
 };
 
 __device__ __forceinline__ void
@@ -321,6 +420,36 @@ topo_visibility_kernel(TopoArgs A)
     // patch's pixels
     bool visible = true;
     double worst = 0.0;
+    // (one pixel with either kind of quotients; false: outside the neighbour's
+    // image, the reference stops looking at the patch)
+    auto const pixel = [&](auto const &wq, Warp const &wp, const double *sp, double w) -> bool {
+        double const qx = wq.x(wp) - 0.5, qy = wq.y(wp) - 0.5;
+        if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
+            || qy >= sh - cutoffset) {
+            visible = false;
+            return false;
+        }
+        int const cx = (int)qx, cy = (int)qy;
+        for (int dx = -1; dx < 2; ++dx)
+            for (int dy = -1; dy < 2; ++dy)
+                if (wp.d * 0.95 > zbuf[(unsigned)(cy + dy) * (unsigned)zw + (unsigned)(cx + dx)])
+                    visible = false;
+        // ratio of the squared singular values of the warp Jacobian
+        double const wx = sp[1], wy = sp[2];
+        double jac[4];
+        wq.jacobian(wp, M, w, wx, wy, jac);
+        double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
+            + (jac[1] + jac[2]) * (jac[1] + jac[2]));
+        double const g = sqrt((jac[0] + jac[3]) * (jac[0] + jac[3])
+            + (jac[1] - jac[2]) * (jac[1] - jac[2]));
+        double const s0 = (e + g) / 2.0;
+        double const s1 = fabs(s0 - e);
+        double const hi = s0 < s1 ? s1 : s0, lo = s1 < s0 ? s1 : s0;
+        double const ratio = (hi * hi) / (lo * lo);
+        // std::max(worst, ratio): a NaN ratio leaves worst unchanged
+        worst = worst < ratio ? ratio : worst;
+        return true;
+    };
     if (alive)
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
@@ -328,31 +457,11 @@ topo_visibility_kernel(TopoArgs A)
             const double *sp = A.pix + ((unsigned)(py + j) * (unsigned)A.W + (unsigned)(px + i)) * 3u;
             double const w = sp[0];
             Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
-            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
-            if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
-                || qy >= sh - cutoffset) {
-                visible = false;
+            WarpQuotients<true> const wq(wp, A.exact_divisions == 0);
+            bool const go_on = wq.plain() ? pixel(wq, wp, sp, w)
+                : pixel(WarpQuotients<false>(wp), wp, sp, w);
+            if (!go_on)
                 break;
-            }
-            int const cx = (int)qx, cy = (int)qy;
-            for (int dx = -1; dx < 2; ++dx)
-                for (int dy = -1; dy < 2; ++dy)
-                    if (wp.d * 0.95 > zbuf[(unsigned)(cy + dy) * (unsigned)zw + (unsigned)(cx + dx)])
-                        visible = false;
-            // ratio of the squared singular values of the warp Jacobian
-            double const wx = sp[1], wy = sp[2];
-            double jac[4];
-            wp.jacobian(M, w, wx, wy, jac);
-            double const e = sqrt((jac[0] - jac[3]) * (jac[0] - jac[3])
-                + (jac[1] + jac[2]) * (jac[1] + jac[2]));
-            double const g = sqrt((jac[0] + jac[3]) * (jac[0] + jac[3])
-                + (jac[1] - jac[2]) * (jac[1] - jac[2]));
-            double const s0 = (e + g) / 2.0;
-            double const s1 = fabs(s0 - e);
-            double const hi = s0 < s1 ? s1 : s0, lo = s1 < s0 ? s1 : s0;
-            double const ratio = (hi * hi) / (lo * lo);
-            // std::max(worst, ratio): a NaN ratio leaves worst unchanged
-            worst = worst < ratio ? ratio : worst;
         }
     visible = group_all(visible, G, lane, red);
     worst = group_max(worst, G, red);
@@ -395,7 +504,8 @@ topo_visibility_kernel(TopoArgs A)
             double const sx = (double)(px + smp.dx);
             double const sy = (double)(py + smp.dy);
             Warp wp(M, t, sx + 0.5, sy + 0.5, depth);
-            double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
+            SharedDivisor const by_d(wp.d, A.exact_divisions == 0);
+            double const qx = by_d.quotient(wp.a) - 0.5, qy = by_d.quotient(wp.b) - 0.5;
             if (check && (qx < 1 || qx > sv.w - 2 || qy < 1 || qy > sv.h - 2))
                 return false;
             if (mv.c == 3 && sv.c == 3) {
@@ -481,9 +591,10 @@ topo_visibility_kernel(TopoArgs A)
             }
             if (pass == 0) {
                 inside = group_all(inside, G, lane, red);
+                SharedDivisor const by_n((double)n, A.exact_divisions == 0);
                 for (int c = 0; c < 3; ++c) {
-                    mean0[c] = group_sum(sum0[c], G, red) / n;
-                    mean1[c] = group_sum(sum1[c], G, red) / n;
+                    mean0[c] = by_n.quotient(group_sum(sum0[c], G, red));
+                    mean1[c] = by_n.quotient(group_sum(sum1[c], G, red));
                 }
             }
         }
@@ -501,7 +612,56 @@ topo_visibility_kernel(TopoArgs A)
         atomicOr(&A.vis_out[p], 1u << s);
 }
 
-// ---- mse_for_patch (:747-790), one lane group per patch ----
+// ---- mse_for_patch (:747-790) ----
+// Which patches are asked about: all valid ones, or (cut_boundaries) those
+// with a node that has lost more than one neighbour (:401-428) -- the rim of
+// the surface; the others are not evaluated (0: never above 0.05).  One thread
+// per patch writes the answer of everything that is not evaluated and appends
+// the rest to a list, so that the kernel doing the arithmetic is launched over
+// the few per cent that need it: sixteen lanes per patch of a 129 k-patch grid
+// were 32 k waves that each waited for two dependent loads to learn that they
+// had nothing to do -- that, not the arithmetic, was the 35-40 us of a pass.
+// (The order of the list is whatever the atomics make it; an entry's result
+// does not depend on its place.)
+__global__ void __launch_bounds__(256)
+topo_mse_candidates_kernel(TopoArgs A)
+{
+    int const p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool const in_range = p < A.num_patches;
+    bool const valid = in_range && A.patch_valid[p];
+    bool alive = valid;
+    if (valid && A.only_candidates) {
+        int const n00 = (p / A.npx) * A.stride + p % A.npx;
+        alive = (A.border_node[n00] | A.border_node[n00 + 1] | A.border_node[n00 + A.stride]
+            | A.border_node[n00 + A.stride + 1]) != 0;
+    }
+    if (in_range && !alive)
+        A.mse_out[p] = valid ? 0.0 : -1.0;
+    // one atomic per workgroup: the list's end is one word for the whole grid
+    __shared__ int wave_count[4];
+    __shared__ int block_base;
+    unsigned long long const mask = __ballot(alive);
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        wave_count[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int const total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        block_base = total > 0 ? atomicAdd(A.mse_count, total) : 0;
+    }
+    __syncthreads();
+    if (alive) {
+        int at = block_base + __popcll(mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w)
+            at += wave_count[w];
+        A.mse_list[at] = p;
+    }
+}
+
+// One lane group per listed patch; the launch is bounded and a group takes
+// every (number of groups)-th entry.  AT_ONCE: neighbours whose warps and
+// gathers are issued together.
+template <int AT_ONCE>
 __global__ void __launch_bounds__(256)
 topo_mse_kernel(TopoArgs A)
 {
@@ -510,27 +670,22 @@ topo_mse_kernel(TopoArgs A)
     int const ps = A.ps;
     int const G = group_size(ps, MSE_WORKGROUP_FROM);
     int const gl = threadIdx.x & (G - 1);
-    int const p = (int)(((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x)
-        >> (31 - __clz(G)));
-    bool const in_range = p < A.num_patches;
-    bool const valid = in_range && A.patch_valid[p];
-    bool alive = valid;
-    if (valid && A.only_candidates) {
-        // cut_boundaries reads the error only of patches with a node that has
-        // lost more than one neighbour (:401-428): the others -- all but the
-        // rim of the surface -- are not evaluated (0: never above 0.05)
-        int const n00 = (p / A.npx) * A.stride + p % A.npx;
-        alive = (A.border_node[n00] | A.border_node[n00 + 1] | A.border_node[n00 + A.stride]
-            | A.border_node[n00 + A.stride + 1]) != 0;
-    }
-    int const pc = alive ? p : 0;
-    double n16[16];
-    load_patch_nodes(A, pc, n16);
-    int const px = A.start_x + (pc % A.npx) * ps;
-    int const py = A.start_y + (pc / A.npx) * ps;
-    uint32_t const vis = alive ? A.patch_vis[pc] : 0u;
-    double error = 0.0, counter = 0.0;
-    if (alive)
+    int const g_log2 = 31 - __clz(G);
+    int const group = (int)(((unsigned)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2);
+    int const groups = (int)(((unsigned)gridDim.x * blockDim.x) >> g_log2);
+    int const count = *A.mse_count;
+    // (G == 256: the group is the workgroup, its threads loop together and
+    // meet in group_sum's barriers; smaller groups only shuffle among
+    // themselves)
+    for (int item = group; item < count; item += groups) {
+        int const p = A.mse_list[item];
+        double n16[16];
+        load_patch_nodes(A, p, n16);
+        int const px = A.start_x + (p % A.npx) * ps;
+        int const py = A.start_y + (p / A.npx) * ps;
+        // (bits of neighbours the context does not have are not looked at)
+        uint32_t const vis = A.patch_vis[p] & ((1u << A.n_subs) - 1u);
+        double error = 0.0, counter = 0.0;
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
             // (x / ps == x * (1 / ps) exactly: ps is a power of two)
@@ -540,32 +695,60 @@ topo_mse_kernel(TopoArgs A)
             double const wy = smvs_topo::patch_eval(n16, u, v, 0, 1) * A.inv_ps;
             float2 const gm = A.main_grad[(size_t)(py + j) * A.W + (px + i)];
             double const gm0 = gm.x, gm1 = gm.y;
-            for (int s = 0; s < A.n_subs; ++s) {
-                if (!(vis & (1u << s)))
+            // The neighbours AT_ONCE at a time: the warps, then the gathers of
+            // all of them, then the sum in the neighbours' order (the few rim
+            // patches this kernel is asked about make a launch as long as one
+            // lane's chain of dependent divisions and gathers).
+            for (int s0 = 0; s0 < A.n_subs; s0 += AT_ONCE) {
+                uint32_t const some = (vis >> s0) & ((1u << AT_ONCE) - 1u);
+                if (some == 0u)
                     continue;
-                SubPlanes const sp = A.subs[s];
-                const double *M = A.cams->M[s];
-                Warp wp(M, A.cams->t[s], px + i + 0.5, py + j + 0.5, w);
-                double jac[4];
-                wp.jacobian(M, w, wx, wy, jac);
-                float const qx = (float)(wp.x() - 0.5),
-                    qy = (float)(wp.y() - 0.5);
-                const float *grad = reinterpret_cast<const float *>(sp.grad);
-                double const g0 = smvs_topo::linear_at(grad, sp.width,
-                    sp.height, 2, qx, qy, 0);
-                double const g1 = smvs_topo::linear_at(grad, sp.width,
-                    sp.height, 2, qx, qy, 1);
-                double const d0 = gm0 - (jac[0] * g0 + jac[1] * g1);
-                double const d1 = gm1 - (jac[2] * g0 + jac[3] * g1);
-                error += sqrt(d0 * d0 + d1 * d1);
-                counter += 1.0;
+                double jac[AT_ONCE][4];
+                float g0[AT_ONCE], g1[AT_ONCE];
+                auto const gather = [&](auto tag) {
+#pragma unroll
+                    for (int e = 0; e < AT_ONCE; ++e) {
+                        // (an unseen neighbour: the first one's planes at pixel 0,
+                        // loaded and not used)
+                        bool const on = ((some >> e) & 1u) != 0u;
+                        int const sc = on ? s0 + e : s0;
+                        const double *M = A.cams->M[sc];
+                        Warp wp(M, A.cams->t[sc], px + i + 0.5, py + j + 0.5, w);
+                        WarpQuotients<decltype(tag)::value> const wq(wp);
+                        wq.jacobian(wp, M, w, wx, wy, jac[e]);
+                        float const qx = on ? (float)(wq.x(wp) - 0.5) : 0.0f;
+                        float const qy = on ? (float)(wq.y(wp) - 0.5) : 0.0f;
+                        SubPlanes const sp = A.subs[sc];
+                        linear_at_pair(sp.grad, sp.width, sp.height, qx, qy, &g0[e], &g1[e]);
+                    }
+                };
+                bool plain = A.exact_divisions == 0;
+#pragma unroll
+                for (int e = 0; e < AT_ONCE; ++e) {
+                    int const sc = ((some >> e) & 1u) != 0u ? s0 + e : s0;
+                    Warp wp(A.cams->M[sc], A.cams->t[sc], px + i + 0.5, py + j + 0.5, w);
+                    plain = plain && WarpQuotients<true>(wp).plain();
+                }
+                if (plain)
+                    gather(std::true_type());
+                else
+                    gather(std::false_type());
+#pragma unroll
+                for (int e = 0; e < AT_ONCE; ++e) {
+                    if (((some >> e) & 1u) == 0u)
+                        continue;
+                    double const d0 = gm0 - (jac[e][0] * (double)g0[e] + jac[e][1] * (double)g1[e]);
+                    double const d1 = gm1 - (jac[e][2] * (double)g0[e] + jac[e][3] * (double)g1[e]);
+                    error += sqrt(d0 * d0 + d1 * d1);
+                    counter += 1.0;
+                }
             }
         }
-    error = group_sum(error, G, red);
-    counter = group_sum(counter, G, red);
-    if (in_range && gl == 0)
-        A.mse_out[p] = !valid ? -1.0 : (!alive ? 0.0
-            : (counter == 0.0 ? 1.0 : error / counter));
+        error = group_sum(error, G, red);
+        counter = group_sum(counter, G, red);
+        if (gl == 0)
+            A.mse_out[p] = counter == 0.0 ? 1.0 : error / counter;
+    }
 }
 
 // ---- cut_boundaries (:401-428): the nodes with more than one missing
@@ -695,6 +878,10 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
                 * (ctx->images[1 + s].h + 1);
     }
     A->sgm_depth = nullptr;
+    {
+        const char *mode = std::getenv("SMVS_TOPO_DIVIDE");
+        A->exact_divisions = mode != nullptr && std::strcmp(mode, "exact") == 0 ? 1 : 0;
+    }
     A->ncc = ctx->topo_ncc;
     for (int i = 0; i < 33; ++i)
         A->ncc_off[i] = ctx->topo_ncc_off[i];
@@ -716,6 +903,8 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     A->patch_valid_rw = ctx->patch_valid;
     A->node_valid_rw = ctx->node_valid;
     A->deleted = ctx->status + I_TOPO_DELETED;
+    A->mse_list = ctx->topo_mse_list;
+    A->mse_count = ctx->status + I_TOPO_CANDIDATES;
     A->num_nodes = ctx->num_nodes;
     A->border_node = ctx->topo_border;
     A->only_candidates = 0;
@@ -871,16 +1060,39 @@ prepare_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
             return rc;
         ctx->topo_border_cap = (size_t)ctx->num_nodes;
     }
+    if ((size_t)ctx->num_patches > ctx->topo_mse_list_cap) {
+        if ((rc = device_alloc(&ctx->topo_mse_list, (size_t)ctx->num_patches)) != SMVS_OK)
+            return rc;
+        ctx->topo_mse_list_cap = (size_t)ctx->num_patches;
+    }
     return fill_args(ctx, A, who);
 }
 
+// The candidate list, then the errors of its entries.  count_is_zero: the
+// caller has cleared I_TOPO_CANDIDATES on the stream (with its own words).
 static int
-launch_patch_mse(smvs_ctx *ctx, TopoArgs const &A)
+launch_patch_mse(smvs_ctx *ctx, TopoArgs const &A, bool count_is_zero)
 {
+    if (!count_is_zero)
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_TOPO_CANDIDATES, 0, sizeof(int),
+            ctx->stream));
+    hipLaunchKernelGGL(topo_mse_candidates_kernel,
+        dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    // enough groups for every CU to hold its fill of waves, never more than the
+    // patches: a group walks the list with that stride
     long long const group = group_size(ctx->patchsize, MSE_WORKGROUP_FROM);
     long long const items = (long long)ctx->num_patches * group;
-    hipLaunchKernelGGL(topo_mse_kernel,
-        dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    long long blocks = (items + 255) / 256;
+    if (blocks > 1024)
+        blocks = 1024;
+    // SMVS_MSE_SUBS=1: the neighbours of a pixel one after the other
+    const char *subs = std::getenv("SMVS_MSE_SUBS");
+    if (subs != nullptr && std::atoi(subs) == 1)
+        hipLaunchKernelGGL(topo_mse_kernel<1>, dim3((unsigned)blocks), dim3(256), 0,
+            ctx->stream, A);
+    else
+        hipLaunchKernelGGL(topo_mse_kernel<4>, dim3((unsigned)blocks), dim3(256), 0,
+            ctx->stream, A);
     SMVS_HIP_CHECK(hipGetLastError());
     return SMVS_OK;
 }
@@ -893,7 +1105,7 @@ smvs_topology_patch_mse(smvs_ctx *ctx, double *mse_out)
     TopoArgs A;
     int rc = prepare_patch_mse(ctx, &A, "smvs_topology_patch_mse");
     if (rc == SMVS_OK)
-        rc = launch_patch_mse(ctx, A);
+        rc = launch_patch_mse(ctx, A, false);
     if (rc != SMVS_OK)
         return rc;
     SMVS_HIP_CHECK(hipMemcpyAsync(mse_out, ctx->topo_mse,
@@ -922,13 +1134,15 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     A.only_candidates = 1;
     int total = 0;
     int deleted = 11;
+    bool const trace = std::getenv("SMVS_TOPO_TRACE") != nullptr;
     while (deleted > 10) {   // depth_optimizer.cc:186-190, 323-337
+        static_assert(I_TOPO_CANDIDATES == I_TOPO_DELETED + 1, "cleared together");
         SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_TOPO_DELETED, 0,
-            sizeof(int), ctx->stream));
+            2 * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(topo_border_nodes_kernel,
             dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
             ctx->stream, A);
-        int const mrc = launch_patch_mse(ctx, A);
+        int const mrc = launch_patch_mse(ctx, A, true);
         if (mrc != SMVS_OK)
             return mrc;
         hipLaunchKernelGGL(topo_cut_patches_kernel,
@@ -939,11 +1153,14 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
             ctx->stream, A);
         SMVS_HIP_CHECK(hipGetLastError());
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host + I_TOPO_DELETED,
-            ctx->status + I_TOPO_DELETED, sizeof(int), hipMemcpyDeviceToHost,
+            ctx->status + I_TOPO_DELETED, 2 * sizeof(int), hipMemcpyDeviceToHost,
             ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         deleted = ctx->status_host[I_TOPO_DELETED];
         total += deleted;
+        if (trace)
+            std::fprintf(stderr, "[smvs topo] cut pass: %d of %d patches evaluated, %d deleted\n",
+                ctx->status_host[I_TOPO_CANDIDATES], ctx->num_patches, deleted);
     }
     if (patch_valid_out != nullptr)
         SMVS_HIP_CHECK(hipMemcpyAsync(patch_valid_out, ctx->patch_valid,

@@ -92,7 +92,10 @@ def _marshal(inputs, keep):
 
 def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
              min_scale=2, use_shading=False, sgm_depth=None,
-             full_optimization=False, device=0, solver="auto"):
+             full_optimization=False, device=0, solver="auto", want_maps=True):
+    """want_maps=False: optimize() only -- the depth / normal maps the reference
+    reads back with get_depth() / get_normals() afterwards are not fetched (the
+    embeddings optimize() itself writes are; tools/optimize_timeline.py)."""
     lib = load()
     keep = []
     main, subs, n_subs, b = _marshal(inputs, keep)
@@ -113,7 +116,8 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
     rc = lib.smvs_host_optimize(C.byref(main), subs, n_subs, C.byref(b),
         sd.ctypes.data_as(_fp) if sd is not None else None, sw, sh,
         rt.ctypes.data_as(_fp) if rt is not None else None, C.byref(o),
-        depth.ctypes.data_as(_fp), normals.ctypes.data_as(_fp), C.byref(log))
+        depth.ctypes.data_as(_fp) if want_maps else None,
+        normals.ctypes.data_as(_fp) if want_maps else None, C.byref(log))
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
     steps = [dict(scale=log.scale[i], iter=log.iter[i],
@@ -122,7 +126,8 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
                   cg_iterations=log.cg_iterations[i],
                   active_patch_steps=log.active_patch_steps[i],
                   loop_seconds=log.loop_seconds[i]) for i in range(log.count)]
-    return dict(depth=depth, normals=normals, log=steps, sgm_roundtrip=rt,
+    return dict(depth=depth if want_maps else None,
+                normals=normals if want_maps else None, log=steps, sgm_roundtrip=rt,
                 lighting=np.array(log.lighting[:]) if log.has_lighting else None)
 
 

@@ -684,6 +684,38 @@ def test_topology_subviews_mse_and_cuts_match_oracle(hip, oracle, size, n_subs, 
     ctx.close()
 
 
+@pytest.mark.parametrize("size,n_subs,scale", [((320, 256), 6, 2), ((576, 416), 3, 5)])
+def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle, monkeypatch,
+                                                                   size, n_subs, scale):
+    """The visibility and MSE kernels take the ten quotients of a warp from one
+    refined reciprocal of d and one of d * d (csrc/topology.hip, SharedDivisor):
+    the instruction sequence of the division without its scaling steps.  With
+    SMVS_TOPO_DIVIDE=exact every quotient is the division itself -- masks and
+    errors must be the same bits (and the oracle's, the tests above)."""
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, size[0], size[1], n_subs, scale, 0.01)
+    tp.subviews()
+    surf2 = dict(surf)
+    surf2["patch_valid"] = tp.patch_valid.copy()
+    surf2["node_valid"] = tp.node_valid.copy()
+    surf2["patch_vis"] = tp.patch_vis.copy()
+    got = {}
+    for mode in ("shared", "exact"):
+        if mode == "exact":
+            monkeypatch.setenv("SMVS_TOPO_DIVIDE", "exact")
+        else:
+            monkeypatch.delenv("SMVS_TOPO_DIVIDE", raising=False)
+        ctx.set_surface(surf)
+        vis = ctx.topology_subviews(None, use_ncc=True).copy()
+        ctx.set_surface(surf2)
+        got[mode] = (vis, ctx.topology_patch_mse().copy())
+    monkeypatch.delenv("SMVS_TOPO_DIVIDE", raising=False)
+    assert np.array_equal(got["shared"][0], got["exact"][0])
+    assert np.array_equal(got["shared"][1], got["exact"][1])
+    assert np.array_equal(got["shared"][0], tp.patch_vis)
+    assert (got["shared"][1] > 0).any()
+    ctx.close()
+
+
 def test_topology_subviews_with_sgm_depth(hip, oracle):
     """use_sgm variant: the SGM depth is splatted into the z-buffers too and
     the NCC test is skipped (depth_optimizer.cc:463-466, 577-580)."""

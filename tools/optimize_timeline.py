@@ -5,7 +5,8 @@ neighbours, --no-sgm unless --sgm) for profiles/: run under
     rocprofv3 --kernel-trace --output-format csv -d DIR -o run -- \
         python tools/optimize_timeline.py run [--sgm]
 
-(two optimize() calls 0.7 s apart; the second is the warm one), then
+(two optimize() calls 0.7 s apart; the second is the warm one; the maps a caller
+may fetch afterwards with get_depth() / get_normals() are not part of it), then
 
     python tools/optimize_timeline.py report DIR/**/run_kernel_trace.csv
 
@@ -24,7 +25,7 @@ def run(sgm):
         time.sleep(0.7)
         t = time.perf_counter()
         out = host.optimize(inp, regularization=0.01, num_iterations=5, min_scale=2,
-                            sgm_depth=sd)
+                            sgm_depth=sd, want_maps=False)
         wall = time.perf_counter() - t
         loops = sum(e["loop_seconds"] for e in out["log"])
         aps = sum(e["active_patch_steps"] for e in out["log"])
