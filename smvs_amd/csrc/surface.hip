@@ -75,8 +75,9 @@ surf_scatter_depth_kernel(const int *__restrict__ pixel, const float *__restrict
 // are dealt to the lanes; quadrant minima and the count of positive depths by
 // group reductions; the median -- std::nth_element's element of rank
 // count / 2 -- by a radix selection on the bit patterns of the positive
-// floats, most significant bit first: 31 counting passes over the window
-// (L1 hits; windows of <= 256 pixels stay in registers).
+// floats, most significant bit first: 31 counting passes over the window's
+// keys, which a lane keeps in registers (CACHE = 4, 16 or 64 of them: patch
+// sizes up to 64; beyond that the passes re-read the depth map, L1 hits).
 template <int CACHE>
 __global__ void __launch_bounds__(256)
 surf_init_nodes_kernel(SurfArgs A, int G, int glog)
@@ -549,8 +550,17 @@ launch_fill_from_depth(smvs_ctx *ctx, SurfArgs const &A)
             glog += 1;
         size_t const threads = (size_t)A.num_nodes * (size_t)G;
         int const E = T / G;
+        // (the window's keys of a lane in registers up to 64 of them -- patch
+        // size 64, the coarsest scale of a 1920 x 1080 view: the 31 counting
+        // passes of the rank selection re-read nothing)
         if (E <= 4)
             hipLaunchKernelGGL((surf_init_nodes_kernel<4>), dim3(blocks_for(threads)),
+                dim3(256), 0, ctx->stream, A, G, glog);
+        else if (E <= 16)
+            hipLaunchKernelGGL((surf_init_nodes_kernel<16>), dim3(blocks_for(threads)),
+                dim3(256), 0, ctx->stream, A, G, glog);
+        else if (E <= 64)
+            hipLaunchKernelGGL((surf_init_nodes_kernel<64>), dim3(blocks_for(threads)),
                 dim3(256), 0, ctx->stream, A, G, glog);
         else
             hipLaunchKernelGGL((surf_init_nodes_kernel<0>), dim3(blocks_for(threads)),
