@@ -167,6 +167,8 @@ struct TopoArgs {
     // SMVS_TOPO_DIVIDE=exact: every quotient by the division itself
     // (SharedDivisor; the test that both give the same bits)
     int exact_divisions;
+    // SMVS_NCC_PAIRS=0: the NCC samples of a lane one after the other
+    int ncc_pairs;
 };
 
 __device__ __forceinline__ void
@@ -557,8 +559,128 @@ topo_visibility_kernel(TopoArgs A)
             }
             return true;
         };
+        // Two samples of an RGB pair of views side by side: both template
+        // entries, then both depths, both warps, the nine taps of both, the
+        // arithmetic.  A lane's samples were three chains of three dependent
+        // round trips each (template entry -> depth -> taps), one after the
+        // other: the waves of this kernel wait for memory more than half of
+        // their life (profiles/r5_visibility_counters.txt).  Values and the
+        // order they are summed in are those of `colours`; a sample outside the
+        // neighbour's image reads clamped taps (the sums of such a patch are
+        // never used: ncc = -1).
+        bool const rgb = mv.c == 3 && sv.c == 3;
+        struct NccTaps { unsigned o00, o10, o01, o11; float k00, k10, k01, k11; };
+        auto const taps_at = [&](double qx, double qy) -> NccTaps {
+            float x = (float)qx, y = (float)qy;
+            x = x == x ? x : 0.0f;   // (outside anyway; keeps the conversion defined)
+            y = y == y ? y : 0.0f;
+            x = x < 0.0f ? 0.0f : (x > (float)(sv.w - 1) ? (float)(sv.w - 1) : x);
+            y = y < 0.0f ? 0.0f : (y > (float)(sv.h - 1) ? (float)(sv.h - 1) : y);
+            int const fx = (int)x, fy = (int)y;
+            int const fx1 = fx + 1 < sv.w - 1 ? fx + 1 : sv.w - 1;
+            int const fy1 = fy + 1 < sv.h - 1 ? fy + 1 : sv.h - 1;
+            float const w1 = x - (float)fx, w0 = 1.0f - w1;
+            float const w3 = y - (float)fy, w2 = 1.0f - w3;
+            unsigned const row0 = (unsigned)fy * (unsigned)sv.w, row1 = (unsigned)fy1 * (unsigned)sv.w;
+            NccTaps tp;
+            tp.o00 = (row0 + (unsigned)fx) * 3u;  tp.o10 = (row0 + (unsigned)fx1) * 3u;
+            tp.o01 = (row1 + (unsigned)fx) * 3u;  tp.o11 = (row1 + (unsigned)fx1) * 3u;
+            tp.k00 = w0 * w2; tp.k10 = w1 * w2; tp.k01 = w0 * w3; tp.k11 = w1 * w3;
+            return tp;
+        };
+        auto const depth_of = [&](NccSample const &smp) -> const double * {
+            int const corner = -1 - smp.src;
+            int const n00 = (pc / A.npx) * A.stride + pc % A.npx;
+            const double *at_pixel = A.pix + ((unsigned)(py + (smp.src >> A.ps_log2)) * (unsigned)A.W
+                + (unsigned)(px + (smp.src & (ps - 1)))) * 3u;
+            const double *at_node = A.nodes + 4 * (size_t)(n00 + (corner & 1)
+                + (corner >> 1) * A.stride);
+            return smp.src >= 0 ? at_pixel : at_node;
+        };
+        auto const pair = [&](int ia, int ib, float (&ma)[3], float (&sa)[3], bool &oka,
+                float (&mb)[3], float (&sb)[3], bool &okb) {
+            NccSample const a = tpl[ia], b = tpl[ib];
+            const double *pa = depth_of(a), *pb = depth_of(b);
+            double const da = *pa, db = *pb;
+            // (the scheduler would sink the second sample's loads below the first
+            // one's arithmetic to save registers: both are asked for first)
+            __builtin_amdgcn_sched_barrier(0);
+            Warp const wa(M, t, (double)(px + a.dx) + 0.5, (double)(py + a.dy) + 0.5, da);
+            Warp const wb(M, t, (double)(px + b.dx) + 0.5, (double)(py + b.dy) + 0.5, db);
+            SharedDivisor const qa(wa.d, A.exact_divisions == 0), qb(wb.d, A.exact_divisions == 0);
+            double ax, ay, bx, by;
+            if (qa.plain && qb.plain) {
+                ax = qa.under(wa.a) - 0.5;  ay = qa.under(wa.b) - 0.5;
+                bx = qb.under(wb.a) - 0.5;  by = qb.under(wb.b) - 0.5;
+            } else {
+                ax = wa.x() - 0.5;  ay = wa.y() - 0.5;
+                bx = wb.x() - 0.5;  by = wb.y() - 0.5;
+            }
+            oka = !(ax < 1 || ax > sv.w - 2 || ay < 1 || ay > sv.h - 2);
+            okb = !(bx < 1 || bx > sv.w - 2 || by < 1 || by > sv.h - 2);
+            NccTaps const ta = taps_at(ax, ay), tb = taps_at(bx, by);
+            const float *img = sv.image;
+            float3_r const am = *reinterpret_cast<const float3_r *>(mv.image
+                + ((unsigned)(py + a.dy) * (unsigned)mv.w + (unsigned)(px + a.dx)) * 3u);
+            float3_r const bm = *reinterpret_cast<const float3_r *>(mv.image
+                + ((unsigned)(py + b.dy) * (unsigned)mv.w + (unsigned)(px + b.dx)) * 3u);
+            float3_r const a00 = *reinterpret_cast<const float3_r *>(img + ta.o00);
+            float3_r const a10 = *reinterpret_cast<const float3_r *>(img + ta.o10);
+            float3_r const a01 = *reinterpret_cast<const float3_r *>(img + ta.o01);
+            float3_r const a11 = *reinterpret_cast<const float3_r *>(img + ta.o11);
+            float3_r const b00 = *reinterpret_cast<const float3_r *>(img + tb.o00);
+            float3_r const b10 = *reinterpret_cast<const float3_r *>(img + tb.o10);
+            float3_r const b01 = *reinterpret_cast<const float3_r *>(img + tb.o01);
+            float3_r const b11 = *reinterpret_cast<const float3_r *>(img + tb.o11);
+            __builtin_amdgcn_sched_barrier(0);
+            ma[0] = am.x; ma[1] = am.y; ma[2] = am.z;
+            mb[0] = bm.x; mb[1] = bm.y; mb[2] = bm.z;
+            sa[0] = a00.x * ta.k00 + a10.x * ta.k10 + a01.x * ta.k01 + a11.x * ta.k11;
+            sa[1] = a00.y * ta.k00 + a10.y * ta.k10 + a01.y * ta.k01 + a11.y * ta.k11;
+            sa[2] = a00.z * ta.k00 + a10.z * ta.k10 + a01.z * ta.k01 + a11.z * ta.k11;
+            sb[0] = b00.x * tb.k00 + b10.x * tb.k10 + b01.x * tb.k01 + b11.x * tb.k11;
+            sb[1] = b00.y * tb.k00 + b10.y * tb.k10 + b01.y * tb.k01 + b11.y * tb.k11;
+            sb[2] = b00.z * tb.k00 + b10.z * tb.k10 + b01.z * tb.k01 + b11.z * tb.k11;
+        };
+        if (alive && rgb && A.ncc_pairs != 0) {
+            // pass 0 of the loop below, two samples at a time
+            int slot = 0;
+            for (int i = gl; i < n; i += 2 * G, slot += 2) {
+                int const i2 = i + G;
+                bool const two = i2 < n;
+                float ma[3], sa[3], mb[3], sb[3];
+                bool oka, okb;
+                pair(i, two ? i2 : i, ma, sa, oka, mb, sb, okb);
+                inside = oka && inside;
+#pragma unroll
+                for (int k = 0; k < NCC_KEEP; ++k)
+                    if (slot == k)
+                        for (int c = 0; c < 3; ++c) {
+                            keep_m[k][c] = ma[c];
+                            keep_s[k][c] = sa[c];
+                        }
+                for (int c = 0; c < 3; ++c) {
+                    sum0[c] += (double)ma[c];
+                    sum1[c] += (double)sa[c];
+                }
+                if (two) {
+                    inside = okb && inside;
+#pragma unroll
+                    for (int k = 0; k < NCC_KEEP; ++k)
+                        if (slot + 1 == k)
+                            for (int c = 0; c < 3; ++c) {
+                                keep_m[k][c] = mb[c];
+                                keep_s[k][c] = sb[c];
+                            }
+                    for (int c = 0; c < 3; ++c) {
+                        sum0[c] += (double)mb[c];
+                        sum1[c] += (double)sb[c];
+                    }
+                }
+            }
+        }
         for (int pass = 0; pass < 2; ++pass) {
-            if (alive && inside) {
+            if (alive && inside && !(pass == 0 && rgb && A.ncc_pairs != 0)) {
                 int slot = 0;
                 for (int i = gl; i < n; i += G, ++slot) {
                     double cm[3], cs[3];
@@ -894,6 +1016,8 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     {
         const char *mode = std::getenv("SMVS_TOPO_DIVIDE");
         A->exact_divisions = mode != nullptr && std::strcmp(mode, "exact") == 0 ? 1 : 0;
+        const char *pairs = std::getenv("SMVS_NCC_PAIRS");
+        A->ncc_pairs = pairs != nullptr && std::atoi(pairs) == 0 ? 0 : 1;
     }
     A->ncc = ctx->topo_ncc;
     for (int i = 0; i < 33; ++i)

@@ -691,7 +691,10 @@ def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle,
     refined reciprocal of d and one of d * d (csrc/topology.hip, SharedDivisor):
     the instruction sequence of the division without its scaling steps.  With
     SMVS_TOPO_DIVIDE=exact every quotient is the division itself -- masks and
-    errors must be the same bits (and the oracle's, the tests above)."""
+    errors must be the same bits (and the oracle's, the tests above).  So must
+    they be with the NCC samples of a lane taken one at a time instead of in
+    pairs and the neighbours of the MSE kernel one by one instead of four at
+    once: those only change when loads are issued."""
     prob, surf, ctx, tp = _topology_setup(hip, oracle, size[0], size[1], n_subs, scale, 0.01)
     tp.subviews()
     surf2 = dict(surf)
@@ -699,18 +702,24 @@ def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle,
     surf2["node_valid"] = tp.node_valid.copy()
     surf2["patch_vis"] = tp.patch_vis.copy()
     got = {}
-    for mode in ("shared", "exact"):
+    for mode in ("shared", "exact", "one_sample_at_a_time", "one_neighbour_at_a_time"):
+        for name in ("SMVS_TOPO_DIVIDE", "SMVS_NCC_PAIRS", "SMVS_MSE_SUBS"):
+            monkeypatch.delenv(name, raising=False)
         if mode == "exact":
             monkeypatch.setenv("SMVS_TOPO_DIVIDE", "exact")
-        else:
-            monkeypatch.delenv("SMVS_TOPO_DIVIDE", raising=False)
+        elif mode == "one_sample_at_a_time":       # the NCC samples of a lane, not in pairs
+            monkeypatch.setenv("SMVS_NCC_PAIRS", "0")
+        elif mode == "one_neighbour_at_a_time":    # the MSE kernel's neighbours, not four at once
+            monkeypatch.setenv("SMVS_MSE_SUBS", "1")
         ctx.set_surface(surf)
         vis = ctx.topology_subviews(None, use_ncc=True).copy()
         ctx.set_surface(surf2)
         got[mode] = (vis, ctx.topology_patch_mse().copy())
-    monkeypatch.delenv("SMVS_TOPO_DIVIDE", raising=False)
-    assert np.array_equal(got["shared"][0], got["exact"][0])
-    assert np.array_equal(got["shared"][1], got["exact"][1])
+    for name in ("SMVS_TOPO_DIVIDE", "SMVS_NCC_PAIRS", "SMVS_MSE_SUBS"):
+        monkeypatch.delenv(name, raising=False)
+    for mode in ("exact", "one_sample_at_a_time", "one_neighbour_at_a_time"):
+        assert np.array_equal(got["shared"][0], got[mode][0]), mode
+        assert np.array_equal(got["shared"][1], got[mode][1]), mode
     assert np.array_equal(got["shared"][0], tp.patch_vis)
     assert (got["shared"][1] > 0).any()
     ctx.close()
