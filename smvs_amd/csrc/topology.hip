@@ -400,9 +400,9 @@ topo_pixel_surface_kernel(TopoArgs A)
 
 // ---- visibility of every patch in every neighbour (:472-590), incl.
 // ncc_for_patch (:792-912) ----
-// (192 VGPRs, two waves per SIMD; forcing three or four by launch bounds
-// measured no gain / a loss to spills: the kernel issues two thirds of the
-// time, profiles/r4_visibility_counters.txt)
+// (159 VGPRs: three waves per SIMD -- round 4: 192, two.  Launch bounds that
+// force 128 VGPRs and four waves put 116 bytes per lane into scratch:
+// 610 -> 762 us, measured)
 __global__ void __launch_bounds__(256, 2)
 topo_visibility_kernel(TopoArgs A)
 {
