@@ -1,15 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: Gauss-Newton iterations/s x active patches on a
 1920x1080 reference view with 8 neighbours (BASELINE.json configs[1]:
-synthetic textured sphere, -o2, basic photometric optimizer).
+synthetic textured sphere, -o2, basic photometric optimizer) over BASELINE.md's
+own timed region -- ALL Newton loops of ALL scales of one
+DepthOptimizer::optimize (lib/depth_optimizer.cc:219-304 entered once per
+batch, :53-162).
 
-A "step" is one pass of the Newton loop of lib/depth_optimizer.cc:219-304
-(construct + PCG solve + node update + re-activation) at scale 2 over the
-evolving active set; when the loop ends (active <= initial/20, :220) the
-surface is reset to the same perturbed start and the loop restarts.
-value = sum over timed steps of active patches / wall time, inputs resident
-in HBM.  One process per GPU; ranks work on independent reference views
-(weak scaling, no data-path collective).
+A "step" is one pass over the Newton loops of one optimize(): each of its
+batches (15 at 1920x1080: scales 6 .. 2, three batches per scale) runs
+construct + PCG solve + node update + re-activation until its active set is
+spent (:220).  The start state of every batch -- the scale's planes of all nine
+views, cameras, surface, visibility masks -- is recorded from a real optimize()
+during set-up (smvs_ctx_clone_loop_state: 15 device-resident contexts) and the
+timed region replays exactly those loops; the set-up asserts that the replay
+reproduces the optimize()'s own batch log (Newton steps, active patch-steps, CG
+iterations per batch).  What lies between the batches in optimize() (topology
+tests, grid surgery, scale space) is outside the reference's loop timers and
+outside this region; whole views per second are in `secondary`.
+value = sum over the timed passes of active patch-steps / wall time, inputs
+resident in HBM.  One process per GPU; ranks work on independent reference
+views (weak scaling, no data-path collective).
 
     python bench.py --gpus N --steps K --warmup W [--repeats R] [--config 1|5]
 
@@ -19,12 +29,16 @@ warm-up steps the K-step region (barrier + device synchronisation on both
 sides, time = max over ranks) is measured R times; `value` / `ms_per_step` are
 the MEDIAN repeat, min and max are in "timing".
 
+--workload newton_steps is the headline of rounds 1-5 (the scale-2 loop of the
+same view replayed from a perturbed start surface; a step = one Newton step):
+now `secondary.scale2_replay` of the default run.
+
 --config 5 (BASELINE.json configs[4]): every rank holds --views-per-rank
 reference views (64 over 8 GPUs), shading-aware (-S): per view the
 GlobalLighting normal equations are accumulated on the device, optionally
 summed over the lock-step round of views with an RCCL all-reduce on the device
 buffers ("--shared-lighting"; the reference fits per view, which is the parity
-default), solved, and the Newton loop runs with the shading term.
+default), solved, and the scale-2 Newton loop runs with the shading term.
 
 Prints ONE JSON line on rank 0.
 """
@@ -95,6 +109,227 @@ def run_steps(ctx, prob, steps, lighting=None):
     return patch_steps, cg_its
 
 
+# ------------------------------------------ the Newton loops of one optimize()
+PATCH_FLOPS_FILE = os.path.join(ROOT, "profiles", "patch_flops_r6.json")
+
+
+def scene_inputs(rank, small=False):
+    """The view of `secondary.optimize` / --workload optimize; ranks get
+    different textures and features (independent reference views)."""
+    from smvs_amd import synth
+    w, h = (480, 270) if small else (W, H)
+    return synth.pipeline_inputs("sphere", w, h, NSUBS, flen=1.2, seed=1234 + rank)
+
+
+class LoopReplay:
+    """All Newton loops of ONE DepthOptimizer::optimize, resident: the start
+    state of every batch as its own device context (smvs_ctx_clone_loop_state,
+    recorded while a real optimize() ran), replayed with the parameters the
+    optimizer used.  run_pass() is the bench's "step"."""
+
+    def __init__(self, inp, device=0):
+        import ctypes as C
+        from smvs_amd import host, _capi
+        self.C = C
+        self.lib = _capi.load()
+        kw = dict(regularization=REG, num_iterations=5, min_scale=SCALE, device=device,
+                  want_maps=False)
+        host.optimize(inp, **kw)          # warm: library, pools, the resident plan
+        host.record_loops(True)
+        try:
+            r = host.optimize(inp, **kw)
+        finally:
+            host.record_loops(False)
+        self.log = r["log"]
+        self.loops = host.take_recorded_loops()
+        if len(self.loops) != len(self.log):
+            raise RuntimeError("recorded %d loops for %d batches" % (len(self.loops), len(self.log)))
+        geom = (C.c_int * 6)()
+        for L in self.loops:
+            _capi.check(self.lib.smvs_surface_info(L["handle"], geom, None))
+            L["nodes"] = (geom[2] + 1) * (geom[3] + 1)
+            L["patches"] = geom[2] * geom[3]
+        self.stats = _capi.LoopStats()
+        self.check = _capi.check
+
+    def run_loop(self, L):
+        C = self.C
+        self.check(self.lib.smvs_ctx_restore_nodes(L["handle"]))
+        self.check(self.lib.smvs_gn_run_loop(L["handle"], C.byref(L["params"]),
+                                             C.byref(self.stats)))
+        s = self.stats
+        return s.newton_steps, s.active_patch_steps, s.linear_iterations
+
+    def run_pass(self):
+        """-> (active patch-steps, CG iterations, Newton steps) of one pass."""
+        ps = its = ns = 0
+        for L in self.loops:
+            n, p, i = self.run_loop(L)
+            ns += n; ps += p; its += i
+        return ps, its, ns
+
+    def verify(self):
+        """The replay is the optimize() it was recorded from: per batch the
+        same Newton steps, active patch-steps and CG iterations."""
+        for L, e in zip(self.loops, self.log):
+            got = self.run_loop(L)
+            want = (e["newton_steps"], e["active_patch_steps"], e["cg_iterations"])
+            if got != want or L["scale"] != e["scale"]:
+                raise RuntimeError("replayed loop (scale %d, iteration %d) ran %r, the "
+                                   "optimize() it was recorded from %r"
+                                   % (L["scale"], L["iter"], got, want))
+
+    def synchronize(self):
+        for L in self.loops:
+            self.check(self.lib.smvs_ctx_synchronize(L["handle"]))
+
+    def profile_pass(self):
+        """One more pass with HIP-event timing of every kernel class on the
+        contexts' streams (untimed region) -> per batch (scale, nodes, Newton
+        steps, active patch-steps, CG iterations, {class: (ms, launches)})."""
+        C = self.C
+        from smvs_amd import _capi
+        out = []
+        for L in self.loops:
+            h = L["handle"]
+            self.check(self.lib.smvs_profile_enable(h, 1))
+            self.check(self.lib.smvs_profile_reset(h))
+            n, p, i = self.run_loop(L)
+            ms = (C.c_double * 8)(); cnt = (C.c_longlong * 8)()
+            self.check(self.lib.smvs_profile_get(h, ms, cnt))
+            self.check(self.lib.smvs_profile_enable(h, 0))
+            out.append(dict(scale=L["scale"], nodes=L["nodes"], newton_steps=n,
+                            active_patch_steps=p, cg_iterations=i,
+                            kernels={k: (ms[j], int(cnt[j]))
+                                     for j, k in enumerate(_capi.K_NAMES)}))
+        return out
+
+    def close(self):
+        for L in self.loops:
+            self.lib.smvs_ctx_destroy(L["handle"])
+        self.loops = []
+
+
+def patch_flops_table():
+    """FP64 flops the patch kernel executes per active patch, per kernel form
+    (= per samples-per-patch), from SQ instruction counters of one optimize()
+    (tools/patch_flops.sh -> profiles/patch_flops_r6.json).  Without the file:
+    round 3's constant for the 16-sample form, scaled by the samples."""
+    try:
+        with open(PATCH_FLOPS_FILE) as f:
+            t = json.load(f)
+        return {int(k): float(v) for k, v in t["flop_per_patch_by_scale"].items()}, \
+            "profiles/patch_flops_r6.json (rocprofv3 --pmc SQ_INSTS_VALU_*_F64 / MFMA, committed)"
+    except (OSError, KeyError, ValueError):
+        per16 = FLOP_PER_PATCH
+        return {2: per16, 3: per16, 4: 4 * per16, 5: 4 * per16, 6: 16 * per16}, \
+            "estimate: round-3 counters of the 16-sample form x samples per patch / 16"
+
+
+def loops_roofline(replay, steps, ms_per_step, with_peaks=True):
+    """Roofline of the timed region's dominant kernel (the one with the largest
+    share of the Newton loops of one optimize()), per_kernel for patch and
+    solve, by_scale split."""
+    batches = replay.profile_pass()
+    peaks = measured_peaks() if with_peaks else None
+    hbm_measured = (peaks or {}).get("hbm_read_GBps")
+    flops_by_scale, flops_source = patch_flops_table()
+    tot = {}
+    for b in batches:
+        for k, (ms, cnt) in b["kernels"].items():
+            a = tot.setdefault(k, [0.0, 0])
+            a[0] += ms; a[1] += cnt
+    kernels = {k: dict(ms=round(v[0], 3), launches=int(v[1]),
+                       avg_us=round(1e3 * v[0] / max(v[1], 1), 2)) for k, v in tot.items()}
+    loop_ms = 1e3 * sum(e["loop_seconds"] for e in replay.log)
+    busy_ms = sum(v[0] for v in tot.values())
+    name = max(tot.items(), key=lambda kv: kv[1][0])[0]
+
+    def hbm_fracs(achieved_GBps):
+        out = dict(frac=round(achieved_GBps / HBM_PEAK_GBPS, 4))
+        if hbm_measured:
+            out["frac_of_measured_read_peak"] = round(achieved_GBps / hbm_measured, 4)
+            out["measured_read_peak_GBps"] = hbm_measured
+        return out
+
+    lines = {}
+    # resident PCG: one launch per solve; algorithmic bytes = its one pass over
+    # the per-patch systems of the live patches + x and b of every node
+    ms_k, cnt_k = tot.get("cg_resident", (0.0, 0))
+    if cnt_k > 0:
+        byts = sum(RESIDENT_BYTES_PER_PATCH * b["active_patch_steps"]
+                   + RESIDENT_BYTES_PER_NODE * b["nodes"] * b["kernels"]["cg_resident"][1]
+                   for b in batches)
+        its = sum(b["cg_iterations"] for b in batches)
+        avg_s = 1e-3 * ms_k / cnt_k
+        ach = byts / cnt_k / avg_s / 1e9
+        lines["cg_resident"] = dict(
+            bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+            **hbm_fracs(ach), bytes_per_launch=int(byts / cnt_k), avg_us=round(1e6 * avg_s, 2),
+            launches=int(cnt_k), iterations_per_launch=round(its / cnt_k, 1),
+            us_per_iteration_incl_prologue=round(1e3 * ms_k / max(its, 1), 2),
+            latency_floor_us_per_iteration=round(1e6 * EXCHANGE_FLOOR_S, 2),
+            frac_of_latency_floor=round(its * EXCHANGE_FLOOR_S / (1e-3 * ms_k), 4),
+            note="whole PCG solve in one launch, H assembled into registers from the "
+                 "per-patch systems (%d B per live patch + %d B per node, read once): "
+                 "after that pass the kernel is bound by the latency of its one grid-wide "
+                 "exchange per iteration, not by HBM -- frac_of_latency_floor prices an "
+                 "iteration at two idle cross-CU hand-offs (MI355X_MICROARCH.md)"
+                 % (RESIDENT_BYTES_PER_PATCH, RESIDENT_BYTES_PER_NODE))
+    ms_k, cnt_k = tot.get("patch", (0.0, 0))
+    if cnt_k > 0:
+        flops = sum(flops_by_scale.get(b["scale"], FLOP_PER_PATCH) * b["active_patch_steps"]
+                    for b in batches)
+        avg_s = 1e-3 * ms_k / cnt_k
+        ach = flops / cnt_k / avg_s / 1e12
+        by = {}
+        for b in batches:
+            d = by.setdefault(str(b["scale"]), [0.0, 0.0])
+            d[0] += flops_by_scale.get(b["scale"], FLOP_PER_PATCH) * b["active_patch_steps"]
+            d[1] += 1e-3 * b["kernels"]["patch"][0]
+        lines["patch"] = dict(
+            bound="fp64-issue", achieved=round(ach, 3), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+            frac=round(ach / FP64_PEAK_TFLOPS, 4), flops_per_launch=flops / cnt_k,
+            avg_us=round(1e6 * avg_s, 2), launches=int(cnt_k),
+            flop_per_patch_by_scale={str(k): v for k, v in sorted(flops_by_scale.items())},
+            flop_per_patch_source=flops_source,
+            frac_by_scale={k: round(v[0] / v[1] / 1e12 / FP64_PEAK_TFLOPS, 4)
+                           for k, v in by.items() if v[1] > 0})
+    # committed counter traffic of the dominant kernel (own rocprofv3 --pmc passes)
+    traffic = traffic_source = None
+    for tf in ("traffic_r6.json", "traffic_r5.json"):
+        tfile = os.path.join(ROOT, "profiles", tf)
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get(name)
+            traffic_source = ("profiles/" + tf + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                              "their own passes, committed; not measured in this run)")
+            break
+    by_scale = {}
+    for b, e in zip(batches, replay.log):
+        d = by_scale.setdefault(str(b["scale"]), dict(active_patch_steps=0, newton_steps=0,
+                                                      cg_iterations=0, kernel_ms={}))
+        d["active_patch_steps"] += b["active_patch_steps"]
+        d["newton_steps"] += b["newton_steps"]
+        d["cg_iterations"] += b["cg_iterations"]
+        for k, (ms, cnt) in b["kernels"].items():
+            if cnt:
+                d["kernel_ms"][k] = round(d["kernel_ms"].get(k, 0.0) + ms, 3)
+    out = dict(kernel=name, traffic=traffic, traffic_source=traffic_source, kernels=kernels,
+               region_share={k: round(v[0] / max(busy_ms, 1e-9), 4) for k, v in tot.items() if v[1]},
+               region_kernel_ms=round(busy_ms, 3), region_wall_ms=round(ms_per_step, 3),
+               per_kernel=lines, by_scale=by_scale,
+               peaks_assumed=dict(hbm_GBps=HBM_PEAK_GBPS, fp64_TFLOPs=FP64_PEAK_TFLOPS),
+               peaks_measured=peaks,
+               note="kernel = the class with the largest share of the region's kernel time "
+                    "(HIP events on the contexts' streams, one profiled pass); top-level "
+                    "bound / achieved / peak / frac are that kernel's")
+    if name in lines:
+        out.update({k: lines[name][k] for k in ("bound", "achieved", "peak", "unit", "frac")})
+        out["avg_us"] = lines[name]["avg_us"]
+    return out
+
+
 # --------------------------------------------------------------- CPU baseline
 def _cpu_model():
     try:
@@ -118,103 +353,62 @@ def _oracle_flags():
     return "unknown"
 
 
-def _one_cpu_step(prob):
-    """One full Newton step of the workload with the oracle; seconds per phase."""
-    from oracle import pyoracle
-    surf = prob["surf"]
-    active = np.ascontiguousarray(surf["node_valid"], dtype=np.uint8)
-    orc = pyoracle.OracleProblem(surf, prob["views"])
-    t0 = time.perf_counter()
-    ref = orc.gn_construct(active, REG)
-    t1 = time.perf_counter()
-    x, it, _ = orc.cg_solve(ref["H9"], ref["present"], ref["P"], -ref["g"], 200,
-                            0.01 * np.linalg.norm(ref["g"]), 1e-3)
-    t2 = time.perf_counter()
-    orc.update_and_reactivate(x, active)
-    t3 = time.perf_counter()
-    return ref["active_patches"], it, (t1 - t0, t2 - t1, t3 - t2)
-
-
-def _cpu_worker(prob):
-    t = time.perf_counter()
-    patches, _, _ = _one_cpu_step(prob)
-    return patches, time.perf_counter() - t
-
-
-def cpu_baseline(prob, all_cores=True):
+def cpu_baseline(small=False):
     """The oracle (CPU restatement of the reference; SSE2 two-lane inner loop
-    like lib/gauss_newton_step.cc:252-333) timed on this host on ONE full
-    Newton step of the same workload with every valid node active (the first
-    step of a batch):
-      value     1 thread = the reference's per-view behaviour (it parallelises
-                over views, app/smvsrecon.cc:658-733, not inside one)
-      all_cores the same step as one process per view on many cores at once
-                (how the reference fills a host, app/smvsrecon.cc:49,558) and
-                with OpenMP inside one view."""
+    like lib/gauss_newton_step.cc:252-333) on the SAME region as `value`: the
+    Newton loops of one whole DepthOptimizer::optimize of the same scene, timed
+    by the oracle's own loop timers (orc_opt_log.loop_seconds around
+    lib/depth_optimizer.cc:219-304).  One optimize() gives both numbers:
+      value      ONE thread -- the reference's per-view behaviour (it
+                 parallelises over views, app/smvsrecon.cc:658-733, not inside
+                 one) -- on a bounded sample: the first batch of every scale
+                 (5 of the 15 batches, a third of the patch-steps in the
+                 region's own proportions);
+      all_cores  OpenMP over the patches of the view (up to 64 threads) in the
+                 other ten batches -- and in everything between the batches,
+                 which neither side's timers count."""
     from oracle import pyoracle
     L = pyoracle.lib()
     nproc = os.cpu_count() or 1
-    L.orc_set_threads(1)
-    patches, it, (tc, ts, tu) = _one_cpu_step(prob)
-    one = patches / (tc + ts + tu)
-    out = dict(value=one, unit="active-patch-steps/s", cores=1, kind="port",
-               nproc=nproc, cpu_model=_cpu_model(), compiler_flags=_oracle_flags(),
-               sample="1 Newton step, all %d patches active (first step of a batch of the "
-                      "%dx%d / %d-neighbour workload): construct %.2fs, PCG %d it %.2fs, "
-                      "update %.2fs" % (patches, prob["surf"]["width"],
-                                        prob["surf"]["height"], NSUBS, tc, it, ts, tu))
-    if all_cores and nproc > 1:
-        # OpenMP over the patches of one view
-        th = min(nproc, 64)
-        L.orc_set_threads(th)
-        p2, _, (tc2, ts2, tu2) = _one_cpu_step(prob)
-        L.orc_set_threads(1)
-        out["openmp_one_view"] = dict(value=p2 / (tc2 + ts2 + tu2), threads=th,
-                                      construct_s=round(tc2, 3), pcg_s=round(ts2, 3),
-                                      update_s=round(tu2, 3))
-        # one view per core, like the reference's thread pool over views
-        import multiprocessing as mp
-        procs = min(max(nproc // 2, 1), 32)
-        t = time.perf_counter()
-        with mp.get_context("fork").Pool(procs) as pool:
-            res = pool.map(_cpu_worker, [prob] * procs)
-        wall = time.perf_counter() - t
-        out["all_cores"] = dict(value=sum(r[0] for r in res) / wall, processes=procs,
-                                wall_s=round(wall, 2),
-                                note="one view (one full Newton step) per process, "
-                                     "all at once")
-        # BASELINE.md's timed region on the CPU: all Newton loops of one whole
-        # optimize() of the `--workload optimize` scene (the oracle's own loop
-        # timers), OpenMP inside the view
-        try:
-            out["optimize"] = cpu_optimize_baseline(prob["surf"]["width"] < 1000, th)
-        except Exception as e:   # a report, never a reason to lose the rest
-            out["optimize"] = dict(error=repr(e))
-    return out
-
-
-def cpu_optimize_baseline(small, threads):
-    """The oracle's DepthOptimizer::optimize on the scene of `--workload
-    optimize` / secondary.optimize: sum of active patch-steps over the sum of
-    its Newton loops' wall time (orc_opt_log.loop_seconds), `threads` OpenMP
-    threads inside the one view."""
-    from oracle import pyoracle
-    from smvs_amd import synth
-    w, h = (480, 270) if small else (W, H)
-    inp = synth.pipeline_inputs("sphere", w, h, NSUBS, flen=1.2)
-    pyoracle.lib().orc_set_threads(threads)
+    th = min(nproc, 64)
+    inp = scene_inputs(0, small)
+    L.orc_set_threads(th)
+    L.orc_set_first_batch_loop_threads(1)
     t = time.perf_counter()
-    r = pyoracle.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+    try:
+        r = pyoracle.optimize(inp, regularization=REG, num_iterations=5, min_scale=SCALE)
+    finally:
+        L.orc_set_first_batch_loop_threads(0)
+        L.orc_set_threads(1)
     wall = time.perf_counter() - t
-    pyoracle.lib().orc_set_threads(1)
-    aps = sum(e["active_patch_steps"] for e in r["log"])
-    loop_s = sum(e["loop_seconds"] for e in r["log"])
-    return dict(value=aps / loop_s, unit="active-patch-steps/s", threads=threads,
-                active_patch_steps=int(aps), newton_loop_s=round(loop_s, 2),
-                optimize_wall_s=round(wall, 2), batches=len(r["log"]),
-                sample="one whole optimize() (scales init .. %d, %d batches) of the %dx%d / "
-                       "%d-neighbour sphere scene, --no-sgm; the same scene and units as "
-                       "value_optimize" % (SCALE, len(r["log"]), w, h, NSUBS))
+    first = [e for e in r["log"] if e["iter"] == 0]
+    rest = [e for e in r["log"] if e["iter"] != 0]
+    aps1 = sum(e["active_patch_steps"] for e in first)
+    s1 = sum(e["loop_seconds"] for e in first)
+    w, h = (480, 270) if small else (W, H)
+    out = dict(value=aps1 / s1, unit="active-patch-steps/s", cores=1, kind="port",
+               nproc=nproc, cpu_model=_cpu_model(), compiler_flags=_oracle_flags(),
+               active_patch_steps=int(aps1), newton_loop_s=round(s1, 2),
+               by_scale={str(e["scale"]): dict(active_patch_steps=int(e["active_patch_steps"]),
+                                               newton_steps=int(e["newton_steps"]),
+                                               cg_iterations=int(e["cg_iterations"]),
+                                               loop_s=round(e["loop_seconds"], 3))
+                         for e in first},
+               sample="Newton loops (the oracle's own loop timers) of the first batch of "
+                      "every scale (%d .. %d: %d of %d batches, %d of %d active patch-steps) "
+                      "of one whole optimize() of the %dx%d / %d-neighbour sphere scene, "
+                      "--no-sgm, 1 thread: the same scene, region and units as `value`"
+                      % (max(e["scale"] for e in first), SCALE, len(first), len(r["log"]),
+                         aps1, sum(e["active_patch_steps"] for e in r["log"]), w, h, NSUBS))
+    if rest:
+        apsN = sum(e["active_patch_steps"] for e in rest)
+        sN = sum(e["loop_seconds"] for e in rest)
+        out["all_cores"] = dict(value=apsN / sN, unit="active-patch-steps/s", threads=th,
+                                active_patch_steps=int(apsN), newton_loop_s=round(sN, 2),
+                                sample="the other %d batches of the same optimize(), OpenMP "
+                                       "over the patches of the view" % len(rest))
+    out["optimize_wall_s"] = round(wall, 1)
+    return out
 
 
 # ------------------------------------------------------------------- roofline
@@ -651,6 +845,25 @@ def optimize_workload(args):
         "roofline": None, "cpu_baseline": None}))
 
 
+def scale2_replay(args):
+    """`--workload newton_steps` in a child process: the headline of rounds
+    1-5 (scale-2 Newton steps from a perturbed start surface)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "newton_steps",
+           "--steps", "20", "--warmup", "5", "--repeats", "30", "--no-cpu-baseline",
+           "--no-secondary", "--no-peaks"]
+    if args.small:
+        cmd.append("--small")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    line = json.loads([l for l in res.stdout.splitlines() if l.strip().startswith("{")][-1])
+    roof = line.get("roofline") or {}
+    return dict(value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"],
+                steps=line["steps"], cg_iterations_per_step=line["config"]["cg_iterations_per_step"],
+                per_kernel=roof.get("per_kernel"), step_frac=roof.get("step_frac"),
+                note="a step = one Newton step of the scale-2 loop of the same view, replayed "
+                     "from a perturbed start surface (`python bench.py --workload newton_steps`): "
+                     "fewer CG iterations per step than optimize()'s own scale-2 batches")
+
+
 # ----------------------------------------------------------------------- main
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a torch.distributed environment:
@@ -693,11 +906,15 @@ def main():
                          "SGM kernels)")
     ap.add_argument("--no-peaks", action="store_true",
                     help="skip the peak microbenchmarks (profiling runs)")
-    ap.add_argument("--workload", default="newton_steps", choices=("newton_steps", "optimize"),
-                    help="newton_steps (default, the headline): Newton steps of configs[1] at "
-                         "scale 2; optimize: BASELINE.md's timed region literally -- all "
-                         "Newton loops of all scales of --steps whole optimize() calls of the "
-                         "same scene (also reported as secondary.optimize of the default run)")
+    ap.add_argument("--workload", default="optimize_loops",
+                    choices=("optimize_loops", "newton_steps", "optimize"),
+                    help="optimize_loops (default, the headline): BASELINE.md's timed region "
+                         "-- all Newton loops of all scales of one optimize() of configs[1], "
+                         "replayed from their recorded start states (a step = one pass over "
+                         "them); newton_steps: the scale-2 loop replayed from a perturbed start "
+                         "surface (a step = one Newton step; the headline of rounds 1-5, "
+                         "secondary.scale2_replay of the default run); optimize: --steps whole "
+                         "optimize() calls timed by the C++ loop timers (secondary.optimize)")
     ap.add_argument("--views-worker", action="store_true",
                     help="internal: one process of the multi-GPU views workload")
     ap.add_argument("--first-device", type=int, default=0, help="--views-worker")
@@ -726,10 +943,15 @@ def main():
         return optimize_workload(args)
 
     shading = args.config == 5
-    prob = make_problem(rank, args.small, shading=shading)
+    loops_mode = args.config == 1 and args.workload == "optimize_loops"
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(prob)))
+        print(json.dumps(cpu_baseline(args.small)))
         return
+    if loops_mode and args.views_in_flight > 1:
+        raise SystemExit("--views-in-flight > 1: use --workload newton_steps (the replayed "
+                         "loops run one view per GPU; views in flight are measured as whole "
+                         "views in secondary.views_per_s)")
+    prob = None if loops_mode else make_problem(rank, args.small, shading=shading)
 
     import torch  # device plumbing + torch.distributed only
     import smvs_amd
@@ -756,8 +978,19 @@ def main():
                 dist.init_process_group(backend)
             dist.barrier()
 
-    surf = prob["surf"]
-    w, h = surf["width"], surf["height"]
+    replay = None
+    if loops_mode:
+        # set-up: one optimize() of this rank's view, every Newton batch's start
+        # state kept as its own resident context; the replay must reproduce the
+        # optimize()'s batch log
+        w, h = (480, 270) if args.small else (W, H)
+        replay = LoopReplay(scene_inputs(rank, args.small), device=local_rank)
+        replay.verify()
+        replay_log = list(replay.log)
+        surf = None
+    else:
+        surf = prob["surf"]
+        w, h = surf["width"], surf["height"]
     n_views = max(args.views_per_rank, 1) if args.config == 5 else 1
     n_views = max(n_views, max(args.views_in_flight, 1))
 
@@ -765,7 +998,7 @@ def main():
     # --config 5 they are distinct reference views in cost: same image planes,
     # individually perturbed start surfaces.
     ctxs, starts = [], []
-    for v in range(n_views):
+    for v in range(0 if loops_mode else n_views):
         c = smvs_amd.ViewContext(w, h, NSUBS, device=local_rank)
         c.set_views(prob["views"])
         s = dict(surf)
@@ -778,11 +1011,13 @@ def main():
         c.save_nodes()   # the start surface stays resident in HBM
         ctxs.append(c)
         starts.append(dict(prob, surf=s))
-    ctx = ctxs[0]
+    ctx = ctxs[0] if ctxs else None
 
     def barrier():
         for c in ctxs:
             c.synchronize()
+        if replay is not None:
+            replay.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -801,8 +1036,16 @@ def main():
         return [shard.solve_lighting(*c.light_download()) for c in round_ctxs]
 
     def run_all(steps):
-        """K steps on this rank: --config 1 on the (views-in-flight) contexts
-        concurrently, --config 5 view after view (lock step across ranks)."""
+        """K steps on this rank: the default workload K passes over the recorded
+        Newton loops of one optimize(); --workload newton_steps on the
+        (views-in-flight) contexts concurrently, --config 5 view after view
+        (lock step across ranks)."""
+        if replay is not None:
+            ps = its = 0
+            for _ in range(steps):
+                p, i, _n = replay.run_pass()
+                ps += p; its += i
+            return ps, its
         if args.config == 5:
             done = ps = its = 0
             v = 0
@@ -850,7 +1093,10 @@ def main():
     value, secs, units, cg_total = repeats[len(repeats) // 2]
 
     roof = None
-    if rank == 0:
+    if rank == 0 and replay is not None:
+        roof = loops_roofline(replay, args.steps, 1e3 * secs / args.steps,
+                              with_peaks=not args.no_peaks)
+    elif rank == 0:
         lighting = fit_lighting([ctx])[0] if args.config == 5 else None
         if args.config == 5:
             ctx.set_nodes(surf["nodes"])
@@ -895,9 +1141,13 @@ def main():
                 n_seen, r_seen = comm.ranks()
                 box.update(n_ranks_seen_by_rccl=int(n_seen), rank_seen_by_rccl=int(r_seen))
                 pattern = np.arange(1.0, 273.0)
-                ctx.light_upload((rank + 1) * pattern[:256], (rank + 1) * pattern[256:])
-                comm.allreduce_lighting([ctx])
-                A_sum, b_sum = ctx.light_download()
+                pc = ctx if ctx is not None else smvs_amd.ViewContext(w, h, NSUBS,
+                                                                      device=local_rank)
+                pc.light_upload((rank + 1) * pattern[:256], (rank + 1) * pattern[256:])
+                comm.allreduce_lighting([pc])
+                A_sum, b_sum = pc.light_download()
+                if pc is not ctx:
+                    pc.close()
                 total = 0.5 * world * (world + 1)
                 box["allreduce_summed_every_rank"] = bool(
                     np.array_equal(A_sum.reshape(-1), total * pattern[:256])
@@ -928,6 +1178,8 @@ def main():
                 native = None
             for c in ctxs:
                 c.close()
+            if replay is not None:
+                replay.close()
         ctxs = []
         if dist is not None and not proof_hung:
             # (with a deadline as well: a rank whose RCCL check failed differently
@@ -973,6 +1225,12 @@ def main():
                 secondary = secondary_workloads(args)
             except Exception as e:   # a report, never a reason to lose the headline
                 secondary = dict(error=repr(e))
+            if loops_mode and isinstance(secondary, dict):
+                # the headline of rounds 1-5, in a child process of its own
+                try:
+                    secondary["scale2_replay"] = scale2_replay(args)
+                except Exception as e:
+                    secondary["scale2_replay"] = dict(error=repr(e))
         if not args.no_cpu_baseline:
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
             if args.small:
@@ -984,11 +1242,26 @@ def main():
                 cpu = dict(error=(res.stderr or res.stdout)[-500:])
     if rank == 0:
         views_in_flight = max(args.views_in_flight, 1) if args.config == 1 else 1
-        workload = ("configs[1]: %dx%d synthetic textured sphere, 1 ref + %d neighbours, -o2 "
-                    "(scale 2, %d patches), basic photometric optimizer, %s"
-                    % (w, h, NSUBS, int(surf["patch_valid"].sum()),
-                       "one reference view per GPU" if views_in_flight <= 1
-                       else "%d reference views in flight per GPU" % views_in_flight))
+        steps_per_unit = args.steps * world * views_in_flight
+        config_extra = {}
+        if loops_mode:
+            ns = sum(e["newton_steps"] for e in replay_log)
+            workload = ("configs[1]: %dx%d synthetic textured sphere, 1 ref + %d neighbours, -o2, "
+                        "basic photometric optimizer, --no-sgm: all Newton loops of all scales "
+                        "(%d .. %d) of one DepthOptimizer::optimize -- %d batches, %d Newton "
+                        "steps, %d active patch-steps per pass (a step = one pass), replayed "
+                        "from the batches' recorded start states; one reference view per GPU"
+                        % (w, h, NSUBS, max(e["scale"] for e in replay_log), SCALE,
+                           len(replay_log), ns,
+                           sum(e["active_patch_steps"] for e in replay_log)))
+            config_extra = dict(batches_per_step=len(replay_log), newton_steps_per_step=ns,
+                                replay_verified_against_optimize_log=True)
+        else:
+            workload = ("configs[1]: %dx%d synthetic textured sphere, 1 ref + %d neighbours, "
+                        "-o2 (scale 2, %d patches), basic photometric optimizer, %s"
+                        % (w, h, NSUBS, int(surf["patch_valid"].sum()),
+                           "one reference view per GPU" if views_in_flight <= 1
+                           else "%d reference views in flight per GPU" % views_in_flight))
         if args.config == 5:
             workload = ("configs[4]: %d reference views x %d neighbours at %dx%d (%d per GPU), "
                         "-S shading-aware (SH lighting fit per view%s + shading residual), "
@@ -1003,10 +1276,9 @@ def main():
             "ms_per_step": 1e3 * secs / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "regularization": REG,
-                       "cg_iterations_per_step": cg_total / max(args.steps * world
-                                                                * views_in_flight, 1),
-                       "views_in_flight_per_gpu": views_in_flight},
+            "config": dict({"workload": workload, "regularization": REG,
+                            "cg_iterations_per_step": cg_total / max(steps_per_unit, 1),
+                            "views_in_flight_per_gpu": views_in_flight}, **config_extra),
             "timing": {"repeats": len(repeats), "statistic": "median",
                        "value_min": repeats[0][0], "value_max": repeats[-1][0],
                        "ms_per_step_min": 1e3 * repeats[-1][1] / args.steps,
@@ -1023,9 +1295,13 @@ def main():
             out["value_optimize"] = secondary["optimize"]["value"]
             out["value_optimize_note"] = (
                 "active patch-steps / second over ALL Newton loops (scales init .. %d) of "
-                "one whole DepthOptimizer::optimize of the same scene -- BASELINE.md's "
-                "timed region; `value` replays the scale-%d loop of that workload from a "
-                "resident start surface (see secondary.optimize)" % (SCALE, SCALE))
+                "one whole DepthOptimizer::optimize of the same scene, timed in place by "
+                "the C++ host's loop timers (secondary.optimize) -- BASELINE.md's timed "
+                "region; %s" % (SCALE, "`value` replays exactly these loops from resident "
+                                "start states inside one barrier-bracketed region"
+                                if loops_mode else
+                                "`value` replays the scale-%d loop of that workload from a "
+                                "resident start surface" % SCALE))
         shard.flush_c_stdio()   # (whatever a C library still holds goes out first)
         print(json.dumps(out))
         sys.stdout.flush()

@@ -151,6 +151,15 @@ int smvs_set_nodes(smvs_ctx *ctx, const double *nodes);
  * returns SMVS_ERR_STATE. */
 int smvs_ctx_save_nodes(smvs_ctx *ctx);
 int smvs_ctx_restore_nodes(smvs_ctx *ctx);
+/* A second context that holds everything the Newton loop of `src` reads at
+ * this moment -- cameras, the scale's gradient / Hessian planes of all views,
+ * the surface (nodes, validity, visibility masks), the lighting -- copied on
+ * the device, with its nodes saved (smvs_ctx_restore_nodes).  Not in the
+ * reference: it is how bench.py keeps the start state of every Newton batch of
+ * one DepthOptimizer::optimize (lib/depth_optimizer.cc:219-304 is entered 15
+ * times per view) resident in HBM and replays exactly those loops as its timed
+ * region.  The clone is an ordinary context (smvs_ctx_destroy). */
+int smvs_ctx_clone_loop_state(smvs_ctx *src, smvs_ctx **out);
 
 /* ------------------------------------------------------------------ */
 /* Gauss-Newton step                                                  */

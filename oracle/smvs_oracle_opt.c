@@ -1244,6 +1244,15 @@ opt_dump(const OOpt *O, int iter, const char *tag)
     fclose(f);
 }
 
+/* Measurement control (bench.py's cpu_baseline, not part of the restated
+ * algorithm): with n > 0 the Newton loop of the FIRST batch of every scale runs
+ * with n OpenMP threads whatever orc_set_threads says for the rest -- one
+ * optimize() then times the reference's one-thread-per-view loop on a bounded
+ * sample (a batch of every scale) while the other batches and everything
+ * between them use all cores.  The results do not depend on the thread count. */
+static int g_first_batch_loop_threads = 0;
+void orc_set_first_batch_loop_threads(int n) { g_first_batch_loop_threads = n < 0 ? 0 : n; }
+
 /* depth_optimizer.cc:164-358 */
 static void
 opt_run_newton_iterations(OOpt *O, int num_iters)
@@ -1283,6 +1292,9 @@ opt_run_newton_iterations(OOpt *O, int num_iters)
         make_views(O, &V, sv);
         orc_gn_options gopts = { O->opts->regularization,
             O->opts->light_surf_regularization };
+        int const threads_outside = orc_get_threads();
+        if (g_first_batch_loop_threads > 0 && iter == 0)
+            orc_set_threads(g_first_batch_loop_threads);
         double const t_loop = wall_seconds();
         long long patch_steps = 0;
         for (; newton_step < 200 && num_active > num_initial / 20;)
@@ -1312,6 +1324,7 @@ opt_run_newton_iterations(OOpt *O, int num_iters)
             num_active = (size_t)r;
         }
         double const loop_seconds = wall_seconds() - t_loop;
+        orc_set_threads(threads_outside);
         free(H9); free(present); free(g); free(P); free(x); free(sv);
         free(active);
         log_push(O->log, S->s.scale, iter, (int)newton_step, num_valid_patches,

@@ -139,6 +139,11 @@ int orc_surface_script(const orc_view_input *main_view, const orc_bundle *bundle
     int delete_every, int *info, double *nodes_out, uint8_t *node_valid_out,
     uint8_t *patch_valid_out);
 
+/* Measurement control for bench.py's cpu_baseline (no counterpart in the
+ * reference): n > 0 runs the Newton loop of the first batch of every scale of
+ * orc_optimize with n OpenMP threads, independent of orc_set_threads. */
+void orc_set_first_batch_loop_threads(int n);
+
 /* what ViewSelection reads of an mve::View (view_selection.cc:23-159) */
 typedef struct {
     int present;                   /* 0: a null entry of the scene's view list */

@@ -2492,6 +2492,7 @@ DeviceTileBudget::acquire(int device, int tiles)
     // wait for the head
     turn.wait(guard, [&] { return serving == ticket && used + tiles <= capacity; });
     auto const now = std::chrono::steady_clock::now();
+    bool handed_back = false;
     if (fd >= 0 && now >= no_file_until) {
         if (file_locked && now - file_since > FILE_HOLD) {
             // this process has had the GPU's barrier kernels to itself long
@@ -2499,9 +2500,16 @@ DeviceTileBudget::acquire(int device, int tiles)
             // line meanwhile) and hand the lock back before taking it again
             turn.wait(guard, [&] { return holders == 0; });
             unlock_file();
+            handed_back = true;
         }
         if (!file_locked) {
             guard.unlock();
+            // (flock is not FIFO and a waiting process polls every 50 us: taking
+            // the lock again at once would win it back nearly every time, and
+            // the waiter would starve into its 20 s give-up.  Four of its poll
+            // periods are its turn.)
+            if (handed_back)
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
             bool const got = take_file_lock();
             guard.lock();
             file_locked = got;

@@ -848,6 +848,98 @@ smvs_ctx_restore_nodes(smvs_ctx *ctx)
 }
 
 extern "C" int
+smvs_ctx_clone_loop_state(smvs_ctx *src, smvs_ctx **out)
+{
+    SMVS_REQUIRE(src != nullptr && out != nullptr, "null argument");
+    if (!src->has_surface || !src->has_cameras) {
+        set_error("smvs_ctx_clone_loop_state: the context holds no surface / cameras");
+        return SMVS_ERR_STATE;
+    }
+    smvs_ctx *dst = nullptr;
+    int rc = smvs_ctx_create(src->device, src->width, src->height, src->n_subs, &dst);
+    if (rc != SMVS_OK)
+        return rc;
+    auto fail = [&](int code) {
+        (void)smvs_ctx_destroy(dst);
+        return code;
+    };
+    if (set_device(src->device) != hipSuccess)
+        return fail(SMVS_ERR_HIP);
+    // everything below is ordered behind the source's pending work
+    if (hipStreamSynchronize(src->stream) != hipSuccess)
+        return fail(SMVS_ERR_HIP);
+    hipStream_t const st = dst->stream;
+    auto copy = [&](void *to, const void *from, size_t bytes) {
+        return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    };
+    size_t const npix = (size_t)src->width * src->height;
+    bool ok = copy(dst->cams, src->cams, sizeof(DeviceCameras))
+        && copy(dst->main_grad, src->main_grad, npix * sizeof(float2))
+        && copy(dst->lighting, src->lighting, 16 * sizeof(double));
+    dst->flen = src->flen;
+    dst->inv_flen = src->inv_flen;
+    dst->has_cameras = true;
+    dst->solver_mode = src->solver_mode;
+    if (ok && src->has_shading) {
+        if (dst->main_shading == nullptr
+            && ((rc = device_alloc(&dst->main_shading, npix)) != SMVS_OK
+                || (rc = device_alloc(&dst->main_shading_grad, npix)) != SMVS_OK))
+            return fail(rc);
+        ok = copy(dst->main_shading, src->main_shading, npix * sizeof(float))
+            && copy(dst->main_shading_grad, src->main_shading_grad, npix * sizeof(float2));
+        dst->has_shading = true;
+    }
+    for (int j = 0; ok && j < src->n_subs; ++j) {
+        if (!((src->planes_ok >> j) & 1u))
+            continue;
+        SubPlanes const &from = src->subs[j];
+        SubPlanes &to = dst->subs[j];
+        size_t const n = (size_t)from.width * from.height;
+        if (to.width != from.width || to.height != from.height || to.grad == nullptr
+            || to.hess == nullptr) {
+            to.width = to.height = 0;
+            if ((rc = device_alloc(&to.grad, n)) != SMVS_OK
+                || (rc = device_alloc(&to.hess, n)) != SMVS_OK) {
+                (void)device_alloc(&to.grad, 0);
+                (void)device_alloc(&to.hess, 0);
+                return fail(rc);
+            }
+            to.width = from.width;
+            to.height = from.height;
+        }
+        ok = copy(to.grad, from.grad, n * sizeof(*from.grad))
+            && copy(to.hess, from.hess, n * sizeof(*from.hess));
+        dst->planes_ok |= 1u << j;
+    }
+    if (ok)
+        ok = hipMemcpyAsync(dst->subs_dev, dst->subs, sizeof(SubPlanes) * SMVS_MAX_SUBS,
+            hipMemcpyHostToDevice, st) == hipSuccess;
+    if (!ok)
+        return fail(SMVS_ERR_HIP);
+    if ((rc = ctx_ensure_grid(dst, src->scale, src->npx, src->npy, src->start_x,
+             src->start_y)) != SMVS_OK)
+        return fail(rc);
+    size_t const N = (size_t)src->num_nodes, P = (size_t)src->num_patches;
+    ok = copy(dst->nodes, src->nodes, N * 4 * sizeof(double))
+        && copy(dst->node_valid, src->node_valid, N)
+        && copy(dst->patch_valid, src->patch_valid, P)
+        && copy(dst->patch_vis, src->patch_vis, P * sizeof(uint32_t));
+    if (!ok)
+        return fail(SMVS_ERR_HIP);
+    hipLaunchKernelGGL(init_active_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+        st, dst->node_valid, dst->active, (int)N);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(SMVS_ERR_HIP);
+    dst->has_surface = true;
+    if ((rc = smvs_ctx_save_nodes(dst)) != SMVS_OK)
+        return fail(rc);
+    if (hipStreamSynchronize(st) != hipSuccess)
+        return fail(SMVS_ERR_HIP);
+    *out = dst;
+    return SMVS_OK;
+}
+
+extern "C" int
 smvs_profile_enable(smvs_ctx *ctx, int on)
 {
     SMVS_REQUIRE(ctx != nullptr, "null context");

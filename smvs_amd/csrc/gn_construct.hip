@@ -18,7 +18,9 @@
 // and a 6x6 symmetric M6 / 6-vector v6 that carry all the view, IRLS-weight
 // and lighting dependence.  Phase 1 computes (M6, v6) with one lane per
 // sampled pixel (FP64 VALU); phase 2 contracts sum_pix D6^T (M6 D6) on the
-// matrix cores (v_mfma_f64_16x16x4_f64), K = 6 rows per pixel.
+// matrix cores, K = 6 rows per pixel: three v_mfma_f64_4x4x4 per row (four
+// independent 4 x 4 node blocks each) cover the ten node blocks (bi <= bj) of
+// the symmetric 16 x 16 patch system; a 16x16x4 would compute all sixteen.
 // One wavefront owns 64 sampled pixels = 4 patches at the fine scales.
 #include "common.h"
 

@@ -396,6 +396,20 @@ DepthOptimizer::upload_surface(void)
     uploaded_subs_rev = subs_rev;
 }
 
+std::vector<RecordedLoop>&
+recorded_loops(void)
+{
+    static thread_local std::vector<RecordedLoop> loops;
+    return loops;
+}
+
+bool&
+recording_loops(void)
+{
+    static thread_local bool on = false;
+    return on;
+}
+
 void
 DepthOptimizer::fit_lighting(void)
 {
@@ -568,6 +582,11 @@ DepthOptimizer::run_newton_iterations(int num_iters)
         prm.use_lighting = lit ? 1 : 0;
         std::copy(lighting, lighting + 16, prm.lighting);
         prm.reset_active = 1;
+        if (recording_loops()) {
+            smvs_ctx* clone = nullptr;
+            check(smvs_ctx_clone_loop_state(ctx, &clone), "smvs_ctx_clone_loop_state");
+            recorded_loops().push_back({ clone, prm, current_scale(), iter });
+        }
         smvs_gn_loop_stats stats;
         double loop_seconds = 0.0;
         {

@@ -17,6 +17,20 @@
 
 namespace smvs_amd {
 
+// Measurement hook (not in the reference): while a recording is on -- per host
+// thread -- every Newton batch leaves a device-resident clone of what its loop
+// reads (smvs_ctx_clone_loop_state) together with the parameters it was run
+// with, taken just before smvs_gn_run_loop.  bench.py replays exactly these
+// loops as its timed region (the Newton loops of optimize()).
+struct RecordedLoop
+{
+    smvs_ctx* ctx;
+    smvs_gn_loop_params params;
+    int scale, iter;
+};
+std::vector<RecordedLoop>& recorded_loops(void);   // of this thread
+bool& recording_loops(void);                       // of this thread
+
 class DepthOptimizer
 {
 public:

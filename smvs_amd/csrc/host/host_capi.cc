@@ -118,6 +118,45 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
 }
 
 extern "C" int
+smvs_host_release_recorded_loops(int destroy)
+{
+    auto& loops = recorded_loops();
+    int const n = (int)loops.size();
+    if (destroy)
+        for (auto& l : loops)
+            (void)smvs_ctx_destroy(l.ctx);
+    loops.clear();
+    return n;
+}
+
+extern "C" int
+smvs_host_record_loops(int on)
+{
+    if (on)
+        (void)smvs_host_release_recorded_loops(1);
+    recording_loops() = on != 0;
+    return 0;
+}
+
+extern "C" int
+smvs_host_recorded_loops(void **ctxs, void *params, int *scales, int *iters, int cap)
+{
+    auto const& loops = recorded_loops();
+    smvs_gn_loop_params *prm = static_cast<smvs_gn_loop_params *>(params);
+    for (int i = 0; i < (int)loops.size() && i < cap; ++i) {
+        if (ctxs != nullptr)
+            ctxs[i] = loops[i].ctx;
+        if (prm != nullptr)
+            prm[i] = loops[i].params;
+        if (scales != nullptr)
+            scales[i] = loops[i].scale;
+        if (iters != nullptr)
+            iters[i] = loops[i].iter;
+    }
+    return (int)loops.size();
+}
+
+extern "C" int
 smvs_host_sgm_depth(const smvs_host_view *main_in, const smvs_host_view *subs_in,
     int n_subs, const smvs_host_bundle *bundle_in, int sgm_scale,
     float min_depth, float max_depth, int device, float *depth_out, int *out_w,

@@ -64,6 +64,20 @@ int smvs_host_optimize(const smvs_host_view *main_view,
     const smvs_host_options *opts, float *depth_out, float *normals_out,
     smvs_host_log *log);
 
+/* Loop recording (measurement, see RecordedLoop in depth_optimizer.h):
+ * smvs_host_record_loops(1) drops what this thread recorded before (the clones
+ * are destroyed) and starts recording, (0) stops; every smvs_host_optimize of
+ * the thread in between leaves one entry per Newton batch.
+ * smvs_host_recorded_loops copies up to `cap` entries -- context handle, loop
+ * parameters (a smvs_gn_loop_params each), scale, iteration -- and returns how
+ * many were recorded.  The contexts belong to the recorder until
+ * smvs_host_release_recorded_loops: destroy != 0 destroys them, 0 hands them
+ * to the caller (who ends each with smvs_ctx_destroy). */
+int smvs_host_record_loops(int on);
+int smvs_host_recorded_loops(void **ctxs, void *params, int *scales, int *iters,
+    int cap);
+int smvs_host_release_recorded_loops(int destroy);
+
 /* reconstruct_sgm_depth_for_view (app/smvsrecon.cc:346-384): returns the
  * merged z-depth map at SGM resolution ((w+1)>>scale ...). */
 int smvs_host_sgm_depth(const smvs_host_view *main_view,

@@ -352,6 +352,8 @@ block_sequential(Decoder& d, Component& c, int16_t* coef)
     if (s > 15)
         d.fail("corrupt entropy-coded data (DC size)");
     c.pred += s ? extend(get_bits(d, s), s) : 0;
+    if (c.pred < -(1 << 20) || c.pred > (1 << 20))
+        d.fail("corrupt entropy-coded data (DC value out of range)");
     coef[0] = (int16_t)c.pred;
     for (int k = 1; k < 64;) {
         int const rs = decode_symbol(d, act);
@@ -378,6 +380,8 @@ block_dc_first(Decoder& d, Component& c, int16_t* coef, int al)
     if (s > 15)
         d.fail("corrupt entropy-coded data (DC size)");
     c.pred += s ? extend(get_bits(d, s), s) : 0;
+    if (c.pred < -(1 << 20) || c.pred > (1 << 20))
+        d.fail("corrupt entropy-coded data (DC value out of range)");
     coef[0] = (int16_t)(c.pred * (1 << al));
 }
 
@@ -706,8 +710,11 @@ upsample(Component const& c, int hf, int vf, int out_w, int out_h,
         for (int r = 0; r < dh; ++r) {
             const unsigned char* in = row_in(r);
             unsigned char* o = out->data() + (std::size_t)r * ow;
-            if (dw == 1) {
-                o[0] = o[1] = in[0];
+            if (dw <= 2) {
+                // (jdsample.c: the triangle filter only when downsampled_width > 2,
+                // h2v1_upsample's replication otherwise)
+                for (int i = 0; i < dw; ++i)
+                    o[2 * i] = o[2 * i + 1] = in[i];
                 continue;
             }
             o[0] = in[0];
@@ -727,10 +734,11 @@ upsample(Component const& c, int hf, int vf, int out_w, int out_h,
                 const unsigned char* in0 = row_in(r);
                 const unsigned char* in1 = row_in(half == 0 ? r - 1 : r + 1);
                 unsigned char* o = out->data() + ((std::size_t)2 * r + half) * ow;
-                if (dw == 1) {
-                    int const s = in0[0] * 3 + in1[0];
-                    o[0] = (unsigned char)((s * 4 + 8) >> 4);
-                    o[1] = (unsigned char)((s * 4 + 7) >> 4);
+                if (dw <= 2) {
+                    // (jdsample.c: h2v2_upsample's replication unless
+                    // downsampled_width > 2)
+                    for (int i = 0; i < dw; ++i)
+                        o[2 * i] = o[2 * i + 1] = in0[i];
                     continue;
                 }
                 int thiscol = in0[0] * 3 + in1[0];
@@ -814,7 +822,12 @@ decode(std::string const& path, bool header_only, int* whc)
     }
     // every scan of the frame (one for most sequential files, about ten for a
     // progressive one), then the inverse DCT of what has arrived
+    // (a progressive file has about ten scans; a file of thousands of empty
+    // ones would walk every block of the frame once per scan)
+    int scans = 0;
     do {
+        if (++scans > 256)
+            d.fail("more than 256 scans");
         decode_scan(d, sc, mcux, mcuy);
     } while (next_scan(d, &sc));
     for (Component& c : d.comps) {

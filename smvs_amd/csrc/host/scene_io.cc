@@ -185,7 +185,8 @@ SceneView::has_image(std::string const& embedding) const
 {
     return present && (file_exists(directory + "/" + embedding + ".mvei")
         || file_exists(directory + "/" + embedding + ".png")
-        || file_exists(directory + "/" + embedding + ".jpg"));
+        || file_exists(directory + "/" + embedding + ".jpg")
+        || file_exists(directory + "/" + embedding + ".jpeg"));
 }
 
 std::string
@@ -198,6 +199,8 @@ SceneView::image_path(std::string const& embedding) const
         return base + ".png";
     if (!file_exists(base + ".mvei") && file_exists(base + ".jpg"))
         return base + ".jpg";
+    if (!file_exists(base + ".mvei") && file_exists(base + ".jpeg"))
+        return base + ".jpeg";
     return base + ".mvei";
 }
 
@@ -207,7 +210,8 @@ SceneView::load_byte_image(std::string const& embedding) const
     std::string const path = image_path(embedding);
     if (path.size() > 4 && path.substr(path.size() - 4) == ".png")
         return load_png_u8(path);
-    if (path.size() > 4 && path.substr(path.size() - 4) == ".jpg")
+    if ((path.size() > 4 && path.substr(path.size() - 4) == ".jpg")
+        || (path.size() > 5 && path.substr(path.size() - 5) == ".jpeg"))
         return load_jpeg_u8(path);
     return load_mvei_u8(path);
 }
@@ -218,7 +222,8 @@ SceneView::image_size(std::string const& embedding, int* whc) const
     std::string const path = image_path(embedding);
     if (path.size() > 4 && path.substr(path.size() - 4) == ".png")
         return png_header(path, whc);
-    if (path.size() > 4 && path.substr(path.size() - 4) == ".jpg")
+    if ((path.size() > 4 && path.substr(path.size() - 4) == ".jpg")
+        || (path.size() > 5 && path.substr(path.size() - 5) == ".jpeg"))
         return jpeg_header(path, whc);
     int whct[4] = { 0, 0, 0, 0 };
     if (!mvei_header(path, whct))

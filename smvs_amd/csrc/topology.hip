@@ -40,7 +40,15 @@ struct __attribute__((packed, aligned(4))) float3_r { float x, y, z; };
 // bit for bit, it is the same sequence of roundings -- comes from the shared
 // refined reciprocal in three instructions plus the fix-up (zero, infinite and
 // NaN numerators).  Any other denominator (zero, NaN, 1e-70 ...) is `plain ==
-// false`: the caller divides.  The warp of a pixel divides ten times by d and
+// false`: the caller divides.  The guarantee is conditional on the NUMERATOR
+// as well: v_div_scale also rescales for numerators whose exponent is extreme
+// (|a| beyond ~1e230 or denormal, quotients near overflow / underflow), and
+// only the denominator is tested here.  The numerators of this file are
+// projective coordinates and their pixel derivatives -- products of image
+// coordinates (< 1e5), camera entries and depths, |a| < 1e20 and either exactly
+// zero or > 1e-60 for any scene the surface tests accept -- so the condition
+// holds; SMVS_TOPO_DIVIDE=exact runs the divisions themselves and the GPU
+// suite demands identical masks.  The warp of a pixel divides ten times by d and
 // d * d (Correspondence, topo_math.h): the visibility kernel issues a vector
 // instruction every cycle it can, and a seventh of them were these.
 struct SharedDivisor {
@@ -1187,17 +1195,23 @@ prepare_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
         }
     int rc;
     if ((size_t)ctx->num_patches > ctx->topo_mse_cap) {
+        ctx->topo_mse_cap = 0;
         if ((rc = device_alloc(&ctx->topo_mse, (size_t)ctx->num_patches))
             != SMVS_OK)
             return rc;
         ctx->topo_mse_cap = (size_t)ctx->num_patches;
     }
+    // (device_alloc frees the old buffer first: the capacity goes to zero with
+    // it, so that a failed allocation is tried again by the next call instead of
+    // leaving a null pointer behind a capacity that says it is there)
     if ((size_t)ctx->num_nodes > ctx->topo_border_cap) {
+        ctx->topo_border_cap = 0;
         if ((rc = device_alloc(&ctx->topo_border, (size_t)ctx->num_nodes)) != SMVS_OK)
             return rc;
         ctx->topo_border_cap = (size_t)ctx->num_nodes;
     }
     if ((size_t)ctx->num_patches > ctx->topo_mse_list_cap) {
+        ctx->topo_mse_list_cap = 0;
         if ((rc = device_alloc(&ctx->topo_mse_list, (size_t)ctx->num_patches)) != SMVS_OK)
             return rc;
         ctx->topo_mse_list_cap = (size_t)ctx->num_patches;

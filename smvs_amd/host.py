@@ -514,3 +514,29 @@ def block_multiply(H9, node_stride, x):
     if rc != 0:
         raise _capi.SmvsError(rc, lib.smvs_host_last_error().decode())
     return y
+
+
+# ------------------------------------------------------------ loop recording
+def record_loops(on=True):
+    """smvs_host_record_loops: while on, every Newton batch of this thread's
+    optimize() calls leaves a device-resident clone of its loop's start state
+    (smvs_ctx_clone_loop_state); starting a recording drops what the recorder
+    still owns."""
+    load().smvs_host_record_loops(1 if on else 0)
+
+
+def take_recorded_loops():
+    """-> [dict(handle, params, scale, iter)] of this thread's recording; the
+    contexts now belong to the caller (smvs_ctx_destroy each)."""
+    lib = load()
+    n = lib.smvs_host_recorded_loops(None, None, None, None, 0)
+    if n == 0:
+        return []
+    ctxs = (C.c_void_p * n)()
+    prm = (_capi.LoopParams * n)()
+    scales = (C.c_int * n)()
+    iters = (C.c_int * n)()
+    lib.smvs_host_recorded_loops(ctxs, prm, scales, iters, n)
+    lib.smvs_host_release_recorded_loops(0)
+    return [dict(handle=C.c_void_p(ctxs[i]), params=prm[i], scale=scales[i], iter=iters[i])
+            for i in range(n)]

@@ -691,12 +691,15 @@ def test_reconstruct_scene_makescene_directory_with_automatic_input_scale(
 
 def test_bench_contract_small(hip):
     """bench.py prints ONE JSON line with the fields the driver reads; run at
-    the 480x270 debug size (the numbers mean nothing, the structure does)."""
+    the 480x270 debug size (the numbers mean nothing, the structure does).
+    The headline is BASELINE.md's region: a step = one pass over all Newton
+    loops of one optimize(), replayed from the recorded batch start states (the
+    bench itself asserts that the replay reproduces the optimize()'s log)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "3",
            "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--no-peaks"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -707,16 +710,29 @@ def test_bench_contract_small(hip):
         assert out[key] == want, (key, out[key])
     assert out["metric"].startswith("Gauss-Newton iters/sec x active patches")
     assert out["value"] > 0 and out["ms_per_step"] > 0
-    assert "workload" in out["config"] and "model" not in out["config"]
+    cfg = out["config"]
+    assert "workload" in cfg and "model" not in cfg
+    assert "all Newton loops of all scales" in cfg["workload"]
+    assert cfg["replay_verified_against_optimize_log"] is True
+    assert cfg["batches_per_step"] >= 9 and cfg["newton_steps_per_step"] >= cfg["batches_per_step"]
     roof = out["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_frac", "per_kernel"):
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "per_kernel",
+                "region_share", "by_scale"):
         assert key in roof, key
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    assert out["cpu_baseline"] is None                 # --no-cpu-baseline
+    assert roof["kernel"] == max(roof["region_share"], key=roof["region_share"].get)
+    assert set(roof["per_kernel"]) >= {"patch", "cg_resident"}
+    assert roof["per_kernel"]["patch"]["flop_per_patch_by_scale"]["2"] > 0
+    # the headline and the in-place timers of secondary.optimize count the same units
     sec = out["secondary"]
     assert "error" not in sec, sec
+    steps_units = sum(v["active_patch_steps"] for v in roof["by_scale"].values())
+    assert steps_units == sec["optimize"]["active_patch_steps"]
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - steps_units) < 1e-6 * steps_units
+    assert out["cpu_baseline"] is None                 # --no-cpu-baseline
     assert sec["optimize"]["value"] > 0 and sec["views_per_s"]["per_gpu"]["sgm_in_flight_8"]["views_per_s"] > 0
     assert sec["sgm_front_end"]["kernels"]["paths"]["frac"] > 0
+    assert sec["scale2_replay"]["value"] > 0 and sec["scale2_replay"]["per_kernel"]["patch"]["frac"] > 0
     # the whole-optimize workload as its own line
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--small", "--workload",
                           "optimize", "--steps", "2", "--warmup", "1"], capture_output=True,
@@ -728,13 +744,14 @@ def test_bench_contract_small(hip):
 
 
 def test_bench_contract_value_optimize_and_traffic_source(hip):
-    """The honesty fields: `value_optimize` (BASELINE.md's timed region) at the
-    top level beside the headline, the committed source of `roofline.traffic`,
-    HBM fractions also against the read peak measured on the box."""
+    """The honesty fields: `value_optimize` (the same region timed in place by
+    the C++ loop timers) at the top level beside the headline, the committed
+    source of `roofline.traffic`, HBM fractions also against the read peak
+    measured on the box, and the CPU baseline on the same region."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "3",
-           "--warmup", "1", "--repeats", "2", "--no-cpu-baseline"]
+           "--warmup", "1", "--repeats", "2"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
@@ -746,6 +763,29 @@ def test_bench_contract_value_optimize_and_traffic_source(hip):
     assert cg["measured_read_peak_GBps"] > 1000
     assert abs(cg["frac_of_measured_read_peak"]
                - cg["achieved"] / cg["measured_read_peak_GBps"]) < 1e-3
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0
+    assert "first batch of every scale" in cpu["sample"]
+    assert cpu["all_cores"]["value"] > 0
+    # both sides count the same batches: the oracle's first batches are the
+    # device's (identical active patch-steps per batch is what the parity tests assert)
+    assert sum(v["active_patch_steps"] for v in cpu["by_scale"].values()) == cpu["active_patch_steps"]
+
+
+def test_bench_newton_steps_workload_is_still_there(hip):
+    """`--workload newton_steps` (the headline of rounds 1-5, now
+    secondary.scale2_replay): a step = one Newton step at scale 2."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--small", "--workload", "newton_steps",
+           "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--no-peaks",
+           "--no-secondary"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert out["steps"] == 3 and out["value"] > 0
+    assert "scale 2" in out["config"]["workload"]
+    assert "step_frac" in out["roofline"]
 
 
 def test_bench_config5_runs_whole_views_in_child_processes(hip):
