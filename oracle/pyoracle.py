@@ -472,7 +472,7 @@ class OptOptions(C.Structure):
                 ("num_iterations", C.c_int), ("min_scale", C.c_int),
                 ("use_shading", C.c_int), ("use_sgm", C.c_int),
                 ("full_optimization", C.c_int), ("sgm_width", C.c_int),
-                ("sgm_height", C.c_int)]
+                ("sgm_height", C.c_int), ("gamma_correction", C.c_int)]
 
 
 class OptLog(C.Structure):
@@ -504,7 +504,7 @@ def _view_input(img, cam, view_id, keep):
 
 def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
              min_scale=2, use_shading=False, sgm_depth=None,
-             full_optimization=False):
+             full_optimization=False, gamma_correction=False):
     """orc_optimize on the dict of smvs_amd.synth.pipeline_inputs()."""
     keep = []
     cams, images = inputs["cams"], inputs["images"]
@@ -525,6 +525,7 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
     o.use_shading = 1 if use_shading else 0
     o.use_sgm = 1 if sgm_depth is not None else 0
     o.full_optimization = 1 if full_optimization else 0
+    o.gamma_correction = 1 if gamma_correction else 0
     sd = None
     if sgm_depth is not None:
         sd = f32(sgm_depth)

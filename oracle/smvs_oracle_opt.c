@@ -217,8 +217,24 @@ oview_init(OView *v, const orc_view_input *in, int linear)
     memcpy(v->trans, in->trans, sizeof(v->trans));
     if (linear)
     {
-        /* StereoView::initialize_linear without gamma (stereo_view.cc:64-84) */
-        v->shading = desaturate(v->image, v->w, v->h, v->c);
+        /* StereoView::initialize_linear (stereo_view.cc:64-84): linear == 2 with
+         * gamma_correction -- the duplicate of the image through
+         * mve::image::gamma_correct_inv_srgb<float> (tests/golden/README.md M9)
+         * before it is desaturated; the photometric planes keep the image */
+        float *lin = v->image;
+        if (linear == 2)
+        {
+            lin = (float *)malloc(sizeof(float) * n);
+            for (size_t i = 0; i < n; ++i)
+            {
+                float const x = v->image[i];
+                lin[i] = x <= 0.04045f ? x / 12.92f
+                    : powf((x + 0.055f) / 1.055f, 2.4f);
+            }
+        }
+        v->shading = desaturate(lin, v->w, v->h, v->c);
+        if (lin != v->image)
+            free(lin);
         v->shading_grad = (float *)malloc(sizeof(float) * 2 * (size_t)v->w * v->h);
         orc_gradients_and_hessian(v->shading, v->w, v->h, v->shading_grad, NULL);
     }
@@ -1374,7 +1390,7 @@ orc_optimize(const orc_view_input *main_in, const orc_view_input *subs_in,
     O.n_subs = n_subs;
     O.log = log;
     OView mainv;
-    oview_init(&mainv, main_in, opts->use_shading);
+    oview_init(&mainv, main_in, opts->use_shading ? (opts->gamma_correction ? 2 : 1) : 0);
     O.main = &mainv;
     O.subs = (OView *)malloc(sizeof(OView) * n_subs);
     for (int j = 0; j < n_subs; ++j)

@@ -36,6 +36,9 @@ typedef struct {                   /* DepthOptimizer::Options, depth_optimizer.h
     int use_sgm;
     int full_optimization;
     int sgm_width, sgm_height;     /* size of the "smvs-sgm" depth map */
+    int gamma_correction;          /* StereoView::create(.., use_shading, gamma_correction),
+                                      app/smvsrecon.cc:52, 669: inverse sRGB gamma on the
+                                      main view's linear image (with use_shading only) */
 } orc_opt_options;
 
 #define ORC_OPT_LOG_MAX 256

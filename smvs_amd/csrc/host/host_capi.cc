@@ -36,7 +36,7 @@ smvs_host_last_error(void)
 static void fill_log(DepthOptimizer const& optimizer, smvs_host_log *log);
 
 static StereoView::Ptr
-make_view(smvs_host_view const& v, bool linear)
+make_view(smvs_host_view const& v, bool linear, bool gamma = false)
 {
     ByteImage::Ptr img = ByteImage::create_for_overwrite(v.width, v.height, v.channels);
     std::memcpy(img->begin(), v.bytes, (size_t)v.width * v.height * v.channels);
@@ -44,7 +44,7 @@ make_view(smvs_host_view const& v, bool linear)
     cam.flen = v.flen;
     std::copy(v.rot, v.rot + 9, cam.rot);
     std::copy(v.trans, v.trans + 3, cam.trans);
-    return StereoView::create(v.view_id, img, cam, linear, false);
+    return StereoView::create(v.view_id, img, cam, linear, gamma);
 }
 
 static Bundle::Ptr
@@ -70,7 +70,7 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
     float *depth_out, float *normals_out, smvs_host_log *log)
 {
     try {
-        StereoView::Ptr main_view = make_view(*main_in, o->use_shading != 0);
+        StereoView::Ptr main_view = make_view(*main_in, o->use_shading != 0, o->gamma_correction != 0);
         std::vector<StereoView::Ptr> subs;
         for (int j = 0; j < n_subs; ++j)
             subs.push_back(make_view(subs_in[j], false));

@@ -36,6 +36,8 @@ typedef struct {                /* DepthOptimizer::Options */
     int full_optimization;
     int device;
     int solver;                 /* smvs_solver_mode of include/smvs_hip.h */
+    int gamma_correction;       /* StereoView::create's fourth argument for the main view
+                                   (app/smvsrecon.cc:52, 669), with use_shading only */
 } smvs_host_options;
 
 #define SMVS_HOST_LOG_MAX 256

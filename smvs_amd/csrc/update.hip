@@ -65,10 +65,21 @@ struct ReactivateArgs {
 // One thread per (patch, full-resolution pixel): project with the old and
 // the updated nodes into every visible neighbour (pixel coordinates WITHOUT
 // the +0.5 convention, depth_optimizer.cc:669-672).
+//
+// A workgroup's 256 pixels belong to at most 16 patches (scale 2; one patch
+// from scale 4 on).  Their corner nodes and deltas -- 32 doubles per patch --
+// are staged in LDS once per workgroup by the first 32 threads per patch
+// (rounds 1-5: every pixel thread loaded its patch's 32 doubles itself, 256 B
+// per pixel through the vector L1: 530 MB per launch at every scale, which is
+// what the kernel's 20-26 us were).  The arithmetic per pixel is unchanged.
 __global__ void __launch_bounds__(256)
 reactivate_kernel(ReactivateArgs A)
 {
-    long long const gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_theta[16][32];   // per patch: nodes [4][4], then deltas [4][4]
+    __shared__ int s_patch[16];          // patch id, or -1: nothing to evaluate
+    __shared__ uint32_t s_vis[16];
+    int const tid = (int)threadIdx.x;
+    long long const gid0 = (long long)blockIdx.x * blockDim.x + tid;
     // the pipelined Newton loop: the loop has already ended / the solver of
     // this step gave up (finish_step_kernel reports it)
     if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
@@ -93,29 +104,54 @@ reactivate_kernel(ReactivateArgs A)
     // (measured: one thread per 16-pixel chunk, loading the nodes once per
     // chunk, is slower -- 40 instead of 25 us: too few waves to hide the
     // latency of its serial pixels)
-    int const slot = (int)(gid0 >> (2 * A.ps_log2));
-    int const pid = (int)(gid0 & (long long)((1 << (2 * A.ps_log2)) - 1));
-    int patch = A.num_patches;
-    if (slot < live_count)
-        patch = A.live_list != nullptr ? A.live_list[slot] : slot;
+    int const shift = 2 * A.ps_log2;
+    int const per_block = shift >= 8 ? 1 : 256 >> shift;   // patches of this workgroup
+    int const first_slot = (int)(((long long)blockIdx.x * blockDim.x) >> shift);
+    if (tid < per_block * 32) {
+        int const q = tid >> 5, k = tid & 31;
+        int const slot = first_slot + q;
+        int patch = A.num_patches;
+        if (slot < live_count)
+            patch = A.live_list != nullptr ? A.live_list[slot] : slot;
+        bool evaluate = false;
+        double value = 0.0;
+        if (patch < A.num_patches && A.patch_valid[patch]) {
+            int const ix = patch % A.npx, iy = patch / A.npx;
+            int const n00 = iy * A.stride + ix;
+            int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+            evaluate = (A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
+                | A.active[ids[3]]) != 0;
+            if (evaluate) {
+                // w1 - w0 is the patch evaluated on the node deltas (the patch
+                // is linear in its nodes)
+                int const n = (k >> 2) & 3;
+                const double *src = k < 16 ? A.nodes : A.x;
+                value = src[4 * (size_t)ids[n] + (k & 3)];
+            }
+        }
+        s_theta[q][k] = value;
+        if (k == 0) {
+            s_patch[q] = evaluate ? patch : -1;
+            s_vis[q] = evaluate ? A.patch_vis[patch] : 0u;
+        }
+    }
+    __syncthreads();
+    int const q = shift >= 8 ? 0 : tid >> shift;
+    int const pid = (int)(gid0 & (long long)((1 << shift) - 1));
+    int const patch = s_patch[q];
     double sum = 0.0, cnt = 0.0;
-    if (patch < A.num_patches && A.patch_valid[patch]) {
+    if (patch >= 0) {
         int const ix = patch % A.npx, iy = patch / A.npx;
         int const n00 = iy * A.stride + ix;
         int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
-        if ((A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
-            | A.active[ids[3]]) != 0) {
-            // w1 - w0 is the patch evaluated on the node deltas (the patch
-            // is linear in its nodes)
+        {
             double th0[16], thd[16];
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    th0[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
-                    thd[4 * n + k] = A.x[4 * (size_t)ids[n] + k];
-                }
-            uint32_t const vis = A.patch_vis[patch];
+            for (int k = 0; k < 16; ++k) {
+                th0[k] = s_theta[q][k];
+                thd[k] = s_theta[q][16 + k];
+            }
+            uint32_t const vis = s_vis[q];
             double const th2 = A.threshold * A.threshold;
             bool moved = false;
             int const ci = pid & (A.ps - 1), cj = pid >> A.ps_log2;

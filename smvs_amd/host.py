@@ -33,7 +33,7 @@ class HostOptions(C.Structure):
                 ("num_iterations", C.c_int), ("min_scale", C.c_int),
                 ("use_shading", C.c_int), ("use_sgm", C.c_int),
                 ("full_optimization", C.c_int), ("device", C.c_int),
-                ("solver", C.c_int)]
+                ("solver", C.c_int), ("gamma_correction", C.c_int)]
 
 
 class HostLog(C.Structure):
@@ -92,7 +92,8 @@ def _marshal(inputs, keep):
 
 def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
              min_scale=2, use_shading=False, sgm_depth=None,
-             full_optimization=False, device=0, solver="auto", want_maps=True):
+             full_optimization=False, device=0, solver="auto", want_maps=True,
+             gamma_correction=False):
     """want_maps=False: optimize() only -- the depth / normal maps the reference
     reads back with get_depth() / get_normals() afterwards are not fetched (the
     embeddings optimize() itself writes are; tools/optimize_timeline.py)."""
@@ -102,7 +103,8 @@ def optimize(inputs, regularization=0.01, light_reg=0.0, num_iterations=5,
     o = HostOptions(regularization, light_reg, num_iterations, min_scale,
                     1 if use_shading else 0, 1 if sgm_depth is not None else 0,
                     1 if full_optimization else 0, device,
-                    dict(auto=0, streaming=1, resident_ref=2)[solver])
+                    dict(auto=0, streaming=1, resident_ref=2)[solver],
+                    1 if gamma_correction else 0)
     h, w = main.height, main.width
     depth = np.zeros((h, w), dtype=np.float32)
     normals = np.zeros((h, w, 3), dtype=np.float32)
@@ -150,7 +152,7 @@ def optimize_views(inputs, n_jobs, regularization=0.01, light_reg=0.0,
             all_subs[j * n_subs + k] = subs[k]
     o = HostOptions(regularization, light_reg, num_iterations, min_scale,
                     1 if use_shading else 0, 1 if sgm_scale is not None else 0,
-                    0, first_device, dict(auto=0, streaming=1, resident_ref=2)[solver])
+                    0, first_device, dict(auto=0, streaming=1, resident_ref=2)[solver], 0)
     h, w = main.height, main.width
     depth = np.zeros((h, w), dtype=np.float32)
     normals = np.zeros((h, w, 3), dtype=np.float32)

@@ -84,7 +84,7 @@ def assert_same_units(got, want, width, height, tag):
     try:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r5_units_%s.txt" % tag), "w") as f:
+        with open(os.path.join(out, "units_%s.txt" % tag), "w") as f:
             f.write("# %s: batch log of DepthOptimizer::optimize, device (C++ host + HIP) / oracle\n%s\n"
                     % (tag, text))
     except OSError:

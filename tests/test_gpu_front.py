@@ -268,6 +268,65 @@ def test_full_size_view_of_config5_sgm_and_shading_matches_oracle(hip, oracle, o
     assert _rel(got["depth"], want["depth"]) <= 1e-4
 
 
+# ---- the reference's other operating points, whole optimize() against the oracle
+# (app/smvsrecon.cc:43-46: six neighbours, output scale 1 by default; -o3;
+# portrait images; -S with --gamma-srgb, lib/stereo_view.cc:64-84)
+def _operating_point(oracle, tag, width, height, n_subs, min_scale, **kw):
+    from smvs_amd import synth, host
+    lighting = kw.pop("lighting", None)
+    inputs = synth.pipeline_inputs("sphere", width, height, n_subs, flen=1.2, lighting=lighting)
+    got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=min_scale, **kw)
+    want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=min_scale,
+                           **kw)
+    assert min(e["scale"] for e in want["log"]) == min_scale
+    assert_same_units(got["log"], want["log"], width, height, tag)
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert (want["depth"] > 0).mean() > 0.2
+    print("%s: depth rel. L2 %.2e" % (tag, _rel(got["depth"], want["depth"])))
+    assert _rel(got["depth"], want["depth"]) <= 1e-4
+    return got, want, inputs
+
+
+def test_optimize_default_operating_point_six_neighbours_scale_1(hip, oracle, oracle_threads):
+    """smvsrecon's defaults: six neighbours, optimisation down to scale 1
+    (patches of 2 x 2 pixels, one sample per pixel): 960x540, so that the
+    finest grid (479 x 269 patches, 129,600 nodes) is as large as the bench
+    workload's and uses the resident solver at its capacity."""
+    _operating_point(oracle, "defaults_6_neighbours_scale1_960x540", 960, 540, 6, 1)
+
+
+def test_optimize_output_scale_3_portrait(hip, oracle, oracle_threads):
+    """-o3 on a PORTRAIT image (height > width: fill_calibration's max(w, h),
+    the tile plans of a tall node grid), four neighbours."""
+    _operating_point(oracle, "scale3_portrait_720x1280", 720, 1280, 4, 3)
+
+
+def test_optimize_scale_1_portrait_five_neighbours(hip, oracle, oracle_threads):
+    """Scale 1 on a small portrait image with an odd neighbour count."""
+    _operating_point(oracle, "scale1_portrait_300x420", 300, 420, 5, 1)
+
+
+def test_optimize_shading_with_gamma_correction(hip, oracle, oracle_threads):
+    """-S --gamma-srgb (app/smvsrecon.cc:52, 110, 669): the main view's linear
+    image goes through gamma_correct_inv_srgb before it is desaturated into the
+    shading image (lib/stereo_view.cc:64-84; tests/golden/README.md M9 -- the
+    one path of StereoView no other test exercises).  The lighting fit and the
+    shading rows then see a different image than without the flag."""
+    rng = np.random.default_rng(77)
+    lighting = np.zeros(16); lighting[0] = 0.9
+    lighting[1:4] = rng.uniform(-0.2, 0.2, 3)
+    got, want, inputs = _operating_point(oracle, "shading_gamma_640x480", 640, 480, 3, 2,
+                                         lighting=lighting, use_shading=True,
+                                         gamma_correction=True)
+    assert got["lighting"] is not None and want["lighting"] is not None
+    assert _rel(got["lighting"], want["lighting"]) < 1e-3
+    # the flag changes the result (the test would pass vacuously otherwise)
+    from smvs_amd import host
+    plain = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=2,
+                          use_shading=True)
+    assert _rel(plain["lighting"], got["lighting"]) > 1e-3
+
+
 # ------------------------- configs[4] code path (views sharded, shading-aware)
 def test_config5_lighting_round_on_device_buffers(hip, oracle):
     """The --config 5 path of bench.py on one rank with two views in a

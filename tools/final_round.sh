@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): everything the round's profiles/ hold.
 # Usage: final_round.sh [round]
-R=${1:-r5}
+R=${1:-r6}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.txt 2>&1
@@ -11,7 +11,7 @@ timeout 900 bash tools/collect_profiles.sh $R > gpurun_out/${R}_collect.log 2>&1
 tail -3 gpurun_out/${R}_collect.log
 cp gpurun_out/prof_${R}/summary/traffic_${R}.json profiles/ 2>/dev/null
 # the batch logs of the whole-optimize() parity tests, device / oracle, one table
-cat gpurun_out/r5_units_configs*.txt gpurun_out/r5_units_sphere_960x540.txt gpurun_out/r5_units_sgm_shading_384x256.txt gpurun_out/r5_units_config5_round_robin_view*.txt > gpurun_out/${R}_parity_units.txt 2>/dev/null
+cat gpurun_out/units_*.txt > gpurun_out/${R}_parity_units.txt 2>/dev/null
 timeout 600 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 python - <<PY
 import json
