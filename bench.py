@@ -111,6 +111,7 @@ def run_steps(ctx, prob, steps, lighting=None):
 
 # ------------------------------------------ the Newton loops of one optimize()
 PATCH_FLOPS_FILE = os.path.join(ROOT, "profiles", "patch_flops_r6.json")
+SAMPLES_PER_PATCH = {0: 1, 1: 4, 2: 16, 3: 16, 4: 64, 5: 64, 6: 256}   # sampled pixels (gn_construct.hip)
 
 
 def scene_inputs(rank, small=False):
@@ -253,29 +254,47 @@ def loops_roofline(replay, steps, ms_per_step, with_peaks=True):
         return out
 
     lines = {}
-    # resident PCG: one launch per solve; algorithmic bytes = its one pass over
-    # the per-patch systems of the live patches + x and b of every node
+    # Resident PCG, one launch per solve.  `achieved` follows the contract:
+    # ALGORITHMIC bytes per launch -- SURVEY.md 8(d)'s per-unit figure for the PCG
+    # phase (bytes per node and CG iteration: the upper half of H, P and the
+    # vectors, what a streaming solver moves; 1,154 B with this repo's symmetric
+    # storage, the survey prices the full stencil at 1.66 KB) x the nodes x the
+    # iterations of the launch -- over the launch's duration.  The kernel holds H
+    # in registers, so it moves almost none of them (design_bytes_per_launch:
+    # its one pass over the per-patch systems + x and b) and the figure comes out
+    # ABOVE the HBM peak: what bounds the kernel is the latency of its one
+    # grid-wide exchange per iteration (frac_of_latency_floor).
     ms_k, cnt_k = tot.get("cg_resident", (0.0, 0))
     if cnt_k > 0:
+        cg_bytes_node = CG_BYTES["cg_spmv"] + CG_BYTES["cg_update"]
+        alg = sum(cg_bytes_node * b["nodes"] * b["cg_iterations"] for b in batches)
         byts = sum(RESIDENT_BYTES_PER_PATCH * b["active_patch_steps"]
                    + RESIDENT_BYTES_PER_NODE * b["nodes"] * b["kernels"]["cg_resident"][1]
                    for b in batches)
         its = sum(b["cg_iterations"] for b in batches)
         avg_s = 1e-3 * ms_k / cnt_k
-        ach = byts / cnt_k / avg_s / 1e9
+        ach = alg / cnt_k / avg_s / 1e9
+        moved = byts / cnt_k / avg_s / 1e9
         lines["cg_resident"] = dict(
             bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-            **hbm_fracs(ach), bytes_per_launch=int(byts / cnt_k), avg_us=round(1e6 * avg_s, 2),
+            **hbm_fracs(ach), bytes_per_launch=int(alg / cnt_k),
+            bytes_per_node_and_iteration=cg_bytes_node, avg_us=round(1e6 * avg_s, 2),
             launches=int(cnt_k), iterations_per_launch=round(its / cnt_k, 1),
+            design_bytes_per_launch=int(byts / cnt_k), design_GBps=round(moved, 1),
+            frac_of_what_the_design_moves=round(moved / HBM_PEAK_GBPS, 4),
             us_per_iteration_incl_prologue=round(1e3 * ms_k / max(its, 1), 2),
             latency_floor_us_per_iteration=round(1e6 * EXCHANGE_FLOOR_S, 2),
             frac_of_latency_floor=round(its * EXCHANGE_FLOOR_S / (1e-3 * ms_k), 4),
             note="whole PCG solve in one launch, H assembled into registers from the "
-                 "per-patch systems (%d B per live patch + %d B per node, read once): "
-                 "after that pass the kernel is bound by the latency of its one grid-wide "
-                 "exchange per iteration, not by HBM -- frac_of_latency_floor prices an "
-                 "iteration at two idle cross-CU hand-offs (MI355X_MICROARCH.md)"
-                 % (RESIDENT_BYTES_PER_PATCH, RESIDENT_BYTES_PER_NODE))
+                 "per-patch systems (%d B per live patch + %d B per node, read once = "
+                 "design_bytes_per_launch).  achieved / frac price the launch at the "
+                 "algorithmic bytes of SURVEY.md 8(d) (%d B per node and iteration x nodes x "
+                 "iterations): above 1 because a resident H is not re-read, NOT a claim of "
+                 "HBM utilisation -- the kernel's HBM traffic is design_GBps "
+                 "(frac_of_what_the_design_moves) and its bound is the latency of one "
+                 "two-hop grid-wide exchange per iteration: frac_of_latency_floor prices an "
+                 "iteration at two idle cross-CU hand-offs (MI355X_MICROARCH.md, 1.1 us each)"
+                 % (RESIDENT_BYTES_PER_PATCH, RESIDENT_BYTES_PER_NODE, cg_bytes_node))
     ms_k, cnt_k = tot.get("patch", (0.0, 0))
     if cnt_k > 0:
         flops = sum(flops_by_scale.get(b["scale"], FLOP_PER_PATCH) * b["active_patch_steps"]
@@ -293,6 +312,15 @@ def loops_roofline(replay, steps, ms_per_step, with_peaks=True):
             avg_us=round(1e6 * avg_s, 2), launches=int(cnt_k),
             flop_per_patch_by_scale={str(k): v for k, v in sorted(flops_by_scale.items())},
             flop_per_patch_source=flops_source,
+            frac_with_survey_flops=round(
+                sum(FLOP_PER_PATCH_SURVEY / 16.0 * SAMPLES_PER_PATCH.get(b["scale"], 16)
+                    * b["active_patch_steps"] for b in batches)
+                / cnt_k / avg_s / 1e12 / FP64_PEAK_TFLOPS, 4),
+            note="frac = FP64 flops the factored kernel EXECUTES (SQ counters per kernel "
+                 "form) over the peak: a pipe utilisation; SURVEY.md 8(d) prices the "
+                 "reference's unfactored rows at 0.50 MFLOP per 16-sample patch "
+                 "(frac_with_survey_flops, above the executed figure by the factor the "
+                 "6 x 6 reformulation saves)",
             frac_by_scale={k: round(v[0] / v[1] / 1e12 / FP64_PEAK_TFLOPS, 4)
                            for k, v in by.items() if v[1] > 0})
     # committed counter traffic of the dominant kernel (own rocprofv3 --pmc passes)
@@ -315,7 +343,29 @@ def loops_roofline(replay, steps, ms_per_step, with_peaks=True):
         for k, (ms, cnt) in b["kernels"].items():
             if cnt:
                 d["kernel_ms"][k] = round(d["kernel_ms"].get(k, 0.0) + ms, 3)
+    # T_min / T of the whole region, T_min = sum over the steps of
+    # max(F_construct / pi, B_construct / beta) + N_cg B_cg / beta with the measured
+    # per-batch patches, nodes and iterations
+    beta, pi = HBM_PEAK_GBPS * 1e9, FP64_PEAK_TFLOPS * 1e12
+    cgb = CG_BYTES["cg_spmv"] + CG_BYTES["cg_update"]
+    t_exec = t_survey = 0.0
+    for b in batches:
+        t_cg = b["cg_iterations"] * cgb * b["nodes"] / beta
+        b_con = b["active_patch_steps"] * BYTES_PER_PATCH / beta
+        t_exec += max(flops_by_scale.get(b["scale"], FLOP_PER_PATCH) * b["active_patch_steps"] / pi,
+                      b_con) + t_cg
+        t_survey += max(FLOP_PER_PATCH_SURVEY / 16.0 * SAMPLES_PER_PATCH.get(b["scale"], 16)
+                        * b["active_patch_steps"] / pi, b_con) + t_cg
+    region = dict(t_min_ms_executed_flops=round(1e3 * t_exec, 3),
+                  t_min_ms_survey_flops=round(1e3 * t_survey, 3),
+                  frac_executed_flops=round(1e3 * t_exec / ms_per_step, 4),
+                  frac_survey_flops=round(1e3 * t_survey / ms_per_step, 4),
+                  note="SURVEY.md 8(d)'s T_min / T for one pass: construction at the FP64 peak "
+                       "(executed flops of the factored kernel / the survey's 0.50 MFLOP per "
+                       "16-sample patch) + the PCG streamed from HBM at %d B per node and "
+                       "iteration; above 1 where the resident solver does not stream" % cgb)
     out = dict(kernel=name, traffic=traffic, traffic_source=traffic_source, kernels=kernels,
+               region_model=region,
                region_share={k: round(v[0] / max(busy_ms, 1e-9), 4) for k, v in tot.items() if v[1]},
                region_kernel_ms=round(busy_ms, 3), region_wall_ms=round(ms_per_step, 3),
                per_kernel=lines, by_scale=by_scale,

@@ -123,6 +123,17 @@ int smvs_ctx_upload_sub(smvs_ctx *ctx, int sub, int width, int height,
  * topology code; hess3 may be NULL (the main view keeps no Hessian). */
 int smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
     int channels, const uint8_t *bytes);
+/* The same without waiting for the transfer (StereoView::create x 9 at the
+ * start of a view's task, app/smvsrecon.cc:662-691, costs the reference
+ * nothing on the device; here it is 56 MB over PCIe): with `bytes` in
+ * page-locked memory (smvs_pinned_alloc) the DMA is enqueued on a copy stream
+ * of the context and the call returns at once; the byte -> float conversion
+ * runs where the image is first needed (smvs_ctx_set_scale converts view by
+ * view, so a view's blur and gradients overlap the next views' transfers).
+ * `bytes` must stay valid and unchanged until smvs_ctx_synchronize / the
+ * context's destruction.  Pageable memory: identical to smvs_ctx_upload_image. */
+int smvs_ctx_upload_image_async(smvs_ctx *ctx, int view, int width, int height,
+    int channels, const uint8_t *bytes);
 int smvs_ctx_set_scale(smvs_ctx *ctx, int scale);
 int smvs_ctx_download_planes(smvs_ctx *ctx, int view, float *grad2,
     float *hess3);

@@ -174,6 +174,16 @@ struct smvs_ctx {
     size_t pin_cap = 0;
     uint8_t *byte_stage = nullptr;  // device staging of smvs_ctx_upload_image
     size_t byte_stage_cap = 0;
+    // smvs_ctx_upload_image_async (scale.hip): the DMA of view v runs on a stream
+    // of its own into a staging buffer per view; `image_ready[v]` is recorded
+    // behind it, and the conversion to float is enqueued on the context's
+    // stream (behind a wait for that event) where the image is first needed
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t image_ready[SMVS_MAX_SUBS + 1] = { nullptr };
+    uint8_t *upload_stage[SMVS_MAX_SUBS + 1] = { nullptr };
+    size_t upload_stage_cap[SMVS_MAX_SUBS + 1] = { 0 };
+    uint32_t image_pending = 0;     // bit v: staged, not yet converted
+    uint32_t upload_stage_busy = 0; // bit v: a conversion from upload_stage[v] may be in flight
     // resident PCG (cg_resident.hip)
     double *res_work = nullptr;     // partial sums + barrier words
     double *res_zx = nullptr;       // [cap_nodes][4] z exchanged between workgroups
@@ -261,6 +271,11 @@ int pinned_pool_release(void);   // pool.hip -> buffers returned to the driver
 // Contents of the node / patch arrays are unspecified afterwards when the grid
 // grew.  Leaves has_surface untouched.
 int ctx_ensure_grid(smvs_ctx *ctx, int scale, int npx, int npy, int start_x, int start_y);
+// Images handed over by smvs_ctx_upload_image_async that have not been
+// converted yet: the wait for their DMA and the conversion are enqueued on the
+// context's stream (views: bit v = view v - 1 as in image_ok; every consumer of
+// ctx->images calls this for the views it reads).
+int ctx_materialise_images(smvs_ctx *ctx, uint32_t views);
 
 // hipMalloc that does not give up on memory the library itself is holding:
 // when the driver reports out-of-memory, the parked contexts and the idle

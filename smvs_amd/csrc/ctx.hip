@@ -220,6 +220,8 @@ void
 ctx_reset_for_reuse(smvs_ctx *ctx)
 {
     ctx->image_ok = ctx->planes_ok = 0;
+    ctx->image_pending = 0;
+    ctx->upload_stage_busy = 0;   // (the caller has synchronised the stream)
     ctx->sgm_resident = false;
     ctx->surf_depth_ok = false;
     ctx->has_cameras = ctx->has_surface = ctx->has_system = false;
@@ -324,6 +326,10 @@ smvs_ctx_destroy(smvs_ctx *ctx)
         return SMVS_OK;
     // park it for the next view of this geometry
     (void)set_device(ctx->device);
+    // (a DMA of smvs_ctx_upload_image_async nobody waited for reads the caller's
+    // buffer: it must have ended when this returns)
+    if (ctx->copy_stream != nullptr)
+        (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream != nullptr && hipStreamSynchronize(ctx->stream) == hipSuccess) {
         ctx_reset_for_reuse(ctx);
         // The pool is bounded by count.  What it holds goes back to the driver
@@ -374,8 +380,18 @@ ctx_free(smvs_ctx *ctx)
     if (ctx == nullptr)
         return SMVS_OK;
     (void)set_device(ctx->device);
+    if (ctx->copy_stream)
+        (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i <= SMVS_MAX_SUBS; ++i) {
+        if (ctx->upload_stage[i])
+            (void)hipFree(ctx->upload_stage[i]);
+        if (ctx->image_ready[i])
+            (void)hipEventDestroy(ctx->image_ready[i]);
+    }
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     void *bufs[] = { ctx->main_grad, ctx->main_shading, ctx->main_shading_grad,
         ctx->cams, ctx->subs_dev, ctx->nodes, ctx->node_valid, ctx->patch_valid,
         ctx->patch_vis, ctx->active, ctx->active_next, ctx->cg_mask, ctx->hermite_all,
@@ -448,7 +464,10 @@ smvs_ctx_synchronize(smvs_ctx *ctx)
 {
     SMVS_REQUIRE(ctx != nullptr, "null context");
     SMVS_HIP_CHECK(set_device(ctx->device));
+    if (ctx->copy_stream != nullptr)
+        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->copy_stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->upload_stage_busy = 0;
     return SMVS_OK;
 }
 

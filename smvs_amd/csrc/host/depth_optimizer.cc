@@ -242,6 +242,9 @@ DepthOptimizer::create_initial_surface(void)
     // lib/depth_optimizer.cc:35-51
     int const init_scale = (int)std::max(std::ceil(std::log2(
         main_view->get_width() * main_view->get_height() / 1.7e6) / 2) + 4, 4.0);
+    // (first of all: the nine image transfers are only enqueued, and run while
+    // the host converts the SGM map / projects the bundle below)
+    this->upload_images();
     if (opts.use_sgm) {
         FloatImage::Ptr init = main_view->get_sgm_depth();
         if (init == nullptr)
@@ -249,7 +252,6 @@ DepthOptimizer::create_initial_surface(void)
         // depthmap_bilateral_filter(init, main_view->get_image()) guided by
         // the main image on the device; the filtered map also stays there for
         // create_subview_surfaces (:463-466 splats the same map)
-        this->upload_images();
         if (!host_surgery) {
             // ... and for Surface::create: the nodes are initialised from it
             // where it lies (no 8 MB round trip, no host Surface)
@@ -323,13 +325,16 @@ void
 DepthOptimizer::upload_images(void)
 {
     if (!images_uploaded) {
+        // (asynchronous: the views' bytes are page-locked (pinned_images.cc) and
+        // outlive the optimizer; the nine transfers run on the context's copy
+        // stream under the first kernels that need them)
         ByteImage::ConstPtr mb = main_view->get_raw_bytes();
-        check(smvs_ctx_upload_image(ctx, -1, mb->width(), mb->height(),
-            mb->channels(), mb->begin()), "smvs_ctx_upload_image");
+        check(smvs_ctx_upload_image_async(ctx, -1, mb->width(), mb->height(),
+            mb->channels(), mb->begin()), "smvs_ctx_upload_image_async");
         for (std::size_t j = 0; j < sub_views.size(); ++j) {
             ByteImage::ConstPtr sb = sub_views[j]->get_raw_bytes();
-            check(smvs_ctx_upload_image(ctx, (int)j, sb->width(), sb->height(),
-                sb->channels(), sb->begin()), "smvs_ctx_upload_image");
+            check(smvs_ctx_upload_image_async(ctx, (int)j, sb->width(), sb->height(),
+                sb->channels(), sb->begin()), "smvs_ctx_upload_image_async");
         }
         if (opts.use_shading)
             check(smvs_ctx_upload_shading(ctx,

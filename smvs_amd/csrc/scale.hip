@@ -10,6 +10,8 @@
 // MVE's blur_gaussian / desaturate semantics are recalled [MVE-unverified].
 #include "common.h"
 
+#include <cstdlib>
+
 #include <cmath>
 #include <vector>
 
@@ -293,6 +295,7 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
         vi.c = channels;
     }
     ctx->image_ok &= ~(1u << (view + 1));
+    ctx->image_pending &= ~(1u << (view + 1));   // (this upload replaces one on its way)
     // (device staging owned by the context: no allocation per image; the
     // bytes cross PCIe from pinned memory)
     if (ctx->byte_stage_cap < n) {
@@ -315,6 +318,102 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
         return SMVS_ERR_HIP;
     }
     ctx->image_ok |= 1u << (view + 1);
+    return SMVS_OK;
+}
+
+// StereoView::create's byte_to_float_image without waiting for it: when `bytes`
+// is page-locked memory (smvs_pinned_alloc) the DMA is enqueued on the
+// context's copy stream into the view's own staging buffer and the call
+// returns; the conversion follows on the context's stream where the image is
+// first needed (ctx_materialise_images), behind an event -- the nine uploads
+// of a view overlap each other's conversion and the first scale's blur and
+// gradient kernels instead of alternating with them (round 5: 9 x (138 us of
+// DMA + 17 us of kernel), the GPU's compute idle for 1.3 ms per view).
+// `bytes` must stay valid and unchanged until the context has been
+// synchronised.  Pageable memory: the same as smvs_ctx_upload_image.
+extern "C" int
+smvs_ctx_upload_image_async(smvs_ctx *ctx, int view, int width, int height,
+    int channels, const uint8_t *bytes)
+{
+    SMVS_REQUIRE(ctx && bytes, "null argument");
+    SMVS_REQUIRE(view >= -1 && view < ctx->n_subs, "view index out of range");
+    SMVS_REQUIRE(width > 2 && height > 2 && (channels == 1 || channels == 3),
+        "bad image");
+    size_t const n = (size_t)width * height * channels;
+    if (n < ((size_t)1 << 20) || !host_pointer_is_pinned(bytes))
+        return smvs_ctx_upload_image(ctx, view, width, height, channels, bytes);
+    if (view == -1)
+        SMVS_REQUIRE(width == ctx->width && height == ctx->height,
+            "main image size differs from the context");
+    SMVS_HIP_CHECK(set_device(ctx->device));
+    int const v = view + 1;
+    smvs_ctx::ViewImage &vi = ctx->images[v];
+    int rc;
+    if (vi.w != width || vi.h != height || vi.c != channels || !vi.data) {
+        if ((rc = device_alloc(&vi.data, n)) != SMVS_OK)
+            return rc;
+        vi.w = width;
+        vi.h = height;
+        vi.c = channels;
+    }
+    ctx->image_ok &= ~(1u << v);
+    ctx->image_pending &= ~(1u << v);
+    if (ctx->upload_stage_cap[v] < n) {
+        ctx->upload_stage_cap[v] = 0;
+        if ((rc = device_alloc(&ctx->upload_stage[v], n)) != SMVS_OK)
+            return rc;
+        ctx->upload_stage_cap[v] = n;
+    }
+    // SMVS_UPLOAD_STREAM=same: the copies on the context's own stream (A/B)
+    static bool const same_stream = [] {
+        const char *e = std::getenv("SMVS_UPLOAD_STREAM");
+        return e != nullptr && e[0] == 's';
+    }();
+    if (same_stream) {
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->upload_stage[v], bytes, n, hipMemcpyHostToDevice,
+            ctx->stream));
+        hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+            dim3(256), 0, ctx->stream, ctx->upload_stage[v], vi.data, n);
+        SMVS_HIP_CHECK(hipGetLastError());
+        ctx->image_ok |= 1u << v;
+        return SMVS_OK;
+    }
+    if (ctx->copy_stream == nullptr)
+        SMVS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (ctx->image_ready[v] == nullptr)
+        SMVS_HIP_CHECK(hipEventCreateWithFlags(&ctx->image_ready[v], hipEventDisableTiming));
+    // (a conversion still reading this staging buffer: only a second upload
+    // of the same view before the first was read -- the copy then waits for the
+    // context's stream; the common case has nothing to wait for and must not be
+    // chained behind whatever the context's stream is doing)
+    if (ctx->upload_stage_busy & (1u << v)) {
+        SMVS_HIP_CHECK(hipEventRecord(ctx->image_ready[v], ctx->stream));
+        SMVS_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, ctx->image_ready[v], 0));
+    }
+    SMVS_HIP_CHECK(hipMemcpyAsync(ctx->upload_stage[v], bytes, n, hipMemcpyHostToDevice,
+        ctx->copy_stream));
+    SMVS_HIP_CHECK(hipEventRecord(ctx->image_ready[v], ctx->copy_stream));
+    ctx->image_pending |= 1u << v;
+    ctx->image_ok |= 1u << v;   // (every consumer materialises what it reads)
+    return SMVS_OK;
+}
+
+int
+smvs_hip::ctx_materialise_images(smvs_ctx *ctx, uint32_t views)
+{
+    uint32_t const todo = ctx->image_pending & views;
+    for (int v = 0; v <= SMVS_MAX_SUBS; ++v) {
+        if (!((todo >> v) & 1u))
+            continue;
+        smvs_ctx::ViewImage const &vi = ctx->images[v];
+        size_t const n = (size_t)vi.w * vi.h * vi.c;
+        SMVS_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->image_ready[v], 0));
+        hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+            dim3(256), 0, ctx->stream, ctx->upload_stage[v], vi.data, n);
+        SMVS_HIP_CHECK(hipGetLastError());
+        ctx->image_pending &= ~(1u << v);
+        ctx->upload_stage_busy |= 1u << v;   // until the context's stream has been waited for
+    }
     return SMVS_OK;
 }
 
@@ -352,6 +451,10 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
     bool const blur = !(std::fabs(sigma) < 0.1f);
 
     for (int v = 0; v <= ctx->n_subs && e == hipSuccess; ++v) {
+        // (an image still on its way: its conversion goes here, so that this
+        // view's blur and gradients run while the next views' DMA is in flight)
+        if ((rc = ctx_materialise_images(ctx, 1u << v)) != SMVS_OK)
+            return rc;
         smvs_ctx::ViewImage const &vi = ctx->images[v];
         size_t const n = (size_t)vi.w * vi.h * vi.c;
         if (n > ctx->blur_cap) {

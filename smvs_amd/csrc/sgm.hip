@@ -1652,6 +1652,9 @@ smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
     }
     SMVS_HIP_CHECK(set_device(ctx->device));
     int rc;
+    // (the guide image may still be on its way: smvs_ctx_upload_image_async)
+    if ((rc = ctx_materialise_images(ctx, 1u)) != SMVS_OK)
+        return rc;
     size_t const n = (size_t)ctx->width * ctx->height;
     size_t const n_low = (size_t)dm_w * dm_h;
     if (ctx->sgm_lowres_cap < n_low) {

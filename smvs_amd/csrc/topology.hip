@@ -1000,6 +1000,12 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
                 v - 1);
             return SMVS_ERR_STATE;
         }
+    {
+        // (images handed over by smvs_ctx_upload_image_async and not read yet)
+        int const rc = ctx_materialise_images(ctx, ~0u);
+        if (rc != SMVS_OK)
+            return rc;
+    }
     A->nodes = ctx->nodes;
     A->patch_valid = ctx->patch_valid;
     A->patch_vis = ctx->patch_vis;

@@ -107,8 +107,9 @@ reactivate_kernel(ReactivateArgs A)
     int const shift = 2 * A.ps_log2;
     int const per_block = shift >= 8 ? 1 : 256 >> shift;   // patches of this workgroup
     int const first_slot = (int)(((long long)blockIdx.x * blockDim.x) >> shift);
-    if (tid < per_block * 32) {
-        int const q = tid >> 5, k = tid & 31;
+    // (16 patches x 32 values at scale 2: two sweeps of the workgroup)
+    for (int item = tid; item < per_block * 32; item += 256) {
+        int const q = item >> 5, k = item & 31;
         int const slot = first_slot + q;
         int patch = A.num_patches;
         if (slot < live_count)

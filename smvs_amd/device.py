@@ -50,6 +50,9 @@ class ViewContext:
         if self.handle:
             self.lib.smvs_ctx_destroy(self.handle)
             self.handle = C.c_void_p()
+            for ptr in getattr(self, "_pinned", []):
+                self.lib.smvs_pinned_free(ptr)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -89,6 +92,26 @@ class ViewContext:
         h, w, c = img.shape
         check(self.lib.smvs_ctx_upload_image(self.handle, view, w, h, c,
                                              _p(img, _u8p)))
+        if not hasattr(self, "_image_shapes"):
+            self._image_shapes = {}
+        self._image_shapes[view] = (h, w)
+
+    def upload_image_async(self, view, img_u8):
+        """smvs_ctx_upload_image_async from page-locked memory: the image is
+        copied into a smvs_pinned_alloc buffer that this object keeps until
+        close(); the transfer and the conversion are only enqueued."""
+        img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        h, w, c = img.shape
+        ptr = C.c_void_p()
+        check(self.lib.smvs_pinned_alloc(C.c_size_t(img.size), C.byref(ptr)))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(ptr)
+        C.memmove(ptr, img.ctypes.data, img.size)
+        check(self.lib.smvs_ctx_upload_image_async(self.handle, view, w, h, c,
+                                                   C.cast(ptr, _u8p)))
         if not hasattr(self, "_image_shapes"):
             self._image_shapes = {}
         self._image_shapes[view] = (h, w)

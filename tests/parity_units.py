@@ -76,9 +76,18 @@ def cg_bound(entry, width, height):
     return max(2, -(-entry["cg_iterations"] // 10))
 
 
-def assert_same_units(got, want, width, height, tag):
+def assert_same_units(got, want, width, height, tag, drift_after_divergence=False):
     """got / want: batch logs of host.optimize / oracle.optimize.  Returns True
-    when every batch agrees in every unit exactly."""
+    when every batch agrees in every unit exactly.
+
+    drift_after_divergence: for operating points whose solves run INTO the
+    iteration limit (scale 1 at 960x540: the block-Jacobi PCG does not converge
+    in 200 iterations, so 'converged after 198' and 'stopped at 200' are both
+    roundings of the same solve).  Up to and including the first batch whose CG
+    iteration counts differ everything is held to the strict rule; from the next
+    batch on the surfaces differ by what 200 - 198 iterations leave, and the
+    valid patches / active patch-steps of a batch may then differ by
+    max(2, 1e-4 x count) -- scale, iteration and Newton steps stay identical."""
     text = table(got, want, width, height)
     print("%s\n%s" % (tag, text))
     try:
@@ -89,14 +98,22 @@ def assert_same_units(got, want, width, height, tag):
                     % (tag, text))
     except OSError:
         pass
-    assert control_flow(got) == control_flow(want), text
-    assert len(got) == len(want)
+    assert len(got) == len(want), text
+    if not drift_after_divergence:
+        assert control_flow(got) == control_flow(want), text
     exact = True
+    diverged = False
     for a, b in zip(got, want):
-        assert a["active_patch_steps"] == b["active_patch_steps"], text
+        assert (a["scale"], a["iter"], a["newton_steps"]) \
+            == (b["scale"], b["iter"], b["newton_steps"]), text
+        for key in ("valid_patches", "active_patch_steps"):
+            slack = max(2, int(1e-4 * b[key])) if (drift_after_divergence and diverged) else 0
+            assert abs(a[key] - b[key]) <= slack, text
+            exact = exact and a[key] == b[key]
         diff = abs(a["cg_iterations"] - b["cg_iterations"])
         assert diff <= cg_bound(b, width, height), text
         exact = exact and diff == 0
+        diverged = diverged or diff != 0
     total_got = sum(e["cg_iterations"] for e in got)
     total_want = sum(e["cg_iterations"] for e in want)
     assert abs(total_got - total_want) <= max(2, 0.03 * total_want), text

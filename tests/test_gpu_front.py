@@ -272,18 +272,40 @@ def test_full_size_view_of_config5_sgm_and_shading_matches_oracle(hip, oracle, o
 # (app/smvsrecon.cc:43-46: six neighbours, output scale 1 by default; -o3;
 # portrait images; -S with --gamma-srgb, lib/stereo_view.cc:64-84)
 def _operating_point(oracle, tag, width, height, n_subs, min_scale, **kw):
+    """Whole optimize() against the oracle at one operating point.  The batch
+    log must be identical in every unit up to and including the first batch
+    whose CG iteration counts differ (inside the written bound); behind such a
+    batch the two surfaces differ by what one more or fewer PCG iteration
+    leaves, a validity decision on its threshold can go the other way, and the
+    later batches are held to the written drift (tests/parity_units.py:
+    max(2, 1e-4 x count) patches) -- measured in round 6: 3 of 12,500 patches at
+    -o3 portrait after a 66 / 65 solve, 2 of 120,295 at scale 1 after solves
+    that ran into the iteration limit."""
     from smvs_amd import synth, host
     lighting = kw.pop("lighting", None)
+    kw_drift = kw.pop("drift_after_divergence", True)
     inputs = synth.pipeline_inputs("sphere", width, height, n_subs, flen=1.2, lighting=lighting)
     got = host.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=min_scale, **kw)
     want = oracle.optimize(inputs, regularization=0.01, num_iterations=5, min_scale=min_scale,
                            **kw)
     assert min(e["scale"] for e in want["log"]) == min_scale
-    assert_same_units(got["log"], want["log"], width, height, tag)
-    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    exact = assert_same_units(got["log"], want["log"], width, height, tag,
+                              drift_after_divergence=kw_drift)
     assert (want["depth"] > 0).mean() > 0.2
-    print("%s: depth rel. L2 %.2e" % (tag, _rel(got["depth"], want["depth"])))
-    assert _rel(got["depth"], want["depth"]) <= 1e-4
+    if exact or not kw_drift:
+        assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+        print("%s: depth rel. L2 %.2e" % (tag, _rel(got["depth"], want["depth"])))
+        assert _rel(got["depth"], want["depth"]) <= 1e-4
+    else:
+        # solves ended apart at the iteration limit (see assert_same_units): the
+        # masks may differ where a validity decision sat on its threshold, the
+        # common pixels to the bound written for a solve that ended apart
+        both = (got["depth"] > 0) & (want["depth"] > 0)
+        differ = ((got["depth"] > 0) != (want["depth"] > 0)).mean()
+        rel = _rel(got["depth"][both], want["depth"][both])
+        print("%s: solves ended apart at the iteration limit; masks differ on %.2e of the "
+              "pixels, depth rel. L2 on the common ones %.2e" % (tag, differ, rel))
+        assert differ <= 1e-4 and rel <= 5e-4
     return got, want, inputs
 
 
@@ -291,8 +313,13 @@ def test_optimize_default_operating_point_six_neighbours_scale_1(hip, oracle, or
     """smvsrecon's defaults: six neighbours, optimisation down to scale 1
     (patches of 2 x 2 pixels, one sample per pixel): 960x540, so that the
     finest grid (479 x 269 patches, 129,600 nodes) is as large as the bench
-    workload's and uses the resident solver at its capacity."""
-    _operating_point(oracle, "defaults_6_neighbours_scale1_960x540", 960, 540, 6, 1)
+    workload's and uses the resident solver at its capacity.  At scale 1 the
+    block-Jacobi PCG runs into its 200-iteration limit (device and oracle
+    alike: 200 / 200, 200 / 198, 200 / 189 in round 6's run), so the batches
+    behind the first solve that ended apart are held to the written drift
+    (tests/parity_units.py) instead of identity."""
+    _operating_point(oracle, "defaults_6_neighbours_scale1_960x540", 960, 540, 6, 1,
+                     drift_after_divergence=True)
 
 
 def test_optimize_output_scale_3_portrait(hip, oracle, oracle_threads):

@@ -464,6 +464,39 @@ def test_device_scale_space_is_bit_exact(hip, oracle, scale):
     ctx.close()
 
 
+def test_async_image_upload_gives_the_same_planes(hip, oracle):
+    """smvs_ctx_upload_image_async (page-locked source, DMA on the context's copy
+    stream, conversion where the image is first needed) against the
+    synchronous upload and the oracle: images of more than a megabyte (smaller
+    ones take the synchronous path by design), one of them replaced by a second
+    upload before it was ever read, set_scale twice (the second finds nothing
+    pending), planes bit-identical."""
+    rng = np.random.default_rng(11)
+    w, h = 800, 600
+    imgs = [rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(3)]
+    stale = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    ctx = hip.ViewContext(w, h, 2)
+    ctx.upload_image_async(-1, imgs[0])
+    ctx.upload_image_async(0, stale)        # never read: replaced below
+    ctx.upload_image_async(0, imgs[1])
+    ctx.upload_image_async(1, imgs[2])
+    for scale in (3, 2):
+        ctx.set_scale(scale)
+        for view, img in ((-1, imgs[0]), (0, imgs[1]), (1, imgs[2])):
+            g_ref, h_ref = oracle.scale_planes(img, scale)
+            g, hs = ctx.download_planes(view)
+            assert np.array_equal(g, g_ref), (scale, view)
+            if view >= 0:
+                assert np.array_equal(hs, h_ref), (scale, view)
+    # a synchronous upload over an asynchronous one
+    ctx.upload_image(1, imgs[0])
+    ctx.set_scale(2)
+    g, hs = ctx.download_planes(1)
+    g_ref, h_ref = oracle.scale_planes(imgs[0], 2)
+    assert np.array_equal(g, g_ref) and np.array_equal(hs, h_ref)
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json's full sizes (configs[1] / configs[2])
 # ---------------------------------------------------------------------------
