@@ -73,8 +73,11 @@ enum {
                      // the steps enqueued behind it change nothing
     I_SURF_VALID,    // valid patches of the device surface (surface.hip)
     I_SURF_CHANGED,  // patches filled / deleted by the last grid operation
-    I_NUM = 16
+    I_TOPO_PASS0 = 16,   // cut_boundaries passes enqueued ahead: {deleted, candidates} of
+                         // pass k at I_TOPO_PASS0 + 2 k (topology.hip), TOPO_AHEAD passes
+    I_NUM = 24
 };
+constexpr int TOPO_AHEAD = 4;
 
 struct SubPlanes {
     int width = 0, height = 0;
@@ -230,6 +233,8 @@ struct smvs_ctx {
     size_t topo_mse_list_cap = 0;
     double *topo_pix = nullptr;       // [H][W][3]: surface depth, d/dx, d/dy per pixel
     size_t topo_pix_cap = 0;
+    uint8_t *topo_pair_alive = nullptr;   // [P][n_subs]: verdict of the visibility test's
+    size_t topo_pair_cap = 0;             // geometric half (topo_visibility_kernel<1>)
 
     // grid surgery on the device (surface.hip)
     float *surf_depth = nullptr;       // [H][W] Surface::depth (surface.cc:46-50): the

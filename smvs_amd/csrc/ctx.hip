@@ -427,6 +427,8 @@ ctx_free(smvs_ctx *ctx)
         (void)hipFree(ctx->topo_mse_list);
     if (ctx->topo_pix)
         (void)hipFree(ctx->topo_pix);
+    if (ctx->topo_pair_alive)
+        (void)hipFree(ctx->topo_pair_alive);
     if (ctx->blur_tmp[0])
         (void)hipFree(ctx->blur_tmp[0]);
     if (ctx->blur_tmp[1])

@@ -177,6 +177,14 @@ struct TopoArgs {
     int exact_divisions;
     // SMVS_NCC_PAIRS=0: the NCC samples of a lane one after the other
     int ncc_pairs;
+    // the two halves of the visibility test as launches of their own
+    // (topo_visibility_kernel<1> / <2>): what the geometric half decided per
+    // (patch, neighbour), [num_patches][n_subs]
+    uint8_t *pair_alive;
+    // cut_boundaries passes enqueued ahead of their predecessor's count: a pass
+    // whose predecessor deleted at most 10 patches does nothing
+    // (`while (deleted > 10)`, depth_optimizer.cc:186-190)
+    const int *pass_gate;
 };
 
 __device__ __forceinline__ void
@@ -411,6 +419,18 @@ topo_pixel_surface_kernel(TopoArgs A)
 // (159 VGPRs: three waves per SIMD -- round 4: 192, two.  Launch bounds that
 // force 128 VGPRs and four waves put 116 bytes per lane into scratch:
 // 610 -> 762 us, measured)
+//
+// PART 0: the whole test in one launch (the default).  SMVS_VIS_SPLIT=1
+// (round 6, an experiment that did not pay: 3 % slower) runs the two halves
+// as launches of their own with the NCC on, PART 1 = the pass over the patch's pixels (borders,
+// z-buffer, warp anisotropy) leaving its verdict per (patch, neighbour) in
+// `pair_alive`, PART 2 = ncc_for_patch for the pairs that are still alive:
+// the same statements in the same order (one body, `if constexpr`), so the
+// masks are those of PART 0 bit for bit -- but each half is compiled for its
+// own registers: the waves of the fused kernel waited for memory half of
+// their life at three per SIMD (profiles/r5_visibility_counters.txt), and the
+// NCC half without the Jacobian's live range fits more of them.
+template <int PART>
 __global__ void __launch_bounds__(256, 2)
 topo_visibility_kernel(TopoArgs A)
 {
@@ -472,7 +492,7 @@ topo_visibility_kernel(TopoArgs A)
         worst = worst < ratio ? ratio : worst;
         return true;
     };
-    if (alive)
+    if (PART != 2 && alive)
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
             // depth and pixel derivatives of the surface (topo_pixel_surface_kernel)
@@ -485,13 +505,23 @@ topo_visibility_kernel(TopoArgs A)
             if (!go_on)
                 break;
         }
-    visible = group_all(visible, G, lane, red);
-    worst = group_max(worst, G, red);
-    alive = alive && visible && !(worst > 8.0);
+    if constexpr (PART != 2) {
+        visible = group_all(visible, G, lane, red);
+        worst = group_max(worst, G, red);
+        alive = alive && visible && !(worst > 8.0);
+    } else {
+        // (the verdict of the geometric half: the whole group reads one byte)
+        alive = alive && A.pair_alive[gid] != 0;
+    }
+    if constexpr (PART == 1) {
+        if (gl == 0 && p < A.num_patches)
+            A.pair_alive[gid] = alive ? 1 : 0;
+        return;
+    }
 
     // ncc_for_patch
     double ncc = 1.0;
-    if (A.use_ncc) {
+    if (PART != 1 && A.use_ncc) {
         int const flags = smvs_topo::ncc_flags(px, py, ps, mv.w, mv.h);
         const NccSample *tpl = A.ncc + A.ncc_off[flags];
         int const n = A.ncc_off[flags + 1] - A.ncc_off[flags];
@@ -768,6 +798,10 @@ topo_visibility_kernel(TopoArgs A)
 __global__ void __launch_bounds__(256)
 topo_mse_candidates_kernel(TopoArgs A)
 {
+    // (a pass enqueued ahead whose predecessor ended the loop: every thread of
+    // the launch reads the same word)
+    if (A.pass_gate != nullptr && *A.pass_gate <= 10)
+        return;
     int const p = blockIdx.x * blockDim.x + threadIdx.x;
     bool const in_range = p < A.num_patches;
     bool const valid = in_range && A.patch_valid[p];
@@ -809,6 +843,10 @@ topo_mse_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
     __shared__ double red[4];
+    // (a pass enqueued ahead whose predecessor ended the loop: every thread of
+    // the launch reads the same word)
+    if (A.pass_gate != nullptr && *A.pass_gate <= 10)
+        return;
     int const ps = A.ps;
     int const G = group_size(ps, MSE_WORKGROUP_FROM);
     int const gl = threadIdx.x & (G - 1);
@@ -899,6 +937,10 @@ topo_mse_kernel(TopoArgs A)
 __global__ void __launch_bounds__(256)
 topo_border_nodes_kernel(TopoArgs A)
 {
+    // (a pass enqueued ahead whose predecessor ended the loop: every thread of
+    // the launch reads the same word)
+    if (A.pass_gate != nullptr && *A.pass_gate <= 10)
+        return;
     int const n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= A.num_nodes)
         return;
@@ -921,6 +963,10 @@ __global__ void __launch_bounds__(256)
 topo_cut_patches_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
+    // (a pass enqueued ahead whose predecessor ended the loop: every thread of
+    // the launch reads the same word)
+    if (A.pass_gate != nullptr && *A.pass_gate <= 10)
+        return;
     int const p = blockIdx.x * blockDim.x + threadIdx.x;
     bool remove = false;
     if (p < A.num_patches && A.patch_valid_rw[p]) {
@@ -971,6 +1017,10 @@ topo_cut_patches_kernel(TopoArgs A)
 __global__ void __launch_bounds__(256)
 topo_cut_nodes_kernel(TopoArgs A)
 {
+    // (a pass enqueued ahead whose predecessor ended the loop: every thread of
+    // the launch reads the same word)
+    if (A.pass_gate != nullptr && *A.pass_gate <= 10)
+        return;
     int const n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= A.num_nodes || !A.node_valid_rw[n])
         return;
@@ -1033,6 +1083,8 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
         const char *pairs = std::getenv("SMVS_NCC_PAIRS");
         A->ncc_pairs = pairs != nullptr && std::atoi(pairs) == 0 ? 0 : 1;
     }
+    A->pair_alive = nullptr;
+    A->pass_gate = nullptr;
     A->ncc = ctx->topo_ncc;
     for (int i = 0; i < 33; ++i)
         A->ncc_off[i] = ctx->topo_ncc_off[i];
@@ -1175,8 +1227,31 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
     }
     long long const group = group_size(ctx->patchsize, VIS_WORKGROUP_FROM);
     long long const items = (long long)ctx->num_patches * ctx->n_subs * group;
-    hipLaunchKernelGGL(topo_visibility_kernel,
-        dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    // SMVS_VIS_SPLIT=1: the two halves as launches of their own.  Measured
+    // (profiles/r6_visibility_split.txt): 165 + 461 us against 606 us fused --
+    // the NCC half keeps its 159 VGPRs, and the fused kernel overlaps the two
+    // halves' waits; the default stays fused.
+    static bool const split = [] {
+        const char *e = std::getenv("SMVS_VIS_SPLIT");
+        return e != nullptr && e[0] == '1';
+    }();
+    if (use_ncc && split) {
+        size_t const pairs = (size_t)ctx->num_patches * ctx->n_subs;
+        if (pairs > ctx->topo_pair_cap) {
+            ctx->topo_pair_cap = 0;
+            if ((rc = device_alloc(&ctx->topo_pair_alive, pairs)) != SMVS_OK)
+                return rc;
+            ctx->topo_pair_cap = pairs;
+        }
+        A.pair_alive = ctx->topo_pair_alive;
+        hipLaunchKernelGGL(topo_visibility_kernel<1>,
+            dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+        hipLaunchKernelGGL(topo_visibility_kernel<2>,
+            dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    } else {
+        hipLaunchKernelGGL(topo_visibility_kernel<0>,
+            dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    }
     SMVS_HIP_CHECK(hipGetLastError());
     if (patch_vis_out == nullptr)
         return SMVS_OK;   // (the masks stay on the device: surface.hip)
@@ -1293,32 +1368,53 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     int total = 0;
     int deleted = 11;
     bool const trace = std::getenv("SMVS_TOPO_TRACE") != nullptr;
-    while (deleted > 10) {   // depth_optimizer.cc:186-190, 323-337
-        static_assert(I_TOPO_CANDIDATES == I_TOPO_DELETED + 1, "cleared together");
-        SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_TOPO_DELETED, 0,
-            2 * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(topo_border_nodes_kernel,
-            dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
-            ctx->stream, A);
-        int const mrc = launch_patch_mse(ctx, A, true);
-        if (mrc != SMVS_OK)
-            return mrc;
-        hipLaunchKernelGGL(topo_cut_patches_kernel,
-            dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0,
-            ctx->stream, A);
-        hipLaunchKernelGGL(topo_cut_nodes_kernel,
-            dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
-            ctx->stream, A);
+    // `while (deleted > 10) deleted = cut_boundaries();` (depth_optimizer.cc:
+    // 186-190, 323-337) with the passes enqueued TOPO_AHEAD at a time: pass k + 1
+    // is gated on pass k's count ON THE DEVICE (its kernels leave at once when
+    // that count is <= 10), and the host reads the counts of the whole chunk
+    // with one synchronisation.  Round 5 synchronised after every pass -- a call
+    // is three passes on average, 24 passes and 24 round trips per view; an
+    // enqueued pass that turns out not to be needed costs five empty launches
+    // (~15 us), a round trip 45-60 us of an idle GPU.  SMVS_TOPO_AHEAD=1: one
+    // pass per synchronisation (A/B).
+    static int const ahead = [] {
+        const char *e = std::getenv("SMVS_TOPO_AHEAD");
+        int const v = e != nullptr ? std::atoi(e) : TOPO_AHEAD;
+        return v < 1 ? 1 : (v > TOPO_AHEAD ? TOPO_AHEAD : v);
+    }();
+    while (deleted > 10) {
+        SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_TOPO_PASS0, 0,
+            2 * TOPO_AHEAD * sizeof(int), ctx->stream));
+        for (int k = 0; k < ahead; ++k) {
+            TopoArgs P = A;
+            P.deleted = ctx->status + I_TOPO_PASS0 + 2 * k;
+            P.mse_count = ctx->status + I_TOPO_PASS0 + 2 * k + 1;
+            P.pass_gate = k == 0 ? nullptr : ctx->status + I_TOPO_PASS0 + 2 * (k - 1);
+            hipLaunchKernelGGL(topo_border_nodes_kernel,
+                dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
+                ctx->stream, P);
+            int const mrc = launch_patch_mse(ctx, P, true);
+            if (mrc != SMVS_OK)
+                return mrc;
+            hipLaunchKernelGGL(topo_cut_patches_kernel,
+                dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0,
+                ctx->stream, P);
+            hipLaunchKernelGGL(topo_cut_nodes_kernel,
+                dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0,
+                ctx->stream, P);
+        }
         SMVS_HIP_CHECK(hipGetLastError());
-        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host + I_TOPO_DELETED,
-            ctx->status + I_TOPO_DELETED, 2 * sizeof(int), hipMemcpyDeviceToHost,
+        SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host + I_TOPO_PASS0,
+            ctx->status + I_TOPO_PASS0, 2 * TOPO_AHEAD * sizeof(int), hipMemcpyDeviceToHost,
             ctx->stream));
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        deleted = ctx->status_host[I_TOPO_DELETED];
-        total += deleted;
-        if (trace)
-            std::fprintf(stderr, "[smvs topo] cut pass: %d of %d patches evaluated, %d deleted\n",
-                ctx->status_host[I_TOPO_CANDIDATES], ctx->num_patches, deleted);
+        for (int k = 0; k < ahead && deleted > 10; ++k) {
+            deleted = ctx->status_host[I_TOPO_PASS0 + 2 * k];
+            total += deleted;
+            if (trace)
+                std::fprintf(stderr, "[smvs topo] cut pass: %d of %d patches evaluated, %d deleted\n",
+                    ctx->status_host[I_TOPO_PASS0 + 2 * k + 1], ctx->num_patches, deleted);
+        }
     }
     if (patch_valid_out != nullptr)
         SMVS_HIP_CHECK(hipMemcpyAsync(patch_valid_out, ctx->patch_valid,

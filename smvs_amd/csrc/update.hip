@@ -65,21 +65,16 @@ struct ReactivateArgs {
 // One thread per (patch, full-resolution pixel): project with the old and
 // the updated nodes into every visible neighbour (pixel coordinates WITHOUT
 // the +0.5 convention, depth_optimizer.cc:669-672).
-//
-// A workgroup's 256 pixels belong to at most 16 patches (scale 2; one patch
-// from scale 4 on).  Their corner nodes and deltas -- 32 doubles per patch --
-// are staged in LDS once per workgroup by the first 32 threads per patch
-// (rounds 1-5: every pixel thread loaded its patch's 32 doubles itself, 256 B
-// per pixel through the vector L1: 530 MB per launch at every scale, which is
-// what the kernel's 20-26 us were).  The arithmetic per pixel is unchanged.
+// (Round 6 measured a variant that stages the 32 doubles of a workgroup's
+// <= 64 patches in LDS instead of loading them per pixel thread -- 256 B per
+// pixel through the vector L1 looked like the bound: 23.5 / 27.9 us against
+// 26.4 us on three boxes, i.e. nothing outside the box-to-box spread; the
+// kernel is bound by its ~350 vector instructions per pixel (176 of them
+// FP64), not by those loads.  Not kept.)
 __global__ void __launch_bounds__(256)
 reactivate_kernel(ReactivateArgs A)
 {
-    __shared__ double s_theta[16][32];   // per patch: nodes [4][4], then deltas [4][4]
-    __shared__ int s_patch[16];          // patch id, or -1: nothing to evaluate
-    __shared__ uint32_t s_vis[16];
-    int const tid = (int)threadIdx.x;
-    long long const gid0 = (long long)blockIdx.x * blockDim.x + tid;
+    long long const gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     // the pipelined Newton loop: the loop has already ended / the solver of
     // this step gave up (finish_step_kernel reports it)
     if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
@@ -104,55 +99,29 @@ reactivate_kernel(ReactivateArgs A)
     // (measured: one thread per 16-pixel chunk, loading the nodes once per
     // chunk, is slower -- 40 instead of 25 us: too few waves to hide the
     // latency of its serial pixels)
-    int const shift = 2 * A.ps_log2;
-    int const per_block = shift >= 8 ? 1 : 256 >> shift;   // patches of this workgroup
-    int const first_slot = (int)(((long long)blockIdx.x * blockDim.x) >> shift);
-    // (16 patches x 32 values at scale 2: two sweeps of the workgroup)
-    for (int item = tid; item < per_block * 32; item += 256) {
-        int const q = item >> 5, k = item & 31;
-        int const slot = first_slot + q;
-        int patch = A.num_patches;
-        if (slot < live_count)
-            patch = A.live_list != nullptr ? A.live_list[slot] : slot;
-        bool evaluate = false;
-        double value = 0.0;
-        if (patch < A.num_patches && A.patch_valid[patch]) {
-            int const ix = patch % A.npx, iy = patch / A.npx;
-            int const n00 = iy * A.stride + ix;
-            int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
-            evaluate = (A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
-                | A.active[ids[3]]) != 0;
-            if (evaluate) {
-                // w1 - w0 is the patch evaluated on the node deltas (the patch
-                // is linear in its nodes)
-                int const n = (k >> 2) & 3;
-                const double *src = k < 16 ? A.nodes : A.x;
-                value = src[4 * (size_t)ids[n] + (k & 3)];
-            }
-        }
-        s_theta[q][k] = value;
-        if (k == 0) {
-            s_patch[q] = evaluate ? patch : -1;
-            s_vis[q] = evaluate ? A.patch_vis[patch] : 0u;
-        }
-    }
-    __syncthreads();
-    int const q = shift >= 8 ? 0 : tid >> shift;
-    int const pid = (int)(gid0 & (long long)((1 << shift) - 1));
-    int const patch = s_patch[q];
+    int const slot = (int)(gid0 >> (2 * A.ps_log2));
+    int const pid = (int)(gid0 & (long long)((1 << (2 * A.ps_log2)) - 1));
+    int patch = A.num_patches;
+    if (slot < live_count)
+        patch = A.live_list != nullptr ? A.live_list[slot] : slot;
     double sum = 0.0, cnt = 0.0;
-    if (patch >= 0) {
+    if (patch < A.num_patches && A.patch_valid[patch]) {
         int const ix = patch % A.npx, iy = patch / A.npx;
         int const n00 = iy * A.stride + ix;
         int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
-        {
+        if ((A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
+            | A.active[ids[3]]) != 0) {
+            // w1 - w0 is the patch evaluated on the node deltas (the patch
+            // is linear in its nodes)
             double th0[16], thd[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                th0[k] = s_theta[q][k];
-                thd[k] = s_theta[q][16 + k];
-            }
-            uint32_t const vis = s_vis[q];
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    th0[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
+                    thd[4 * n + k] = A.x[4 * (size_t)ids[n] + k];
+                }
+            uint32_t const vis = A.patch_vis[patch];
             double const th2 = A.threshold * A.threshold;
             bool moved = false;
             int const ci = pid & (A.ps - 1), cj = pid >> A.ps_log2;
@@ -361,6 +330,19 @@ finish_step_kernel(FinishArgs A)
                 && (flag | f[c + 1] | f[c + A.stride] | f[c + A.stride + 1]) != 0;
         }
     }
+    // What the publishing thread reports besides the counts was written by
+    // earlier launches of the stream: asked for here, all at once, instead of
+    // one dependent round trip after the other behind the atomics (a launch of
+    // ONE workgroup took 8.5 us, most of it that chain).
+    int pre_active_patches = 0, pre_initial = 0, pre_iter = 0;
+    double pre_sum_diff = 0.0, pre_count_diff = 0.0;
+    if (threadIdx.x == 0) {
+        pre_active_patches = A.status[I_ACTIVE_PATCHES];
+        pre_initial = A.status[I_NUM_INITIAL];
+        pre_iter = A.status[I_ITER];
+        pre_sum_diff = A.scalars[S_SUMDIFF];
+        pre_count_diff = A.scalars[S_COUNT_DIFF];
+    }
     constexpr int WAVES = FINISH_THREADS / 64;
     __shared__ int wave_cnt[WAVES];
     __shared__ int base;
@@ -423,10 +405,15 @@ finish_step_kernel(FinishArgs A)
             : (int)((seen >> 24) & 0xFFFFFFull);
         A.counter[0] = 0ull;   // (nobody else touches them any more) for the next launch
         A.counter[1] = 0ull;
+        // (the publishing workgroup is whichever arrives last; thread 0 of
+        // every workgroup has asked for the same words)
+        int active_patches = pre_active_patches, initial = pre_initial;
         if (begin) {
             A.status[I_NUM_INITIAL] = num_active;
             A.status[I_STEP_ABORT] = 0;
             A.status[I_ACTIVE_PATCHES] = 0;
+            active_patches = 0;
+            initial = num_active;
         }
         A.status[I_NAN] = skip ? 1 : 0;
         A.status[I_NUM_ACTIVE] = num_active;
@@ -435,24 +422,24 @@ finish_step_kernel(FinishArgs A)
             __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(A.host_words + 2, skip ? 1 : 0, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(A.host_words + 3, A.status[I_ACTIVE_PATCHES],
+        __hip_atomic_store(A.host_words + 3, active_patches,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(A.host_words + 4, next_live, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
-        double const sum_diff = A.scalars[S_SUMDIFF];
-        double const count_diff = A.scalars[S_COUNT_DIFF];
+        double const sum_diff = pre_sum_diff;
+        double const count_diff = pre_count_diff;
         // does the loop go on?  (depth_optimizer.cc:219-220, 267-268, 277-288;
         // the step limit is the host's business)
         bool stop = skip;
         if (A.full_optimization && !begin)
             stop = stop || sum_diff / count_diff < A.full_opt_threshold;
         else
-            stop = stop || !(num_active > A.status[I_NUM_INITIAL] / 20);
+            stop = stop || !(num_active > initial / 20);
         if (A.check_stop || begin)
             A.status[I_STOP] = stop ? 1 : 0;
         __hip_atomic_store(A.host_words + 5, 0, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(A.host_words + 6, begin ? 0 : A.status[I_ITER], __ATOMIC_RELAXED,
+        __hip_atomic_store(A.host_words + 6, begin ? 0 : pre_iter, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(A.host_words + 7, stop ? 1 : 0, __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_SYSTEM);

