@@ -2096,6 +2096,7 @@ cg_resident_kernel(ResArgs A)
                 break;
             stamp(k, 3);
             skew(k, 2, 0);
+            sweep_mark(22, -1);      // per wave: the totals are in, the update starts
             double const dq = v8[0], rq = v8[1], qq = v8[2], s1 = v8[3], wq = v8[4],
                 dr = v8[5], rr = v8[6];
             // z.r of the current vectors, summed directly like r.r (d_1 = z_0:
@@ -2198,6 +2199,7 @@ cg_resident_kernel(ResArgs A)
                 }
             }
             stamp(k, 4);
+            sweep_mark(23, -1);      // per wave: own node (and, lanes < ring, halo node) updated
             xbr = new_xbr;
             st.rr = new_zr;
             st.q0 = Q1;

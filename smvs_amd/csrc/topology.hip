@@ -1369,17 +1369,18 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
     int deleted = 11;
     bool const trace = std::getenv("SMVS_TOPO_TRACE") != nullptr;
     // `while (deleted > 10) deleted = cut_boundaries();` (depth_optimizer.cc:
-    // 186-190, 323-337) with the passes enqueued TOPO_AHEAD at a time: pass k + 1
-    // is gated on pass k's count ON THE DEVICE (its kernels leave at once when
-    // that count is <= 10), and the host reads the counts of the whole chunk
-    // with one synchronisation.  Round 5 synchronised after every pass -- a call
-    // is three passes on average, 24 passes and 24 round trips per view; an
-    // enqueued pass that turns out not to be needed costs five empty launches
-    // (~15 us), a round trip 45-60 us of an idle GPU.  SMVS_TOPO_AHEAD=1: one
-    // pass per synchronisation (A/B).
+    // 186-190, 323-337).  The passes CAN be enqueued ahead, SMVS_TOPO_AHEAD=2..4
+    // at a time: pass k + 1 is gated on pass k's count on the device (its
+    // kernels leave at once when that count is <= 10) and the host reads the
+    // counts of the whole chunk with one synchronisation.  Measured in round 6
+    // (profiles/r6_cut_passes_ahead.txt): four ahead is SLOWER, a warm optimize()
+    // 18.5 -> 19.4 ms with SGM and 30.9 -> 34.0 ms without -- most calls end
+    // after their first pass (24 passes in ~20 calls per view), and the 118
+    // launches that then do nothing cost more than the round trips they save.
+    // The default is one pass per synchronisation, as in round 5.
     static int const ahead = [] {
         const char *e = std::getenv("SMVS_TOPO_AHEAD");
-        int const v = e != nullptr ? std::atoi(e) : TOPO_AHEAD;
+        int const v = e != nullptr ? std::atoi(e) : 1;
         return v < 1 ? 1 : (v > TOPO_AHEAD ? TOPO_AHEAD : v);
     }();
     while (deleted > 10) {

@@ -43,11 +43,13 @@ for block in open(path).read().split("solve")[1:]:
               % os.environ.get("SMVS_CG_TRACE_WG", "0"))
         # stamps 16 .. 21 of the kernel: start, product done, sums formed, rim's stores issued (before the
         # arithmetic of the sums), partial sums in LDS, (the wave that stores the sums) all eight waves' seen
-        print("    wave   start  product  rim stores issued  sums formed  partial sums in LDS  all partial sums seen")
+        print("    wave   start  product  rim stores issued  sums formed  partial sums in LDS  all partial sums seen"
+              "  totals in  update done")
         cell = lambda x: "%6.2f" % ((x - t0) / 100.0) if x > 0 else "     -"
         for w in waves:
-            print("    %4d  %s  %s  %s            %s       %s               %s"
-                  % (w[0], cell(w[1]), cell(w[2]), cell(w[4]), cell(w[3]), cell(w[5]), cell(w[6])))
+            print("    %4d  %s  %s  %s            %s       %s               %s              %s     %s"
+                  % (w[0], cell(w[1]), cell(w[2]), cell(w[4]), cell(w[3]), cell(w[5]), cell(w[6]),
+                     cell(w[7]), cell(w[8])))
     if len(skew) and skew[:, 1].min() > 0:
         t0 = skew[:, 1].min()
         print("  iteration 5 over the %d workgroups, us after the first one started it:" % len(skew))

@@ -12,11 +12,11 @@ tail -3 gpurun_out/${R}_collect.log
 cp gpurun_out/prof_${R}/summary/traffic_${R}.json profiles/ 2>/dev/null
 # the batch logs of the whole-optimize() parity tests, device / oracle, one table
 cat gpurun_out/units_*.txt > gpurun_out/${R}_parity_units.txt 2>/dev/null
-timeout 600 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
+timeout 900 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${R}_bench_default.json"))
-print("bench", d["value"], d["ms_per_step"], d["roofline"]["step_frac"], d["cpu_baseline"])
+print("bench", d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["cpu_baseline"]["value"])
 print({k: v for k, v in d["secondary"]["views_per_s"]["per_gpu"].items()} if "views_per_s" in d.get("secondary", {}) else d.get("secondary"))
 PY
 timeout 300 python bench.py --workload optimize > gpurun_out/${R}_bench_optimize.json 2>> gpurun_out/${R}_bench_default.err
@@ -36,4 +36,5 @@ for mode in "" "--sgm"; do
   rm -rf gpurun_out/${R}_$tagname
   head -3 gpurun_out/${R}_optimize_timeline_${tagname}.txt
 done
+(timeout 300 python tools/upload_overlap.py) > gpurun_out/${R}_upload_overlap.txt 2>&1; tail -2 gpurun_out/${R}_upload_overlap.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
