@@ -161,8 +161,21 @@ launch_blur_ks(hipStream_t stream, const float *in, float *tmp, float *out, int 
     else
         hipLaunchKernelGGL((blur_x_kernel<3, KS>), dim3(bx, (unsigned)h), dim3(256), 0,
             stream, in, tmp, w, h, taps);
+    // The y pass re-reads every input row for the 2 KS / BLUR_ROWS + 1 row blocks
+    // it is a tap of; the reuse has to happen in an L2, and each XCD has its own.
+    // Workgroups go to the XCDs round robin by linear id (x fastest): with the
+    // 23 column blocks of a 1920 x 3 row, vertically adjacent row blocks landed
+    // on different XCDs and the kernel fetched 8 x its input (225 MB at KS = 23,
+    // profiles/r6_hbm_traffic.txt).  A row of the grid padded to a multiple of 8
+    // keeps a column of blocks on ONE XCD (the padding blocks leave at once).
+    // SMVS_BLUR_XCD=0: unpadded (A/B).
+    static bool const pad = [] {
+        const char *e = std::getenv("SMVS_BLUR_XCD");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    unsigned const by = pad ? (bx + 7u) & ~7u : bx;
     hipLaunchKernelGGL(blur_y_kernel<KS>,
-        dim3(bx, (unsigned)((h + BLUR_ROWS - 1) / BLUR_ROWS)), dim3(256), 0, stream, tmp,
+        dim3(by, (unsigned)((h + BLUR_ROWS - 1) / BLUR_ROWS)), dim3(256), 0, stream, tmp,
         out, w * c, h, taps);
 }
 
@@ -496,7 +509,11 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
         }
         {
             ScopedKernelTimer timer(ctx, SMVS_K_MISC);
-            hipLaunchKernelGGL(gradients_kernel, dim3((vi.w + 255) / 256, vi.h),
+            // (a row of the grid is a multiple of 8 workgroups, so that the three
+            // rows a window spans meet in ONE XCD's L2 -- see launch_blur_ks; at
+            // w = 1920 the 8 column blocks happen to be that already)
+            hipLaunchKernelGGL(gradients_kernel,
+                dim3((((unsigned)vi.w + 255u) / 256u + 7u) & ~7u, vi.h),
                 dim3(256), 0, ctx->stream, src, vi.w, vi.h, vi.c, fit, grad, hess);
         }
         e = hipGetLastError();

@@ -217,13 +217,22 @@ for_each_index(F &f, std::integer_sequence<int, I...>)
 __global__ void __launch_bounds__(256)
 cost_packed_kernel(const uint8_t *__restrict__ warped,
     const unsigned long long *__restrict__ main_census, int w, int h, int D,
-    uint8_t *__restrict__ cost)
+    uint8_t *__restrict__ cost, int xcd_bands)
 {
     constexpr int TW = CP_W + 8;
     __shared__ uint8_t tile[(CP_H + 6) * TW * CP_D];
     int const tiles_x = (w + CP_W - 1) / CP_W;
-    int const x0 = (blockIdx.x % tiles_x) * CP_W;
-    int const y0 = (blockIdx.x / tiles_x) * CP_H;
+    // Tiles are dealt to the XCDs in contiguous bands (round 6): a tile stages a
+    // (16 + 8) x (8 + 6) window, 2.6 x its own pixels, and with neighbouring tiles
+    // on different XCDs (workgroups go round robin) that halo came from HBM every
+    // time: 178 MB read per launch for a 66 MB volume (profiles/r6_sgm_counters.txt).
+    // The launch is padded to eight bands of equal length.
+    unsigned const band = gridDim.x >> 3;
+    unsigned const tile_id = xcd_bands ? (blockIdx.x & 7u) * band + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile_id >= (unsigned)(tiles_x * ((h + CP_H - 1) / CP_H)))
+        return;
+    int const x0 = (int)(tile_id % (unsigned)tiles_x) * CP_W;
+    int const y0 = (int)(tile_id / (unsigned)tiles_x) * CP_H;
     int const dbase = blockIdx.y * CP_D;
     int const tid = threadIdx.x;
 
@@ -1250,10 +1259,16 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
             const char *e = std::getenv("SMVS_SGM_COST");
             return e != nullptr && e[0] == 't';
         }();
+        // (SMVS_SGM_XCD=0: tiles in plain order, rounds 1-5; A/B)
+        static bool const bands = [] {
+            const char *e = std::getenv("SMVS_SGM_XCD");
+            return !(e != nullptr && e[0] == '0');
+        }();
         if ((num_steps & 3) == 0 && !force_tiled)
             hipLaunchKernelGGL(cost_packed_kernel,
-                dim3(tiles, (num_steps + CP_D - 1) / CP_D), dim3(256), 0, stream,
-                B.warped, B.census, w, h, num_steps, B.cost);
+                dim3(bands ? ((tiles + 7) / 8) * 8 : tiles, (num_steps + CP_D - 1) / CP_D),
+                dim3(256), 0, stream, B.warped, B.census, w, h, num_steps, B.cost,
+                bands ? 1 : 0);
         else
             hipLaunchKernelGGL(cost_tiled_kernel,
                 dim3(tiles, (num_steps + CT_D - 1) / CT_D), dim3(256), 0, stream,

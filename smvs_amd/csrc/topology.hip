@@ -442,7 +442,16 @@ topo_visibility_kernel(TopoArgs A)
     int const g_log2 = 31 - __clz(G);           // G = 1 << g_log2
     int const gl = threadIdx.x & (G - 1);     // lane inside the group
     // (group index < num_patches * n_subs: 32 bits)
-    unsigned const gid = (unsigned)(((unsigned long long)blockIdx.x * blockDim.x
+    // (Round 6 measured two other orders of the groups, because the kernel
+    // fetches 1,007 MB per call at 1920 x 1080 for ~340 MB of planes
+    // (profiles/r6_hbm_traffic.txt): neighbour-major -- the groups in flight read
+    // ONE neighbour's image -- and the workgroups dealt to the XCDs in contiguous
+    // bands of the patch grid, as the patch kernel's are.  Neither changed the
+    // traffic (1,007 MB) or the time (610 / 623 against 605-611 us): the fetches are
+    // 12-byte taps and 4-byte z-buffer cells out of 128-byte lines, not lines
+    // fetched by several XCDs.  Plain order.)
+    unsigned const vb = blockIdx.x;
+    unsigned const gid = (unsigned)(((unsigned long long)vb * blockDim.x
         + threadIdx.x) >> g_log2);
     int const p = (int)(gid / (unsigned)A.n_subs);
     int const s = (int)(gid - (unsigned)p * (unsigned)A.n_subs);
@@ -511,7 +520,7 @@ topo_visibility_kernel(TopoArgs A)
         alive = alive && visible && !(worst > 8.0);
     } else {
         // (the verdict of the geometric half: the whole group reads one byte)
-        alive = alive && A.pair_alive[gid] != 0;
+        alive = alive && A.pair_alive[gid] != 0;   // (alive implies gid in range)
     }
     if constexpr (PART == 1) {
         if (gl == 0 && p < A.num_patches)
@@ -1085,6 +1094,7 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
     }
     A->pair_alive = nullptr;
     A->pass_gate = nullptr;
+
     A->ncc = ctx->topo_ncc;
     for (int i = 0; i < 33; ++i)
         A->ncc_off[i] = ctx->topo_ncc_off[i];
@@ -1217,7 +1227,9 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
             zw = std::max(zw, ctx->images[1 + s].w + 1);
             zh = std::max(zh, ctx->images[1 + s].h + 1);
         }
-        hipLaunchKernelGGL(topo_dilate_kernel, dim3((zw + 255) / 256,
+        // (column blocks padded to a multiple of 8: vertically adjacent row blocks
+        // then share an XCD's L2, csrc/scale.hip launch_blur_ks)
+        hipLaunchKernelGGL(topo_dilate_kernel, dim3((((unsigned)zw + 255u) / 256u + 7u) & ~7u,
             (zh + DILATE_ROWS - 1) / DILATE_ROWS, ctx->n_subs), dim3(256), 0, ctx->stream, A);
     }
     {

@@ -179,6 +179,17 @@ class ViewContext:
     def restore_nodes(self):
         check(self.lib.smvs_ctx_restore_nodes(self.handle))
 
+    def clone_loop_state(self):
+        """smvs_ctx_clone_loop_state: a second context holding what this one's
+        Newton loop reads now (planes, cameras, surface, masks), nodes saved."""
+        other = ViewContext.__new__(ViewContext)
+        other.lib = self.lib
+        other.width, other.height, other.n_subs = self.width, self.height, self.n_subs
+        other.handle = C.c_void_p()
+        check(self.lib.smvs_ctx_clone_loop_state(self.handle, C.byref(other.handle)))
+        other.num_nodes, other.num_patches = self.num_nodes, self.num_patches
+        return other
+
     # ------------------------------------------------------------ GN step
     def gn_construct(self, regularization, light_reg=0.0, lighting=None):
         lt = _f64(lighting) if lighting is not None else None

@@ -464,6 +464,34 @@ def test_device_scale_space_is_bit_exact(hip, oracle, scale):
     ctx.close()
 
 
+def test_cloned_loop_state_runs_the_same_loop(hip):
+    """smvs_ctx_clone_loop_state (what bench.py's timed region replays): the
+    clone's Newton loop -- and its rerun after smvs_ctx_restore_nodes -- is the
+    original's to the bit, with and without the shading term; the original is
+    untouched by the clone's runs."""
+    from smvs_amd import synth
+    for shading in (False, True):
+        prob = synth.make_problem(256, 192, 3, 2, noise=0.003, shading=shading)
+        lighting = None
+        if shading:
+            lighting = np.zeros(16); lighting[0] = 0.9; lighting[2] = 0.1
+        ctx = hip.ViewContext(256, 192, 3)
+        ctx.set_views(prob["views"]); ctx.set_surface(prob["surf"])
+        clone = ctx.clone_loop_state()
+        start = ctx.get_nodes()
+        a = clone.run_loop(0.01, lighting=lighting)
+        nodes_a = clone.get_nodes()
+        assert a["newton_steps"] >= 1 and not np.array_equal(nodes_a, start)
+        assert np.array_equal(ctx.get_nodes(), start)        # the original did not move
+        clone.restore_nodes()
+        assert np.array_equal(clone.get_nodes(), start)
+        b = clone.run_loop(0.01, lighting=lighting)
+        assert a == b and np.array_equal(clone.get_nodes(), nodes_a)
+        c = ctx.run_loop(0.01, lighting=lighting)
+        assert c == a and np.array_equal(ctx.get_nodes(), nodes_a)
+        clone.close(); ctx.close()
+
+
 def test_async_image_upload_gives_the_same_planes(hip, oracle):
     """smvs_ctx_upload_image_async (page-locked source, DMA on the context's copy
     stream, conversion where the image is first needed) against the
