@@ -48,6 +48,8 @@ struct BlurTaps {
 // stereo_view.cc:29-31 give 1, 2, 2, 4, 7, 12, 23): the tap loops unroll, the
 // weights sit in scalar registers and the loads of a thread are all in
 // flight at once.  KS == 0: any half width, taps.ks at run time.
+constexpr int BLUR_X_LDS_FROM = 12;   // half width from which blur_x_kernel stages its row segment in LDS
+
 template <int C, int KS>
 __global__ void __launch_bounds__(256)
 blur_x_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h,
@@ -59,6 +61,38 @@ blur_x_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int 
     int const y = (int)blockIdx.y;
     int const ks = KS > 0 ? KS : taps.ks;
     const float *row = in + (size_t)y * w * C;
+    if constexpr (KS >= BLUR_X_LDS_FROM) {
+        // Round 6: the workgroup's pixels and their KS neighbours on either side
+        // go through LDS once -- every element is a tap of 2 KS + 1 outputs, and
+        // those 47 loads per thread at KS = 23 through the vector L1 were the
+        // kernel's time (47 -> 29 us per image at scale 6, 29 -> 22-27 at scale 5; at
+        // half widths up to 7 the staging and its barrier cost more than the loads
+        // they replace -- 22 -> 25, 20 -> 24, 18 -> 23 us measured -- so those keep
+        // the per-thread loads below).  A staged value is the CLAMPED
+        // pixel's, so the taps need no clamp and see exactly the operands of the
+        // per-thread loop below, in the same ascending order.
+        constexpr int SPAN = (255 / C + 2 + 2 * KS) * C;    // pixels the 256 elements touch
+        __shared__ float seg[SPAN];
+        if (e0 >= w * C)
+            return;
+        int const x_first = e0 / C;
+        for (int j = (int)threadIdx.x; j < SPAN; j += 256) {
+            int const xp = x_first - KS + j / C;
+            int const xx = min(max(xp, 0), w - 1);
+            seg[j] = row[xx * C + (j - (j / C) * C)];
+        }
+        __syncthreads();
+        if (e >= w * C)
+            return;
+        int const x = e / C, cc = e - x * C;
+        const float *p = seg + (x - x_first + KS) * C + cc;
+        float av = 0.0f;
+#pragma unroll
+        for (int k = -KS; k <= KS; ++k)
+            av += p[k * C] * taps.k[k < 0 ? -k : k];
+        out[(size_t)y * w * C + e] = av / taps.wsum;
+        return;
+    }
     bool const interior = e0 / C - ks >= 0 && (e0 + 255) / C + ks <= w - 1;
     if (e >= w * C)
         return;
@@ -198,23 +232,32 @@ launch_blur(hipStream_t stream, const float *in, float *tmp, float *out, int w, 
 // accumulation in the reference's order (stereo_view.cc:167-187)
 struct FitMatrix { double m[6][9]; };
 
+// GRAD_ROWS output rows per workgroup (round 6; one row before): the luminance
+// of a pixel is formed once for the up to three output rows it is a tap of
+// instead of once per row -- the rows' windows overlap in LDS, not in the L2 --
+// and a launch is 1,080 workgroups of real work instead of 8,640 short ones.
+constexpr int GRAD_ROWS = 8;
+
 __global__ void __launch_bounds__(256)
 gradients_kernel(const float *__restrict__ img, int w, int h, int c,
     FitMatrix fit, float2 *__restrict__ grad, float4 *__restrict__ hess)
 {
 #pragma clang fp contract(off)
     // The luminance of a pixel is needed by its nine neighbours: a workgroup
-    // (256 pixels of a row) forms it once per pixel for the three rows of its
+    // (256 pixels of GRAD_ROWS rows) forms it once per pixel for the rows of its
     // windows in LDS -- the same float expression, so the same values.
-    __shared__ float lum[3][256 + 2];
+    __shared__ float lum[GRAD_ROWS + 2][256 + 2];
     int const x0 = blockIdx.x * blockDim.x;
     int const t = threadIdx.x;
-    int const y = blockIdx.y;
+    int const y0 = blockIdx.y * GRAD_ROWS;
+    // (padding workgroups of the row, see the launch: nothing to do)
+    if (x0 >= w)
+        return;
     for (int col = t; col < 256 + 2; col += 256) {
         int const gx = min(max(x0 + col - 1, 0), w - 1);
 #pragma unroll
-        for (int row = 0; row < 3; ++row) {
-            int const gy = min(max(y + row - 1, 0), h - 1);
+        for (int row = 0; row < GRAD_ROWS + 2; ++row) {
+            int const gy = min(max(y0 + row - 1, 0), h - 1);
             const float *px = img + ((size_t)gy * w + gx) * c;
             lum[row][col] = c >= 3 ? px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f : px[0];
         }
@@ -223,29 +266,35 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
     int const x = x0 + t;
     if (x >= w)
         return;
-    size_t const p = (size_t)y * w + x;
-    float2 g = make_float2(0.f, 0.f);
-    float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        double v[9];
-        int k = 0;
-        for (int a = -1; a < 2; ++a)
-            for (int b = -1; b < 2; ++b)
-                v[k++] = lum[b + 1][t + 1 + a];
-        double r[6];
-        for (int q = 0; q < 6; ++q) {
-            double s = 0.0;
-            for (int i = 0; i < 9; ++i)
-                s += fit.m[q][i] * v[i];
-            r[q] = s;
+#pragma unroll 1
+    for (int r = 0; r < GRAD_ROWS; ++r) {
+        int const y = y0 + r;
+        if (y >= h)
+            break;
+        size_t const p = (size_t)y * w + x;
+        float2 g = make_float2(0.f, 0.f);
+        float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+            double v[9];
+            int k = 0;
+            for (int a = -1; a < 2; ++a)
+                for (int b = -1; b < 2; ++b)
+                    v[k++] = lum[r + b + 1][t + 1 + a];
+            double rr[6];
+            for (int q = 0; q < 6; ++q) {
+                double sum = 0.0;
+                for (int i = 0; i < 9; ++i)
+                    sum += fit.m[q][i] * v[i];
+                rr[q] = sum;
+            }
+            g = make_float2((float)rr[3], (float)rr[4]);
+            hs = make_float4((float)(2.0 * rr[0]), (float)rr[2], (float)(2.0 * rr[1]),
+                0.f);
         }
-        g = make_float2((float)r[3], (float)r[4]);
-        hs = make_float4((float)(2.0 * r[0]), (float)r[2], (float)(2.0 * r[1]),
-            0.f);
+        grad[p] = g;
+        if (hess != nullptr)
+            hess[p] = hs;
     }
-    grad[p] = g;
-    if (hess != nullptr)
-        hess[p] = hs;
 }
 
 __global__ void __launch_bounds__(256)
@@ -513,7 +562,8 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
             // rows a window spans meet in ONE XCD's L2 -- see launch_blur_ks; at
             // w = 1920 the 8 column blocks happen to be that already)
             hipLaunchKernelGGL(gradients_kernel,
-                dim3((((unsigned)vi.w + 255u) / 256u + 7u) & ~7u, vi.h),
+                dim3((((unsigned)vi.w + 255u) / 256u + 7u) & ~7u,
+                    ((unsigned)vi.h + GRAD_ROWS - 1) / GRAD_ROWS),
                 dim3(256), 0, ctx->stream, src, vi.w, vi.h, vi.c, fit, grad, hess);
         }
         e = hipGetLastError();
