@@ -255,8 +255,15 @@ DepthOptimizer::create_initial_surface(void)
         if (!host_surgery) {
             // ... and for Surface::create: the nodes are initialised from it
             // where it lies (no 8 MB round trip, no host Surface)
+            FloatImage::Ptr filtered;
+            if (opts.debug_lvl > 1)     // :44-45
+                filtered = FloatImage::create_for_overwrite(main_view->get_width(),
+                    main_view->get_height(), 1);
             check(smvs_ctx_sgm_init_depth(ctx, init->begin(), init->width(),
-                init->height(), 5.0f, 5, nullptr), "smvs_ctx_sgm_init_depth");
+                init->height(), 5.0f, 5, filtered ? filtered->begin() : nullptr),
+                "smvs_ctx_sgm_init_depth");
+            if (filtered)
+                main_view->write_depth_to_view(filtered, "smvs-sgm-filtered");
             check(smvs_surface_create(ctx, init_scale, nullptr, nullptr, nullptr, 0,
                 &valid_patches), "smvs_surface_create");
             this->surface_on_device();
@@ -401,6 +408,87 @@ DepthOptimizer::upload_surface(void)
     uploaded_subs_rev = subs_rev;
 }
 
+// GlobalLighting::render_normal_map (lib/global_lighting.cc:61-79) with
+// sh::evaluate_4_band (lib/spherical_harmonics.h:53-73, 133-151): per pixel the
+// dot product of the 16 lighting parameters with the scaled basis; pixels whose
+// normal is not of unit length (no surface) stay zero.
+static FloatImage::Ptr
+render_normal_map(double const* lighting, FloatImage::ConstPtr normals)
+{
+    FloatImage::Ptr image = FloatImage::create(normals->width(), normals->height(), 1);
+    int64_t const n = (int64_t)normals->get_pixel_amount();
+    for (int64_t i = 0; i < n; ++i) {
+        double const x = normals->at(i, 0), y = normals->at(i, 1), z = normals->at(i, 2);
+        if (std::fabs(std::sqrt(x * x + y * y + z * z) - 1.0) > 1e-6)
+            continue;
+        double const x2 = x * x, y2 = y * y, z2 = z * z;
+        double const sh[16] = { 1.0, y, z, x, x * y, y * z, -x2 - y2 + 2.0 * z2, x * z,
+            x * x - y * y, (3.0 * x2 - y2) * y, x * y * z, (4.0 * z2 - x2 - y2) * y,
+            (2.0 * z2 - 3.0 * x2 - 3.0 * y2) * z, (4.0 * z2 - x2 - y2) * x, (x2 - y2) * z,
+            (x2 - 3.0 * y2) * x };
+        double v = 0.0;
+        for (int k = 0; k < 16; ++k)
+            v += lighting[k] * sh[k];
+        image->at(i, 0) = (float)v;
+    }
+    return image;
+}
+
+// get_sphere_normals (lib/global_lighting.cc:24-50)
+static FloatImage::Ptr
+sphere_normals(int dim)
+{
+    if (dim % 2 == 0)
+        dim += 1;
+    FloatImage::Ptr normals = FloatImage::create(dim, dim, 3);
+    for (int x = 0; x < dim; ++x)
+        for (int y = 0; y < dim; ++y) {
+            float const nx = 2.0f * (float)(x - dim / 2) / (float)dim;
+            float const ny = 2.0f * (float)(dim / 2 - y) / (float)dim;
+            if ((nx * nx + ny * ny) > 1.)
+                continue;
+            float const nz = std::sqrt(1 - nx * nx - ny * ny);
+            int64_t const i = (int64_t)y * dim + x;
+            normals->at(i, 0) = nx;
+            normals->at(i, 1) = ny;
+            normals->at(i, 2) = nz;
+        }
+    return normals;
+}
+
+void
+DepthOptimizer::write_debug_depth(std::string const& postfix)
+{
+    // lib/depth_optimizer.h:150-160: "smvs-L<scale><postfix>" (the calls inside
+    // the Newton loop, :242, write the same name as the one after it: the
+    // embedding a caller finds is the last one of the scale)
+    if (opts.debug_lvl < 2)
+        return;
+    main_view->write_depth_to_view(this->get_depth(),
+        "smvs-L" + std::to_string(current_scale()) + postfix);
+}
+
+void
+DepthOptimizer::write_debug_shading(bool with_albedo)
+{
+    // lib/depth_optimizer.cc:119-127, 139-156
+    if (opts.debug_lvl < 2 || !lit)
+        return;
+    FloatImage::Ptr shaded = render_normal_map(lighting, this->get_normals());
+    main_view->write_image_to_view(shaded, "smvs-shaded");
+    main_view->write_image_to_view(render_normal_map(lighting, sphere_normals(555)),
+        "smvs-shaded-sphere");
+    if (!with_albedo || main_view->get_linear_image() == nullptr)
+        return;
+    FloatImage::Ptr albedo = main_view->get_linear_image()->duplicate();
+    int64_t const n = (int64_t)albedo->get_pixel_amount();
+    for (int64_t p = 0; p < n; ++p)
+        for (int c = 0; c < albedo->channels(); ++c)
+            albedo->at(p, c) = shaded->at(p, 0) > 0.0 ? albedo->at(p, c) / shaded->at(p, 0)
+                : 0.0f;
+    main_view->write_image_to_view(albedo, "smvs-implicit-albedo");
+}
+
 std::vector<RecordedLoop>&
 recorded_loops(void)
 {
@@ -442,8 +530,11 @@ DepthOptimizer::optimize(void)
     // Options::debug_lvl (lib/depth_optimizer.h:36): level 1 and above print
     // what the reference prints per scale and per iteration (:58-60, 84-86,
     // 92-94, 112-113, 132-134, 185-187, 306-316), fed from the batch log and
-    // the device's kernel timers; the images the reference writes at levels 2
-    // and 3 (smvs-initial, smvs-shaded, reprojections) are not produced.
+    // the device's kernel timers; level 2 also leaves the reference's
+    // intermediate embeddings in the main view (smvs-sgm-filtered, smvs-initial,
+    // smvs-L<scale>[-exp], smvs-shaded, smvs-shaded-sphere, smvs-implicit-albedo:
+    // write_debug_depth / write_debug_shading); level 3's per-neighbour
+    // reprojection images (reproject_neighbor, :701-745) are not produced.
     auto const scale_start = [this](int scale) {
         if (opts.debug_lvl > 0)
             std::cout << "########### Scale " << scale << " ###########" << std::endl;
@@ -459,8 +550,11 @@ DepthOptimizer::optimize(void)
         check(smvs_profile_enable(ctx, 1), "smvs_profile_enable");
     auto scale_timer = scale_start(current_scale());
     this->set_scale_everywhere(current_scale());
+    if (opts.debug_lvl > 1)     // :68-70
+        main_view->write_depth_to_view(this->get_depth(), "smvs-initial");
     this->run_newton_iterations(opts.num_iterations);
     scale_end(scale_timer);
+    this->write_debug_depth();  // :87
 
     while (current_scale() > opts.min_scale && current_scale() > 0) {
         scale_timer = scale_start(current_scale() - 1);
@@ -475,6 +569,7 @@ DepthOptimizer::optimize(void)
                 surface->subdivide_patches();
         }
         this->set_scale_everywhere(current_scale());
+        this->write_debug_depth();  // :104
         {
             ScopedHostTimer timer("fill_patches_from_depth");
             if (device_surface)
@@ -489,9 +584,12 @@ DepthOptimizer::optimize(void)
             ScopedHostTimer timer("fit_lighting");
             this->fit_lighting();
         }
+        this->write_debug_shading(false);   // :119-127
         this->run_newton_iterations(opts.num_iterations);
         scale_end(scale_timer);
+        this->write_debug_depth();  // :135
     }
+    this->write_debug_shading(true);        // :139-156
     {
         // get_depth() + get_normals() (:150-160) in one pass over the surface
         ScopedHostTimer timer("depth + normal maps");
@@ -638,6 +736,7 @@ DepthOptimizer::run_newton_iterations(int num_iters)
                     << ", device loop " << 1e3 * loop_seconds << " ms" << std::endl;
         }
         this->dump_state(iter, "newton");
+        this->write_debug_depth();  // :317
 
         if (finished)
             break;
@@ -655,6 +754,7 @@ DepthOptimizer::run_newton_iterations(int num_iters)
                 else
                     surface->expand();
             }
+            this->write_debug_depth("-exp");    // :332
             {
                 ScopedHostTimer timer("create_subview_surfaces");
                 this->create_subview_surfaces();
@@ -671,6 +771,7 @@ DepthOptimizer::run_newton_iterations(int num_iters)
                 surface->remove_isolated_patches();
         }
 
+        this->write_debug_depth();  // :352
         int const num_valid_new = device_surface ? valid_patches
             : surface->count_valid_patches();
         double const change = 1.0

@@ -107,6 +107,10 @@ private:
     void upload_surface(void);
     void check(int status, char const* what) const;
     void dump_state(int iter, char const* tag) const;
+    // Options::debug_lvl >= 2 (lib/depth_optimizer.h:150-160, depth_optimizer.cc:
+    // 44-45, 68-70, 119-127, 139-156): the intermediate embeddings
+    void write_debug_depth(std::string const& postfix = "");
+    void write_debug_shading(bool with_albedo);
 
 private:
     Options const& opts;

@@ -3,6 +3,7 @@
 #include "jpeg_io.h"
 
 #include <algorithm>
+#include <map>
 #include <cstring>
 #include <exception>
 #include <stdexcept>
@@ -34,6 +35,14 @@ smvs_host_last_error(void)
 }
 
 static void fill_log(DepthOptimizer const& optimizer, smvs_host_log *log);
+
+// the main view's embeddings after this thread's last smvs_host_optimize
+static std::map<std::string, FloatImage::Ptr>&
+last_embeddings(void)
+{
+    static thread_local std::map<std::string, FloatImage::Ptr> m;
+    return m;
+}
 
 static StereoView::Ptr
 make_view(smvs_host_view const& v, bool linear, bool gamma = false)
@@ -110,11 +119,45 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
                 sizeof(float) * 3 * npix);
         if (log != nullptr)
             fill_log(optimizer, log);
+        last_embeddings() = main_view->get_embeddings();
         return 0;
     } catch (std::exception const& e) {
         g_host_error = e.what();
         return -1;
     }
+}
+
+extern "C" int
+smvs_host_embedding_names(char *names_out, int cap)
+{
+    std::string all;
+    for (auto const& kv : last_embeddings())
+        all += kv.first + "\n";
+    if (names_out != nullptr && cap > 0) {
+        std::size_t const n = std::min(all.size(), (std::size_t)cap - 1);
+        std::memcpy(names_out, all.data(), n);
+        names_out[n] = 0;
+    }
+    return (int)last_embeddings().size();
+}
+
+extern "C" int
+smvs_host_embedding(const char *name, float *out, long long cap_floats, int *whc)
+{
+    auto it = last_embeddings().find(name ? name : "");
+    if (it == last_embeddings().end() || it->second == nullptr)
+        return -1;
+    FloatImage::Ptr img = it->second;
+    long long const n = (long long)img->get_pixel_amount() * img->channels();
+    if (whc != nullptr) {
+        whc[0] = img->width();
+        whc[1] = img->height();
+        whc[2] = img->channels();
+    }
+    if (out == nullptr || cap_floats < n)
+        return (int)n;
+    std::memcpy(out, img->begin(), sizeof(float) * (std::size_t)n);
+    return 0;
 }
 
 extern "C" int

@@ -66,6 +66,17 @@ int smvs_host_optimize(const smvs_host_view *main_view,
     const smvs_host_options *opts, float *depth_out, float *normals_out,
     smvs_host_log *log);
 
+/* The embeddings the last smvs_host_optimize of this thread left in its main
+ * view (write_depth_to_view / write_image_to_view: the result "smvs" / "smvsN",
+ * and with Options::debug_lvl >= 2 -- SMVS_DEBUG_LVL -- the reference's
+ * intermediate ones, lib/depth_optimizer.cc:44-45, 68-70, 119-156,
+ * depth_optimizer.h:150-160).  names_out: the names, separated by newlines
+ * (truncated to cap bytes); returns their number.  smvs_host_embedding copies
+ * one (whc = width, height, channels; returns 0, -1 if there is none, or the
+ * number of floats needed when cap_floats is too small). */
+int smvs_host_embedding_names(char *names_out, int cap);
+int smvs_host_embedding(const char *name, float *out, long long cap_floats, int *whc);
+
 /* Loop recording (measurement, see RecordedLoop in depth_optimizer.h):
  * smvs_host_record_loops(1) drops what this thread recorded before (the clones
  * are destroyed) and starts recording, (0) stops; every smvs_host_optimize of

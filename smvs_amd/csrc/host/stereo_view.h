@@ -51,6 +51,7 @@ public:
     FloatImage::Ptr get_sgm_depth(void) const;
     bool has_embedding(std::string const& name) const;
     FloatImage::Ptr get_embedding(std::string const& name) const;
+    std::map<std::string, FloatImage::Ptr> const& get_embeddings(void) const { return embeddings; }
 
     void write_image_to_view(FloatImage::Ptr image, std::string const& name);
     void write_depth_to_view(FloatImage::Ptr depth, std::string const& name);

@@ -542,3 +542,25 @@ def take_recorded_loops():
     lib.smvs_host_release_recorded_loops(0)
     return [dict(handle=C.c_void_p(ctxs[i]), params=prm[i], scale=scales[i], iter=iters[i])
             for i in range(n)]
+
+
+# ---------------------------------------------------------------- embeddings
+def last_embeddings():
+    """{name: array} of what the last optimize() of this thread wrote into its
+    main view (smvs_host_embedding_names / smvs_host_embedding): the results and,
+    with SMVS_DEBUG_LVL >= 2, the reference's intermediate embeddings."""
+    lib = load()
+    buf = C.create_string_buffer(4096)
+    lib.smvs_host_embedding_names(buf, 4096)
+    out = {}
+    for name in buf.value.decode().split("\n"):
+        if not name:
+            continue
+        whc = (C.c_int * 3)()
+        n = lib.smvs_host_embedding(name.encode(), None, C.c_longlong(0), whc)
+        if n <= 0:
+            continue
+        a = np.zeros(n, dtype=np.float32)
+        if lib.smvs_host_embedding(name.encode(), a.ctypes.data_as(_fp), C.c_longlong(n), whc) == 0:
+            out[name] = a.reshape(whc[1], whc[0], whc[2]).squeeze()
+    return out

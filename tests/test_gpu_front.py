@@ -602,6 +602,78 @@ def test_debug_lvl_prints_the_reference_report(hip):
     assert res0.returncode == 0 and "Scale" not in res0.stdout
 
 
+_DEBUG2_PROBE = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime, see conftest.py)
+sys.path.insert(0, sys.argv[1])
+from smvs_amd import synth, host
+lighting = np.zeros(16); lighting[0] = 0.9; lighting[2] = 0.15
+inputs = synth.pipeline_inputs("sphere", 384, 256, 3, flen=1.2, lighting=lighting)
+sgm = host.sgm_depth(inputs, sgm_scale=1)
+out = host.optimize(inputs, regularization=0.01, num_iterations=3, min_scale=2,
+                    use_shading=True, sgm_depth=sgm)
+emb = host.last_embeddings()
+np.savez(sys.argv[2], depth=out["depth"], normals=out["normals"], lighting=out["lighting"],
+         flen=inputs["cams"][0].flen, **{k.replace("-", "_"): v for k, v in emb.items()})
+print("NAMES " + json.dumps(sorted(emb)))
+"""
+
+
+def test_debug_lvl_2_leaves_the_reference_embeddings(hip, tmp_path):
+    """Options::debug_lvl = 2 (lib/depth_optimizer.cc:44-45, 68-70, 119-127,
+    139-156, depth_optimizer.h:150-160): the filtered SGM map, the initial depth,
+    one depth map per scale (and '-exp' after an expansion, which the SGM mode
+    does not run), the rendered shading, the rendered sphere and the implicit
+    albedo are left in the main view beside the results; the shading image is
+    the lighting applied to the final normals (GlobalLighting::render_normal_map),
+    the last scale's depth map is the result."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "emb.npz")
+    res = subprocess.run([sys.executable, "-c", _DEBUG2_PROBE, root, out],
+                         env=dict(os.environ, SMVS_DEBUG_LVL="2"), capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    names = json.loads([l for l in res.stdout.splitlines() if l.startswith("NAMES ")][-1][6:])
+    for want in ("smvs", "smvsN", "smvs-sgm", "smvs-sgm-filtered", "smvs-initial", "smvs-L2",
+                 "smvs-L3", "smvs-L4", "smvs-shaded", "smvs-shaded-sphere",
+                 "smvs-implicit-albedo"):
+        assert want in names, (want, names)
+    z = np.load(out)
+    assert z["smvs_shaded_sphere"].shape == (555, 555)
+    # the scale-2 debug depth is the result embedding (one converted on the host,
+    # one where it is computed)
+    assert np.allclose(z["smvs_L2"], z["smvs"], rtol=1e-6, atol=0)
+    assert not np.array_equal(z["smvs_L3"], z["smvs"]) and (z["smvs_initial"] > 0).any()
+    # smvs-shaded = lighting . sh(normal) wherever there is a surface
+    n = z["normals"].astype(np.float64)
+    x, y, zz = n[..., 0], n[..., 1], n[..., 2]
+    x2, y2, z2 = x * x, y * y, zz * zz
+    sh = np.stack([np.ones_like(x), y, zz, x, x * y, y * zz, -x2 - y2 + 2 * z2, x * zz, x2 - y2,
+                   (3 * x2 - y2) * y, x * y * zz, (4 * z2 - x2 - y2) * y,
+                   (2 * z2 - 3 * x2 - 3 * y2) * zz, (4 * z2 - x2 - y2) * x, (x2 - y2) * zz,
+                   (x2 - 3 * y2) * x], axis=-1)
+    want = (sh * z["lighting"]).sum(-1)
+    unit = np.abs(np.sqrt(x2 + y2 + z2) - 1.0) <= 1e-6
+    assert unit.mean() > 0.3
+    assert np.allclose(z["smvs_shaded"][unit], want[unit], rtol=1e-5, atol=1e-6)
+    assert np.all(z["smvs_shaded"][~unit] == 0)
+    # the stored depths are in MVE's ray-length convention: depth x |K^-1 (x + .5, y + .5, 1)|
+    h, w = z["depth"].shape
+    ax = float(z["flen"]) * max(w, h)
+    ys, xs = np.mgrid[0:h, 0:w]
+    length = np.sqrt(((xs + 0.5 - w / 2) / ax) ** 2 + ((ys + 0.5 - h / 2) / ax) ** 2 + 1.0)
+    ok = z["depth"] > 0
+    assert np.allclose(z["smvs"][ok], (z["depth"] * length)[ok], rtol=1e-5)
+    # without the level nothing but the results (and the input) is written
+    res0 = subprocess.run([sys.executable, "-c", _DEBUG2_PROBE, root, out],
+                          env={k: v for k, v in os.environ.items() if k != "SMVS_DEBUG_LVL"},
+                          capture_output=True, text=True, timeout=900)
+    names0 = json.loads([l for l in res0.stdout.splitlines() if l.startswith("NAMES ")][-1][6:])
+    assert sorted(names0) == ["smvs", "smvs-sgm", "smvsN"]
+
+
 _DEVICE_MAP_PROBE = r"""
 import json, sys
 import numpy as np
