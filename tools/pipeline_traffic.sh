@@ -1,4 +1,6 @@
 #!/bin/bash
+# Per-kernel HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) and times of one whole reference view
+# with SGM (tools/pipeline_profile.py) -> gpurun_out/r6_pipeline_traffic.txt.  Runs on the GPU box.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 ROOT=$(pwd)
 mkdir -p gpurun_out/pipe_traffic
