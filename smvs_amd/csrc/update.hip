@@ -65,24 +65,34 @@ struct ReactivateArgs {
 // One thread per (patch, full-resolution pixel): project with the old and
 // the updated nodes into every visible neighbour (pixel coordinates WITHOUT
 // the +0.5 convention, depth_optimizer.cc:669-672).
-// (Round 6 measured a variant that stages the 32 doubles of a workgroup's
-// <= 64 patches in LDS instead of loading them per pixel thread -- 256 B per
-// pixel through the vector L1 looked like the bound: 23.5 / 27.9 us against
-// 26.4 us on three boxes, i.e. nothing outside the box-to-box spread; the
-// kernel is bound by its ~350 vector instructions per pixel (176 of them
-// FP64), not by those loads.  Not kept.)
+// (Round 6 also measured a variant that stages the 32 doubles of a workgroup's
+// <= 64 patches in LDS instead of loading them per pixel thread: 23.5 / 27.9 us
+// against 26.4 us on three boxes, nothing outside the box-to-box spread.  Not
+// kept.)
+// FULL: DepthOptimizer::Options::full_optimization (the mean shift instead of
+// the active set, depth_optimizer.cc:277-288).  A template argument since round
+// 6: as a run-time flag the compiler evaluated BOTH variants of the test for
+// every neighbour and selected (38 FP64 instructions per neighbour where the
+// active-set test needs 20).
+template <bool FULL>
 __global__ void __launch_bounds__(256)
 reactivate_kernel(ReactivateArgs A)
 {
     long long const gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (the wave-uniform words every thread needs first, asked for together: as
+    // three tests in a row they were three scalar round trips before a wave's
+    // first vector load)
+    int const stop_words = A.status[I_STOP] | A.status[I_STEP_ABORT];
+    int const live_on_device = A.status[I_LIVE_PATCHES];
+    double const x0 = A.x[0];
     // the pipelined Newton loop: the loop has already ended / the solver of
     // this step gave up (finish_step_kernel reports it)
-    if (A.check_stop && (A.status[I_STOP] | A.status[I_STEP_ABORT]) != 0)
+    if (A.check_stop && stop_words != 0)
         return;
     // the list length is read on the device when the launch was sized before
     // it was known (live_count < 0)
     int const live_count = A.live_list == nullptr ? A.num_patches
-        : (A.live_count >= 0 ? A.live_count : A.status[I_LIVE_PATCHES]);
+        : (A.live_count >= 0 ? A.live_count : live_on_device);
     if (((long long)live_count << (2 * A.ps_log2))
         > (long long)gridDim.x * blockDim.x) {
         // (cannot happen behind a patch kernel of the same step, which is
@@ -92,7 +102,7 @@ reactivate_kernel(ReactivateArgs A)
         return;
     }
     // NaN guard of the reference on delta[0] (depth_optimizer.cc:267)
-    if (isnan(A.x[0]))
+    if (isnan(x0))
         return;
     // (the patch size is a power of two: shifts instead of 64-bit divisions,
     // which cost more than the arithmetic of a pixel)
@@ -101,29 +111,44 @@ reactivate_kernel(ReactivateArgs A)
     // latency of its serial pixels)
     int const slot = (int)(gid0 >> (2 * A.ps_log2));
     int const pid = (int)(gid0 & (long long)((1 << (2 * A.ps_log2)) - 1));
-    int patch = A.num_patches;
+    // Round 6: ONE level of dependent loads behind the list entry (before: list
+    // entry -> validity -> active flags -> nodes and deltas -> visibility mask):
+    // everything that depends only on the patch id is asked for at once, whether
+    // or not the patch turns out to need evaluation.
+    // (What the kernel's 24 us are -- measured, profiles/r6_reactivate_counters.txt:
+    // a wave lives 11,600 cycles at eight per SIMD, issuing 16 % of them, waiting
+    // for memory 45 %, stalled at issue 39 % (109 FP64 instructions per wave at
+    // four cycles each, eight waves taking turns).  Round 6 halved its vector
+    // instructions (the template argument), flattened this chain and cut its
+    // stores to one lane per patch, each for nothing measurable: the three
+    // effects overlap, and what remains is ~27 waves per SIMD x 4.8 us / 8.)
+    int patch = -1;
     if (slot < live_count)
         patch = A.live_list != nullptr ? A.live_list[slot] : slot;
+    bool const in_range = patch >= 0 && patch < A.num_patches;
+    int const pc = in_range ? patch : 0;
+    int const ix = pc % A.npx, iy = pc / A.npx;
+    int const n00 = iy * A.stride + ix;
+    int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+    uint8_t const valid = A.patch_valid[pc];
+    uint8_t const act = A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
+        | A.active[ids[3]];
+    uint32_t const vis = A.patch_vis[pc];
+    // w1 - w0 is the patch evaluated on the node deltas (the patch
+    // is linear in its nodes)
+    double th0[16], thd[16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            th0[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
+            thd[4 * n + k] = A.x[4 * (size_t)ids[n] + k];
+        }
     double sum = 0.0, cnt = 0.0;
-    if (patch < A.num_patches && A.patch_valid[patch]) {
-        int const ix = patch % A.npx, iy = patch / A.npx;
-        int const n00 = iy * A.stride + ix;
-        int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
-        if ((A.active[ids[0]] | A.active[ids[1]] | A.active[ids[2]]
-            | A.active[ids[3]]) != 0) {
-            // w1 - w0 is the patch evaluated on the node deltas (the patch
-            // is linear in its nodes)
-            double th0[16], thd[16];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    th0[4 * n + k] = A.nodes[4 * (size_t)ids[n] + k];
-                    thd[4 * n + k] = A.x[4 * (size_t)ids[n] + k];
-                }
-            uint32_t const vis = A.patch_vis[patch];
+    bool moved = false;
+    if (in_range && valid && act != 0) {
+        {
             double const th2 = A.threshold * A.threshold;
-            bool moved = false;
             int const ci = pid & (A.ps - 1), cj = pid >> A.ps_log2;
             double w0, dw, dum0, dum1;
             eval_patch(A.hermite_tab, ci, cj, th0, &w0, &dum0, &dum1);
@@ -147,7 +172,7 @@ reactivate_kernel(ReactivateArgs A)
                 double const den = (w0 * r + t[2]) * (w1 * r + t[2]);
                 double const num2 = dw * dw * (nx * nx + ny * ny);
                 cnt += 1.0;
-                if (A.full_optimization) {
+                if (FULL) {
                     // the mean shift needs the quotient itself
                     double inv = __builtin_amdgcn_rcp(den);
                     inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
@@ -160,15 +185,27 @@ reactivate_kernel(ReactivateArgs A)
                     moved |= num2 > th2 * (den * den);
                 }
             }
-            if (moved && !A.full_optimization) {
-                A.active_next[ids[0]] = 1;
-                A.active_next[ids[1]] = 1;
-                A.active_next[ids[2]] = 1;
-                A.active_next[ids[3]] = 1;
-            }
         }
     }
-    if (!A.full_optimization)
+    if (!FULL) {
+        // One lane per patch and wave raises the four flags (rounds 1-5: every
+        // pixel that moved wrote them -- in a first step nearly all of 2 M
+        // threads, four byte stores each to 128 k distinct bytes).  The lanes of
+        // a patch are an aligned group of min(64, ps^2): they share the patch and
+        // its node ids.
+        int const lane = (int)(threadIdx.x & 63u);
+        int const group = 2 * A.ps_log2 >= 6 ? 64 : 1 << (2 * A.ps_log2);
+        unsigned long long const votes = __ballot(moved);
+        unsigned long long const mine = group >= 64 ? ~0ull
+            : ((1ull << group) - 1ull) << (lane & ~(group - 1));
+        if ((votes & mine) != 0ull && (lane & (group - 1)) == 0) {
+            A.active_next[ids[0]] = 1;
+            A.active_next[ids[1]] = 1;
+            A.active_next[ids[2]] = 1;
+            A.active_next[ids[3]] = 1;
+        }
+    }
+    if (!FULL)
         return;
     // mean reprojection delta (depth_optimizer.cc:277-282)
     __shared__ double red[2][4];
@@ -554,9 +591,11 @@ reactivate_launch(smvs_ctx *ctx, double threshold, int full_optimization,
         : ctx->num_patches) * ctx->patchsize * ctx->patchsize;
     {
         ScopedKernelTimer timer(ctx, SMVS_K_REACTIVATE);
-        hipLaunchKernelGGL(reactivate_kernel,
-            dim3((unsigned)((items + 255) / 256 > 0 ? (items + 255) / 256 : 1)),
-            dim3(256), 0, ctx->stream, A);
+        dim3 const grid((unsigned)((items + 255) / 256 > 0 ? (items + 255) / 256 : 1));
+        if (full_optimization)
+            hipLaunchKernelGGL(reactivate_kernel<true>, grid, dim3(256), 0, ctx->stream, A);
+        else
+            hipLaunchKernelGGL(reactivate_kernel<false>, grid, dim3(256), 0, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
     if (publish_seq != 0) {
