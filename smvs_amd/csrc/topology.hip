@@ -185,6 +185,9 @@ struct TopoArgs {
     // whose predecessor deleted at most 10 patches does nothing
     // (`while (deleted > 10)`, depth_optimizer.cc:186-190)
     const int *pass_gate;
+    // topo_visibility_kernel: lanes per (patch, neighbour) and the stash slots
+    // per thread its launch reserves (vis_launch_shape)
+    int vis_group, ncc_stash_slots;
 };
 
 __device__ __forceinline__ void
@@ -335,6 +338,12 @@ group_size(int ps, int whole_workgroup_from)
     return pp >= 64 ? 64 : pp;
 }
 constexpr int VIS_WORKGROUP_FROM = 64;   // topo_visibility_kernel
+// samples of ncc_for_patch a lane keeps in registers between the two passes;
+// the following NCC_STASH_MAX live in LDS (48 KB per workgroup at most: three
+// workgroups per CU, what the kernel's registers allow), any beyond are
+// recomputed
+constexpr int NCC_KEEP = 4;
+constexpr int NCC_STASH_MAX = 16;
 constexpr int MSE_WORKGROUP_FROM = 16;   // topo_mse_kernel
 
 // Reductions over a lane group.  G <= 64: xor-shuffles inside the wave.
@@ -386,6 +395,116 @@ group_all(bool ok, int G, int lane, double *red)
     return (b & gmask) == gmask;
 }
 
+// ---- lane-group reductions of the visibility kernel on the VALU (round 6) ----
+// __shfl_xor of a double is two ds_bpermute_b32 through the CU's one LDS pipe
+// and a round trip per step; the kernel's eleven reductions of up to six steps
+// each were ~5 us of every wave's life at patch size 8, more than its samples
+// (wave life = 5.0 us + 1.9 us per pixel / sample slot, from the per-call times
+// of a --no-sgm view).  DPP moves inside a row of 16 lanes and gfx950's
+// v_permlane16_swap / v_permlane32_swap across the rows do the same butterflies
+// without LDS.  Every lane of the group gets the result, bit-identical in all
+// of them (each step adds / compares the same two numbers in both lanes of a
+// pair).
+template <int CTRL>
+__device__ __forceinline__ double
+vis_dpp(double v)
+{
+    unsigned long long const b = (unsigned long long)__double_as_longlong(v);
+    int const lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    int const hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf,
+        false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32)
+        | (unsigned)lo));
+}
+
+// the partner's value across rows (HALF = 16: rows 2k <-> 2k + 1) or halves of
+// the wave (HALF = 32): both values of the pair, lower lane's first
+template <int HALF>
+__device__ __forceinline__ void
+vis_swap(double v, double &lower, double &upper)
+{
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    unsigned long long const b = (unsigned long long)__double_as_longlong(v);
+    u2 lo, hi;
+    if constexpr (HALF == 32) {
+        lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false,
+            false);
+    } else {
+        lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false,
+            false);
+    }
+    lower = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    upper = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+
+// op over the min(G, 64) lanes of a group inside the wave (G a power of two)
+template <typename Op>
+__device__ __forceinline__ double
+vis_lanes_reduce(double v, int G, Op const &op)
+{
+    if (G >= 2)
+        v = op(v, vis_dpp<0xB1>(v));      // quad_perm [1, 0, 3, 2]
+    if (G >= 4)
+        v = op(v, vis_dpp<0x4E>(v));      // quad_perm [2, 3, 0, 1]
+    if (G >= 8)
+        v = op(v, vis_dpp<0x141>(v));     // row_half_mirror
+    if (G >= 16)
+        v = op(v, vis_dpp<0x140>(v));     // row_mirror
+    if (G >= 32) {
+        double a, b;
+        vis_swap<16>(v, a, b);
+        v = op(a, b);
+    }
+    if (G >= 64) {
+        double a, b;
+        vis_swap<32>(v, a, b);
+        v = op(a, b);
+    }
+    return v;
+}
+
+// K sums over the group at once; G == 256: the per-wave sums of all K meet in
+// LDS behind ONE pair of barriers (`red` holds K x 4 doubles; every thread of
+// the workgroup must call)
+template <int K>
+__device__ __forceinline__ void
+vis_group_sums(double (&v)[K], int G, double *red)
+{
+    auto const add = [](double a, double b) { return a + b; };
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        v[k] = vis_lanes_reduce(v[k], G, add);
+    if (G > 64) {
+        __syncthreads();   // (the previous reduction's readers are done)
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                red[k * 4 + (threadIdx.x >> 6)] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            v[k] = ((red[k * 4] + red[k * 4 + 1]) + red[k * 4 + 2]) + red[k * 4 + 3];
+    }
+}
+
+__device__ __forceinline__ double
+vis_group_max(double v, int G, double *red)
+{
+    auto const larger = [](double a, double b) { return a < b ? b : a; };
+    v = vis_lanes_reduce(v, G, larger);
+    if (G > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+            red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w)
+            v = v < red[w] ? red[w] : v;
+    }
+    return v;
+}
+
 // ---- the surface at every pixel of every valid patch: depth w and its pixel
 // derivatives wx, wy.  The visibility kernel needs them per (pixel, neighbour)
 // and, for the NCC samples, per (sample, neighbour): evaluated here ONCE per
@@ -435,9 +554,12 @@ __global__ void __launch_bounds__(256, 2)
 topo_visibility_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
-    __shared__ double red[4];
+    __shared__ double red[6 * 4];
+    // the warped colours of the samples a lane does not keep in registers,
+    // [slot][channel][thread] floats (A.ncc_stash_slots of them, sized by the host)
+    extern __shared__ float ncc_stash[];
     int const ps = A.ps;
-    int const G = group_size(ps, VIS_WORKGROUP_FROM);
+    int const G = A.vis_group;
     int const lane = threadIdx.x & 63;
     int const g_log2 = 31 - __clz(G);           // G = 1 << g_log2
     int const gl = threadIdx.x & (G - 1);     // lane inside the group
@@ -516,7 +638,7 @@ topo_visibility_kernel(TopoArgs A)
         }
     if constexpr (PART != 2) {
         visible = group_all(visible, G, lane, red);
-        worst = group_max(worst, G, red);
+        worst = vis_group_max(worst, G, red);
         alive = alive && visible && !(worst > 8.0);
     } else {
         // (the verdict of the geometric half: the whole group reads one byte)
@@ -543,10 +665,18 @@ topo_visibility_kernel(TopoArgs A)
         // a lane keeps its first NCC_KEEP samples in registers -- all of them
         // at the fine scales, where the border samples make the templates
         // 2 - 3 x the patch -- and recomputes the rest.
-        constexpr int NCC_KEEP = 4;
         // (float: the kept values ARE floats -- an image value, linear_at's
         // float result -- widened when they are used)
         float keep_m[NCC_KEEP][3], keep_s[NCC_KEEP][3];
+        // Round 6: what does not fit the registers goes to LDS instead of being
+        // recomputed in the second pass -- at patch sizes 32 and 64 a lane has
+        // ~18 samples, so the second pass warped and interpolated 14 of them
+        // again (only the thread itself reads its slots: no barrier)
+        auto const stash_put = [&](int slot, float const (&cs)[3]) {
+            if (slot - NCC_KEEP < A.ncc_stash_slots)
+                for (int c = 0; c < 3; ++c)
+                    ncc_stash[((slot - NCC_KEEP) * 3 + c) * 256 + threadIdx.x] = cs[c];
+        };
         auto colours = [&](int i, double (&cm)[3], double (&cs)[3], bool check) -> bool {
             NccSample const smp = tpl[i];
             // the depth of grid sample src is the surface at that pixel; the
@@ -706,6 +836,8 @@ topo_visibility_kernel(TopoArgs A)
                             keep_m[k][c] = ma[c];
                             keep_s[k][c] = sa[c];
                         }
+                if (slot >= NCC_KEEP)
+                    stash_put(slot, sa);
                 for (int c = 0; c < 3; ++c) {
                     sum0[c] += (double)ma[c];
                     sum1[c] += (double)sa[c];
@@ -719,6 +851,8 @@ topo_visibility_kernel(TopoArgs A)
                                 keep_m[k][c] = mb[c];
                                 keep_s[k][c] = sb[c];
                             }
+                    if (slot + 1 >= NCC_KEEP)
+                        stash_put(slot + 1, sb);
                     for (int c = 0; c < 3; ++c) {
                         sum0[c] += (double)mb[c];
                         sum1[c] += (double)sb[c];
@@ -744,6 +878,11 @@ topo_visibility_kernel(TopoArgs A)
                                     keep_m[k][c] = (float)cm[c];
                                     keep_s[k][c] = (float)cs[c];
                                 }
+                        if (slot >= NCC_KEEP) {
+                            // (cs[] ARE floats widened: linear_at's results)
+                            float const sf[3] = { (float)cs[0], (float)cs[1], (float)cs[2] };
+                            stash_put(slot, sf);
+                        }
                         for (int c = 0; c < 3; ++c) {
                             sum0[c] += cm[c];
                             sum1[c] += cs[c];
@@ -757,6 +896,17 @@ topo_visibility_kernel(TopoArgs A)
                                         cm[c] = keep_m[k][c];
                                         cs[c] = keep_s[k][c];
                                     }
+                        } else if (slot - NCC_KEEP < A.ncc_stash_slots) {
+                            // the neighbour's colour from the stash, the main
+                            // view's read again (one load against a warp, a
+                            // division and four taps)
+                            NccSample const smp = tpl[i];
+                            size_t const at = (size_t)(py + smp.dy) * mv.w + (px + smp.dx);
+                            for (int c = 0; c < 3; ++c) {
+                                int const cmi = c < mv.c - 1 ? c : mv.c - 1;
+                                cm[c] = mv.image[at * mv.c + cmi];
+                                cs[c] = ncc_stash[((slot - NCC_KEEP) * 3 + c) * 256 + threadIdx.x];
+                            }
                         } else {
                             (void)colours(i, cm, cs, false);
                         }
@@ -773,15 +923,19 @@ topo_visibility_kernel(TopoArgs A)
             if (pass == 0) {
                 inside = group_all(inside, G, lane, red);
                 SharedDivisor const by_n((double)n, A.exact_divisions == 0);
+                double six[6] = { sum0[0], sum0[1], sum0[2], sum1[0], sum1[1], sum1[2] };
+                vis_group_sums<6>(six, G, red);
                 for (int c = 0; c < 3; ++c) {
-                    mean0[c] = by_n.quotient(group_sum(sum0[c], G, red));
-                    mean1[c] = by_n.quotient(group_sum(sum1[c], G, red));
+                    mean0[c] = by_n.quotient(six[c]);
+                    mean1[c] = by_n.quotient(six[3 + c]);
                 }
             }
         }
-        n0 = sqrt(group_sum(n0, G, red));
-        n1 = sqrt(group_sum(n1, G, red));
-        dot = group_sum(dot, G, red);
+        double three[3] = { n0, n1, dot };
+        vis_group_sums<3>(three, G, red);
+        n0 = sqrt(three[0]);
+        n1 = sqrt(three[1]);
+        dot = three[2];
         if (!inside)
             ncc = -1.0;
         else if (n0 + n1 < 0.001 * n)
@@ -1237,8 +1391,46 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         hipLaunchKernelGGL(topo_pixel_surface_kernel, dim3((unsigned)((pixels + 255) / 256)),
             dim3(256), 0, ctx->stream, A);
     }
-    long long const group = group_size(ctx->patchsize, VIS_WORKGROUP_FROM);
+    // Lanes per (patch, neighbour), measured per patch size on a --no-sgm view at
+    // 1920 x 1080 x 8 (profiles/r6_visibility_groups.txt; SMVS_VIS_GROUP_<ps>=<lanes>
+    // is the A/B switch).  Few lanes win wherever there are enough groups to fill
+    // the chip: a lane's pixels and samples are independent chains either way, and
+    // the group's set-up and eleven reductions are paid once per group --
+    // patch size 4 (16 pixels, 44 samples): 4 lanes 627 us, 8: 704, 16: 880;
+    // patch size 8: 8 lanes 443, 16: 460, 32: 525, 64: 680; 16: 32 lanes 365, 64: 385;
+    // 32: 64 lanes 310, 32: 385 (a lane's samples outgrow the stash), 256: 365;
+    // 64: the workgroup 290, 64 lanes 415.
+    long long group = group_size(ctx->patchsize, VIS_WORKGROUP_FROM);
+    switch (ctx->patchsize) {
+    case 2: group = 2; break;
+    case 4: group = 4; break;
+    case 8: group = 8; break;
+    case 16: group = 32; break;
+    default: break;
+    }
+    {
+        char name[32];
+        std::snprintf(name, sizeof(name), "SMVS_VIS_GROUP_%d", ctx->patchsize);
+        const char *e = std::getenv(name);
+        int const g = e != nullptr ? std::atoi(e) : 0;
+        if (g == 256 || (g >= 1 && g <= 64 && (g & (g - 1)) == 0))
+            group = g;
+    }
     long long const items = (long long)ctx->num_patches * ctx->n_subs * group;
+    A.vis_group = (int)group;
+    A.ncc_stash_slots = 0;
+    if (use_ncc) {
+        int n_max = 0;
+        for (int f = 0; f < 32; ++f)
+            n_max = std::max(n_max, ctx->topo_ncc_off[f + 1] - ctx->topo_ncc_off[f]);
+        static bool const no_stash = [] {
+            const char *e = std::getenv("SMVS_NCC_STASH");
+            return e != nullptr && e[0] == '0';
+        }();
+        int const per_lane = (int)((n_max + group - 1) / group);
+        A.ncc_stash_slots = no_stash ? 0 : std::min(NCC_STASH_MAX, std::max(0, per_lane - NCC_KEEP));
+    }
+    size_t const stash_bytes = (size_t)A.ncc_stash_slots * 3 * 256 * sizeof(float);
     // SMVS_VIS_SPLIT=1: the two halves as launches of their own.  Measured
     // (profiles/r6_visibility_split.txt): 165 + 461 us against 606 us fused --
     // the NCC half keeps its 159 VGPRs, and the fused kernel overlaps the two
@@ -1259,10 +1451,10 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         hipLaunchKernelGGL(topo_visibility_kernel<1>,
             dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
         hipLaunchKernelGGL(topo_visibility_kernel<2>,
-            dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+            dim3((unsigned)((items + 255) / 256)), dim3(256), stash_bytes, ctx->stream, A);
     } else {
         hipLaunchKernelGGL(topo_visibility_kernel<0>,
-            dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+            dim3((unsigned)((items + 255) / 256)), dim3(256), stash_bytes, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
     if (patch_vis_out == nullptr)
