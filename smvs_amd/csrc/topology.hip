@@ -188,6 +188,9 @@ struct TopoArgs {
     // topo_visibility_kernel: lanes per (patch, neighbour) and the stash slots
     // per thread its launch reserves (vis_launch_shape)
     int vis_group, ncc_stash_slots;
+    // ... and what else of its dynamic LDS is in use: doubles of the staged
+    // depths (0: read from memory), entries of the staged interior template
+    int lds_depth_doubles, lds_tpl_n;
 };
 
 __device__ __forceinline__ void
@@ -555,14 +558,39 @@ topo_visibility_kernel(TopoArgs A)
 {
 #pragma clang fp contract(off)
     __shared__ double red[6 * 4];
-    // the warped colours of the samples a lane does not keep in registers,
-    // [slot][channel][thread] floats (A.ncc_stash_slots of them, sized by the host)
-    extern __shared__ float ncc_stash[];
+    // Dynamic LDS, sized by the host (vis launch shape in smvs_topology_subviews):
+    //  * the depths ncc_for_patch's samples take -- the surface at the patch's
+    //    pixels and its four corner nodes, [group of the workgroup][ps^2 + 4]
+    //    doubles, left there by the pass over the pixels;
+    //  * the sample template of an interior patch (all five border predicates),
+    //    two ints per entry;
+    //  * the warped colours of the samples a lane does not keep in registers,
+    //    [slot][channel][thread] floats.
+    // A sample was three dependent round trips to memory (template entry ->
+    // depth -> taps) in a kernel whose waves wait for memory half of their life;
+    // with the first two in LDS it is one.
+    extern __shared__ double vis_lds[];
+    double *const lds_depth = vis_lds;
+    int *const lds_tpl = reinterpret_cast<int *>(vis_lds + A.lds_depth_doubles);
+    float *const ncc_stash = reinterpret_cast<float *>(lds_tpl + 2 * A.lds_tpl_n);
     int const ps = A.ps;
     int const G = A.vis_group;
     int const lane = threadIdx.x & 63;
     int const g_log2 = 31 - __clz(G);           // G = 1 << g_log2
     int const gl = threadIdx.x & (G - 1);     // lane inside the group
+    int const dstride = ps * ps + 4;
+    // (PART 2 does not walk the pixels)
+    bool const depth_in_lds = PART != 2 && A.lds_depth_doubles > 0;
+    double *const my_depths = lds_depth + (threadIdx.x >> g_log2) * dstride;
+    if (PART != 1 && A.lds_tpl_n > 0) {
+        const NccSample *src = A.ncc + A.ncc_off[31];
+        for (int i = threadIdx.x; i < A.lds_tpl_n; i += 256) {
+            NccSample const e = src[i];
+            lds_tpl[2 * i] = (int)((unsigned)(unsigned short)e.dx | ((unsigned)(unsigned short)e.dy << 16));
+            lds_tpl[2 * i + 1] = e.src;
+        }
+        __syncthreads();
+    }
     // (group index < num_patches * n_subs: 32 bits)
     // (Round 6 measured two other orders of the groups, because the kernel
     // fetches 1,007 MB per call at 1920 x 1080 for ~340 MB of planes
@@ -572,11 +600,13 @@ topo_visibility_kernel(TopoArgs A)
     // traffic (1,007 MB) or the time (610 / 623 against 605-611 us): the fetches are
     // 12-byte taps and 4-byte z-buffer cells out of 128-byte lines, not lines
     // fetched by several XCDs.  Plain order.)
-    unsigned const vb = blockIdx.x;
-    unsigned const gid = (unsigned)(((unsigned long long)vb * blockDim.x
-        + threadIdx.x) >> g_log2);
-    int const p = (int)(gid / (unsigned)A.n_subs);
-    int const s = (int)(gid - (unsigned)p * (unsigned)A.n_subs);
+    // The neighbour is the workgroup's (blockIdx.y): its camera, image size and
+    // pointers are wave-uniform -- scalar registers and scalar loads, operands
+    // of the vector arithmetic instead of 30 vector registers of every lane.
+    int const s = (int)blockIdx.y;
+    int const p = (int)(((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2);
+    // (index of the pair: < num_patches * n_subs, 32 bits)
+    unsigned const gid = (unsigned)p * (unsigned)A.n_subs + (unsigned)s;
     bool alive = p < A.num_patches && A.patch_valid[p];
     int const pc = alive ? p : 0;
     int const px = A.start_x + (pc % A.npx) * ps;
@@ -623,12 +653,19 @@ topo_visibility_kernel(TopoArgs A)
         worst = worst < ratio ? ratio : worst;
         return true;
     };
-    if (PART != 2 && alive)
+    if (PART != 2 && alive) {
+        if (depth_in_lds) {
+            int const n00 = (pc / A.npx) * A.stride + pc % A.npx;
+            for (int c = gl; c < 4; c += G)
+                my_depths[ps * ps + c] = A.nodes[4 * (size_t)(n00 + (c & 1) + (c >> 1) * A.stride)];
+        }
         for (int k = gl; k < ps * ps; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
             // depth and pixel derivatives of the surface (topo_pixel_surface_kernel)
             const double *sp = A.pix + ((unsigned)(py + j) * (unsigned)A.W + (unsigned)(px + i)) * 3u;
             double const w = sp[0];
+            if (depth_in_lds)
+                my_depths[k] = w;
             Warp wp(M, t, px + i + 0.5, py + j + 0.5, w);
             WarpQuotients<true> const wq(wp, A.exact_divisions == 0);
             bool const go_on = wq.plain() ? pixel(wq, wp, sp, w)
@@ -636,6 +673,13 @@ topo_visibility_kernel(TopoArgs A)
             if (!go_on)
                 break;
         }
+    }
+    // (the depths are read by the other lanes of the group: LDS operations of a
+    // wave complete in order, the fences keep the compiler from moving them; a
+    // group of 256 meets in group_all's barrier below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if constexpr (PART != 2) {
         visible = group_all(visible, G, lane, red);
         worst = vis_group_max(worst, G, red);
@@ -656,6 +700,14 @@ topo_visibility_kernel(TopoArgs A)
         int const flags = smvs_topo::ncc_flags(px, py, ps, mv.w, mv.h);
         const NccSample *tpl = A.ncc + A.ncc_off[flags];
         int const n = A.ncc_off[flags + 1] - A.ncc_off[flags];
+        bool const tpl_in_lds = A.lds_tpl_n > 0 && flags == 31;
+        auto const sample_at = [&](int i) -> NccSample {
+            if (tpl_in_lds) {
+                int const a = lds_tpl[2 * i], b = lds_tpl[2 * i + 1];
+                return NccSample{ (short)(a & 0xffff), (short)(a >> 16), (short)b };
+            }
+            return tpl[i];
+        };
         bool inside = true;
         double sum0[3] = { 0, 0, 0 }, sum1[3] = { 0, 0, 0 };
         double mean0[3], mean1[3];
@@ -678,11 +730,13 @@ topo_visibility_kernel(TopoArgs A)
                     ncc_stash[((slot - NCC_KEEP) * 3 + c) * 256 + threadIdx.x] = cs[c];
         };
         auto colours = [&](int i, double (&cm)[3], double (&cs)[3], bool check) -> bool {
-            NccSample const smp = tpl[i];
+            NccSample const smp = sample_at(i);
             // the depth of grid sample src is the surface at that pixel; the
             // corner samples take the corner node's depth (:803-857)
             double depth;
-            if (smp.src >= 0) {
+            if (depth_in_lds) {
+                depth = my_depths[smp.src >= 0 ? smp.src : ps * ps - 1 - smp.src];
+            } else if (smp.src >= 0) {
                 // (32-bit offsets: the host checks that the planes have fewer than
                 // 2^31 elements; 64-bit multiply-adds run at a quarter of the rate)
                 depth = A.pix[((unsigned)(py + (smp.src >> A.ps_log2)) * (unsigned)A.W
@@ -776,9 +830,16 @@ topo_visibility_kernel(TopoArgs A)
         };
         auto const pair = [&](int ia, int ib, float (&ma)[3], float (&sa)[3], bool &oka,
                 float (&mb)[3], float (&sb)[3], bool &okb) {
-            NccSample const a = tpl[ia], b = tpl[ib];
-            const double *pa = depth_of(a), *pb = depth_of(b);
-            double const da = *pa, db = *pb;
+            NccSample const a = sample_at(ia), b = sample_at(ib);
+            double da, db;
+            if (depth_in_lds) {
+                da = my_depths[a.src >= 0 ? a.src : ps * ps - 1 - a.src];
+                db = my_depths[b.src >= 0 ? b.src : ps * ps - 1 - b.src];
+            } else {
+                const double *pa = depth_of(a), *pb = depth_of(b);
+                da = *pa;
+                db = *pb;
+            }
             // (the scheduler would sink the second sample's loads below the first
             // one's arithmetic to save registers: both are asked for first)
             __builtin_amdgcn_sched_barrier(0);
@@ -900,7 +961,7 @@ topo_visibility_kernel(TopoArgs A)
                             // the neighbour's colour from the stash, the main
                             // view's read again (one load against a warp, a
                             // division and four taps)
-                            NccSample const smp = tpl[i];
+                            NccSample const smp = sample_at(i);
                             size_t const at = (size_t)(py + smp.dy) * mv.w + (px + smp.dx);
                             for (int c = 0; c < 3; ++c) {
                                 int const cmi = c < mv.c - 1 ? c : mv.c - 1;
@@ -1416,7 +1477,7 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         if (g == 256 || (g >= 1 && g <= 64 && (g & (g - 1)) == 0))
             group = g;
     }
-    long long const items = (long long)ctx->num_patches * ctx->n_subs * group;
+    long long const items = (long long)ctx->num_patches * group;   // (per neighbour: grid.y)
     A.vis_group = (int)group;
     A.ncc_stash_slots = 0;
     if (use_ncc) {
@@ -1430,7 +1491,28 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         int const per_lane = (int)((n_max + group - 1) / group);
         A.ncc_stash_slots = no_stash ? 0 : std::min(NCC_STASH_MAX, std::max(0, per_lane - NCC_KEEP));
     }
-    size_t const stash_bytes = (size_t)A.ncc_stash_slots * 3 * 256 * sizeof(float);
+    size_t stash_bytes = (size_t)A.ncc_stash_slots * 3 * 256 * sizeof(float);
+    A.lds_depth_doubles = 0;
+    A.lds_tpl_n = 0;
+    if (use_ncc) {
+        // (three workgroups per CU -- what the kernel's registers allow -- leave
+        // each 53 KB of the 160)
+        size_t const budget = 52 * 1024;
+        static bool const no_lds = [] {
+            const char *e = std::getenv("SMVS_NCC_LDS");
+            return e != nullptr && e[0] == '0';
+        }();
+        size_t const depth_doubles = (size_t)(256 / group) * ((size_t)ctx->patchsize * ctx->patchsize + 4);
+        size_t const tpl_n = (size_t)(ctx->topo_ncc_off[32] - ctx->topo_ncc_off[31]);
+        if (!no_lds && group <= 256 && stash_bytes + depth_doubles * 8 <= budget) {
+            A.lds_depth_doubles = (int)depth_doubles;
+            stash_bytes += depth_doubles * 8;
+        }
+        if (!no_lds && stash_bytes + tpl_n * 8 <= budget) {
+            A.lds_tpl_n = (int)tpl_n;
+            stash_bytes += tpl_n * 8;
+        }
+    }
     // SMVS_VIS_SPLIT=1: the two halves as launches of their own.  Measured
     // (profiles/r6_visibility_split.txt): 165 + 461 us against 606 us fused --
     // the NCC half keeps its 159 VGPRs, and the fused kernel overlaps the two
@@ -1449,12 +1531,12 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         }
         A.pair_alive = ctx->topo_pair_alive;
         hipLaunchKernelGGL(topo_visibility_kernel<1>,
-            dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, A);
+            dim3((unsigned)((items + 255) / 256), (unsigned)ctx->n_subs), dim3(256), 0, ctx->stream, A);
         hipLaunchKernelGGL(topo_visibility_kernel<2>,
-            dim3((unsigned)((items + 255) / 256)), dim3(256), stash_bytes, ctx->stream, A);
+            dim3((unsigned)((items + 255) / 256), (unsigned)ctx->n_subs), dim3(256), stash_bytes, ctx->stream, A);
     } else {
         hipLaunchKernelGGL(topo_visibility_kernel<0>,
-            dim3((unsigned)((items + 255) / 256)), dim3(256), stash_bytes, ctx->stream, A);
+            dim3((unsigned)((items + 255) / 256), (unsigned)ctx->n_subs), dim3(256), stash_bytes, ctx->stream, A);
     }
     SMVS_HIP_CHECK(hipGetLastError());
     if (patch_vis_out == nullptr)
