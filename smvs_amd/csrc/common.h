@@ -231,6 +231,10 @@ struct smvs_ctx {
     size_t topo_border_cap = 0;
     int *topo_mse_list = nullptr;     // patches whose error is evaluated (topology.hip)
     size_t topo_mse_list_cap = 0;
+    double *topo_mse_parts = nullptr;  // partial sums of the chunked patch MSE (topology.hip)
+    size_t topo_mse_parts_cap = 0;
+    int *topo_mse_arrived = nullptr;   // ... and its arrival counters (zero between launches)
+    size_t topo_mse_arrived_cap = 0;
     double *topo_pix = nullptr;       // [H][W][3]: surface depth, d/dx, d/dy per pixel
     size_t topo_pix_cap = 0;
     uint8_t *topo_pair_alive = nullptr;   // [P][n_subs]: verdict of the visibility test's

@@ -425,6 +425,10 @@ ctx_free(smvs_ctx *ctx)
         (void)hipFree(ctx->topo_border);
     if (ctx->topo_mse_list)
         (void)hipFree(ctx->topo_mse_list);
+    if (ctx->topo_mse_parts)
+        (void)hipFree(ctx->topo_mse_parts);
+    if (ctx->topo_mse_arrived)
+        (void)hipFree(ctx->topo_mse_arrived);
     if (ctx->topo_pix)
         (void)hipFree(ctx->topo_pix);
     if (ctx->topo_pair_alive)

@@ -191,6 +191,12 @@ struct TopoArgs {
     // ... and what else of its dynamic LDS is in use: doubles of the staged
     // depths (0: read from memory), entries of the staged interior template
     int lds_depth_doubles, lds_tpl_n;
+    // topo_mse_kernel at patch sizes 32 / 64: chunks of 256 pixels per patch,
+    // their partial sums [item][chunk][2] and arrival counters [item] (zero
+    // between launches)
+    int mse_chunks;
+    double *mse_parts;
+    int *mse_arrived;
 };
 
 __device__ __forceinline__ void
@@ -1078,10 +1084,21 @@ topo_mse_kernel(TopoArgs A)
     int const group = (int)(((unsigned)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2);
     int const groups = (int)(((unsigned)gridDim.x * blockDim.x) >> g_log2);
     int const count = *A.mse_count;
+    // Patch sizes 32 and 64: a patch is 4 resp. 16 CHUNKS of 256 pixels, each a
+    // workgroup's item of its own (round 6).  The two coarsest scales have a
+    // few hundred candidates at most, so a workgroup per patch left most of the
+    // chip idle behind chains of 16 pixels x 8 neighbours per lane (140-170 us
+    // per launch at patch size 64).  A chunk leaves its two sums in
+    // `mse_parts`; the chunk that arrives last (one atomic per chunk) adds them
+    // in chunk order -- a fixed order, whichever workgroup does it -- and
+    // clears the counter for the next launch.
+    int const chunks = A.mse_chunks;
     // (G == 256: the group is the workgroup, its threads loop together and
     // meet in group_sum's barriers; smaller groups only shuffle among
     // themselves)
-    for (int item = group; item < count; item += groups) {
+    for (int work = group; work < count * chunks; work += groups) {
+        int const item = chunks > 1 ? work / chunks : work;
+        int const chunk = chunks > 1 ? work - item * chunks : 0;
         int const p = A.mse_list[item];
         double n16[16];
         load_patch_nodes(A, p, n16);
@@ -1090,7 +1107,9 @@ topo_mse_kernel(TopoArgs A)
         // (bits of neighbours the context does not have are not looked at)
         uint32_t const vis = A.patch_vis[p] & ((1u << A.n_subs) - 1u);
         double error = 0.0, counter = 0.0;
-        for (int k = gl; k < ps * ps; k += G) {
+        int const k_begin = chunks > 1 ? chunk * 256 : 0;
+        int const k_end = chunks > 1 ? k_begin + 256 : ps * ps;
+        for (int k = k_begin + gl; k < k_end; k += G) {
             int const i = k & (ps - 1), j = k >> A.ps_log2;
             // (asked for before the surface is evaluated: a cold round trip)
             float2 const gm = A.main_grad[(size_t)(py + j) * A.W + (px + i)];
@@ -1151,8 +1170,30 @@ topo_mse_kernel(TopoArgs A)
         }
         error = group_sum(error, G, red);
         counter = group_sum(counter, G, red);
-        if (gl == 0)
-            A.mse_out[p] = counter == 0.0 ? 1.0 : error / counter;
+        if (chunks == 1) {
+            if (gl == 0)
+                A.mse_out[p] = counter == 0.0 ? 1.0 : error / counter;
+            continue;
+        }
+        // (chunks > 1 only with G == 256: the workgroup is the group)
+        if (threadIdx.x == 0) {
+            double *mine = A.mse_parts + 2 * ((size_t)item * chunks + chunk);
+            __hip_atomic_store(mine, error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int const before = __hip_atomic_fetch_add(A.mse_arrived + item, 1, __ATOMIC_ACQ_REL,
+                __HIP_MEMORY_SCOPE_AGENT);
+            if (before == chunks - 1) {
+                double e = 0.0, c = 0.0;
+                for (int q = 0; q < chunks; ++q) {
+                    const double *part = A.mse_parts + 2 * ((size_t)item * chunks + q);
+                    e += __hip_atomic_load(part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c += __hip_atomic_load(part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                A.mse_out[p] = c == 0.0 ? 1.0 : e / c;
+                __hip_atomic_store(A.mse_arrived + item, 0, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -1583,7 +1624,37 @@ prepare_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
             return rc;
         ctx->topo_mse_list_cap = (size_t)ctx->num_patches;
     }
-    return fill_args(ctx, A, who);
+    // patch sizes 32 and up: the kernel works in chunks of 256 pixels
+    // (SMVS_MSE_CHUNKS=0: a workgroup per patch, as before round 6)
+    static bool const no_chunks = [] {
+        const char *e = std::getenv("SMVS_MSE_CHUNKS");
+        return e != nullptr && e[0] == '0';
+    }();
+    int const pp = ctx->patchsize * ctx->patchsize;
+    int const chunks = !no_chunks && group_size(ctx->patchsize, MSE_WORKGROUP_FROM) == 256
+        && pp > 256 ? pp / 256 : 1;
+    if (chunks > 1) {
+        size_t const parts = (size_t)ctx->num_patches * chunks * 2;
+        if (parts > ctx->topo_mse_parts_cap) {
+            ctx->topo_mse_parts_cap = 0;
+            if ((rc = device_alloc(&ctx->topo_mse_parts, parts)) != SMVS_OK)
+                return rc;
+            ctx->topo_mse_parts_cap = parts;
+        }
+        if ((size_t)ctx->num_patches > ctx->topo_mse_arrived_cap) {
+            ctx->topo_mse_arrived_cap = 0;
+            if ((rc = device_alloc(&ctx->topo_mse_arrived, (size_t)ctx->num_patches)) != SMVS_OK)
+                return rc;
+            SMVS_HIP_CHECK(hipMemsetAsync(ctx->topo_mse_arrived, 0,
+                sizeof(int) * (size_t)ctx->num_patches, ctx->stream));
+            ctx->topo_mse_arrived_cap = (size_t)ctx->num_patches;
+        }
+    }
+    rc = fill_args(ctx, A, who);
+    A->mse_chunks = chunks;
+    A->mse_parts = ctx->topo_mse_parts;
+    A->mse_arrived = ctx->topo_mse_arrived;
+    return rc;
 }
 
 // The candidate list, then the errors of its entries.  count_is_zero: the
@@ -1599,7 +1670,7 @@ launch_patch_mse(smvs_ctx *ctx, TopoArgs const &A, bool count_is_zero)
     // enough groups for every CU to hold its fill of waves, never more than the
     // patches: a group walks the list with that stride
     long long const group = group_size(ctx->patchsize, MSE_WORKGROUP_FROM);
-    long long const items = (long long)ctx->num_patches * group;
+    long long const items = (long long)ctx->num_patches * group * A.mse_chunks;
     long long blocks = (items + 255) / 256;
     if (blocks > 1024)
         blocks = 1024;
