@@ -79,6 +79,11 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
     float *depth_out, float *normals_out, smvs_host_log *log)
 {
     try {
+        // (the previous call's embeddings go back to the page-locked pool BEFORE
+        // this call asks it for its maps: kept until the next call's end, the 33 MB
+        // of a 1920 x 1080 depth + normal pair were allocated afresh every time --
+        // 6.4 instead of 0.7 ms for `depth + normal maps`)
+        last_embeddings().clear();
         StereoView::Ptr main_view = make_view(*main_in, o->use_shading != 0, o->gamma_correction != 0);
         std::vector<StereoView::Ptr> subs;
         for (int j = 0; j < n_subs; ++j)

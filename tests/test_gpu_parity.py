@@ -786,6 +786,31 @@ def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle,
     ctx.close()
 
 
+@pytest.mark.parametrize("size,n_subs,scale", [((320, 256), 4, 2), ((512, 384), 3, 4),
+                                               ((576, 416), 3, 5)])
+def test_visibility_masks_do_not_depend_on_the_lanes_per_pair(hip, oracle, monkeypatch, size,
+                                                              n_subs, scale):
+    """Round 6 chose the lanes per (patch, neighbour) of the visibility kernel by
+    patch size (csrc/topology.hip, SMVS_VIS_GROUP_<ps>): one lane, a row of
+    sixteen, a whole wave and the whole workgroup must give the oracle's masks --
+    the group size changes who sums what (DPP rows, permlane swaps, LDS across
+    waves), which samples go to the LDS stash and how many groups share a
+    workgroup's staged depths, never a decision."""
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, size[0], size[1], n_subs, scale, 0.01)
+    want = tp.subviews()
+    name = "SMVS_VIS_GROUP_%d" % (1 << scale)
+    for lanes in (None, 1, 2, 16, 32, 64, 256):
+        if lanes is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(lanes))
+        ctx.set_surface(surf)
+        got = ctx.topology_subviews(None, use_ncc=True)
+        assert np.array_equal(got, want), lanes
+    monkeypatch.delenv(name, raising=False)
+    ctx.close()
+
+
 def test_topology_subviews_with_sgm_depth(hip, oracle):
     """use_sgm variant: the SGM depth is splatted into the z-buffers too and
     the NCC test is skipped (depth_optimizer.cc:463-466, 577-580)."""
