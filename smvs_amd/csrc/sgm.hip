@@ -21,6 +21,7 @@
 // counts take one launch per direction.  Each path reads C once and
 // read-modify-writes S once.
 #include "common.h"
+#include <type_traits>
 
 #include <utility>
 
@@ -586,6 +587,213 @@ path_line(PathArgs const &A, int line, int *x, int *y, int *len, int *extra)
         *len = min(nx, ny);
     }
     return true;
+}
+
+// ---- two lines per wavefront, four planes per lane, packed 16-bit arithmetic
+// (round 6; DELTA form, plane counts that are multiples of four up to 128) ----
+// sgm_all_paths_kernel spends ~37 vector instructions per step of a line for
+// 128 planes -- two per lane, every minimum and sum a 32-bit operation, and a
+// quarter of them the minimum over the wave -- and the launch is bound by
+// exactly those (profiles/r6_sgm_counters.txt: 54 % issuing, 0.33 of HBM).
+// Here a lane holds FOUR planes as two u16 pairs (v_pk_add_u16 / v_pk_min_u16
+// work on both halves), so 32 lanes cover a line and a wave walks TWO adjacent
+// lines of one direction: the step's instructions are shared by both, the
+// minimum over a line is five DPP steps over a half wave instead of six over a
+// whole one.  Same integers as sgm_all_paths_kernel<K, true> (every value stays
+// below 2^16: L <= 255 + P2, BIG + P1 + P2 < 65536), hence the same bytes.
+typedef unsigned short u16x2_r __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t
+pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2_r)(__builtin_bit_cast(u16x2_r, a)
+        + __builtin_bit_cast(u16x2_r, b)));
+}
+
+__device__ __forceinline__ uint32_t
+pk_sub(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2_r)(__builtin_bit_cast(u16x2_r, a)
+        - __builtin_bit_cast(u16x2_r, b)));
+}
+
+__device__ __forceinline__ uint32_t
+pk_min(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(
+        __builtin_bit_cast(u16x2_r, a), __builtin_bit_cast(u16x2_r, b)));
+}
+
+// max over a DPP pattern with bound_ctrl: a lane without a source reads 0, the
+// identity of an unsigned maximum -- one v_max_u32_dpp, nothing to move into
+// the destination first (the minimum below is taken as the maximum of the
+// complements)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t
+max_dpp0(uint32_t v)
+{
+    return max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true));
+}
+
+// FULL: 128 planes, every lane of a half wave has four (no idle lanes to reset)
+template <int K, bool FULL>
+__global__ void __launch_bounds__(64)
+sgm_paths2_kernel(PathArgs A)
+{
+    int const w = A.w, h = A.h, D = A.D;
+    int const ndiag = w + h - 1;
+    // block -> (direction, pair of lines); the long horizontal lines first
+    int const counts[8] = { h, h, w, ndiag, ndiag, w, ndiag, ndiag };
+    int b = blockIdx.x;
+    int dir = 0;
+    for (; dir < 8; ++dir) {
+        int const pairs_of_dir = (counts[dir] + 1) >> 1;
+        if (b < pairs_of_dir)
+            break;
+        b -= pairs_of_dir;
+    }
+    if (dir > 7)
+        return;
+    int const dirs[8][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 1, 1 }, { -1, 1 },
+        { 0, -1 }, { 1, -1 }, { -1, -1 } };
+    A.dx = dirs[dir][0];
+    A.dy = dirs[dir][1];
+
+    int const lane = threadIdx.x;
+    int const half = lane >> 5, hl = lane & 31;
+    int x0 = 0, y0 = 0, len = 0, extra_seed = 0;
+    bool const has_line = path_line(A, 2 * b + half, &x0, &y0, &len, &extra_seed);
+    if (!has_line)
+        len = 0;
+    bool const upper = half != 0;
+    bool const ok = has_line && (FULL || 4 * hl < D);
+    int const li = ok ? hl : 0;
+    // the line as running pointers, four planes (bytes) per lane
+    size_t const o0 = has_line ? (((size_t)y0 * w + x0) * D >> 2) + li : 0;
+    ptrdiff_t const step = ((ptrdiff_t)A.dy * w + A.dx) * D / 4;
+    const uint32_t *__restrict__ cin = reinterpret_cast<const uint32_t *>(A.cost) + o0;
+    uint32_t *__restrict__ e32
+        = reinterpret_cast<uint32_t *>(A.delta + (size_t)dir * A.vol) + o0;
+    // "no such plane": above every path cost, and + P1 (<= 255 in this form)
+    // still fits 16 bits
+    uint32_t const BIG2 = 0x7FFF7FFFu;
+    uint32_t const p1p1 = (uint32_t)A.p1 | ((uint32_t)A.p1 << 16);
+    uint32_t const p2p2 = (uint32_t)A.p2 | ((uint32_t)A.p2 << 16);
+    // v_perm_b32 selectors of the two neighbour vectors that reach into the
+    // adjacent lanes -- {plane 3 of the lane before, own plane 0} and {own plane
+    // 3, plane 0 of the lane after} -- per lane: at the ends of a line (where
+    // the lane before / after belongs to the OTHER line of the wave) the bytes
+    // 0x00, 0xff instead, i.e. 0xff00: no such plane
+    uint32_t const sel_below = hl == 0 ? 0x05040d0cu : 0x05040302u;   // perm(pa, pb_prev)
+    uint32_t const sel_above = hl == 31 ? 0x0d0c0302u : 0x05040302u;  // perm(pa_next, pb)
+
+    // ---- the first cell of a line: L = C (sgm_stereo.cc:457-464; a corner that
+    // is seeded from its row and from its column adds C twice) ----
+    uint32_t pa = BIG2, pb = BIG2;     // planes {4 hl, 4 hl + 1}, {4 hl + 2, 4 hl + 3}
+    if (has_line) {
+        uint32_t const c = *cin;
+        uint32_t const ca = __builtin_amdgcn_perm(0u, c, 0x0c010c00u);
+        uint32_t const cb = __builtin_amdgcn_perm(0u, c, 0x0c030c02u);
+        if (ok) {
+            pa = ca;
+            pb = cb;
+            *e32 = extra_seed ? c : 0u;
+        }
+    }
+    cin += step;
+    e32 += step;
+    // the remaining steps of the two lines as scalars: every "is this step
+    // inside my line" below is then a lane mask built by scalar instructions
+    int const rest0 = max(__builtin_amdgcn_readlane(len, 0) - 1, 0);
+    int const rest1 = max(__builtin_amdgcn_readlane(len, 32) - 1, 0);
+    int const rest_max = max(rest0, rest1), rest_min = min(rest0, rest1);
+    auto const inside = [&](int r) -> bool {
+        return (!upper & (r < rest0)) | (upper & (r < rest1));
+    };
+
+    uint32_t c_cur[K], c_next[K], outv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        c_cur[k] = 0;
+        if (inside(k))
+            c_cur[k] = cin[(ptrdiff_t)k * step];
+    }
+    cin += (ptrdiff_t)K * step;
+    // one chunk of K steps; FAST: this chunk and the next lie inside both lines
+    // (no predicates on the loads and stores)
+    auto const chunk = [&](auto fast_tag, int base) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            c_next[k] = 0;
+            if (FAST || inside(base + K + k))
+                c_next[k] = cin[(ptrdiff_t)k * step];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            outv[k] = 0;
+            if (FAST || base + k < rest_max) {
+                // the four cost bytes as two u16 pairs
+                uint32_t const ca = __builtin_amdgcn_perm(0u, c_cur[k], 0x0c010c00u);
+                uint32_t const cb = __builtin_amdgcn_perm(0u, c_cur[k], 0x0c030c02u);
+                // the minimum over the line: per lane, then over its half wave
+                uint32_t m = pk_min(pa, pb);
+                m = ~min(m & 0xFFFFu, m >> 16);
+                m = max_dpp0<0x111, 0xf>(m);   // row_shr:1
+                m = max_dpp0<0x112, 0xf>(m);   // row_shr:2
+                m = max_dpp0<0x114, 0xf>(m);   // row_shr:4
+                m = max_dpp0<0x118, 0xf>(m);   // row_shr:8
+                m = max_dpp0<0x142, 0xa>(m);   // row_bcast:15 -> rows 1, 3
+                uint32_t const m_lower = ~(uint32_t)__builtin_amdgcn_readlane((int)m, 31);
+                uint32_t const m_upper = ~(uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+                uint32_t const mm_lower = m_lower | (m_lower << 16);
+                uint32_t const mm_upper = m_upper | (m_upper << 16);
+                uint32_t const mnmn = upper ? mm_upper : mm_lower;
+                uint32_t const far = pk_add(mnmn, p2p2);
+                // neighbouring planes: {3 of the lane before, 0}, {1, 2}, {3, 0 of the lane after}
+                // (wave_shr:1 / wave_shl:1; the lanes without a source are ends of
+                // a line, whose selectors do not look at what arrives)
+                uint32_t const pb_prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pb, 0x138,
+                    0xf, 0xf, true);
+                uint32_t const pa_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pa, 0x130,
+                    0xf, 0xf, true);
+                uint32_t const below_a = __builtin_amdgcn_perm(pa, pb_prev, sel_below);
+                uint32_t const mid = __builtin_amdgcn_alignbit(pb, pa, 16);
+                uint32_t const above_b = __builtin_amdgcn_perm(pa_next, pb, sel_above);
+                uint32_t const mid1 = pk_add(mid, p1p1);
+                // :310-346: L = C + min(L'(d), L'(d -+ 1) + P1, min L' + P2) - min L'
+                uint32_t const ua = pk_min(pk_min(pa, pk_add(below_a, p1p1)), pk_min(mid1, far));
+                uint32_t const ub = pk_min(pk_min(pb, mid1), pk_min(pk_add(above_b, p1p1), far));
+                uint32_t const ea = pk_sub(ua, mnmn), eb = pk_sub(ub, mnmn);
+                pa = pk_add(ca, ea);
+                pb = pk_add(cb, eb);
+                outv[k] = __builtin_amdgcn_perm(eb, ea, 0x06040200u);
+                if (!FULL && !ok)
+                    pa = pb = BIG2;
+            }
+        }
+        if (FULL && FAST) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                e32[(ptrdiff_t)k * step] = outv[k];
+        } else if (ok) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (FAST || inside(base + k))
+                    e32[(ptrdiff_t)k * step] = outv[k];
+        }
+    };
+    for (int base = 0; base < rest_max; base += K) {
+        if (base + 2 * K <= rest_min)
+            chunk(std::true_type(), base);
+        else
+            chunk(std::false_type(), base);
+        cin += (ptrdiff_t)K * step;
+        e32 += (ptrdiff_t)K * step;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            c_cur[k] = c_next[k];
+    }
 }
 
 // All eight path directions in ONE launch.  The recurrences of different
@@ -1293,7 +1501,22 @@ sgm_run_device(SgmWorkspace &B, const uint8_t *d_main,
     P.delta = B.delta;
     P.vol = vol;
     bool const df = SgmWorkspace::delta_form(num_steps, penalty2);
-    if (df) {
+    // (SMVS_SGM_PATHS=wave: a wave per line, two planes per lane -- rounds 3-5)
+    static bool const wave_per_line = [] {
+        const char *e = std::getenv("SMVS_SGM_PATHS");
+        return e != nullptr && e[0] == 'w';
+    }();
+    if (df && (num_steps & 3) == 0 && num_steps <= 128 && !wave_per_line) {
+        P.dx = P.dy = 0;
+        P.first = 0;
+        int const nd = w + h - 1;
+        int const pairs = 2 * ((h + 1) / 2) + 2 * ((w + 1) / 2) + 4 * ((nd + 1) / 2);
+        SgmKernelTimer timer(B.prof, stream, SMVS_SGM_K_PATHS);
+        if (num_steps == 128)
+            hipLaunchKernelGGL((sgm_paths2_kernel<8, true>), dim3(pairs), dim3(64), 0, stream, P);
+        else
+            hipLaunchKernelGGL((sgm_paths2_kernel<8, false>), dim3(pairs), dim3(64), 0, stream, P);
+    } else if (df) {
         P.dx = P.dy = 0;
         P.first = 0;
         int const lines = 2 * h + 2 * w + 4 * (w + h - 1);
