@@ -690,18 +690,24 @@ def secondary_workloads(args):
     # (2) views per second, whole per-view pipeline
     views = {}
     for label, sgm_scale in (("no_sgm", None), ("sgm", 1)):
-        host.optimize_views(inp, 2, regularization=REG, min_scale=SCALE, sgm_scale=sgm_scale)
+        # (warm-up: library, page-locked pools, the workers' contexts of this mode)
+        host.optimize_views(inp, 4, regularization=REG, min_scale=SCALE, sgm_scale=sgm_scale,
+                            views_in_flight=2)
         for in_flight in (1, 4, 8):
             jobs = 4 if in_flight == 1 else 3 * in_flight
-            v = host.optimize_views(inp, jobs, regularization=REG, min_scale=SCALE,
-                                    sgm_scale=sgm_scale, views_in_flight=in_flight)
+            best = None
+            for rep in range(2):
+                v = host.optimize_views(inp, jobs, regularization=REG, min_scale=SCALE,
+                                        sgm_scale=sgm_scale, views_in_flight=in_flight)
+                if best is None or v["views_per_s"] > best["views_per_s"]:
+                    best = v
             views["%s_in_flight_%d" % (label, in_flight)] = dict(
-                views_per_s=round(v["views_per_s"], 2), views=jobs,
-                mean_task_ms=round(1e3 * float(np.mean(v["job_seconds"])), 1))
+                views_per_s=round(best["views_per_s"], 2), views=jobs,
+                mean_task_ms=round(1e3 * float(np.mean(best["job_seconds"])), 1))
     out["views_per_s"] = dict(per_gpu=views,
         note="whole per-view tasks (9 x StereoView::create, [SGM front end,] optimize() of "
              "all scales, depth + normal maps) through smvs_amd::ViewQueue on one GPU, "
-             "%dx%d, %d neighbours" % (w, h, NSUBS))
+             "%dx%d, %d neighbours; the better of two runs of each entry" % (w, h, NSUBS))
     # (3) SGM front end kernels
     lib = _capi.load()
     host.sgm_depth(inp, sgm_scale=1)
