@@ -341,6 +341,9 @@ group_size(int ps, int whole_workgroup_from)
     // 705 -> 585 us; at ps = 16 the barriers of the workgroup-wide reductions
     // cost the visibility kernel more than the shorter chains save:
     // 840 -> 1640 us, so it switches at 64, the mse kernel at 16).
+    // (Round 6: the visibility kernel takes this rule only for ps = 1, 32, 64
+    // and up; in between it runs 2 / 4 / 8 / 32 lanes at ps = 2 / 4 / 8 / 16,
+    // smvs_topology_subviews.)
     int const pp = ps * ps;
     if (ps >= whole_workgroup_from)
         return 256;
@@ -355,7 +358,8 @@ constexpr int NCC_KEEP = 4;
 constexpr int NCC_STASH_MAX = 16;
 constexpr int MSE_WORKGROUP_FROM = 16;   // topo_mse_kernel
 
-// Reductions over a lane group.  G <= 64: xor-shuffles inside the wave.
+// Reductions over a lane group (the patch-MSE kernel's; the visibility
+// kernel's are vis_lanes_reduce below).  G <= 64: xor-shuffles inside the wave.
 // G == 256: the workgroup is the group -- per-wave results meet in LDS (every
 // thread of the workgroup must call; `red` holds 4 doubles).
 template <typename T>
@@ -370,24 +374,6 @@ group_sum(T v, int G, double *red)
             red[threadIdx.x >> 6] = (double)v;
         __syncthreads();
         v = (T)(((red[0] + red[1]) + red[2]) + red[3]);
-    }
-    return v;
-}
-
-__device__ __forceinline__ double
-group_max(double v, int G, double *red)
-{
-    for (int off = (G < 64 ? G : 64) >> 1; off > 0; off >>= 1) {
-        double const o = __shfl_xor(v, off);
-        v = v < o ? o : v;
-    }
-    if (G > 64) {
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0)
-            red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        for (int w = 0; w < 4; ++w)
-            v = v < red[w] ? red[w] : v;
     }
     return v;
 }
@@ -544,9 +530,14 @@ topo_pixel_surface_kernel(TopoArgs A)
 
 // ---- visibility of every patch in every neighbour (:472-590), incl.
 // ncc_for_patch (:792-912) ----
-// (159 VGPRs: three waves per SIMD -- round 4: 192, two.  Launch bounds that
-// force 128 VGPRs and four waves put 116 bytes per lane into scratch:
-// 610 -> 762 us, measured)
+// (153 VGPRs: three waves per SIMD -- round 5: 159, round 4: 192 and two waves.
+// Launch bounds that force 128 VGPRs and four waves put 116-128 bytes per lane
+// into scratch: 610 -> 762 us when it was measured in round 5.)
+// Round 6 (profiles/r6_visibility_groups.txt): the group's reductions on the
+// VALU (vis_lanes_reduce), the lanes per (patch, neighbour) chosen by patch size
+// on the host (A.vis_group), the NCC's warped colours beyond the kept ones in an
+// LDS stash, a sample's depth and template entry from LDS, the neighbour
+// wave-uniform (blockIdx.y): 9.1 -> 5.8 ms per --no-sgm view, masks unchanged.
 //
 // PART 0: the whole test in one launch (the default).  SMVS_VIS_SPLIT=1
 // (round 6, an experiment that did not pay: 3 % slower) runs the two halves
