@@ -233,6 +233,11 @@ topo_clear_kernel(TopoArgs A)
     size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cells)
         A.zraw[s][i] = 10000.0f;
+    // ... and the masks the visibility kernel ORs into start at zero (the first
+    // neighbour's blocks; one runtime fill kernel per call less)
+    if (s == 0)
+        for (size_t p = i; p < (size_t)A.num_patches; p += (size_t)gridDim.x * blockDim.x)
+            A.vis_out[p] = 0u;
 }
 
 // ---- z-buffer splat (depth_optimizer.cc:441-470), one thread per pixel ----
@@ -1193,6 +1198,15 @@ topo_mse_kernel(TopoArgs A)
 __global__ void __launch_bounds__(256)
 topo_border_nodes_kernel(TopoArgs A)
 {
+    // The first kernel of a cut pass also clears the pass's two counters
+    // (patches deleted, candidates listed): the kernels that count run behind
+    // this one on the stream, and the host has read the previous pass's values
+    // before it enqueues this launch -- one runtime fill kernel per pass less
+    // (50 per --no-sgm view) in a loop whose cost is its launches.
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *A.deleted = 0;
+        *A.mse_count = 0;
+    }
     // (a pass enqueued ahead whose predecessor ended the loop: every thread of
     // the launch reads the same word)
     if (A.pass_gate != nullptr && *A.pass_gate <= 10)
@@ -1464,8 +1478,6 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         hipLaunchKernelGGL(topo_clear_kernel, dim3((unsigned)((cells + 255) / 256), 1,
             (unsigned)ctx->n_subs), dim3(256), 0, ctx->stream, A);
     }
-    SMVS_HIP_CHECK(hipMemsetAsync(ctx->patch_vis, 0,
-        sizeof(uint32_t) * ctx->num_patches, ctx->stream));
     hipLaunchKernelGGL(topo_splat_kernel, dim3((ctx->width + 255) / 256,
         ctx->height), dim3(256), 0, ctx->stream, A);
     {
@@ -1732,8 +1744,7 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
         return v < 1 ? 1 : (v > TOPO_AHEAD ? TOPO_AHEAD : v);
     }();
     while (deleted > 10) {
-        SMVS_HIP_CHECK(hipMemsetAsync(ctx->status + I_TOPO_PASS0, 0,
-            2 * TOPO_AHEAD * sizeof(int), ctx->stream));
+        // (the counters of a pass are cleared by its first kernel)
         for (int k = 0; k < ahead; ++k) {
             TopoArgs P = A;
             P.deleted = ctx->status + I_TOPO_PASS0 + 2 * k;
