@@ -690,10 +690,13 @@ def secondary_workloads(args):
     # (2) views per second, whole per-view pipeline
     views = {}
     for label, sgm_scale in (("no_sgm", None), ("sgm", 1)):
-        # (warm-up: library, page-locked pools, the workers' contexts of this mode)
-        host.optimize_views(inp, 4, regularization=REG, min_scale=SCALE, sgm_scale=sgm_scale,
-                            views_in_flight=2)
-        for in_flight in (1, 4, 8):
+        # (warm-up: library, page-locked pools, the workers' contexts of this mode -- and
+        # the GPU's clocks: this section follows half a minute of CPU-only work (the CPU
+        # baseline), and one view at a time leaves the GPU idle a fifth of the time, so the
+        # busiest configuration runs first)
+        host.optimize_views(inp, 16, regularization=REG, min_scale=SCALE, sgm_scale=sgm_scale,
+                            views_in_flight=8)
+        for in_flight in (8, 4, 1):
             jobs = 4 if in_flight == 1 else 3 * in_flight
             best = None
             for rep in range(2):
