@@ -371,6 +371,19 @@ int smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
 int smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
     float sigma, int kernel_size, float *out);
 
+/* The same with the map as the view stores it: dm_mve[dm_w*dm_h] is the
+ * "smvs-sgm" embedding in MVE's ray-length convention
+ * (StereoView::write_depth_to_view, stereo_view.h:100-119) and
+ * inv_calibration9 the inverse calibration of an image of the map's size
+ * (StereoView::get_sgm_depth, stereo_view.h:121-135:
+ * mve::image::depthmap_convert_conventions(depth, invproj, false)).  The
+ * conversion to z-depth runs on the device with the host's float operations
+ * (same bits); a caller that would otherwise convert 0.5 M pixels on the host
+ * while the GPU waits for the map calls this one (create_initial_surface,
+ * depth_optimizer.cc:35-45). */
+int smvs_ctx_sgm_init_depth_mve(smvs_ctx *ctx, const float *dm_mve, int dm_w, int dm_h,
+    const float *inv_calibration9, float sigma, int kernel_size, float *out);
+
 /* ------------------------------------------------------------------ */
 /* topology tests between Newton batches              */
 /* ------------------------------------------------------------------ */

@@ -182,10 +182,17 @@ struct smvs_ctx {
     // behind it, and the conversion to float is enqueued on the context's
     // stream (behind a wait for that event) where the image is first needed
     hipStream_t copy_stream = nullptr;
+    // the low-resolution SGM map on its way to the device (smvs_ctx_sgm_init_depth):
+    // page-locked, read by a kernel over the bus -- a DMA would queue behind the
+    // nine image transfers that are under way at that moment
+    float *sgm_pin = nullptr;
+    size_t sgm_pin_cap = 0;
+    bool sgm_pin_busy = false;
     hipEvent_t image_ready[SMVS_MAX_SUBS + 1] = { nullptr };
     uint8_t *upload_stage[SMVS_MAX_SUBS + 1] = { nullptr };
     size_t upload_stage_cap[SMVS_MAX_SUBS + 1] = { 0 };
-    uint32_t image_pending = 0;     // bit v: staged, not yet converted
+    uint32_t image_pending = 0;     // bit v: on its way (staged or being converted), not yet waited for
+    uint32_t image_direct = 0;      // bit v: converted by the upload itself (no staging buffer)
     uint32_t upload_stage_busy = 0; // bit v: a conversion from upload_stage[v] may be in flight
     // resident PCG (cg_resident.hip)
     double *res_work = nullptr;     // partial sums + barrier words

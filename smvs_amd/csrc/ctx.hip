@@ -221,7 +221,9 @@ ctx_reset_for_reuse(smvs_ctx *ctx)
 {
     ctx->image_ok = ctx->planes_ok = 0;
     ctx->image_pending = 0;
+    ctx->image_direct = 0;
     ctx->upload_stage_busy = 0;   // (the caller has synchronised the stream)
+    ctx->sgm_pin_busy = false;
     ctx->sgm_resident = false;
     ctx->surf_depth_ok = false;
     ctx->has_cameras = ctx->has_surface = ctx->has_system = false;
@@ -392,6 +394,8 @@ ctx_free(smvs_ctx *ctx)
     }
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->sgm_pin)
+        (void)hipHostFree(ctx->sgm_pin);
     void *bufs[] = { ctx->main_grad, ctx->main_shading, ctx->main_shading_grad,
         ctx->cams, ctx->subs_dev, ctx->nodes, ctx->node_valid, ctx->patch_valid,
         ctx->patch_vis, ctx->active, ctx->active_next, ctx->cg_mask, ctx->hermite_all,
@@ -474,6 +478,7 @@ smvs_ctx_synchronize(smvs_ctx *ctx)
         SMVS_HIP_CHECK(hipStreamSynchronize(ctx->copy_stream));
     SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->upload_stage_busy = 0;
+    ctx->sgm_pin_busy = false;
     return SMVS_OK;
 }
 

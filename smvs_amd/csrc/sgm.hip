@@ -1869,8 +1869,64 @@ smvs_bilateral_upsample(int device, const float *dm, int dm_w, int dm_h,
 // smvs_topology_subviews compare with (lib/depth_optimizer.cc:35-51 hands the
 // filtered map to both).  Saves the upload of the float image (25 MB at
 // 1920 x 1080 x 3) and of the result, once per topology pass.
+// The low-resolution SGM map from page-locked host memory (read over the bus)
+// to the device.  from_mve: the map is the view's "smvs-sgm" embedding as
+// StereoView::write_depth_to_view stored it (MVE's ray-length convention) and is
+// turned into z-depth on the way -- mve::image::depthmap_convert_conventions
+// with the float operations of host/stereo_view.cc (StereoView::get_sgm_depth,
+// stereo_view.h:121-135), so the same bits as the host conversion.
+struct SgmMapUpload {
+    const float *src;
+    float *dst;
+    int w, h;
+    int from_mve;
+    float invproj[9];
+};
+
+__global__ void __launch_bounds__(256)
+sgm_map_upload_kernel(SgmMapUpload A)
+{
+#pragma clang fp contract(off)
+    size_t const i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)A.w * A.h)
+        return;
+    float d = A.src[i];
+    if (A.from_mve) {
+        int const y = (int)(i / (size_t)A.w), x = (int)(i - (size_t)y * A.w);
+        float const px = (float)x + 0.5f, py = (float)y + 0.5f;
+        float v[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            v[r] = A.invproj[3 * r] * px + A.invproj[3 * r + 1] * py + A.invproj[3 * r + 2];
+        float const len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        // `double len = px.norm(); dm *= 1.0 / len` [MVE-unverified, M10]
+        double const len_d = (double)len;
+        d = (float)((double)d * (1.0 / len_d));
+    }
+    A.dst[i] = d;
+}
+
+static int
+sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *inv_calibration9,
+    float sigma, int kernel_size, float *out);
+
 extern "C" int
 smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
+    float sigma, int kernel_size, float *out)
+{
+    return sgm_init_depth(ctx, dm, dm_w, dm_h, nullptr, sigma, kernel_size, out);
+}
+
+extern "C" int
+smvs_ctx_sgm_init_depth_mve(smvs_ctx *ctx, const float *dm_mve, int dm_w, int dm_h,
+    const float *inv_calibration9, float sigma, int kernel_size, float *out)
+{
+    SMVS_REQUIRE(dm_mve == nullptr || inv_calibration9 != nullptr, "null argument");
+    return sgm_init_depth(ctx, dm_mve, dm_w, dm_h, inv_calibration9, sigma, kernel_size, out);
+}
+
+static int
+sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *inv_calibration9,
     float sigma, int kernel_size, float *out)
 {
     SMVS_REQUIRE(ctx != nullptr, "null argument");
@@ -1906,8 +1962,39 @@ smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
         ctx->topo_sgm_cap = n;
     }
     ctx->sgm_resident = false;
-    if ((rc = ctx_upload(ctx, ctx->sgm_lowres, dm, sizeof(float) * n_low)) != SMVS_OK)
-        return rc;
+    {
+        // The map goes to the device through a kernel that reads page-locked
+        // memory over the bus, not as a DMA: at this moment the nine images of the
+        // view are on their way (smvs_ctx_upload_image_async) and a tenth transfer
+        // queues behind them, with the host waiting for it before it can launch
+        // the filter (round 6, profiles/r6_upload_overlap.txt).
+        if (ctx->sgm_pin_busy) {
+            SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ctx->sgm_pin_busy = false;
+        }
+        if (ctx->sgm_pin_cap < n_low) {
+            if (ctx->sgm_pin != nullptr)
+                (void)hipHostFree(ctx->sgm_pin);
+            ctx->sgm_pin = nullptr;
+            ctx->sgm_pin_cap = 0;
+            SMVS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->sgm_pin),
+                sizeof(float) * n_low, hipHostMallocDefault));
+            ctx->sgm_pin_cap = n_low;
+        }
+        std::memcpy(ctx->sgm_pin, dm, sizeof(float) * n_low);
+        SgmMapUpload U;
+        U.src = ctx->sgm_pin;
+        U.dst = ctx->sgm_lowres;
+        U.w = dm_w;
+        U.h = dm_h;
+        U.from_mve = inv_calibration9 != nullptr ? 1 : 0;
+        for (int i = 0; i < 9; ++i)
+            U.invproj[i] = inv_calibration9 != nullptr ? inv_calibration9[i] : 0.0f;
+        hipLaunchKernelGGL(sgm_map_upload_kernel, dim3((unsigned)((n_low + 255) / 256)),
+            dim3(256), 0, ctx->stream, U);
+        SMVS_HIP_CHECK(hipGetLastError());
+        ctx->sgm_pin_busy = true;
+    }
     BilateralArgs A;
     A.dm = ctx->sgm_lowres;
     A.ci = ctx->images[0].data;
@@ -1968,11 +2055,12 @@ smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
         }
     }
     SMVS_HIP_CHECK(hipGetLastError());
+    // (no wait when the caller does not want the filtered map back: whatever
+    // reads it next runs behind the filter on the context's stream)
     if (out != nullptr) {
         if ((rc = ctx_download(ctx, out, ctx->topo_sgm, sizeof(float) * n)) != SMVS_OK)
             return rc;
-    } else {
-        SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->sgm_pin_busy = false;
     }
     ctx->sgm_resident = true;
     return SMVS_OK;

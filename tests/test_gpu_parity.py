@@ -827,6 +827,35 @@ def test_topology_subviews_with_sgm_depth(hip, oracle):
     ctx.close()
 
 
+def test_sgm_init_depth_from_the_stored_map_converts_with_the_hosts_bits(hip, oracle):
+    """smvs_ctx_sgm_init_depth_mve takes the "smvs-sgm" embedding as the view
+    stores it (MVE's ray-length convention, stereo_view.h:100-135) and turns it
+    into z-depth in the kernel that fetches it: the filtered map must be the one
+    smvs_ctx_sgm_init_depth gives for the host's conversion
+    (depthmap_convert_conventions: float products, float square root, the
+    quotient 1 / len and the product in double) -- bit for bit."""
+    from smvs_amd import synth
+    W, H = 320, 256
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, W, H, 3, 2, 0.0)
+    lw, lh = W // 2, H // 2
+    xs, ys = np.meshgrid(np.arange(0, W, 2, dtype=float) + 0.5, np.arange(0, H, 2, dtype=float) + 0.5)
+    z = synth.depth_at(prob["scene"], prob["main"], xs, ys).astype(np.float32)
+    z[::7, ::5] = 0.0
+    inv = _inverse_calibration(prob["main"].flen, lw, lh)
+    f = np.float32
+    px = (np.arange(lw, dtype=np.float32) + f(0.5))[None, :]
+    py = (np.arange(lh, dtype=np.float32) + f(0.5))[:, None]
+    v = [inv[3 * r] * px + inv[3 * r + 1] * py + inv[3 * r + 2] for r in range(3)]
+    length = np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]).astype(np.float32)
+    assert all(a.dtype == np.float32 for a in v)
+    stored = (z.astype(np.float64) * length.astype(np.float64)).astype(np.float32)      # to MVE
+    back = (stored.astype(np.float64) * (1.0 / length.astype(np.float64))).astype(np.float32)
+    want = ctx.sgm_init_depth(back)
+    got = ctx.sgm_init_depth_mve(stored, inv)
+    assert (want > 0).any() and np.array_equal(got, want)
+    ctx.close()
+
+
 def test_context_sgm_init_depth_is_the_bilateral_filter_and_stays_resident(hip, oracle):
     """smvs_ctx_sgm_init_depth: depthmap_bilateral_filter guided by the main
     image the context already holds (depth_optimizer.cc:35-51) -- bit-identical
