@@ -380,9 +380,14 @@ int smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
  * conversion to z-depth runs on the device with the host's float operations
  * (same bits); a caller that would otherwise convert 0.5 M pixels on the host
  * while the GPU waits for the map calls this one (create_initial_surface,
- * depth_optimizer.cc:35-45). */
-int smvs_ctx_sgm_init_depth_mve(smvs_ctx *ctx, const float *dm_mve, int dm_w, int dm_h,
-    const float *inv_calibration9, float sigma, int kernel_size, float *out);
+ * depth_optimizer.cc:35-45).  dm_is_z_depth != 0: dm is still the z-depth map
+ * the SGM front end produced (reconstruct_sgm_depth_for_view,
+ * app/smvsrecon.cc:346-384) and has not been stored yet: the kernel applies
+ * write_depth_to_view's conversion (`dm *= len`) and then get_sgm_depth's
+ * (`dm *= 1.0 / len`) -- the round trip through the embedding the reference
+ * makes, same bits, without the host touching 2 x 0.5 M pixels. */
+int smvs_ctx_sgm_init_depth_mve(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
+    const float *inv_calibration9, int dm_is_z_depth, float sigma, int kernel_size, float *out);
 
 /* ------------------------------------------------------------------ */
 /* topology tests between Newton batches              */

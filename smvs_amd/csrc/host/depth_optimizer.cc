@@ -256,7 +256,13 @@ DepthOptimizer::create_initial_surface(void)
             // to z-depth (0.5 M pixels, ~1.2 ms of the host with the GPU waiting
             // for the map) runs in the kernel that fetches it, with the same
             // float operations.
-            FloatImage::Ptr stored = main_view->get_embedding("smvs-sgm");
+            // (a map the SGM front end has just produced is still z-depth: both of
+            // the view's conversions -- into the embedding and back -- then run
+            // in that kernel)
+            FloatImage::Ptr stored = main_view->get_deferred_depth("smvs-sgm");
+            bool const still_z = stored != nullptr;
+            if (!still_z)
+                stored = main_view->get_embedding("smvs-sgm");
             if (stored == nullptr)
                 throw std::invalid_argument("use_sgm without an smvs-sgm embedding");
             float invproj[9];
@@ -267,8 +273,8 @@ DepthOptimizer::create_initial_surface(void)
                 filtered = FloatImage::create_for_overwrite(main_view->get_width(),
                     main_view->get_height(), 1);
             check(smvs_ctx_sgm_init_depth_mve(ctx, stored->begin(), stored->width(),
-                stored->height(), invproj, 5.0f, 5, filtered ? filtered->begin() : nullptr),
-                "smvs_ctx_sgm_init_depth_mve");
+                stored->height(), invproj, still_z ? 1 : 0, 5.0f, 5,
+                filtered ? filtered->begin() : nullptr), "smvs_ctx_sgm_init_depth_mve");
             if (filtered)
                 main_view->write_depth_to_view(filtered, "smvs-sgm-filtered");
             check(smvs_surface_create(ctx, init_scale, nullptr, nullptr, nullptr, 0,

@@ -92,7 +92,7 @@ smvs_host_optimize(const smvs_host_view *main_in, const smvs_host_view *subs_in,
         if (sgm_depth != nullptr) {
             FloatImage::Ptr d = FloatImage::create_for_overwrite(sgm_w, sgm_h, 1);
             std::memcpy(d->begin(), sgm_depth, sizeof(float) * sgm_w * sgm_h);
-            main_view->write_depth_to_view(d, "smvs-sgm");
+            main_view->write_depth_to_view_deferred(d, "smvs-sgm");
             if (sgm_roundtrip != nullptr) {
                 FloatImage::Ptr back = main_view->get_sgm_depth();
                 std::memcpy(sgm_roundtrip, back->begin(),

@@ -180,7 +180,10 @@ reconstruct_sgm_depth_for_view(SGMStereo::Options opts,
     for (std::size_t k = 0; k < pairs.size(); ++k)
         prepare_pair(opts, main_view, neighbors[k], bundle, &pairs[k]);
     FloatImage::Ptr d1 = run_pairs(opts, main_view, pairs);
-    main_view->write_depth_to_view(d1, "smvs-sgm");
+    // (app/smvsrecon.cc:383: write_depth_to_view -- the conversion of the stored
+    // copy to MVE's convention waits until the embedding is read; the optimizer
+    // of this view takes the map as it is and converts on the device)
+    main_view->write_depth_to_view_deferred(d1, "smvs-sgm");
     return d1;
 }
 

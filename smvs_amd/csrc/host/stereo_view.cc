@@ -260,14 +260,53 @@ StereoView::get_byte_image(void) const
 bool
 StereoView::has_embedding(std::string const& name) const
 {
-    return embeddings.count(name) != 0;
+    return embeddings.count(name) != 0 || deferred_depth.count(name) != 0;
+}
+
+// the conversion write_depth_to_view_deferred put off
+void
+StereoView::store_deferred(std::string const& name) const
+{
+    auto it = deferred_depth.find(name);
+    if (it == deferred_depth.end())
+        return;
+    FloatImage::Ptr mve_depth = it->second->duplicate();
+    float invproj[9];
+    camera.fill_inverse_calibration(invproj, (float)mve_depth->width(),
+        (float)mve_depth->height());
+    imgtools::depthmap_convert_conventions(mve_depth, invproj, true);
+    embeddings[name] = mve_depth;
+    deferred_depth.erase(it);
 }
 
 FloatImage::Ptr
 StereoView::get_embedding(std::string const& name) const
 {
+    store_deferred(name);
     auto it = embeddings.find(name);
     return it == embeddings.end() ? nullptr : it->second;
+}
+
+std::map<std::string, FloatImage::Ptr> const&
+StereoView::get_embeddings(void) const
+{
+    while (!deferred_depth.empty())
+        store_deferred(deferred_depth.begin()->first);
+    return embeddings;
+}
+
+void
+StereoView::write_depth_to_view_deferred(FloatImage::Ptr depth, std::string const& name)
+{
+    embeddings.erase(name);
+    deferred_depth[name] = depth;
+}
+
+FloatImage::Ptr
+StereoView::get_deferred_depth(std::string const& name) const
+{
+    auto it = deferred_depth.find(name);
+    return it == deferred_depth.end() ? nullptr : it->second;
 }
 
 FloatImage::Ptr
@@ -287,6 +326,7 @@ StereoView::get_sgm_depth(void) const
 void
 StereoView::write_image_to_view(FloatImage::Ptr img, std::string const& name)
 {
+    deferred_depth.erase(name);
     embeddings[name] = img;
 }
 
@@ -298,6 +338,7 @@ StereoView::write_depth_to_view(FloatImage::Ptr depth, std::string const& name)
     camera.fill_inverse_calibration(invproj, (float)mve_depth->width(),
         (float)mve_depth->height());
     imgtools::depthmap_convert_conventions(mve_depth, invproj, true);
+    deferred_depth.erase(name);
     embeddings[name] = mve_depth;
 }
 

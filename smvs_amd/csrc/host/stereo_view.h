@@ -51,10 +51,19 @@ public:
     FloatImage::Ptr get_sgm_depth(void) const;
     bool has_embedding(std::string const& name) const;
     FloatImage::Ptr get_embedding(std::string const& name) const;
-    std::map<std::string, FloatImage::Ptr> const& get_embeddings(void) const { return embeddings; }
+    std::map<std::string, FloatImage::Ptr> const& get_embeddings(void) const;
 
     void write_image_to_view(FloatImage::Ptr image, std::string const& name);
     void write_depth_to_view(FloatImage::Ptr depth, std::string const& name);
+    // Not in the reference: write_depth_to_view whose conversion to MVE's
+    // convention (0.5 M pixels on the host for an SGM map) happens when the
+    // embedding is first asked for -- any getter sees exactly what
+    // write_depth_to_view would have stored.  A consumer that can convert on the
+    // device (DepthOptimizer::create_initial_surface) takes the z-depth map with
+    // get_deferred_depth() and the embedding is never formed on the host unless
+    // somebody reads or saves it.
+    void write_depth_to_view_deferred(FloatImage::Ptr depth, std::string const& name);
+    FloatImage::Ptr get_deferred_depth(std::string const& name) const;
 
 private:
     StereoView(void) = default;
@@ -68,7 +77,10 @@ private:
     mutable std::once_flag image_once;
     FloatImage::Ptr scaleimage, image_grad, image_hessian;
     FloatImage::Ptr linear_image, shading, shading_grad;
-    std::map<std::string, FloatImage::Ptr> embeddings;
+    mutable std::map<std::string, FloatImage::Ptr> embeddings;
+    // z-depth maps of write_depth_to_view_deferred not yet converted and stored
+    mutable std::map<std::string, FloatImage::Ptr> deferred_depth;
+    void store_deferred(std::string const& name) const;
 };
 
 // image helpers shared with SGMStereo / DepthOptimizer

@@ -1891,7 +1891,7 @@ sgm_map_upload_kernel(SgmMapUpload A)
     if (i >= (size_t)A.w * A.h)
         return;
     float d = A.src[i];
-    if (A.from_mve) {
+    if (A.from_mve != 0) {
         int const y = (int)(i / (size_t)A.w), x = (int)(i - (size_t)y * A.w);
         float const px = (float)x + 0.5f, py = (float)y + 0.5f;
         float v[3];
@@ -1901,6 +1901,11 @@ sgm_map_upload_kernel(SgmMapUpload A)
         float const len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         // `double len = px.norm(); dm *= 1.0 / len` [MVE-unverified, M10]
         double const len_d = (double)len;
+        // (from_mve == 2: the map is still the z-depth the SGM front end produced;
+        // the view would store it as ray length first -- write_depth_to_view,
+        // `dm *= len` -- and the reference reads it back through that embedding)
+        if (A.from_mve == 2)
+            d = (float)((double)d * len_d);
         d = (float)((double)d * (1.0 / len_d));
     }
     A.dst[i] = d;
@@ -1908,26 +1913,27 @@ sgm_map_upload_kernel(SgmMapUpload A)
 
 static int
 sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *inv_calibration9,
-    float sigma, int kernel_size, float *out);
+    int dm_is_z_depth, float sigma, int kernel_size, float *out);
 
 extern "C" int
 smvs_ctx_sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
     float sigma, int kernel_size, float *out)
 {
-    return sgm_init_depth(ctx, dm, dm_w, dm_h, nullptr, sigma, kernel_size, out);
+    return sgm_init_depth(ctx, dm, dm_w, dm_h, nullptr, 0, sigma, kernel_size, out);
 }
 
 extern "C" int
-smvs_ctx_sgm_init_depth_mve(smvs_ctx *ctx, const float *dm_mve, int dm_w, int dm_h,
-    const float *inv_calibration9, float sigma, int kernel_size, float *out)
+smvs_ctx_sgm_init_depth_mve(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h,
+    const float *inv_calibration9, int dm_is_z_depth, float sigma, int kernel_size, float *out)
 {
-    SMVS_REQUIRE(dm_mve == nullptr || inv_calibration9 != nullptr, "null argument");
-    return sgm_init_depth(ctx, dm_mve, dm_w, dm_h, inv_calibration9, sigma, kernel_size, out);
+    SMVS_REQUIRE(dm == nullptr || inv_calibration9 != nullptr, "null argument");
+    return sgm_init_depth(ctx, dm, dm_w, dm_h, inv_calibration9, dm_is_z_depth != 0 ? 1 : 0, sigma,
+        kernel_size, out);
 }
 
 static int
 sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *inv_calibration9,
-    float sigma, int kernel_size, float *out)
+    int dm_is_z_depth, float sigma, int kernel_size, float *out)
 {
     SMVS_REQUIRE(ctx != nullptr, "null argument");
     if (dm == nullptr) {   // forget the resident map
@@ -1987,7 +1993,7 @@ sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *
         U.dst = ctx->sgm_lowres;
         U.w = dm_w;
         U.h = dm_h;
-        U.from_mve = inv_calibration9 != nullptr ? 1 : 0;
+        U.from_mve = inv_calibration9 != nullptr ? (dm_is_z_depth ? 2 : 1) : 0;
         for (int i = 0; i < 9; ++i)
             U.invproj[i] = inv_calibration9 != nullptr ? inv_calibration9[i] : 0.0f;
         hipLaunchKernelGGL(sgm_map_upload_kernel, dim3((unsigned)((n_low + 255) / 256)),

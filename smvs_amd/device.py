@@ -129,14 +129,16 @@ class ViewContext:
               d.shape[0], C.c_float(sigma), kernel_size, _p(out, _fp)))
         return out
 
-    def sgm_init_depth_mve(self, dm_mve, inv_calibration9, sigma=5.0, kernel_size=5):
+    def sgm_init_depth_mve(self, dm_mve, inv_calibration9, sigma=5.0, kernel_size=5,
+                           dm_is_z_depth=False):
         """sgm_init_depth() from the map as the view stores it (MVE's ray-length
         convention): converted to z-depth on the device (smvs_ctx_sgm_init_depth_mve)."""
         d = _f32(dm_mve)
         inv = _f32(np.asarray(inv_calibration9).reshape(9))
         out = np.zeros((self.height, self.width), dtype=np.float32)
         check(self.lib.smvs_ctx_sgm_init_depth_mve(self.handle, _p(d, _fp), d.shape[1],
-              d.shape[0], _p(inv, _fp), C.c_float(sigma), kernel_size, _p(out, _fp)))
+              d.shape[0], _p(inv, _fp), 1 if dm_is_z_depth else 0, C.c_float(sigma),
+              kernel_size, _p(out, _fp)))
         return out
 
     def set_scale(self, scale):

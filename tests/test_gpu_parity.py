@@ -840,6 +840,9 @@ def test_sgm_init_depth_from_the_stored_map_converts_with_the_hosts_bits(hip, or
     lw, lh = W // 2, H // 2
     xs, ys = np.meshgrid(np.arange(0, W, 2, dtype=float) + 0.5, np.arange(0, H, 2, dtype=float) + 0.5)
     z = synth.depth_at(prob["scene"], prob["main"], xs, ys).astype(np.float32)
+    # (the scene is a plane at depth 8: make the values ones that do not survive
+    # the round trip through the embedding unchanged)
+    z *= (np.float32(1.0) + np.float32(0.1) * np.random.default_rng(5).random(z.shape, dtype=np.float32))
     z[::7, ::5] = 0.0
     inv = _inverse_calibration(prob["main"].flen, lw, lh)
     f = np.float32
@@ -853,6 +856,9 @@ def test_sgm_init_depth_from_the_stored_map_converts_with_the_hosts_bits(hip, or
     want = ctx.sgm_init_depth(back)
     got = ctx.sgm_init_depth_mve(stored, inv)
     assert (want > 0).any() and np.array_equal(got, want)
+    # ... and from the z-depth the SGM front end produced, both conversions on the device
+    assert np.array_equal(ctx.sgm_init_depth_mve(z, inv, dm_is_z_depth=True), want)
+    assert not np.array_equal(back, z)       # (the round trip is not the identity)
     ctx.close()
 
 
