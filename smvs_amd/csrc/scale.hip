@@ -78,15 +78,23 @@ struct BlurTaps {
 // flight at once.  KS == 0: any half width, taps.ks at run time.
 constexpr int BLUR_X_LDS_FROM = 12;   // half width from which blur_x_kernel stages its row segment in LDS
 
-template <int C, int KS>
+// ROWS (round 6, the per-thread-loads form only): image rows per workgroup.  With
+// one row a 1920 x 1080 x 3 image was 24,840 workgroups of one output per
+// thread; the rows of a thread are independent, so their loads are all in flight
+// together and a launch is a quarter of the workgroups (SMVS_BLUR_X_ROWS=1: one
+// row, A/B).
+constexpr int BLUR_X_ROWS = 4;
+
+template <int C, int KS, int ROWS>
 __global__ void __launch_bounds__(256)
 blur_x_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h,
     BlurTaps taps)
 {
 #pragma clang fp contract(off)
+    static_assert(ROWS == 1 || KS < BLUR_X_LDS_FROM, "the LDS form takes one row");
     int const e0 = (int)(blockIdx.x * blockDim.x);
     int const e = e0 + (int)threadIdx.x;       // element of the row
-    int const y = (int)blockIdx.y;
+    int const y = (int)blockIdx.y * ROWS;
     int const ks = KS > 0 ? KS : taps.ks;
     const float *row = in + (size_t)y * w * C;
     if constexpr (KS >= BLUR_X_LDS_FROM) {
@@ -124,29 +132,45 @@ blur_x_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int 
     bool const interior = e0 / C - ks >= 0 && (e0 + 255) / C + ks <= w - 1;
     if (e >= w * C)
         return;
-    float av = 0.0f;
-    if (interior) {
-        const float *p = row + e;
-        if (KS > 0) {
-            float v[2 * KS + 1];
+    if (interior && KS > 0) {
+        // every load of the thread's rows is issued before its values are used
+        float v[ROWS][2 * KS + 1];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            // (a row below the image repeats the last one; it is not stored)
+            const float *p = in + (size_t)min(y + r, h - 1) * w * C + e;
 #pragma unroll
             for (int k = -KS; k <= KS; ++k)
-                v[k + KS] = p[k * C];
+                v[r][k + KS] = p[k * C];
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float av = 0.0f;
 #pragma unroll
             for (int k = -KS; k <= KS; ++k)
-                av += v[k + KS] * taps.k[k < 0 ? -k : k];
-        } else {
+                av += v[r][k + KS] * taps.k[k < 0 ? -k : k];
+            if (y + r < h)
+                out[(size_t)(y + r) * w * C + e] = av / taps.wsum;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int r = 0; r < ROWS && y + r < h; ++r) {
+        const float *rw = row + (size_t)r * w * C;
+        float av = 0.0f;
+        if (interior) {
+            const float *p = rw + e;
             for (int k = -ks; k <= ks; ++k)
                 av += p[k * C] * taps.k[k < 0 ? -k : k];
+        } else {
+            int const x = e / C, cc = e - x * C;
+            for (int k = -ks; k <= ks; ++k) {
+                int const xx = min(max(x + k, 0), w - 1);
+                av += rw[xx * C + cc] * taps.k[k < 0 ? -k : k];
+            }
         }
-    } else {
-        int const x = e / C, cc = e - x * C;
-        for (int k = -ks; k <= ks; ++k) {
-            int const xx = min(max(x + k, 0), w - 1);
-            av += row[xx * C + cc] * taps.k[k < 0 ? -k : k];
-        }
+        out[(size_t)(y + r) * w * C + e] = av / taps.wsum;
     }
-    out[(size_t)y * w * C + e] = av / taps.wsum;
 }
 
 // Separable pass along y, BLUR_ROWS output rows per thread: a loaded value
@@ -213,16 +237,38 @@ blur_y_kernel(const float *__restrict__ in, float *__restrict__ out, int row_len
 
 template <int KS>
 static void
+launch_blur_x(hipStream_t stream, const float *in, float *tmp, int w, int h, int c,
+    BlurTaps const &taps)
+{
+    unsigned const bx = (unsigned)((w * c + 255) / 256);
+    constexpr bool staged = KS >= BLUR_X_LDS_FROM;
+    const char *env = std::getenv("SMVS_BLUR_X_ROWS");
+    if (staged || (env != nullptr && env[0] == '1')) {
+        if (c == 1)
+            hipLaunchKernelGGL((blur_x_kernel<1, KS, 1>), dim3(bx, (unsigned)h), dim3(256), 0,
+                stream, in, tmp, w, h, taps);
+        else
+            hipLaunchKernelGGL((blur_x_kernel<3, KS, 1>), dim3(bx, (unsigned)h), dim3(256), 0,
+                stream, in, tmp, w, h, taps);
+        return;
+    }
+    constexpr int ROWS = staged ? 1 : BLUR_X_ROWS;
+    dim3 const grid(bx, (unsigned)((h + ROWS - 1) / ROWS));
+    if (c == 1)
+        hipLaunchKernelGGL((blur_x_kernel<1, KS, ROWS>), grid, dim3(256), 0, stream, in, tmp,
+            w, h, taps);
+    else
+        hipLaunchKernelGGL((blur_x_kernel<3, KS, ROWS>), grid, dim3(256), 0, stream, in, tmp,
+            w, h, taps);
+}
+
+template <int KS>
+static void
 launch_blur_ks(hipStream_t stream, const float *in, float *tmp, float *out, int w, int h,
     int c, BlurTaps const &taps)
 {
     unsigned const bx = (unsigned)((w * c + 255) / 256);
-    if (c == 1)
-        hipLaunchKernelGGL((blur_x_kernel<1, KS>), dim3(bx, (unsigned)h), dim3(256), 0,
-            stream, in, tmp, w, h, taps);
-    else
-        hipLaunchKernelGGL((blur_x_kernel<3, KS>), dim3(bx, (unsigned)h), dim3(256), 0,
-            stream, in, tmp, w, h, taps);
+    launch_blur_x<KS>(stream, in, tmp, w, h, c, taps);
     // The y pass re-reads every input row for the 2 KS / BLUR_ROWS + 1 row blocks
     // it is a tap of; the reuse has to happen in an L2, and each XCD has its own.
     // Workgroups go to the XCDs round robin by linear id (x fastest): with the
@@ -325,6 +371,125 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
     }
 }
 
+// The y pass of the blur, the luminance and the quadratic fit in ONE kernel
+// (round 6): blur_y_kernel wrote the blurred image (25 MB at 1920 x 1080 x 3)
+// only for gradients_kernel to read it back -- nothing else uses it.  A
+// workgroup owns FUSE_COLS x FUSE_ROWS output pixels; its 256 threads first
+// form the blurred values of the (FUSE_ROWS + 2) x 256 pixels its windows span
+// -- one thread per ELEMENT column (pixel x channel: the loads of a wave are
+// contiguous), FUSE_ROWS + 2 output rows per thread, every loaded row feeding
+// all the outputs it is a tap of in ascending tap order, exactly blur_y_kernel's
+// operations with BLUR_ROWS = FUSE_ROWS + 2 -- into LDS, then the luminance per
+// pixel (gradients_kernel's float expression), then the fit.  Same operands,
+// same order, same bits: tests/test_gpu_parity.py compares both forms with the
+// oracle and with each other at 1920 x 1080.  SMVS_SCALE_FUSED=0: the two
+// kernels (A/B).
+constexpr int FUSE_ROWS = 8;
+constexpr int FUSE_COLS = 254;          // + the two halo columns = 256 pixels = the workgroup
+
+template <int C, int KS>
+__global__ void __launch_bounds__(256)
+blur_y_gradients_kernel(const float *__restrict__ in, int w, int h, BlurTaps taps,
+    FitMatrix fit, float2 *__restrict__ grad, float4 *__restrict__ hess)
+{
+#pragma clang fp contract(off)
+    constexpr int R = FUSE_ROWS + 2;
+    __shared__ float blurred[R][256 * C];
+    __shared__ float lum[R][256];
+    int const x0 = (int)blockIdx.x * FUSE_COLS;     // first output pixel; tile column j is pixel x0 - 1 + j
+    int const y0 = (int)blockIdx.y * FUSE_ROWS;
+    int const t = (int)threadIdx.x;
+    // (padding workgroups of a grid row, see the launch)
+    if (x0 >= w)
+        return;
+    int const row_len = w * C;
+    // the tap rows of the tile stay inside the image: no clamps along y (wave-uniform)
+    bool const inner = y0 - 1 - KS >= 0 && y0 + FUSE_ROWS + KS <= h - 1;
+#pragma unroll 1
+    for (int part = 0; part < C; ++part) {
+        int const ec = part * 256 + t;              // element column of the tile
+        int const px = ec / C, ch = ec - px * C;
+        int const gx = min(max(x0 - 1 + px, 0), w - 1);
+        const float *col = in + (size_t)gx * C + ch;
+        float av[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            av[j] = 0.0f;
+        // tile row j (image row y0 - 1 + j) takes input row y0 - 1 - KS + i as
+        // its tap k = i - KS - j; at the image border the input row is clamped
+        // like blur_y_kernel's.  (A tile row outside the image then holds
+        // something else than the reference's clamped row -- only the zero
+        // gradients of the image's rim look at it.)
+        constexpr int N = 2 * KS + R;
+        constexpr int GROUP = 16;
+        int const first = y0 - 1 - KS;
+#pragma unroll
+        for (int g = 0; g < N; g += GROUP) {
+            float v[GROUP];
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i)
+                if (g + i < N) {
+                    int const yy = inner ? first + g + i
+                        : min(max(first + g + i, 0), h - 1);
+                    v[i] = col[(size_t)yy * row_len];
+                }
+#pragma unroll
+            for (int i = 0; i < GROUP; ++i)
+                if (g + i < N) {
+                    int const tt = g + i - KS;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        int const k = tt - j;     // tap of tile row j
+                        if (k >= -KS && k <= KS)
+                            av[j] += v[i] * taps.k[k < 0 ? -k : k];
+                    }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            blurred[j][ec] = av[j] / taps.wsum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float *px = &blurred[j][t * C];
+        lum[j][t] = C >= 3 ? px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f : px[0];
+    }
+    __syncthreads();
+    int const x = x0 + t;
+    if (t >= FUSE_COLS || x >= w)
+        return;
+#pragma unroll 1
+    for (int r = 0; r < FUSE_ROWS; ++r) {
+        int const y = y0 + r;
+        if (y >= h)
+            break;
+        size_t const p = (size_t)y * w + x;
+        float2 g = make_float2(0.f, 0.f);
+        float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+            double v[9];
+            int k = 0;
+            for (int a = -1; a < 2; ++a)
+                for (int b = -1; b < 2; ++b)
+                    v[k++] = lum[r + b + 1][t + 1 + a];
+            double rr[6];
+            for (int q = 0; q < 6; ++q) {
+                double sum = 0.0;
+                for (int i = 0; i < 9; ++i)
+                    sum += fit.m[q][i] * v[i];
+                rr[q] = sum;
+            }
+            g = make_float2((float)rr[3], (float)rr[4]);
+            hs = make_float4((float)(2.0 * rr[0]), (float)rr[2], (float)(2.0 * rr[1]),
+                0.f);
+        }
+        grad[p] = g;
+        if (hess != nullptr)
+            hess[p] = hs;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 compact_hessian_kernel(const float4 *__restrict__ src, float *__restrict__ dst,
     size_t count)
@@ -356,6 +521,49 @@ quadratic_fit_matrix(void)
                 : ((a == 0 || b == 0) ? 2.0 / 9.0 : -1.0 / 9.0);
         }
     return f;
+}
+
+// blur_x + the fused y pass / luminance / fit (the half widths of the scales
+// 0 .. 5 only: any other takes the separate kernels).  false: not launched.
+template <int KS>
+static bool
+launch_blur_gradients_ks(hipStream_t stream, const float *in, float *tmp, int w, int h,
+    int c, BlurTaps const &taps, FitMatrix const &fit, float2 *grad, float4 *hess)
+{
+    launch_blur_x<KS>(stream, in, tmp, w, h, c, taps);
+    // (a grid row is a multiple of 8 workgroups: a column of tiles, whose tap rows
+    // overlap, stays on ONE XCD and its L2 -- launch_blur_ks)
+    dim3 const grid((((unsigned)w + FUSE_COLS - 1) / FUSE_COLS + 7u) & ~7u,
+        ((unsigned)h + FUSE_ROWS - 1) / FUSE_ROWS);
+    if (c == 1)
+        hipLaunchKernelGGL((blur_y_gradients_kernel<1, KS>), grid, dim3(256), 0, stream,
+            tmp, w, h, taps, fit, grad, hess);
+    else
+        hipLaunchKernelGGL((blur_y_gradients_kernel<3, KS>), grid, dim3(256), 0, stream,
+            tmp, w, h, taps, fit, grad, hess);
+    return true;
+}
+
+static bool
+launch_blur_gradients(hipStream_t stream, const float *in, float *tmp, int w, int h, int c,
+    BlurTaps const &taps, FitMatrix const &fit, float2 *grad, float4 *hess)
+{
+    // (read per call, a few times per view: a test compares both forms in one process)
+    const char *e = std::getenv("SMVS_SCALE_FUSED");
+    bool const fused = !(e != nullptr && e[0] == '0');
+    if (!fused || (c != 1 && c != 3))
+        return false;
+    switch (taps.ks) {
+    case 1: return launch_blur_gradients_ks<1>(stream, in, tmp, w, h, c, taps, fit, grad, hess);
+    case 2: return launch_blur_gradients_ks<2>(stream, in, tmp, w, h, c, taps, fit, grad, hess);
+    case 4: return launch_blur_gradients_ks<4>(stream, in, tmp, w, h, c, taps, fit, grad, hess);
+    case 7: return launch_blur_gradients_ks<7>(stream, in, tmp, w, h, c, taps, fit, grad, hess);
+    case 12: return launch_blur_gradients_ks<12>(stream, in, tmp, w, h, c, taps, fit, grad, hess);
+    // (half width 23, scale 6: the two rows a tile forms beyond its eight cost more
+    // arithmetic than the round trip of the blurred image -- 0.674 against 0.663 ms
+    // for nine views, profiles/r6_scale_space_cost.txt -- so it keeps the two kernels)
+    default: return false;
+    }
 }
 
 } // namespace smvs_hip
@@ -607,13 +815,6 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
                 return rc;
             ctx->blur_cap = n;
         }
-        const float *src = vi.data;
-        if (blur) {
-            ScopedKernelTimer timer(ctx, SMVS_K_MISC);
-            launch_blur(ctx->stream, vi.data, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w,
-                vi.h, vi.c, taps);
-            src = ctx->blur_tmp[1];
-        }
         float2 *grad;
         float4 *hess;
         if (v == 0) {
@@ -638,7 +839,21 @@ smvs_ctx_set_scale(smvs_ctx *ctx, int scale)
             hess = sp.hess;
             ctx->planes_ok |= 1u << (v - 1);
         }
-        {
+        const float *src = vi.data;
+        bool planes_done = false;
+        if (blur) {
+            ScopedKernelTimer timer(ctx, SMVS_K_MISC);
+            // the y pass, the luminance and the fit in one kernel, or ...
+            planes_done = launch_blur_gradients(ctx->stream, vi.data, ctx->blur_tmp[0], vi.w,
+                vi.h, vi.c, taps, fit, grad, hess);
+            if (!planes_done) {
+                // ... the blurred image written out and read back
+                launch_blur(ctx->stream, vi.data, ctx->blur_tmp[0], ctx->blur_tmp[1], vi.w,
+                    vi.h, vi.c, taps);
+                src = ctx->blur_tmp[1];
+            }
+        }
+        if (!planes_done) {
             ScopedKernelTimer timer(ctx, SMVS_K_MISC);
             // (a row of the grid is a multiple of 8 workgroups, so that the three
             // rows a window spans meet in ONE XCD's L2 -- see launch_blur_ks; at

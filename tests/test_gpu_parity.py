@@ -464,6 +464,69 @@ def test_device_scale_space_is_bit_exact(hip, oracle, scale):
     ctx.close()
 
 
+@pytest.mark.parametrize("scale", [1, 3, 5])
+def test_device_scale_space_is_bit_exact_across_tiles(hip, oracle, scale):
+    """The same planes on images wider and taller than one workgroup's tile
+    of the fused y pass / luminance / fit kernel (254 x 8 pixels, csrc/scale.hip):
+    partial last tiles, grey and RGB, in both forms of the pass."""
+    import os
+    rng = np.random.default_rng(40 + scale)
+    main = rng.integers(0, 256, size=(301, 521, 3)).astype(np.uint8)
+    sub0 = rng.integers(0, 256, size=(259, 509, 3)).astype(np.uint8)
+    sub1 = rng.integers(0, 256, size=(263, 771)).astype(np.uint8)
+    want = [oracle.scale_planes(img, scale) for img in (main, sub0, sub1)]
+    old = os.environ.get("SMVS_SCALE_FUSED")
+    try:
+        for fused in ("1", "0"):
+            os.environ["SMVS_SCALE_FUSED"] = fused
+            ctx = hip.ViewContext(521, 301, 2)
+            ctx.upload_image(-1, main); ctx.upload_image(0, sub0); ctx.upload_image(1, sub1)
+            ctx.set_scale(scale)
+            for view, (g_ref, h_ref) in zip((-1, 0, 1), want):
+                g, h = ctx.download_planes(view)
+                assert np.array_equal(g, g_ref), (fused, view, np.abs(g - g_ref).max())
+                if view >= 0:
+                    assert np.array_equal(h, h_ref), (fused, view, np.abs(h - h_ref).max())
+            ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("SMVS_SCALE_FUSED", None)
+        else:
+            os.environ["SMVS_SCALE_FUSED"] = old
+
+
+def test_fused_scale_space_equals_the_separate_kernels_at_full_size(hip):
+    """1920 x 1080 RGB and a ragged grey neighbour, every scale of optimize()
+    (6 .. 2): the fused pass leaves the planes of blur_y_kernel +
+    gradients_kernel to the bit (those are the oracle's, tests above)."""
+    import os
+    rng = np.random.default_rng(77)
+    main = rng.integers(0, 256, size=(1080, 1920, 3)).astype(np.uint8)
+    sub0 = rng.integers(0, 256, size=(1080, 1920, 3)).astype(np.uint8)
+    sub1 = rng.integers(0, 256, size=(997, 1501)).astype(np.uint8)
+    old = os.environ.get("SMVS_SCALE_FUSED")
+    ctx = hip.ViewContext(1920, 1080, 2)
+    ctx.upload_image(-1, main); ctx.upload_image(0, sub0); ctx.upload_image(1, sub1)
+    try:
+        for scale in (6, 5, 4, 3, 2):
+            planes = {}
+            for fused in ("0", "1"):
+                os.environ["SMVS_SCALE_FUSED"] = fused
+                ctx.set_scale(scale)
+                planes[fused] = [ctx.download_planes(v) for v in (-1, 0, 1)]
+            for v in range(3):
+                assert np.array_equal(planes["0"][v][0], planes["1"][v][0]), (scale, v)
+                assert np.count_nonzero(planes["1"][v][0]) > 0
+                if v > 0:
+                    assert np.array_equal(planes["0"][v][1], planes["1"][v][1]), (scale, v)
+    finally:
+        ctx.close()
+        if old is None:
+            os.environ.pop("SMVS_SCALE_FUSED", None)
+        else:
+            os.environ["SMVS_SCALE_FUSED"] = old
+
+
 def test_cloned_loop_state_runs_the_same_loop(hip):
     """smvs_ctx_clone_loop_state (what bench.py's timed region replays): the
     clone's Newton loop -- and its rerun after smvs_ctx_restore_nodes -- is the
