@@ -148,6 +148,10 @@ struct TopoArgs {
     const SubPlanes *subs;
     float *zbuf[SMVS_MAX_SUBS];     // [(h + 1)][(w + 1)] z-buffer (3 x 3 splats)
     float *zraw[SMVS_MAX_SUBS];     // same shape: nearest depth per centre cell
+    // zbuf holds the 5 x 5 minimum of zraw -- the minimum of the 3 x 3 z-buffer
+    // cells the visibility test compares with -- instead of the 3 x 3 one
+    // (topo_dilate5_kernel; SMVS_ZBUF_WINDOW=3: the z-buffer itself, nine lookups)
+    int zbuf5;
     const float *sgm_depth;         // [H][W] or nullptr
     const NccSample *ncc;           // 32 concatenated templates
     int ncc_off[33];
@@ -326,6 +330,56 @@ topo_dilate_kernel(TopoArgs A)
         if (y0 + r < zh)
             A.zbuf[s][(size_t)(y0 + r) * zw + x]
                 = fminf(fminf(rows[r], rows[r + 1]), rows[r + 2]);
+}
+
+// The visibility test looks at the 3 x 3 z-buffer cells around a pixel's
+// projection and fails when ANY of them is nearer than 0.95 of the pixel's depth
+// (depth_optimizer.cc:792-830) -- i.e. when their MINIMUM is: a > b_i for some i
+// <=> a > min b_i (no NaN is ever splatted).  The minimum of 3 x 3 cells of the
+// 3 x 3 minimum filter is the 5 x 5 minimum filter of zraw, so this kernel leaves
+// THAT in zbuf and the test is one lookup per (pixel, neighbour) instead of nine
+// (round 6: 16 M x 9 four-byte loads per call at 1920 x 1080 x 8 were most of the
+// vector-memory instructions of the visibility kernel's pixel pass).  Cells
+// outside the buffer do not exist, as in the 3 x 3 filter; the test only looks
+// at cells whose 3 x 3 neighbourhood is inside (its 3 % border).
+// A workgroup loads DIL5_ROWS + 4 rows of 256 columns once (coalesced, into
+// LDS), forms the five-column minima per row and the five-row minima of those:
+// 252 x DIL5_ROWS cells per workgroup, 1.5 loads per cell.
+constexpr int DIL5_ROWS = 8;
+constexpr int DIL5_COLS = 252;
+__global__ void __launch_bounds__(256)
+topo_dilate5_kernel(TopoArgs A)
+{
+    __shared__ float tile[DIL5_ROWS + 4][256];
+    int const s = blockIdx.z;
+    int const zw = A.views[1 + s].w + 1, zh = A.views[1 + s].h + 1;
+    int const t = (int)threadIdx.x;
+    int const x0 = (int)blockIdx.x * DIL5_COLS;        // first output column; tile column j is x0 - 2 + j
+    int const y0 = (int)blockIdx.y * DIL5_ROWS;
+    if (x0 >= zw || y0 >= zh)
+        return;
+    const float *raw = A.zraw[s];
+    int const gx = x0 - 2 + t;
+    bool const col_ok = gx >= 0 && gx < zw;
+#pragma unroll
+    for (int r = 0; r < DIL5_ROWS + 4; ++r) {
+        int const gy = y0 - 2 + r;
+        // (a cell that does not exist takes no part in a minimum: +inf)
+        tile[r][t] = col_ok && gy >= 0 && gy < zh ? raw[(size_t)gy * zw + gx] : __builtin_inff();
+    }
+    __syncthreads();
+    if (t < 2 || t >= 2 + DIL5_COLS || gx >= zw)
+        return;
+    float rows[DIL5_ROWS + 4];
+#pragma unroll
+    for (int r = 0; r < DIL5_ROWS + 4; ++r)
+        rows[r] = fminf(fminf(fminf(tile[r][t - 2], tile[r][t - 1]), tile[r][t]),
+            fminf(tile[r][t + 1], tile[r][t + 2]));
+#pragma unroll
+    for (int r = 0; r < DIL5_ROWS; ++r)
+        if (y0 + r < zh)
+            A.zbuf[s][(size_t)(y0 + r) * zw + gx] = fminf(fminf(fminf(rows[r], rows[r + 1]),
+                rows[r + 2]), fminf(rows[r + 3], rows[r + 4]));
 }
 
 // A group of G = min(64, ps^2) consecutive lanes works on one (patch,
@@ -635,10 +689,16 @@ topo_visibility_kernel(TopoArgs A)
             return false;
         }
         int const cx = (int)qx, cy = (int)qy;
-        for (int dx = -1; dx < 2; ++dx)
-            for (int dy = -1; dy < 2; ++dy)
-                if (wp.d * 0.95 > zbuf[(unsigned)(cy + dy) * (unsigned)zw + (unsigned)(cx + dx)])
-                    visible = false;
+        if (A.zbuf5) {
+            // the minimum of the nine cells, formed once per cell (topo_dilate5_kernel)
+            if (wp.d * 0.95 > zbuf[(unsigned)cy * (unsigned)zw + (unsigned)cx])
+                visible = false;
+        } else {
+            for (int dx = -1; dx < 2; ++dx)
+                for (int dy = -1; dy < 2; ++dy)
+                    if (wp.d * 0.95 > zbuf[(unsigned)(cy + dy) * (unsigned)zw + (unsigned)(cx + dx)])
+                        visible = false;
+        }
         // ratio of the squared singular values of the warp Jacobian
         double const wx = sp[1], wy = sp[2];
         double jac[4];
@@ -1352,6 +1412,8 @@ fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
         A->exact_divisions = mode != nullptr && std::strcmp(mode, "exact") == 0 ? 1 : 0;
         const char *pairs = std::getenv("SMVS_NCC_PAIRS");
         A->ncc_pairs = pairs != nullptr && std::atoi(pairs) == 0 ? 0 : 1;
+        const char *window = std::getenv("SMVS_ZBUF_WINDOW");
+        A->zbuf5 = window != nullptr && std::atoi(window) == 3 ? 0 : 1;
     }
     A->pair_alive = nullptr;
     A->pass_gate = nullptr;
@@ -1488,8 +1550,13 @@ smvs_topology_subviews(smvs_ctx *ctx, const float *sgm_depth, int use_ncc,
         }
         // (column blocks padded to a multiple of 8: vertically adjacent row blocks
         // then share an XCD's L2, csrc/scale.hip launch_blur_ks)
-        hipLaunchKernelGGL(topo_dilate_kernel, dim3((((unsigned)zw + 255u) / 256u + 7u) & ~7u,
-            (zh + DILATE_ROWS - 1) / DILATE_ROWS, ctx->n_subs), dim3(256), 0, ctx->stream, A);
+        if (A.zbuf5)
+            hipLaunchKernelGGL(topo_dilate5_kernel,
+                dim3((((unsigned)zw + DIL5_COLS - 1) / DIL5_COLS + 7u) & ~7u,
+                    (zh + DIL5_ROWS - 1) / DIL5_ROWS, ctx->n_subs), dim3(256), 0, ctx->stream, A);
+        else
+            hipLaunchKernelGGL(topo_dilate_kernel, dim3((((unsigned)zw + 255u) / 256u + 7u) & ~7u,
+                (zh + DILATE_ROWS - 1) / DILATE_ROWS, ctx->n_subs), dim3(256), 0, ctx->stream, A);
     }
     {
         long long const pixels = (long long)ctx->num_patches * ctx->patchsize * ctx->patchsize;

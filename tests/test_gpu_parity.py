@@ -818,7 +818,9 @@ def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle,
     errors must be the same bits (and the oracle's, the tests above).  So must
     they be with the NCC samples of a lane taken one at a time instead of in
     pairs and the neighbours of the MSE kernel one by one instead of four at
-    once: those only change when loads are issued."""
+    once: those only change when loads are issued.  And with the z-buffer as the
+    reference keeps it (3 x 3 splats, nine lookups per pixel) instead of its
+    5 x 5 minimum filter and one lookup (round 6, topo_dilate5_kernel)."""
     prob, surf, ctx, tp = _topology_setup(hip, oracle, size[0], size[1], n_subs, scale, 0.01)
     tp.subviews()
     surf2 = dict(surf)
@@ -826,10 +828,13 @@ def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle,
     surf2["node_valid"] = tp.node_valid.copy()
     surf2["patch_vis"] = tp.patch_vis.copy()
     got = {}
-    for mode in ("shared", "exact", "one_sample_at_a_time", "one_neighbour_at_a_time"):
-        for name in ("SMVS_TOPO_DIVIDE", "SMVS_NCC_PAIRS", "SMVS_MSE_SUBS"):
+    for mode in ("shared", "exact", "one_sample_at_a_time", "one_neighbour_at_a_time",
+                 "z_buffer_window_3"):
+        for name in ("SMVS_TOPO_DIVIDE", "SMVS_NCC_PAIRS", "SMVS_MSE_SUBS", "SMVS_ZBUF_WINDOW"):
             monkeypatch.delenv(name, raising=False)
-        if mode == "exact":
+        if mode == "z_buffer_window_3":     # the 3 x 3 z-buffer and nine lookups per pixel
+            monkeypatch.setenv("SMVS_ZBUF_WINDOW", "3")
+        elif mode == "exact":
             monkeypatch.setenv("SMVS_TOPO_DIVIDE", "exact")
         elif mode == "one_sample_at_a_time":       # the NCC samples of a lane, not in pairs
             monkeypatch.setenv("SMVS_NCC_PAIRS", "0")
@@ -839,9 +844,9 @@ def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle,
         vis = ctx.topology_subviews(None, use_ncc=True).copy()
         ctx.set_surface(surf2)
         got[mode] = (vis, ctx.topology_patch_mse().copy())
-    for name in ("SMVS_TOPO_DIVIDE", "SMVS_NCC_PAIRS", "SMVS_MSE_SUBS"):
+    for name in ("SMVS_TOPO_DIVIDE", "SMVS_NCC_PAIRS", "SMVS_MSE_SUBS", "SMVS_ZBUF_WINDOW"):
         monkeypatch.delenv(name, raising=False)
-    for mode in ("exact", "one_sample_at_a_time", "one_neighbour_at_a_time"):
+    for mode in ("exact", "one_sample_at_a_time", "one_neighbour_at_a_time", "z_buffer_window_3"):
         assert np.array_equal(got["shared"][0], got[mode][0]), mode
         assert np.array_equal(got["shared"][1], got[mode][1]), mode
     assert np.array_equal(got["shared"][0], tp.patch_vis)
