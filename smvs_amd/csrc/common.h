@@ -229,6 +229,7 @@ struct smvs_ctx {
     float *sgm_lowres = nullptr; // its input, SGM resolution
     size_t sgm_lowres_cap = 0;
     float *bil_lut = nullptr;    // compressed colour-weight table of the bilateral filter (sgm.hip)
+    float *bil_tri = nullptr;    // ... and the triangle of all byte pairs (round 6)
     smvs_topo::NccSample *topo_ncc = nullptr;
     int topo_ncc_off[33] = { 0 };
     int topo_ncc_ps = 0;

@@ -421,6 +421,8 @@ ctx_free(smvs_ctx *ctx)
         (void)hipFree(ctx->sgm_lowres);
     if (ctx->bil_lut)
         (void)hipFree(ctx->bil_lut);
+    if (ctx->bil_tri)
+        (void)hipFree(ctx->bil_tri);
     if (ctx->topo_ncc)
         (void)hipFree(ctx->topo_ncc);
     if (ctx->topo_mse)

@@ -1217,6 +1217,140 @@ bilateral_colour_table(void)
     return usable ? table.data() : nullptr;
 }
 
+// Round 6: the same weights as ONE lookup per tap and channel.  The colour
+// weight of a pair of bytes is symmetric to the bit -- (float)b / 255 - (float)a
+// / 255 changes its sign exactly when the bytes change places, and the weight
+// squares it -- so the table of all pairs is a triangle of 256 x 257 / 2 floats
+// = 131,584 bytes: it fits the CU's 160 KB of LDS whole.  A persistent grid of
+// one workgroup of 1,024 lanes per CU loads it once and walks over the image;
+// per tap and channel: minimum, maximum, the triangle's index, one LDS read (the
+// compressed table above: two dependent LDS reads and twelve vector
+// instructions, and the kernel was bound by both).  Half width BIL_TRI_K (the
+// reference's default, depth_optimizer.h:70-72) with the window's columns
+// unrolled -- the clamped column of the guidance image and the column of the
+// depth map a tap reads are formed once per pixel, not once per tap.  Same taps,
+// same order, same products: the filtered map is array_equal with the oracle's
+// (tests/test_gpu_front.py).  SMVS_BILATERAL=compressed: the kernel above.
+constexpr int BIL_TRI_K = 5;
+constexpr int BIL_TRI_FLOATS = 256 * 257 / 2;
+constexpr int BIL_TRI_THREADS = 1024;
+
+template <int C>
+__global__ void __launch_bounds__(BIL_TRI_THREADS)
+bilateral_triangle_kernel(BilateralArgs A, const uint8_t *__restrict__ ci8,
+    const float *__restrict__ triangle, BilateralSpatial S)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float tri[];
+    for (int i = threadIdx.x; i < BIL_TRI_FLOATS; i += BIL_TRI_THREADS)
+        tri[i] = triangle[i];
+    __syncthreads();
+    constexpr int KS = BIL_TRI_K, KW = 2 * KS + 1;
+    float const scale_x = (float)A.dm_w / (float)A.w;
+    float const scale_y = (float)A.dm_h / (float)A.h;
+    long long const npix = (long long)A.w * A.h;
+    for (long long pix = (long long)blockIdx.x * BIL_TRI_THREADS + threadIdx.x; pix < npix;
+        pix += (long long)gridDim.x * BIL_TRI_THREADS) {
+        int const y = (int)(pix / A.w), x = (int)(pix - (long long)y * A.w);
+        unsigned centre[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            centre[c] = ci8[(size_t)pix * C + c];
+        // the columns of the window: byte offset in a row of the guidance image,
+        // column of the depth map
+        int col_ci[KW], col_dm[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            int const ci_x = min(max(x + k - KS, 0), A.w - 1);
+            float fx = scale_x * (float)ci_x;
+            fx = fminf(fmaxf(fx, 0.f), (float)A.dm_w - 1.f);
+            col_ci[k] = ci_x * C;
+            col_dm[k] = (int)fx;
+        }
+        float acc_v = 0.0f, acc_w = 0.0f;
+#pragma unroll 1
+        for (int ky = -KS; ky <= KS; ++ky) {
+            int const ci_y = min(max(y + ky, 0), A.h - 1);
+            float fy = scale_y * (float)ci_y;
+            fy = fminf(fmaxf(fy, 0.f), (float)A.dm_h - 1.f);
+            const float *dm_row = A.dm + (size_t)(int)fy * A.dm_w;
+            const uint8_t *ci_row = ci8 + (size_t)ci_y * A.w * C;
+            const float *sw = S.w + (ky + KS) * KW;
+            // every load of a window row is issued before the first is used, the
+            // bytes of a tap without depth included (a tap was: depth -> branch ->
+            // bytes -> table, three round trips in a row, eleven times per row)
+            float dv[KW];
+            unsigned bytes[KW][C];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                dv[k] = dm_row[col_dm[k]];
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    bytes[k][c] = ci_row[col_ci[k] + c];
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                float weight = 1.0f;
+                weight *= sw[k];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    unsigned const b = bytes[k][c];
+                    unsigned const lo = min(b, centre[c]), hi = max(b, centre[c]);
+                    // byte offset 4 (hi (hi + 1) / 2 + lo) = (2 hi) hi + 2 hi + 4 lo:
+                    // a shift, a 24-bit multiply-add, a shift-add
+                    unsigned const h2 = hi << 1;
+                    unsigned t;
+                    asm("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(t) : "v"(h2), "v"(hi));
+                    weight *= *reinterpret_cast<const float *>(
+                        reinterpret_cast<const char *>(tri) + (t + (lo << 2)));
+                }
+                // a tap without depth is skipped by the reference: it adds +0 to
+                // both sums here, which leaves them as they are to the bit (the
+                // sums start at +0 and the weights are positive: never -0)
+                acc_v += dv[k] * weight;
+                acc_w += dv[k] == 0.0f ? 0.0f : weight;
+            }
+        }
+        A.out[pix] = acc_w > 0 ? acc_v / acc_w : 0.0f;
+    }
+}
+
+// The triangle of colour weights (index hi (hi + 1) / 2 + lo), or nullptr when
+// some pair is not symmetric to the bit (it always is, see above; checked
+// because the bits are the host libm's).
+static const float *
+bilateral_colour_triangle(void)
+{
+#pragma clang fp contract(off)
+    static std::vector<float> table;
+    static bool usable = false;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        std::vector<float> t((size_t)BIL_TRI_FLOATS, 0.0f);
+        bool ok = true;
+        for (int a = 0; a < 256 && ok; ++a)
+            for (int b = 0; b < 256; ++b) {
+                // gaussian(tap - centre, 0.1) as the reference evaluates it on floats
+                float const diff = (float)b / 255.0f - (float)a / 255.0f;
+                float const wgt = expf(-(diff * diff) / (2.0f * 0.1f * 0.1f));
+                int const lo = a < b ? a : b, hi = a < b ? b : a;
+                size_t const at = (size_t)hi * (size_t)(hi + 1) / 2 + (size_t)lo;
+                if (a <= b) {
+                    t[at] = wgt;
+                } else {
+                    // (a > b: the mirrored pair has been stored)
+                    if (std::memcmp(&t[at], &wgt, sizeof(float)) != 0) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+        usable = ok;
+        table.swap(t);
+    });
+    return usable ? table.data() : nullptr;
+}
+
 // ------------------------------------------------------- L/R check + merge
 // SGMStereo::reconstruct, sgm_stereo.cc:64-91: the main view's depth is kept
 // where its correspondence in the neighbour (integer pixel coordinates, no
@@ -2017,11 +2151,27 @@ sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *
     if (kernel_size <= BIL_MAX_K && (A.channels == 1 || A.channels == 3))
         host_table = bilateral_colour_table();
     bool const tabled = host_table != nullptr;
+    // the triangle of all pairs in LDS (round 6), unless SMVS_BILATERAL=compressed
+    const float *host_triangle = nullptr;
+    if (tabled && kernel_size == BIL_TRI_K) {
+        const char *form = std::getenv("SMVS_BILATERAL");
+        if (!(form != nullptr && std::strcmp(form, "compressed") == 0))
+            host_triangle = bilateral_colour_triangle();
+    }
     BilateralSpatial S = {};
     size_t const n_img = n * (size_t)A.channels;
     if (tabled) {
 #pragma clang fp contract(off)
-        if (ctx->bil_lut == nullptr) {
+        if (host_triangle != nullptr) {
+            if (ctx->bil_tri == nullptr) {
+                if ((rc = device_alloc(&ctx->bil_tri, BIL_TRI_FLOATS)) != SMVS_OK
+                    || (rc = ctx_upload(ctx, ctx->bil_tri, host_triangle,
+                            BIL_TRI_FLOATS * sizeof(float))) != SMVS_OK) {
+                    (void)device_alloc(&ctx->bil_tri, 0);
+                    return rc;
+                }
+            }
+        } else if (ctx->bil_lut == nullptr) {
             if ((rc = device_alloc(&ctx->bil_lut, BIL_TABLE_WORDS)) != SMVS_OK
                 || (rc = ctx_upload(ctx, ctx->bil_lut, host_table,
                         BIL_TABLE_WORDS * sizeof(uint32_t))) != SMVS_OK)
@@ -2050,7 +2200,27 @@ sgm_init_depth(smvs_ctx *ctx, const float *dm, int dm_w, int dm_h, const float *
             hipLaunchKernelGGL(float_to_byte_kernel, dim3((unsigned)((n_img + 255) / 256)),
                 dim3(256), 0, ctx->stream, ctx->images[0].data, ctx->byte_stage, n_img);
             const uint32_t *table = reinterpret_cast<const uint32_t *>(ctx->bil_lut);
-            if (A.channels == 3)
+            if (host_triangle != nullptr) {
+                // one workgroup per CU, the table in its LDS for the whole image
+                size_t const lds = BIL_TRI_FLOATS * sizeof(float);
+                const void *k = A.channels == 3
+                    ? reinterpret_cast<const void *>(&bilateral_triangle_kernel<3>)
+                    : reinterpret_cast<const void *>(&bilateral_triangle_kernel<1>);
+                if ((rc = allow_dynamic_lds(ctx->device, k, lds)) != SMVS_OK)
+                    return rc;
+                int cus = 0;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                        physical_device(ctx->device)) != hipSuccess || cus <= 0)
+                    cus = 256;
+                unsigned const blocks = (unsigned)std::min<size_t>((size_t)cus,
+                    (n + BIL_TRI_THREADS - 1) / BIL_TRI_THREADS);
+                if (A.channels == 3)
+                    hipLaunchKernelGGL(bilateral_triangle_kernel<3>, dim3(blocks),
+                        dim3(BIL_TRI_THREADS), lds, ctx->stream, A, ctx->byte_stage, ctx->bil_tri, S);
+                else
+                    hipLaunchKernelGGL(bilateral_triangle_kernel<1>, dim3(blocks),
+                        dim3(BIL_TRI_THREADS), lds, ctx->stream, A, ctx->byte_stage, ctx->bil_tri, S);
+            } else if (A.channels == 3)
                 hipLaunchKernelGGL(bilateral_table_kernel<3>, grid, dim3(256), 0, ctx->stream,
                     A, ctx->byte_stage, table, S);
             else

@@ -930,6 +930,37 @@ def test_sgm_init_depth_from_the_stored_map_converts_with_the_hosts_bits(hip, or
     ctx.close()
 
 
+@pytest.mark.parametrize("channels", [3, 1])
+def test_bilateral_filter_from_the_triangle_of_all_pairs_at_full_size(hip, monkeypatch, channels):
+    """Round 6: the colour weights of smvs_ctx_sgm_init_depth as ONE lookup in the
+    triangle of all byte pairs held in LDS (bilateral_triangle_kernel) against
+    the compressed table with its selector (SMVS_BILATERAL=compressed; that one
+    is the oracle's to the bit, test below): 1920 x 1080, RGB and grey guidance,
+    a 960 x 540 map with holes."""
+    rng = np.random.default_rng(5 + channels)
+    W, H = 1920, 1080
+    shape = (H, W, 3) if channels == 3 else (H, W)
+    # smooth + noise: neighbouring bytes differ by small and by large amounts
+    base = rng.integers(0, 256, size=(H // 8 + 1, W // 8 + 1) + shape[2:]).astype(np.float32)
+    img = np.kron(base, np.ones((8, 8) + (1,) * (len(shape) - 2), np.float32))[:H, :W]
+    img = np.clip(img + rng.normal(0, 6, size=shape), 0, 255).astype(np.uint8)
+    low = (2.0 + rng.random((H // 2, W // 2))).astype(np.float32)
+    low[rng.random(low.shape) < 0.2] = 0.0
+    low[100:140, 300:420] = 0.0
+    got = {}
+    for form in ("triangle", "compressed"):
+        monkeypatch.delenv("SMVS_BILATERAL", raising=False)
+        if form == "compressed":
+            monkeypatch.setenv("SMVS_BILATERAL", "compressed")
+        ctx = hip.ViewContext(W, H, 1)
+        ctx.upload_image(-1, img)
+        got[form] = ctx.sgm_init_depth(low)
+        ctx.close()
+    monkeypatch.delenv("SMVS_BILATERAL", raising=False)
+    assert np.count_nonzero(got["triangle"]) > 0.5 * W * H
+    assert np.array_equal(got["triangle"], got["compressed"])
+
+
 def test_context_sgm_init_depth_is_the_bilateral_filter_and_stays_resident(hip, oracle):
     """smvs_ctx_sgm_init_depth: depthmap_bilateral_filter guided by the main
     image the context already holds (depth_optimizer.cc:35-51) -- bit-identical
