@@ -268,28 +268,49 @@ topo_splat_kernel(TopoArgs A)
     }
     if (A.sgm_depth != nullptr)
         depths[1] = A.sgm_depth[(size_t)y * A.W + x];
-    for (int k = 0; k < 2; ++k) {
-        if (depths[k] == 0.0f)   // (NaN splats like the reference: no effect)
-            continue;
-        double const w = depths[k];
-        for (int s = 0; s < A.n_subs; ++s) {
+    // Round 6: the two depths of a pixel (the surface's and the SGM map's) mostly
+    // land in the same cell of a neighbour -- the surface starts as the SGM map --
+    // and the L2 serves one atomic per clock and channel, 32 M of them per call
+    // with SGM: where both centres agree ONE atomic carries the smaller depth (the
+    // minimum is exact and order free, so the buffer is the same to the bit).
+    bool const on[2] = { depths[0] != 0.0f, depths[1] != 0.0f };   // (NaN splats like the reference: no effect)
+    if (!on[0] && !on[1])
+        return;
+    for (int s = 0; s < A.n_subs; ++s) {
+        int const sw = A.views[1 + s].w, sh = A.views[1 + s].h;
+        size_t cell[2] = { 0, 0 };
+        float df[2] = { 0.0f, 0.0f };
+        bool hit[2] = { false, false };
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!on[k])
+                continue;
+            double const w = depths[k];
             Warp wp(A.cams->M[s], A.cams->t[s], x + 0.5, y + 0.5, w);
             double const qx = wp.x() - 0.5, qy = wp.y() - 0.5;
             double const cutoffset = 3.0;
-            int const sw = A.views[1 + s].w, sh = A.views[1 + s].h;
             if (qx < cutoffset || qx >= sw - cutoffset || qy < cutoffset
                 || qy >= sh - cutoffset)
                 continue;
             int const cx = (int)qx, cy = (int)qy;
-            float const df = (float)wp.d;
-            if (!(df == df))
+            df[k] = (float)wp.d;
+            if (!(df[k] == df[k]))
                 continue;
             // The reference writes df into the 3 x 3 cells around (cx, cy)
             // (:455-462).  min is exact and order free, so the same buffer is
             // the 3 x 3 minimum filter of the per-centre minima: one atomic per
-            // (pixel, neighbour) here instead of nine, topo_dilate_kernel does
+            // (pixel, neighbour) here instead of nine, the dilate kernel does
             // the rest.
-            atomic_min_float(A.zraw[s] + (size_t)cy * (sw + 1) + cx, df);
+            cell[k] = (size_t)cy * (sw + 1) + cx;
+            hit[k] = true;
+        }
+        if (hit[0] && hit[1] && cell[0] == cell[1]) {
+            atomic_min_float(A.zraw[s] + cell[0], fminf(df[0], df[1]));
+        } else {
+            if (hit[0])
+                atomic_min_float(A.zraw[s] + cell[0], df[0]);
+            if (hit[1])
+                atomic_min_float(A.zraw[s] + cell[1], df[1]);
         }
     }
 }
