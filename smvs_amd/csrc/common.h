@@ -230,6 +230,8 @@ struct smvs_ctx {
     size_t sgm_lowres_cap = 0;
     float *bil_lut = nullptr;    // compressed colour-weight table of the bilateral filter (sgm.hip)
     float *bil_tri = nullptr;    // ... and the triangle of all byte pairs (round 6)
+    int topo_slot = 0;           // cut_boundaries: the word pair of the next pass (topology.hip)
+    bool topo_slots_clean = false;   // ... and whether both pairs are zero on the stream
     smvs_topo::NccSample *topo_ncc = nullptr;
     int topo_ncc_off[33] = { 0 };
     int topo_ncc_ps = 0;

@@ -1388,6 +1388,159 @@ topo_cut_nodes_kernel(TopoArgs A)
         A.node_valid_rw[n] = 0;
 }
 
+// ---- a cut pass in three launches instead of five (round 6) ----
+// A pass was border nodes -> candidates -> errors -> cut patches -> cut nodes,
+// five launches of ~5 us around one of ~20 us, and a view makes 24-50 passes:
+// what a pass costs is its launches (profiles/r6_cut_passes_ahead.txt).  Both
+// ends are fused by RECOMPUTATION -- the dependences are local:
+//  * topo_border_candidates_kernel: thread i writes the border flag of node i
+//    and decides the candidacy of patch i from the flags of its four nodes,
+//    which it forms itself from the 4 x 4 node validities around the patch (the
+//    same predicate on the same bytes: nobody writes node validity here);
+//  * topo_cut_fused_kernel: thread n evaluates the removal predicate of the (up
+//    to) four patches around node n -- the one whose first node it is, it also
+//    deletes and counts -- and keeps the node iff one of them stays.  A thread
+//    may read a patch's validity before or after its owner cleared it: the
+//    predicate does not depend on any validity, so both give the same answer.
+// The pass's two counters cannot be cleared by its first kernel any more (other
+// workgroups of the same launch add to them): passes alternate between two
+// pairs of words and the LAST kernel of a pass clears the pair of the next one,
+// whose previous values the host has read (it waits for every pass).
+// SMVS_CUT_FUSED=0: the five launches.
+__device__ __forceinline__ bool
+node_on_border(TopoArgs const &A, int n)
+{
+    int const nx = n % A.stride, ny = n / A.stride;
+    int missing = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (!dx && !dy)
+                continue;
+            int const mx = nx + dx, my = ny + dy;
+            bool const exists = mx >= 0 && my >= 0 && mx <= A.npx && my <= A.npy
+                && A.node_valid_rw[(size_t)my * A.stride + mx] != 0;
+            missing += exists ? 0 : 1;
+        }
+    return missing > 1;
+}
+
+__global__ void __launch_bounds__(256)
+topo_border_candidates_kernel(TopoArgs A)
+{
+    int const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < A.num_nodes)
+        A.border_node[i] = node_on_border(A, i) ? 1 : 0;
+    int const p = i;
+    bool const in_range = p < A.num_patches;
+    bool const valid = in_range && A.patch_valid[p];
+    bool alive = valid;
+    if (valid && A.only_candidates) {
+        int const n00 = (p / A.npx) * A.stride + p % A.npx;
+        alive = node_on_border(A, n00) || node_on_border(A, n00 + 1)
+            || node_on_border(A, n00 + A.stride) || node_on_border(A, n00 + A.stride + 1);
+    }
+    if (in_range && !alive)
+        A.mse_out[p] = valid ? 0.0 : -1.0;
+    // one atomic per workgroup: the list's end is one word for the whole grid
+    __shared__ int wave_count[4];
+    __shared__ int block_base;
+    unsigned long long const mask = __ballot(alive);
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        wave_count[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int const total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        block_base = total > 0 ? atomicAdd(A.mse_count, total) : 0;
+    }
+    __syncthreads();
+    if (alive) {
+        int at = block_base + __popcll(mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w)
+            at += wave_count[w];
+        A.mse_list[at] = p;
+    }
+}
+
+// topo_cut_patches_kernel's predicate for a VALID patch (:371-428)
+__device__ __forceinline__ bool
+cut_removes_patch(TopoArgs const &A, int p)
+{
+#pragma clang fp contract(off)
+    int const ix = p % A.npx, iy = p / A.npx;
+    int const n00 = iy * A.stride + ix;
+    int const ids[4] = { n00, n00 + 1, n00 + A.stride, n00 + A.stride + 1 };
+    double f[4];
+    for (int k = 0; k < 4; ++k)
+        f[k] = A.nodes[4 * (size_t)ids[k]];
+    int lo = 0, hi = 0;  // first minimum, last maximum (multimap order)
+    for (int i = 1; i < 4; ++i) {
+        if (f[i] < f[lo])
+            lo = i;
+        if (f[i] >= f[hi])
+            hi = i;
+    }
+    double dd_factor = 5.0;
+    if (lo + hi == 3)
+        dd_factor *= 1.41421356237309504880;
+    int const px = A.start_x + ix * A.ps, py = A.start_y + iy * A.ps;
+    float const fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    float v[3];
+    for (int r = 0; r < 3; ++r)
+        v[r] = A.invproj[3 * r] * fx + A.invproj[3 * r + 1] * fy
+            + A.invproj[3 * r + 2] * 1.0f;
+    float const vnorm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double const threshold = dd_factor * f[lo] * A.invproj[0] * A.ps / vnorm;
+    if (f[hi] - f[lo] > threshold)
+        return true;
+    if (A.mse_out[p] > 0.05)
+        for (int k = 0; k < 4; ++k)
+            if (A.border_node[ids[k]])
+                return true;
+    return false;
+}
+
+__global__ void __launch_bounds__(256)
+topo_cut_fused_kernel(TopoArgs A, int *next_counters)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        next_counters[0] = 0;
+        next_counters[1] = 0;
+    }
+    int const n = blockIdx.x * blockDim.x + threadIdx.x;
+    bool removed_own = false;
+    if (n < A.num_nodes) {
+        int const idx = n % A.stride, idy = n / A.stride;
+        bool const node_valid = A.node_valid_rw[n] != 0;
+        bool any = false;
+        for (int dy = -1; dy <= 0; ++dy)
+            for (int dx = -1; dx <= 0; ++dx) {
+                int const qx = idx + dx, qy = idy + dy;
+                if (!(qx >= 0 && qy >= 0 && qx < A.npx && qy < A.npy))
+                    continue;
+                bool const own = dx == 0 && dy == 0;
+                // (the patches around an invalid node matter only to their owners)
+                if (!own && !node_valid)
+                    continue;
+                int const q = qy * A.npx + qx;
+                if (!A.patch_valid_rw[q])
+                    continue;
+                bool const remove = cut_removes_patch(A, q);
+                if (!remove)
+                    any = true;
+                else if (own) {
+                    A.patch_valid_rw[q] = 0;
+                    removed_own = true;
+                }
+            }
+        if (node_valid && !any)
+            A.node_valid_rw[n] = 0;
+    }
+    int const cnt = __syncthreads_count(removed_own);
+    if (threadIdx.x == 0 && cnt != 0)
+        atomicAdd(A.deleted, cnt);
+}
+
 static int
 fill_args(smvs_ctx *ctx, TopoArgs *A, const char *who)
 {
@@ -1748,6 +1901,8 @@ prepare_patch_mse(smvs_ctx *ctx, TopoArgs *A, const char *who)
     return rc;
 }
 
+static int launch_patch_mse_listed(smvs_ctx *ctx, TopoArgs const &A);
+
 // The candidate list, then the errors of its entries.  count_is_zero: the
 // caller has cleared I_TOPO_CANDIDATES on the stream (with its own words).
 static int
@@ -1758,6 +1913,13 @@ launch_patch_mse(smvs_ctx *ctx, TopoArgs const &A, bool count_is_zero)
             ctx->stream));
     hipLaunchKernelGGL(topo_mse_candidates_kernel,
         dim3((unsigned)((ctx->num_patches + 255) / 256)), dim3(256), 0, ctx->stream, A);
+    return launch_patch_mse_listed(ctx, A);
+}
+
+// The errors of the patches on the list (the candidates are on the stream).
+static int
+launch_patch_mse_listed(smvs_ctx *ctx, TopoArgs const &A)
+{
     // enough groups for every CU to hold its fill of waves, never more than the
     // patches: a group walks the list with that stride
     long long const group = group_size(ctx->patchsize, MSE_WORKGROUP_FROM);
@@ -1831,6 +1993,48 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
         int const v = e != nullptr ? std::atoi(e) : 1;
         return v < 1 ? 1 : (v > TOPO_AHEAD ? TOPO_AHEAD : v);
     }();
+    static bool const fused_passes = [] {
+        const char *e = std::getenv("SMVS_CUT_FUSED");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    if (fused_passes && ahead == 1) {
+        // three launches per pass (topo_border_candidates_kernel); the pass's
+        // counters alternate between the word pairs 0 and 1, each cleared by the
+        // last kernel of the pass before
+        int *const words = ctx->status + I_TOPO_PASS0;
+        if (!ctx->topo_slots_clean) {
+            SMVS_HIP_CHECK(hipMemsetAsync(words, 0, 4 * sizeof(int), ctx->stream));
+            ctx->topo_slot = 0;
+        }
+        ctx->topo_slots_clean = false;
+        unsigned const cover = (unsigned)((std::max(ctx->num_nodes, ctx->num_patches) + 255) / 256);
+        while (deleted > 10) {
+            int const slot = ctx->topo_slot;
+            TopoArgs P = A;
+            P.deleted = words + 2 * slot;
+            P.mse_count = words + 2 * slot + 1;
+            P.pass_gate = nullptr;
+            hipLaunchKernelGGL(topo_border_candidates_kernel, dim3(cover), dim3(256), 0,
+                ctx->stream, P);
+            int const mrc = launch_patch_mse_listed(ctx, P);
+            if (mrc != SMVS_OK)
+                return mrc;
+            hipLaunchKernelGGL(topo_cut_fused_kernel,
+                dim3((unsigned)((ctx->num_nodes + 255) / 256)), dim3(256), 0, ctx->stream, P,
+                words + 2 * (1 - slot));
+            SMVS_HIP_CHECK(hipGetLastError());
+            SMVS_HIP_CHECK(hipMemcpyAsync(ctx->status_host + I_TOPO_PASS0 + 2 * slot,
+                words + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SMVS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ctx->topo_slot = 1 - slot;
+            deleted = ctx->status_host[I_TOPO_PASS0 + 2 * slot];
+            total += deleted;
+            if (trace)
+                std::fprintf(stderr, "[smvs topo] cut pass: %d of %d patches evaluated, %d deleted\n",
+                    ctx->status_host[I_TOPO_PASS0 + 2 * slot + 1], ctx->num_patches, deleted);
+        }
+        ctx->topo_slots_clean = true;
+    }
     while (deleted > 10) {
         // (the counters of a pass are cleared by its first kernel)
         for (int k = 0; k < ahead; ++k) {
