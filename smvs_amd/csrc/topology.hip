@@ -1993,10 +1993,9 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
         int const v = e != nullptr ? std::atoi(e) : 1;
         return v < 1 ? 1 : (v > TOPO_AHEAD ? TOPO_AHEAD : v);
     }();
-    static bool const fused_passes = [] {
-        const char *e = std::getenv("SMVS_CUT_FUSED");
-        return !(e != nullptr && e[0] == '0');
-    }();
+    // (read per call: a test runs both forms in one process)
+    const char *fused_env = std::getenv("SMVS_CUT_FUSED");
+    bool const fused_passes = !(fused_env != nullptr && fused_env[0] == '0');
     if (fused_passes && ahead == 1) {
         // three launches per pass (topo_border_candidates_kernel); the pass's
         // counters alternate between the word pairs 0 and 1, each cleared by the
@@ -2036,7 +2035,9 @@ smvs_topology_cut_boundaries(smvs_ctx *ctx, const float *inv_calibration9,
         ctx->topo_slots_clean = true;
     }
     while (deleted > 10) {
-        // (the counters of a pass are cleared by its first kernel)
+        // (the counters of a pass are cleared by its first kernel; the word pairs
+        // are then no longer what the three-launch form expects to find)
+        ctx->topo_slots_clean = false;
         for (int k = 0; k < ahead; ++k) {
             TopoArgs P = A;
             P.deleted = ctx->status + I_TOPO_PASS0 + 2 * k;

@@ -808,6 +808,33 @@ def test_topology_subviews_mse_and_cuts_match_oracle(hip, oracle, size, n_subs, 
     ctx.close()
 
 
+@pytest.mark.parametrize("size,n_subs,scale", [((320, 256), 4, 2), ((384, 256), 3, 3)])
+def test_cut_boundaries_in_three_launches_and_in_five(hip, oracle, monkeypatch, size, n_subs, scale):
+    """Round 6 fused the two ends of a cut_boundaries pass by recomputation
+    (topo_border_candidates_kernel, topo_cut_fused_kernel; the pass's counters
+    alternate between two word pairs): same deletions, patch and node validity
+    as the five launches (SMVS_CUT_FUSED=0) and as the oracle, also when calls
+    of both forms follow each other on one context."""
+    prob, surf, ctx, tp = _topology_setup(hip, oracle, size[0], size[1], n_subs, scale, 0.01)
+    tp.subviews()
+    surf2 = dict(surf)
+    surf2["patch_valid"] = tp.patch_valid.copy()
+    surf2["node_valid"] = tp.node_valid.copy()
+    surf2["patch_vis"] = tp.patch_vis.copy()
+    inv = _inverse_calibration(prob["main"].flen, size[0], size[1])
+    deleted_ref = tp.cut_boundaries()
+    assert deleted_ref > 0
+    for form in ("1", "0", "1", "1", "0"):
+        monkeypatch.setenv("SMVS_CUT_FUSED", form)
+        ctx.set_surface(surf2)
+        pv, nv, deleted = ctx.topology_cut_boundaries(inv)
+        assert deleted == deleted_ref, form
+        assert np.array_equal(pv, tp.patch_valid), form
+        assert np.array_equal(nv, tp.node_valid), form
+    monkeypatch.delenv("SMVS_CUT_FUSED", raising=False)
+    ctx.close()
+
+
 @pytest.mark.parametrize("size,n_subs,scale", [((320, 256), 6, 2), ((576, 416), 3, 5)])
 def test_topology_shared_reciprocals_give_the_bits_of_the_divisions(hip, oracle, monkeypatch,
                                                                    size, n_subs, scale):
