@@ -312,6 +312,40 @@ struct FitMatrix { double m[6][9]; };
 // and a launch is 1,080 workgroups of real work instead of 8,640 short ones.
 constexpr int GRAD_ROWS = 8;
 
+// r = M v of stereo_view.cc:167-187 without the terms whose coefficient is zero
+// (round 6: 11 of the 45 products of the rows that are used -- the constant row
+// never is).  Such a term is +0 (the window holds blurred luminances: finite,
+// never negative), and a sum that starts at +0 is never -0, so leaving the term
+// out changes no bit: rows x (a = 0 columns) and y (b = 0 columns) keep six
+// terms, row xy its four corners, in ascending column order like the full rows.
+// The main view has no Hessian plane (want_hess false, wave-uniform): its three
+// rows are not formed at all.
+__device__ __forceinline__ void
+quadratic_fit(FitMatrix const &fit, const double (&v)[9], bool want_hess, float2 *g, float4 *hs)
+{
+#pragma clang fp contract(off)
+    double r3 = 0.0, r4 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i / 3 != 1)          // a != 0
+            r3 += fit.m[3][i] * v[i];
+        if (i % 3 != 1)          // b != 0
+            r4 += fit.m[4][i] * v[i];
+    }
+    *g = make_float2((float)r3, (float)r4);
+    if (want_hess) {
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            r0 += fit.m[0][i] * v[i];
+            r1 += fit.m[1][i] * v[i];
+            if (i / 3 != 1 && i % 3 != 1)      // a b != 0
+                r2 += fit.m[2][i] * v[i];
+        }
+        *hs = make_float4((float)(2.0 * r0), (float)r2, (float)(2.0 * r1), 0.f);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 gradients_kernel(const float *__restrict__ img, int w, int h, int c,
     FitMatrix fit, float2 *__restrict__ grad, float4 *__restrict__ hess)
@@ -354,16 +388,7 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
             for (int a = -1; a < 2; ++a)
                 for (int b = -1; b < 2; ++b)
                     v[k++] = lum[r + b + 1][t + 1 + a];
-            double rr[6];
-            for (int q = 0; q < 6; ++q) {
-                double sum = 0.0;
-                for (int i = 0; i < 9; ++i)
-                    sum += fit.m[q][i] * v[i];
-                rr[q] = sum;
-            }
-            g = make_float2((float)rr[3], (float)rr[4]);
-            hs = make_float4((float)(2.0 * rr[0]), (float)rr[2], (float)(2.0 * rr[1]),
-                0.f);
+            quadratic_fit(fit, v, hess != nullptr, &g, &hs);
         }
         grad[p] = g;
         if (hess != nullptr)
@@ -374,7 +399,7 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
 // The y pass of the blur, the luminance and the quadratic fit in ONE kernel
 // (round 6): blur_y_kernel wrote the blurred image (25 MB at 1920 x 1080 x 3)
 // only for gradients_kernel to read it back -- nothing else uses it.  A
-// workgroup owns FUSE_COLS x FUSE_ROWS output pixels; its 256 threads first
+// workgroup owns FUSE_COLS x FUSE_ROWS (254 x 9) output pixels; its 256 threads first
 // form the blurred values of the (FUSE_ROWS + 2) x 256 pixels its windows span
 // -- one thread per ELEMENT column (pixel x channel: the loads of a wave are
 // contiguous), FUSE_ROWS + 2 output rows per thread, every loaded row feeding
@@ -384,18 +409,23 @@ gradients_kernel(const float *__restrict__ img, int w, int h, int c,
 // same order, same bits: tests/test_gpu_parity.py compares both forms with the
 // oracle and with each other at 1920 x 1080.  SMVS_SCALE_FUSED=0: the two
 // kernels (A/B).
-constexpr int FUSE_ROWS = 8;
+// nine rows per tile: 960 tiles at 1920 x 1080, which the chip holds at once (four
+// workgroups of 33 KB per CU); with eight rows the 1,080 tiles ran as a full round
+// and a tail (2.39 against 2.34 ms per view, SMVS_FUSE_ROWS=8)
+constexpr int FUSE_ROWS_DEFAULT = 9;
 constexpr int FUSE_COLS = 254;          // + the two halo columns = 256 pixels = the workgroup
 
-template <int C, int KS>
+template <int C, int KS, int FUSE_ROWS>
 __global__ void __launch_bounds__(256)
 blur_y_gradients_kernel(const float *__restrict__ in, int w, int h, BlurTaps taps,
     FitMatrix fit, float2 *__restrict__ grad, float4 *__restrict__ hess)
 {
 #pragma clang fp contract(off)
     constexpr int R = FUSE_ROWS + 2;
+    // (the luminances take the place of the blurred values they are formed from:
+    // read, barrier, written -- 3 KB per tile row instead of 4)
     __shared__ float blurred[R][256 * C];
-    __shared__ float lum[R][256];
+    float (*const lum)[256] = reinterpret_cast<float (*)[256]>(&blurred[0][0]);
     int const x0 = (int)blockIdx.x * FUSE_COLS;     // first output pixel; tile column j is pixel x0 - 1 + j
     int const y0 = (int)blockIdx.y * FUSE_ROWS;
     int const t = (int)threadIdx.x;
@@ -450,11 +480,16 @@ blur_y_gradients_kernel(const float *__restrict__ in, int w, int h, BlurTaps tap
             blurred[j][ec] = av[j] / taps.wsum;
     }
     __syncthreads();
+    float l[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const float *px = &blurred[j][t * C];
-        lum[j][t] = C >= 3 ? px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f : px[0];
+        l[j] = C >= 3 ? px[0] * 0.21f + px[1] * 0.72f + px[2] * 0.07f : px[0];
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        lum[j][t] = l[j];
     __syncthreads();
     int const x = x0 + t;
     if (t >= FUSE_COLS || x >= w)
@@ -473,16 +508,7 @@ blur_y_gradients_kernel(const float *__restrict__ in, int w, int h, BlurTaps tap
             for (int a = -1; a < 2; ++a)
                 for (int b = -1; b < 2; ++b)
                     v[k++] = lum[r + b + 1][t + 1 + a];
-            double rr[6];
-            for (int q = 0; q < 6; ++q) {
-                double sum = 0.0;
-                for (int i = 0; i < 9; ++i)
-                    sum += fit.m[q][i] * v[i];
-                rr[q] = sum;
-            }
-            g = make_float2((float)rr[3], (float)rr[4]);
-            hs = make_float4((float)(2.0 * rr[0]), (float)rr[2], (float)(2.0 * rr[1]),
-                0.f);
+            quadratic_fit(fit, v, hess != nullptr, &g, &hs);
         }
         grad[p] = g;
         if (hess != nullptr)
@@ -525,23 +551,35 @@ quadratic_fit_matrix(void)
 
 // blur_x + the fused y pass / luminance / fit (the half widths of the scales
 // 0 .. 5 only: any other takes the separate kernels).  false: not launched.
-template <int KS>
+template <int KS, int ROWS>
 static bool
-launch_blur_gradients_ks(hipStream_t stream, const float *in, float *tmp, int w, int h,
+launch_blur_gradients_rows(hipStream_t stream, const float *in, float *tmp, int w, int h,
     int c, BlurTaps const &taps, FitMatrix const &fit, float2 *grad, float4 *hess)
 {
     launch_blur_x<KS>(stream, in, tmp, w, h, c, taps);
     // (a grid row is a multiple of 8 workgroups: a column of tiles, whose tap rows
     // overlap, stays on ONE XCD and its L2 -- launch_blur_ks)
     dim3 const grid((((unsigned)w + FUSE_COLS - 1) / FUSE_COLS + 7u) & ~7u,
-        ((unsigned)h + FUSE_ROWS - 1) / FUSE_ROWS);
+        ((unsigned)h + ROWS - 1) / ROWS);
     if (c == 1)
-        hipLaunchKernelGGL((blur_y_gradients_kernel<1, KS>), grid, dim3(256), 0, stream,
+        hipLaunchKernelGGL((blur_y_gradients_kernel<1, KS, ROWS>), grid, dim3(256), 0, stream,
             tmp, w, h, taps, fit, grad, hess);
     else
-        hipLaunchKernelGGL((blur_y_gradients_kernel<3, KS>), grid, dim3(256), 0, stream,
+        hipLaunchKernelGGL((blur_y_gradients_kernel<3, KS, ROWS>), grid, dim3(256), 0, stream,
             tmp, w, h, taps, fit, grad, hess);
     return true;
+}
+
+template <int KS>
+static bool
+launch_blur_gradients_ks(hipStream_t stream, const float *in, float *tmp, int w, int h,
+    int c, BlurTaps const &taps, FitMatrix const &fit, float2 *grad, float4 *hess)
+{
+    const char *e = std::getenv("SMVS_FUSE_ROWS");
+    if (e != nullptr && std::atoi(e) == 8)
+        return launch_blur_gradients_rows<KS, 8>(stream, in, tmp, w, h, c, taps, fit, grad, hess);
+    return launch_blur_gradients_rows<KS, FUSE_ROWS_DEFAULT>(stream, in, tmp, w, h, c, taps, fit,
+        grad, hess);
 }
 
 static bool
