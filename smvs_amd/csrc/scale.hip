@@ -27,6 +27,40 @@ byte_to_float_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
         out[i] = (float)in[i] / 255.0f;
 }
 
+// Sixteen bytes per thread (one 16-byte load, four 16-byte stores) out of the
+// context's own staging buffers (device allocations: 256-byte aligned) instead
+// of a byte per thread: 24 k workgroups of four-byte stores were 16 us
+// for a 1920 x 1080 x 3 image whose 31 MB cost 8 (round 6).
+__global__ void __launch_bounds__(256)
+byte_to_float16_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+    size_t n)
+{
+#pragma clang fp contract(off)
+    size_t const t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t const chunks = n / 16;
+    if (t < chunks) {
+        uint4 const v = reinterpret_cast<const uint4 *>(in)[t];
+        uint32_t const w[4] = { v.x, v.y, v.z, v.w };
+        float4 *dst = reinterpret_cast<float4 *>(out + t * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            dst[q] = make_float4((float)(w[q] & 0xFFu) / 255.0f,
+                (float)((w[q] >> 8) & 0xFFu) / 255.0f, (float)((w[q] >> 16) & 0xFFu) / 255.0f,
+                (float)(w[q] >> 24) / 255.0f);
+    }
+    // (the last n % 16 bytes: the first threads of the grid)
+    if (t < n - chunks * 16)
+        out[chunks * 16 + t] = (float)in[chunks * 16 + t] / 255.0f;
+}
+
+// its grid for n bytes
+static inline unsigned
+byte_to_float_blocks(size_t n)
+{
+    size_t const threads = std::max<size_t>(n / 16, n % 16);
+    return (unsigned)std::max<size_t>(1, (threads + 255) / 256);
+}
+
 // The same conversion out of the caller's page-locked memory (the bytes cross
 // the bus as the kernel reads them) with a SMALL grid that strides over the
 // image, sixteen bytes per thread and step: enough requests in flight for the
@@ -644,7 +678,7 @@ smvs_ctx_upload_image(smvs_ctx *ctx, int view, int width, int height,
     uint8_t *staging = ctx->byte_stage;
     if ((rc = ctx_upload(ctx, staging, bytes, n)) != SMVS_OK)
         return rc;
-    hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+    hipLaunchKernelGGL(byte_to_float16_kernel, dim3(byte_to_float_blocks(n)),
         dim3(256), 0, ctx->stream, staging, vi.data, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
@@ -716,7 +750,7 @@ smvs_ctx_upload_image_async(smvs_ctx *ctx, int view, int width, int height,
             return rc;
         SMVS_HIP_CHECK(hipMemcpyAsync(ctx->upload_stage[v], bytes, n, hipMemcpyHostToDevice,
             ctx->stream));
-        hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+        hipLaunchKernelGGL(byte_to_float16_kernel, dim3(byte_to_float_blocks(n)),
             dim3(256), 0, ctx->stream, ctx->upload_stage[v], vi.data, n);
         SMVS_HIP_CHECK(hipGetLastError());
         ctx->image_ok |= 1u << v;
@@ -799,7 +833,7 @@ smvs_hip::ctx_materialise_images(smvs_ctx *ctx, uint32_t views)
             ctx->image_direct &= ~(1u << v);     // (converted by the upload itself)
             continue;
         }
-        hipLaunchKernelGGL(byte_to_float_kernel, dim3((unsigned)((n + 255) / 256)),
+        hipLaunchKernelGGL(byte_to_float16_kernel, dim3(byte_to_float_blocks(n)),
             dim3(256), 0, ctx->stream, ctx->upload_stage[v], vi.data, n);
         SMVS_HIP_CHECK(hipGetLastError());
         ctx->upload_stage_busy |= 1u << v;   // until the context's stream has been waited for
